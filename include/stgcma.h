@@ -1,0 +1,166 @@
+/*
+ * libstgcma_hip.so -- C ABI of the MI355X (gfx950) kernels behind the STG-CMA hot path.
+ *
+ * The reference (kaiw7/STG-CMA) has no native layer: its "operator API" is the nn.Module surface of
+ * AVE/model/Swin_AVE.py, AVE/model/CLIP_AVE.py, AVQA/model/Swin_AVQAModel_V1.py, AVS/model/Swin_AVSModel*.py,
+ * which bottoms out in chains of ATen ops.  Each entry point below replaces one such chain; the chain it
+ * replaces is cited as reference file:line (relative to the reference root).  The Python modules in
+ * stg-cma_amd/model/ bind these through ctypes (stg-cma_amd/_lib.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (stg_last_error() holds the message, thread-local);
+ *   - the caller owns all memory (device pointers from the PyTorch allocator), the library never allocates,
+ *     frees or keeps global mutable state => re-entrant across threads / devices / streams;
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, never synchronised;
+ *   - activations are bf16 (uint16 storage) row-major with explicit leading dimensions (in elements);
+ *     statistics, biases, trainable-parameter gradients and logits are fp32;
+ *   - "rows" are tokens of the fused audio+video tensor X[2, B*T, N, C] (modality 0 = video, 1 = audio).
+ */
+#ifndef STGCMA_H
+#define STGCMA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STG_VERSION 100
+
+enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
+enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
+
+int stg_version(void);
+const char* stg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epi( A[M,K] . W[N,K]^T )      (bf16 MFMA 16x16x32, fp32 accumulate)
+ * replaces F.linear / addmm / mm at: Swin_AVE.py:15-16,20-22 (adapters), :119-126 (Mlp), :238,274 (qkv/proj),
+ * :973-979 (PatchMerging.reduction), :1319-1322 (mlp_head); CLIP_AVE.py:56-60,106-108 (c_fc/c_proj/in_proj/out_proj).
+ * The same entry serves dgrad (W := pre-transposed weight) -- frozen weights never get a wgrad.
+ *   t = acc*alpha + bias[n]
+ *   if preact:   preact[m,n] = bf16(t)                       (saved for the activation's backward)
+ *   t = act(t)
+ *   if dact_src: t *= act'(dact_src[m,n])                    (backward through GELU/QuickGELU, act_bwd selects)
+ *   if row_scale: t *= row_scale[(m / rs_outer) * rs_inner + (m % rs_inner)]   (DropPath mask, Swin_AVE.py:709,715)
+ *   if res1: t += res1[m,n];  if res2: t += res2[m,n]        (residual adds, Swin_AVE.py:780-787,810-811)
+ *   C[m,n] = (c_dtype == STG_BF16) ? bf16(t) : t
+ * Requirements: K % 8 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W.
+ */
+typedef struct {
+    const void* A; int64_t lda;
+    const void* W; int64_t ldw;
+    void* C; int64_t ldc; int c_dtype;
+    const float* bias;
+    float alpha;
+    int act;
+    void* preact; int64_t ldp;
+    const void* dact_src; int64_t ldd; int act_bwd;
+    const float* row_scale; int64_t rs_outer; int64_t rs_inner;
+    const void* res1; int64_t ldr1;
+    const void* res2; int64_t ldr2;
+    int64_t M; int N; int K;
+} stg_gemm_args;
+int stg_gemm_nt(const stg_gemm_args* args, void* stream);
+
+/* Weight gradient of a trainable nn.Linear y = x W^T + b   (autograd of Swin_AVE.py:15-16 D_fc1/D_fc2, :1319-1322 head)
+ *   dW[N1,N2] (+)= sum_m dY[m,N1] * X[m,N2]      fp32, atomically accumulated (dW must be zeroed or hold a prior grad)
+ *   db[N1]    (+)= sum_m dY[m,N1]                (optional)
+ */
+int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx,
+                 float* dW, int64_t lddw, float* db, int64_t M, int N1, int N2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm; Swin_AVE.py:341,352 norm1/norm2, :960,976 PatchMerging.norm,
+ * :1099,1117-1119 PatchEmbed3D.norm, :1312 final norm; CLIP_AVE.py:33-39).
+ * gather4 != 0 folds PatchMerging's 2x2 strided gather + cat (Swin_AVE.py:967-972): logical row r of width 4*C is
+ * [x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)] of frame r / (H/2*W/2); C is then the width of one source row.
+ * x_dtype: STG_BF16 or STG_F32 input; y is bf16; mean/rstd fp32 per logical row (may be NULL in inference).
+ */
+int stg_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, float* mean, float* rstd,
+                      int64_t rows, int C, int gather4, int H, int W, void* stream);
+/* dx (bf16) = LN backward wrt input; if add_to != NULL, dx = add_to + LN_bwd (fuses the residual-branch join).
+ * dgamma/dbeta (fp32, atomically accumulated) optional -- only CLIP ln_post is trainable (traintest_adapt_ave29.py:52). */
+int stg_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int x_dtype, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, const void* add_to, int64_t ldadd,
+                      void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                      int64_t rows, int C, int gather4, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic gather-mapped multi-head attention (flash-style, MFMA 32x32x16, scores never hit HBM).
+ * One "problem" p in [0, P) attends n query tokens to n_kv key tokens; token i of problem p lives at row
+ *     row(p,i) = (p / G) * outer + map[(p % G) * n + i]            (map == NULL: identity (p % G) * n + i)
+ * so that torch.roll + window_partition / window_reverse (Swin_AVE.py:130-159,727-740,765-776), the temporal
+ * '(b t) n c -> (b n) t c' rearranges (:705,711) and the per-frame global grouping (:801-805) are pure addressing.
+ *   S = scale * Q K^T + bias[(p / bias_div) % bias_mod][h] + mask[p % G]      (bias: fp32 [*,H,n,n_kv], mask: fp32 [G,n,n_kv])
+ *   O = softmax(S) V ;  lse[p,h,i] = log sum exp (fp32, for backward)
+ * replaces WindowAttention.forward spatial (:256-276) and temporal (:244-255) branches, the cross-modal
+ * softmax(h_v h_a^T) h_a pairs (:753-757, :801-805; CLIP_AVE.py:386-398,415-424) with H=1, scale=1, K=V,
+ * and nn.MultiheadAttention's core (CLIP_AVE.py:106-108).
+ * D (head dim) in {16,32,48,64,96,128}.  Q/K/V/O rows are at base + row*ld + h*D.
+ */
+typedef struct {
+    const void* Q; int64_t ldq;
+    const void* K; int64_t ldk;
+    const void* V; int64_t ldv;
+    void* O; int64_t ldo;
+    float* lse;                       /* [P, H, n] or NULL */
+    const int32_t* map_q; const int32_t* map_kv;
+    int64_t outer_q, outer_kv;
+    int G;
+    int64_t P; int H; int n; int n_kv; int D;
+    float scale;
+    const float* bias; int64_t bias_div; int bias_mod;
+    const float* mask;
+} stg_attn_args;
+int stg_attn_fwd(const stg_attn_args* a, void* stream);
+
+/* Backward: dQ/dK/dV written (not accumulated) with the same addressing as Q/K/V (each row belongs to exactly one problem).
+ * delta[p,h,i] = sum_d dO*O is computed by stg_attn_bwd_prep into a caller workspace.
+ * dbias (fp32 [bias_mod,H,n,n_kv], atomically accumulated) optional: temporal_position_bias_table(_audio) is trainable. */
+typedef struct {
+    stg_attn_args f;                  /* forward description (O = forward output, lse = forward lse) */
+    const void* dO; int64_t lddo;
+    void* dQ; int64_t lddq;
+    void* dK; int64_t lddk;
+    void* dV; int64_t lddv;
+    float* delta;                     /* workspace [P, H, n] */
+    float* dbias;
+} stg_attn_bwd_args;
+int stg_attn_bwd(const stg_attn_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small element-wise / layout kernels
+ */
+/* out = h + gate[0] * r  (Swin_AVE.py:759-760,807-808); all bf16 [rows, d] contiguous-ld tensors, gate fp32 scalar on device */
+int stg_gate_fwd(const void* h, const void* r, const float* gate, void* out, int64_t numel, void* stream);
+/* dh = dout (alias allowed by caller), dr = gate*dout, dgate += sum(dout*r) */
+int stg_gate_bwd(const void* dout, const void* r, const float* gate, void* dr, float* dgate, int64_t numel, void* stream);
+
+/* Conv3d/Conv2d with kernel == stride as a gather (im2col is a pure re-indexing then; Swin_AVE.py:1097,1115 PatchEmbed3D.proj,
+ * CLIP_AVE.py:1091-1094 conv1).  x: [B, Cin, T, Hin, Win] (fp32 or bf16, contiguous) -> out bf16 [B*T*(Hin/p)*(Win/p), Kpad],
+ * column = c*p*p + ph*p + pw, zero-padded to Kpad. */
+int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B, int Cin, int T, int Hin, int Win, int p, int Kpad,
+                     void* stream);
+
+/* fp32 -> bf16 cast (optionally transposed: in [R,Cc] -> out [Cc,R]) for weight shadows */
+int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, void* stream);
+/* bf16 -> fp32 */
+int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
+
+/* token mean over n rows: in bf16 [G, n, C] -> out (bf16 or fp32) [G, C] written at out + g*ldo  (AdaptiveAvgPool1d, Swin_AVE.py:1588-1594) */
+int stg_meanpool_fwd(const void* in, void* out, int out_dtype, int64_t ldo, int64_t G, int n, int C, void* stream);
+int stg_meanpool_bwd(const void* dout, int64_t lddo, void* din, int64_t G, int n, int C, void* stream);
+
+/* out = a + b (bf16), used to join gradient branches */
+int stg_add(const void* a, const void* b, void* out, int64_t numel, void* stream);
+/* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
+int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
+/* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */
+int stg_bias_gather(const float* table, const int64_t* index, float* out, int L, int H, int nn, void* stream);
+/* dtable[index[ij], h] += dbias[h, ij] */
+int stg_bias_scatter(const float* dbias, const int64_t* index, float* dtable, int L, int H, int nn, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

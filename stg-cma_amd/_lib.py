@@ -1,0 +1,122 @@
+"""ctypes binding of libstgcma_hip.so (C ABI declared in include/stgcma.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  `lib()` raises if the shared object was not
+built (run `python __graft_entry__.py` or `make -C stg-cma_amd/csrc`), and every wrapper raises RuntimeError with
+stg_last_error() when a kernel entry point reports a failure.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstgcma_hip.so")
+
+STG_F32, STG_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+
+c_i64 = C.c_int64
+c_vp = C.c_void_p
+c_fp = C.c_void_p  # float* passed as raw address
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_vp), ("lda", c_i64),
+        ("W", c_vp), ("ldw", c_i64),
+        ("C", c_vp), ("ldc", c_i64), ("c_dtype", C.c_int),
+        ("bias", c_vp),
+        ("alpha", C.c_float),
+        ("act", C.c_int),
+        ("preact", c_vp), ("ldp", c_i64),
+        ("dact_src", c_vp), ("ldd", c_i64), ("act_bwd", C.c_int),
+        ("row_scale", c_vp), ("rs_outer", c_i64), ("rs_inner", c_i64),
+        ("res1", c_vp), ("ldr1", c_i64),
+        ("res2", c_vp), ("ldr2", c_i64),
+        ("M", c_i64), ("N", C.c_int), ("K", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("ldq", c_i64),
+        ("K", c_vp), ("ldk", c_i64),
+        ("V", c_vp), ("ldv", c_i64),
+        ("O", c_vp), ("ldo", c_i64),
+        ("lse", c_vp),
+        ("map_q", c_vp), ("map_kv", c_vp),
+        ("outer_q", c_i64), ("outer_kv", c_i64),
+        ("G", C.c_int),
+        ("P", c_i64), ("H", C.c_int), ("n", C.c_int), ("n_kv", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+        ("bias", c_vp), ("bias_div", c_i64), ("bias_mod", C.c_int),
+        ("mask", c_vp),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("f", AttnArgs),
+        ("dO", c_vp), ("lddo", c_i64),
+        ("dQ", c_vp), ("lddq", c_i64),
+        ("dK", c_vp), ("lddk", c_i64),
+        ("dV", c_vp), ("lddv", c_i64),
+        ("delta", c_vp),
+        ("dbias", c_vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/stgcma.h declares
+SIGNATURES = {
+    "stg_version": (C.c_int, []),
+    "stg_last_error": (C.c_char_p, []),
+    "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
+    "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp,
+                                    c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                    c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
+    "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
+    "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_cast_bf16": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp]),
+    "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
+}
+
+_lib = None
+
+
+class StgLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly when the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StgLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            f"(or `make -C stg-cma_amd/csrc`). There is no CPU fallback for the product path.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if handle.stg_version() != 100:
+        raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version 100")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().stg_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,86 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of libstgcma_hip.so.
+// Wave = 64 lanes everywhere; bf16 is carried as raw uint16_t in memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STG_WAVE 64
+
+typedef uint16_t bf16_t;
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 accumulator
+
+struct __attribute__((aligned(16))) u16x8 { uint16_t v[8]; };
+struct __attribute__((aligned(8))) u16x4 { uint16_t v[4]; };
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain integer rounding would turn some NaNs into inf/0)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+enum { STG_ACT_NONE = 0, STG_ACT_GELU = 1, STG_ACT_QUICKGELU = 2 };
+
+__device__ __forceinline__ float act_apply(int act, float x) {
+    if (act == STG_ACT_GELU) return gelu_erf(x);
+    if (act == STG_ACT_QUICKGELU) return quick_gelu(x);
+    return x;
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+    if (act == STG_ACT_GELU) return gelu_erf_grad(x);
+    if (act == STG_ACT_QUICKGELU) return quick_gelu_grad(x);
+    return 1.0f;
+}
+
+template <int W>
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// host-side error plumbing (api.cpp)
+void stg_set_error(const char* fmt, ...);
+#define STG_CHECK(cond, code, ...)                \
+    do {                                          \
+        if (!(cond)) {                            \
+            stg_set_error(__VA_ARGS__);           \
+            return (code);                        \
+        }                                         \
+    } while (0)
+#define STG_LAUNCH_CHECK()                                                   \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            stg_set_error("launch failed: %s", hipGetErrorString(e__));      \
+            return -100;                                                     \
+        }                                                                    \
+    } while (0)

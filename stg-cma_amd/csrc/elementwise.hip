@@ -1,0 +1,326 @@
+// Small HBM-bound element-wise / re-indexing kernels (see include/stgcma.h).  All use 16-byte accesses and a
+// capped grid with a grid-stride loop.
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t work_items, int per_block) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* v) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 o;
+    o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+    return o;
+}
+
+// ---- out = h + gate * r
+__global__ void gate_fwd_kernel(const bf16_t* h, const bf16_t* r, const float* gate, bf16_t* out, int64_t n8, int64_t numel) {
+    const float g = gate[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(reinterpret_cast<const uint4*>(h)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(r)[i], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += g * b[j];
+        reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    }
+    // tail
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        out[i] = f2bf(bf2f(h[i]) + g * bf2f(r[i]));
+    }
+}
+
+// ---- dr = gate * dout ; dgate += sum(dout * r)
+__global__ void gate_bwd_kernel(const bf16_t* dout, const bf16_t* r, const float* gate, bf16_t* dr, float* dgate,
+                                int64_t n8, int64_t numel) {
+    const float g = gate[0];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(reinterpret_cast<const uint4*>(dout)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(r)[i], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc += a[j] * b[j]; a[j] *= g; }
+        reinterpret_cast<uint4*>(dr)[i] = pack8(a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        const float d = bf2f(dout[i]);
+        acc += d * bf2f(r[i]);
+        dr[i] = f2bf(g * d);
+    }
+    acc = wave_sum<64>(acc);
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+        atomicAdd(dgate, t);
+    }
+}
+
+// ---- out = a + b
+__global__ void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n8, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        unpack8(reinterpret_cast<const uint4*>(a)[i], x);
+        unpack8(reinterpret_cast<const uint4*>(b)[i], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        reinterpret_cast<uint4*>(out)[i] = pack8(x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        out[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+    }
+}
+
+// ---- out = a * mask (fp32 mask)
+__global__ void mul_mask_kernel(const bf16_t* a, const float* mask, bf16_t* out, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(bf2f(a[i]) * mask[i]);
+}
+
+// ---- patch gather for kernel==stride convs.  One thread writes 8 output columns (16 bytes).
+__global__ void im2col_kernel(const void* x, int x_f32, bf16_t* out, int64_t B, int Cin, int T, int Hin, int Win, int p,
+                              int Kpad, int64_t nrows) {
+    const int Hp = Hin / p, Wp = Win / p;
+    const int K = Cin * p * p;
+    const int cpr = Kpad / 8;
+    const int64_t total = nrows * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = id / cpr;
+        const int c8 = (int)(id - row * cpr) * 8;
+        // row = ((b*T + t)*Hp + hp)*Wp + wp
+        const int wp = (int)(row % Wp);
+        int64_t r2 = row / Wp;
+        const int hp = (int)(r2 % Hp);
+        r2 /= Hp;
+        const int t = (int)(r2 % T);
+        const int64_t b = r2 / T;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = c8 + j;
+            float val = 0.f;
+            if (col < K) {
+                const int c = col / (p * p);
+                const int rem = col - c * p * p;
+                const int ph = rem / p, pw = rem - ph * p;
+                const int64_t off = (((b * Cin + c) * T + t) * Hin + (hp * p + ph)) * (int64_t)Win + (wp * p + pw);
+                val = x_f32 ? reinterpret_cast<const float*>(x)[off] : bf2f(reinterpret_cast<const bf16_t*>(x)[off]);
+            }
+            v[j] = val;
+        }
+        *reinterpret_cast<uint4*>(out + row * Kpad + c8) = pack8(v);
+    }
+}
+
+// ---- casts
+__global__ void cast_bf16_kernel(const float* in, bf16_t* out, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(in[i]);
+}
+__global__ void cast_bf16_t_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc) {
+    __shared__ float tile[32][33];
+    const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = by + j, c = bx + tx;
+        tile[j][tx] = (r < R && c < Cc) ? in[r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = bx + j, r = by + tx;  // out[c][r]
+        if (c < Cc && r < R) out[c * R + r] = f2bf(tile[tx][j]);
+    }
+}
+__global__ void cast_f32_kernel(const bf16_t* in, float* out, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bf2f(in[i]);
+}
+
+// ---- token mean: in [G, n, C] -> out [G, C].  One thread per (g, 8 columns).
+__global__ void meanpool_fwd_kernel(const bf16_t* in, void* out, int out_f32, int64_t ldo, int64_t G, int n, int C) {
+    const int c8n = C / 8;
+    const int64_t total = G * c8n;
+    const float inv = 1.0f / (float)n;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = id / c8n;
+        const int c8 = (int)(id - g * c8n) * 8;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(in + (g * n + i) * C + c8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] *= inv;
+        if (out_f32) {
+            float* o = reinterpret_cast<float*>(out) + g * ldo + c8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = s[j];
+        } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + g * ldo + c8) = pack8(s);
+        }
+    }
+}
+__global__ void meanpool_bwd_kernel(const bf16_t* dout, int64_t lddo, bf16_t* din, int64_t G, int n, int C) {
+    const int c8n = C / 8;
+    const int64_t total = G * n * c8n;
+    const float inv = 1.0f / (float)n;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = id / c8n;
+        const int c8 = (int)(id - row * c8n) * 8;
+        const int64_t g = row / n;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + g * lddo + c8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= inv;
+        *reinterpret_cast<uint4*>(din + row * C + c8) = pack8(v);
+    }
+}
+
+// ---- relative-position bias expansion: out[h, ij] = table[index[ij], h]
+__global__ void bias_gather_kernel(const float* table, const int64_t* index, float* out, int L, int H, int nn) {
+    const int total = H * nn;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        const int h = id / nn, ij = id - h * nn;
+        int64_t ix = index[ij];
+        if (ix < 0) ix = 0;
+        if (ix >= L) ix = L - 1;
+        out[id] = table[ix * H + h];
+    }
+}
+__global__ void bias_scatter_kernel(const float* dbias, const int64_t* index, float* dtable, int L, int H, int nn) {
+    const int total = H * nn;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        const int h = id / nn, ij = id - h * nn;
+        int64_t ix = index[ij];
+        if (ix < 0 || ix >= L) continue;
+        atomicAdd(dtable + ix * H + h, dbias[id]);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int stg_gate_fwd(const void* h, const void* r, const float* gate, void* out, int64_t numel, void* stream) {
+    STG_CHECK(h && r && gate && out, -1, "stg_gate_fwd: null pointer");
+    STG_CHECK((((uintptr_t)h | (uintptr_t)r | (uintptr_t)out) & 15) == 0, -2, "stg_gate_fwd: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)h, (const bf16_t*)r, gate,
+                       (bf16_t*)out, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_gate_bwd(const void* dout, const void* r, const float* gate, void* dr, float* dgate, int64_t numel,
+                            void* stream) {
+    STG_CHECK(dout && r && gate && dr && dgate, -1, "stg_gate_bwd: null pointer");
+    STG_CHECK((((uintptr_t)dout | (uintptr_t)r | (uintptr_t)dr) & 15) == 0, -2, "stg_gate_bwd: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)dout, (const bf16_t*)r,
+                       gate, (bf16_t*)dr, dgate, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_add(const void* a, const void* b, void* out, int64_t numel, void* stream) {
+    STG_CHECK(a && b && out, -1, "stg_add: null pointer");
+    STG_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, -2, "stg_add: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out,
+                       n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream) {
+    STG_CHECK(a && mask && out, -1, "stg_mul_mask: null pointer");
+    if (numel <= 0) return 0;
+    hipLaunchKernelGGL(mul_mask_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, ST, (const bf16_t*)a, mask, (bf16_t*)out, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B, int Cin, int T, int Hin, int Win, int p,
+                                int Kpad, void* stream) {
+    STG_CHECK(x && out, -1, "stg_im2col_patch: null pointer");
+    STG_CHECK(x_dtype == STG_F32 || x_dtype == STG_BF16, -3, "stg_im2col_patch: unsupported dtype");
+    STG_CHECK(B >= 0 && Cin > 0 && T > 0 && p > 0 && Hin % p == 0 && Win % p == 0, -2, "stg_im2col_patch: bad shape");
+    STG_CHECK(Kpad % 8 == 0 && Kpad >= Cin * p * p, -2, "stg_im2col_patch: Kpad must be a multiple of 8 and >= Cin*p*p");
+    const int64_t nrows = B * T * (Hin / p) * (Win / p);
+    if (nrows == 0) return 0;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(nrows * (Kpad / 8), 256)), dim3(256), 0, ST, x, (int)(x_dtype == STG_F32),
+                       (bf16_t*)out, B, Cin, T, Hin, Win, p, Kpad, nrows);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, void* stream) {
+    STG_CHECK(in && out, -1, "stg_cast_bf16: null pointer");
+    if (R <= 0 || Cc <= 0) return 0;
+    if (!transpose) {
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(R * Cc, 256)), dim3(256), 0, ST, in, (bf16_t*)out, R * Cc);
+    } else {
+        const int64_t gx = (Cc + 31) / 32, gy = (R + 31) / 32;
+        STG_CHECK(gy < 65536, -2, "stg_cast_bf16: too many rows for transpose");
+        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ST, in, (bf16_t*)out, R, Cc);
+    }
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream) {
+    STG_CHECK(in && out, -1, "stg_cast_f32: null pointer");
+    if (numel <= 0) return 0;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, ST, (const bf16_t*)in, out, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_meanpool_fwd(const void* in, void* out, int out_dtype, int64_t ldo, int64_t G, int n, int C, void* stream) {
+    STG_CHECK(in && out, -1, "stg_meanpool_fwd: null pointer");
+    STG_CHECK(C % 8 == 0 && n > 0 && ldo % 8 == 0, -2, "stg_meanpool_fwd: C and ldo must be multiples of 8");
+    if (G <= 0) return 0;
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(grid_for(G * (C / 8), 256)), dim3(256), 0, ST, (const bf16_t*)in, out,
+                       (int)(out_dtype == STG_F32), ldo, G, n, C);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_meanpool_bwd(const void* dout, int64_t lddo, void* din, int64_t G, int n, int C, void* stream) {
+    STG_CHECK(dout && din, -1, "stg_meanpool_bwd: null pointer");
+    STG_CHECK(C % 8 == 0 && n > 0 && lddo % 8 == 0, -2, "stg_meanpool_bwd: C and lddo must be multiples of 8");
+    if (G <= 0) return 0;
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for(G * n * (C / 8), 256)), dim3(256), 0, ST, (const bf16_t*)dout, lddo,
+                       (bf16_t*)din, G, n, C);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_bias_gather(const float* table, const int64_t* index, float* out, int L, int H, int nn, void* stream) {
+    STG_CHECK(table && index && out, -1, "stg_bias_gather: null pointer");
+    STG_CHECK(L > 0 && H > 0 && nn > 0, -2, "stg_bias_gather: bad shape");
+    hipLaunchKernelGGL(bias_gather_kernel, dim3(grid_for((int64_t)H * nn, 256)), dim3(256), 0, ST, table, index, out, L, H, nn);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_bias_scatter(const float* dbias, const int64_t* index, float* dtable, int L, int H, int nn, void* stream) {
+    STG_CHECK(dbias && index && dtable, -1, "stg_bias_scatter: null pointer");
+    STG_CHECK(L > 0 && H > 0 && nn > 0, -2, "stg_bias_scatter: bad shape");
+    hipLaunchKernelGGL(bias_scatter_kernel, dim3(grid_for((int64_t)H * nn, 256)), dim3(256), 0, ST, dbias, index, dtable, L, H, nn);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,375 @@
+// bf16 MFMA GEMM with fused epilogues:  C[M,N] = epi(A[M,K] . W[N,K]^T)   (see include/stgcma.h: stg_gemm_nt)
+//
+// Shape of the work: M = token rows of the fused audio+video tensor (up to 2.0 M at B=32),
+// N,K in {16..4096}.  Both operands are K-contiguous, which is exactly the per-lane layout of
+// v_mfma_f32_16x16x32_bf16 (lane l holds row l&15, k = 8*(l>>4)..+7), so tiles go global -> VGPR -> LDS (16-byte
+// chunks, XOR-swizzled) -> ds_read_b128 fragments with no transposes anywhere.
+//
+// The MFMA is issued "swapped": first operand = W fragment, second = A fragment, so the accumulator holds
+// D[n][m] with m on the lane and 4 consecutive n in registers => the epilogue reads/writes 8-byte bf16x4 runs
+// of a C row (bias, saved pre-activation, activation-gradient source, residuals are all row-major [M,N]).
+//
+// Block tile 128x128x64, 256 threads = 2x2 waves of 64x64, LDS double buffered (64 KiB => 2 blocks / CU),
+// global prefetch of tile k+1 into registers while tile k is in the MFMA loop (one barrier per k-tile).
+// Block ids are remapped so that the N-tiles sharing one A row-panel run on the same XCD (its L2 holds the panel).
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int CPR = BK / 8;  // 16-byte chunks per LDS row
+
+struct GemmParams {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    void* C; int64_t ldc; int c_f32;
+    const float* bias;
+    float alpha;
+    int act;
+    bf16_t* preact; int64_t ldp;
+    const bf16_t* dact_src; int64_t ldd; int act_bwd;
+    const float* row_scale; int64_t rs_outer; int64_t rs_inner;
+    const bf16_t* res1; int64_t ldr1;
+    const bf16_t* res2; int64_t ldr2;
+    int64_t M; int N; int K;
+    int nbm, nbn;
+    int vec_ok;
+};
+
+__device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+
+    // XCD-aware bijective remap: consecutive logical tiles (same A panel) land on one XCD.
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int64_t m0 = (int64_t)bm * BM;
+    const int n0 = bn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, lk = lane >> 4;
+
+    constexpr int ITERS = BM * CPR / 256;  // 4 chunks of A and 4 of W per thread per k-tile
+    uint4 ra[ITERS], rb[ITERS];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CPR, c = id % CPR;
+            const int gk = kt * BK + c * 8;
+            const int64_t gm = m0 + row;
+            const int gn = n0 + row;
+            ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + gk) : zero4;
+            rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const uint4*>(p.W + (int64_t)gn * p.ldw + gk) : zero4;
+        }
+    };
+    auto swrite = [&](int stage) {
+        bf16_t* sA = smem + stage * (BM + BN) * BK;
+        bf16_t* sW = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CPR, c = id % CPR;
+            *reinterpret_cast<uint4*>(sA + row * BK + swz(row, c) * 8) = ra[i];
+            *reinterpret_cast<uint4*>(sW + row * BK + swz(row, c) * 8) = rb[i];
+        }
+    };
+
+    f32x4_t acc[4][4];  // [n tile][m tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const bf16_t* sA = smem + stage * (BM + BN) * BK;
+        const bf16_t* sW = sA + BM * BK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t af[4], wf[4];
+            const int c = 4 * s + lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ar = wm * 64 + i * 16 + lrow;
+                const int wr = wn * 64 + i * 16 + lrow;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + ar * BK + swz(ar, c) * 8);
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + wr * BK + swz(wr, c) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: lane owns row m, 4 consecutive columns n per (ni, mi) tile ----------------
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 16 + lrow;
+        if (m >= p.M) continue;
+        float rs = 1.0f;
+        if (p.row_scale) rs = p.row_scale[(m / p.rs_outer) * p.rs_inner + (m % p.rs_inner)];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + 4 * lk;
+            if (n >= p.N) continue;
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = acc[ni][mi][r] * p.alpha;
+            if (p.vec_ok && n + 3 < p.N) {
+                if (p.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                    t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
+                }
+                if (p.preact) {
+                    uint2 o; o.x = pack_bf2(t[0], t[1]); o.y = pack_bf2(t[2], t[3]);
+                    *reinterpret_cast<uint2*>(p.preact + m * p.ldp + n) = o;
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] = act_apply(p.act, t[r]);
+                }
+                if (p.dact_src) {
+                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.dact_src + m * p.ldd + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] *= act_grad(p.act_bwd, bf2f(z.v[r]));
+                }
+                if (p.row_scale) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] *= rs;
+                }
+                if (p.res1) {
+                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.res1 + m * p.ldr1 + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
+                }
+                if (p.res2) {
+                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.res2 + m * p.ldr2 + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
+                }
+                if (p.c_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) =
+                        make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    uint2 o; o.x = pack_bf2(t[0], t[1]); o.y = pack_bf2(t[2], t[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
+                }
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = n + r;
+                    if (nn >= p.N) break;
+                    float v = t[r];
+                    if (p.bias) v += p.bias[nn];
+                    if (p.preact) p.preact[m * p.ldp + nn] = f2bf(v);
+                    v = act_apply(p.act, v);
+                    if (p.dact_src) v *= act_grad(p.act_bwd, bf2f(p.dact_src[m * p.ldd + nn]));
+                    v *= rs;
+                    if (p.res1) v += bf2f(p.res1[m * p.ldr1 + nn]);
+                    if (p.res2) v += bf2f(p.res2[m * p.ldr2 + nn]);
+                    if (p.c_f32) reinterpret_cast<float*>(p.C)[m * p.ldc + nn] = v;
+                    else reinterpret_cast<bf16_t*>(p.C)[m * p.ldc + nn] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[N1,N2] += sum_m dY[m,N1] X[m,N2]   (reduction over the huge token dimension, tiny output)
+// MFMA k index = token row, so both operands are needed k-major per lane; tiles are staged row-major in LDS
+// (coalesced 16-byte global loads) and fragments are gathered with 16-bit LDS reads (the op is HBM-bound:
+// ~9 KB of HBM per 8 MFMAs).  Output tile 64 (n1) x 128 (n2), split over M across blocks, fp32 atomics.
+constexpr int T1 = 64, T2 = 128, TK = 64;
+
+struct WgradParams {
+    const bf16_t* dY; int64_t lddy;
+    const bf16_t* X; int64_t ldx;
+    float* dW; int64_t lddw;
+    float* db;
+    int64_t M; int N1, N2;
+    int nt1, nt2, msplit;
+    int64_t rows_per_split;
+    int vec_y, vec_x;
+};
+
+__global__ void __launch_bounds__(256, 2) wgrad_tn_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sY[TK * T1];
+    __shared__ __attribute__((aligned(16))) bf16_t sX[TK * T2];
+    const int tile = blockIdx.x;
+    const int t1 = tile / p.nt2, t2 = tile % p.nt2;
+    const int n1_0 = t1 * T1, n2_0 = t2 * T2;
+    const int64_t mbeg = (int64_t)blockIdx.y * p.rows_per_split;
+    int64_t mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    f32x4_t acc[4][2];
+    f32x4_t accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = (p.db != nullptr) && (t2 == 0) && (wave == 0);
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
+
+    for (int64_t mb = mbeg; mb < mend; mb += TK) {
+        // stage dY[mb..mb+64, n1_0..+64] and X[mb..mb+64, n2_0..+128]
+        for (int id = tid; id < TK * T1 / 8; id += 256) {
+            const int row = id / (T1 / 8), c = id % (T1 / 8);
+            const int64_t gm = mb + row;
+            const int gn = n1_0 + c * 8;
+            u16x8 v;
+            if (gm < mend && p.vec_y && gn + 7 < p.N1) {
+                v = *reinterpret_cast<const u16x8*>(p.dY + gm * p.lddy + gn);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v.v[j] = (gm < mend && gn + j < p.N1) ? p.dY[gm * p.lddy + gn + j] : 0;
+            }
+            *reinterpret_cast<u16x8*>(sY + row * T1 + c * 8) = v;
+        }
+        for (int id = tid; id < TK * T2 / 8; id += 256) {
+            const int row = id / (T2 / 8), c = id % (T2 / 8);
+            const int64_t gm = mb + row;
+            const int gn = n2_0 + c * 8;
+            u16x8 v;
+            if (gm < mend && p.vec_x && gn + 7 < p.N2) {
+                v = *reinterpret_cast<const u16x8*>(p.X + gm * p.ldx + gn);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v.v[j] = (gm < mend && gn + j < p.N2) ? p.X[gm * p.ldx + gn + j] : 0;
+            }
+            *reinterpret_cast<u16x8*>(sX + row * T2 + c * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t pf[4], qf[2];
+            const int kr = 32 * s + 8 * lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[i][j] = (short)sY[(kr + j) * T1 + i * 16 + li];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[q][j] = (short)sX[(kr + j) * T2 + (wave * 2 + q) * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[q], acc[i][q], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = n1 (4*lg + r)][col = n2 (li)]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n1_0 + i * 16 + 4 * lg + r;
+            if (n1 >= p.N1) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n2 = n2_0 + (wave * 2 + q) * 16 + li;
+                if (n2 < p.N2) atomicAdd(p.dW + (int64_t)n1 * p.lddw + n2, acc[i][q][r]);
+            }
+            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[i][r]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
+    STG_CHECK(a != nullptr, -1, "stg_gemm_nt: null args");
+    STG_CHECK(a->A && a->W && a->C, -1, "stg_gemm_nt: null A/W/C");
+    STG_CHECK(a->M >= 0 && a->N > 0 && a->K > 0, -2, "stg_gemm_nt: bad shape M=%lld N=%d K=%d", (long long)a->M, a->N, a->K);
+    STG_CHECK(a->K % 8 == 0, -2, "stg_gemm_nt: K=%d must be a multiple of 8", a->K);
+    STG_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, -2, "stg_gemm_nt: lda/ldw must be multiples of 8");
+    STG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, -2, "stg_gemm_nt: A/W must be 16-byte aligned");
+    STG_CHECK(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
+    STG_CHECK(a->c_dtype == STG_BF16 || a->c_dtype == STG_F32, -3, "stg_gemm_nt: unsupported c_dtype %d", a->c_dtype);
+    STG_CHECK(a->act >= 0 && a->act <= 2 && a->act_bwd >= 0 && a->act_bwd <= 2, -3, "stg_gemm_nt: bad act");
+    if (a->row_scale) STG_CHECK(a->rs_outer > 0 && a->rs_inner > 0, -2, "stg_gemm_nt: bad row_scale params");
+    if (a->M == 0) return 0;
+    GemmParams p;
+    p.A = (const bf16_t*)a->A; p.lda = a->lda;
+    p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
+    p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == STG_F32);
+    p.bias = a->bias; p.alpha = a->alpha; p.act = a->act;
+    p.preact = (bf16_t*)a->preact; p.ldp = a->ldp;
+    p.dact_src = (const bf16_t*)a->dact_src; p.ldd = a->ldd; p.act_bwd = a->act_bwd;
+    p.row_scale = a->row_scale; p.rs_outer = a->rs_outer; p.rs_inner = a->rs_inner;
+    p.res1 = (const bf16_t*)a->res1; p.ldr1 = a->ldr1;
+    p.res2 = (const bf16_t*)a->res2; p.ldr2 = a->ldr2;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    const int64_t nbm = (a->M + BM - 1) / BM;
+    const int64_t nbn = (a->N + BN - 1) / BN;
+    STG_CHECK(nbm * nbn < (1ll << 31), -2, "stg_gemm_nt: grid too large");
+    p.nbm = (int)nbm; p.nbn = (int)nbn;
+    auto al = [](const void* ptr, int64_t ld, int bytes_per, int need) {
+        return ptr == nullptr || ((((uintptr_t)ptr) % need) == 0 && (ld * bytes_per) % need == 0);
+    };
+    p.vec_ok = al(a->C, a->ldc, p.c_f32 ? 4 : 2, p.c_f32 ? 16 : 8) && al(a->bias, 4, 4, 16) &&
+               al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) && al(a->res1, a->ldr1, 2, 8) &&
+               al(a->res2, a->ldr2, 2, 8);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
+                            float* db, int64_t M, int N1, int N2, void* stream) {
+    STG_CHECK(dY && X && dW, -1, "stg_wgrad_tn: null pointer");
+    STG_CHECK(M >= 0 && N1 > 0 && N2 > 0, -2, "stg_wgrad_tn: bad shape");
+    STG_CHECK(lddy >= N1 && ldx >= N2 && lddw >= N2, -2, "stg_wgrad_tn: leading dimension too small");
+    if (M == 0) return 0;
+    WgradParams p;
+    p.dY = (const bf16_t*)dY; p.lddy = lddy; p.X = (const bf16_t*)X; p.ldx = ldx;
+    p.dW = dW; p.lddw = lddw; p.db = db; p.M = M; p.N1 = N1; p.N2 = N2;
+    p.nt1 = (N1 + T1 - 1) / T1; p.nt2 = (N2 + T2 - 1) / T2;
+    const int ntiles = p.nt1 * p.nt2;
+    int64_t kchunks = (M + TK - 1) / TK;
+    int64_t msplit = 2048 / ntiles;
+    if (msplit < 1) msplit = 1;
+    if (msplit > kchunks) msplit = kchunks;
+    if (msplit > 65535) msplit = 65535;
+    int64_t cps = (kchunks + msplit - 1) / msplit;  // 64-row chunks per split
+    msplit = (kchunks + cps - 1) / cps;
+    p.msplit = (int)msplit; p.rows_per_split = cps * TK;
+    p.vec_y = (lddy % 8 == 0) && (((uintptr_t)dY & 15) == 0);
+    p.vec_x = (ldx % 8 == 0) && (((uintptr_t)X & 15) == 0);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(ntiles, (unsigned)msplit), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

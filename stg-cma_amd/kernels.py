@@ -1,0 +1,269 @@
+"""Raw (non-autograd) wrappers: torch tensors in, one libstgcma_hip.so launch each, on torch's current HIP stream.
+
+Every wrapper validates shapes/dtypes/devices on the host before the launch -- a kernel must never see an operand whose
+extent differs from what its grid assumes.  PyTorch supplies device memory and the stream only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, STG_BF16, STG_F32  # noqa: F401
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t, name, dtype, cols=None, rows=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"{name}: expected a 2-D row-major tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    if cols is not None and t.shape[1] != cols:
+        raise RuntimeError(f"{name}: expected {cols} columns, got {t.shape[1]}")
+    if rows is not None and t.shape[0] != rows:
+        raise RuntimeError(f"{name}: expected {rows} rows, got {t.shape[0]}")
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        raise RuntimeError(f"{name}: overlapping rows")
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def _chk1d(t, name, dtype, n):
+    if not t.is_cuda or t.dtype != dtype or t.dim() != 1 or t.shape[0] != n or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected contiguous {dtype} GPU vector of length {n}")
+
+
+def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_preact=False, dact_src=None,
+            act_bwd=ACT_NONE, row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None):
+    """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, preact)."""
+    M, K = A.shape
+    N = W.shape[0]
+    _chk2d(A, "A", BF16)
+    _chk2d(W, "W", BF16, cols=K)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    _chk2d(out, "out", out.dtype, cols=N, rows=M)
+    if out.dtype not in (BF16, F32):
+        raise RuntimeError("out dtype must be bf16 or fp32")
+    a = _lib.GemmArgs()
+    a.A, a.lda = _p(A), _ld(A)
+    a.W, a.ldw = _p(W), _ld(W)
+    a.C, a.ldc, a.c_dtype = _p(out), _ld(out), (STG_BF16 if out.dtype == BF16 else STG_F32)
+    if bias is not None:
+        _chk1d(bias, "bias", F32, N)
+    a.bias = _p(bias)
+    a.alpha = float(alpha)
+    a.act = int(act)
+    pre = None
+    if want_preact:
+        pre = torch.empty((M, N), dtype=BF16, device=A.device)
+        a.preact, a.ldp = _p(pre), _ld(pre)
+    if dact_src is not None:
+        _chk2d(dact_src, "dact_src", BF16, cols=N, rows=M)
+        a.dact_src, a.ldd, a.act_bwd = _p(dact_src), _ld(dact_src), int(act_bwd)
+    if row_scale is not None:
+        if not row_scale.is_cuda or row_scale.dtype != F32 or not row_scale.is_contiguous():
+            raise RuntimeError("row_scale: expected contiguous fp32 GPU tensor")
+        need = ((M - 1) // rs_outer) * rs_inner + rs_inner if M > 0 else 0
+        if row_scale.numel() < need:
+            raise RuntimeError(f"row_scale: needs >= {need} entries, got {row_scale.numel()}")
+        a.row_scale, a.rs_outer, a.rs_inner = _p(row_scale), int(rs_outer), int(rs_inner)
+    if res1 is not None:
+        _chk2d(res1, "res1", BF16, cols=N, rows=M)
+        a.res1, a.ldr1 = _p(res1), _ld(res1)
+    if res2 is not None:
+        _chk2d(res2, "res2", BF16, cols=N, rows=M)
+        a.res2, a.ldr2 = _p(res2), _ld(res2)
+    a.M, a.N, a.K = M, N, K
+    _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+    return (out, pre) if want_preact else out
+
+
+def wgrad_tn(dY, X, dW, db=None):
+    """dW[N1,N2] += dY.T @ X ; db[N1] += dY.sum(0)   (fp32 accumulate into existing buffers)."""
+    M, N1 = dY.shape
+    N2 = X.shape[1]
+    _chk2d(dY, "dY", BF16)
+    _chk2d(X, "X", BF16, rows=M)
+    _chk2d(dW, "dW", F32, cols=N2, rows=N1)
+    if db is not None:
+        _chk1d(db, "db", F32, N1)
+    _lib.check(_lib.lib().stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2, _stream()),
+               "stg_wgrad_tn")
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True):
+    """x: [rows, C] bf16/fp32 -> y bf16 (+ mean, rstd).  gather4=(H, W): PatchMerging gather, x is [F*H*W, C] -> y [F*H*W/4, 4C]."""
+    if x.dtype not in (BF16, F32):
+        raise RuntimeError("layernorm: x must be bf16 or fp32")
+    _chk2d(x, "x", x.dtype)
+    R, Cs = x.shape
+    if gather4 is not None:
+        H, W = gather4
+        if R % (H * W) != 0:
+            raise RuntimeError("layernorm gather4: rows not a multiple of H*W")
+        rows, Cl = R // 4, 4 * Cs
+        g4 = 1
+    else:
+        H = W = 0
+        rows, Cl = R, Cs
+        g4 = 0
+    _chk1d(gamma, "gamma", F32, Cl)
+    _chk1d(beta, "beta", F32, Cl)
+    y = torch.empty((rows, Cl), dtype=BF16, device=x.device)
+    mean = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
+    rstd = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
+    _lib.check(_lib.lib().stg_layernorm_fwd(_p(x), STG_BF16 if x.dtype == BF16 else STG_F32, _ld(x), _p(gamma), _p(beta),
+                                            float(eps), _p(y), _ld(y), _p(mean), _p(rstd), rows, Cl, g4, H, W, _stream()),
+               "stg_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_to=None, gather4=None, dgamma=None, dbeta=None):
+    """Returns dx (bf16, shaped like x).  add_to (shaped like x) is added to the result."""
+    _chk2d(x, "x", x.dtype)
+    R, Cs = x.shape
+    if gather4 is not None:
+        H, W = gather4
+        rows, Cl, g4 = R // 4, 4 * Cs, 1
+    else:
+        H = W = 0
+        rows, Cl, g4 = R, Cs, 0
+    _chk2d(dy, "dy", BF16, cols=Cl, rows=rows)
+    _chk1d(gamma, "gamma", F32, Cl)
+    _chk1d(mean, "mean", F32, rows)
+    _chk1d(rstd, "rstd", F32, rows)
+    if add_to is not None:
+        _chk2d(add_to, "add_to", BF16, cols=Cs, rows=R)
+    if dgamma is not None:
+        _chk1d(dgamma, "dgamma", F32, Cl)
+        _chk1d(dbeta, "dbeta", F32, Cl)
+    dx = torch.empty((R, Cs), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_layernorm_bwd(_p(dy), _ld(dy), _p(x), STG_BF16 if x.dtype == BF16 else STG_F32, _ld(x),
+                                            _p(gamma), _p(mean), _p(rstd), _p(add_to), _ld(add_to) if add_to is not None else 0,
+                                            _p(dx), _ld(dx), _p(dgamma), _p(dbeta), rows, Cl, g4, H, W, _stream()),
+               "stg_layernorm_bwd")
+    return dx
+
+
+def _chk_flat(t, name, dtype=BF16):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected contiguous {dtype} GPU tensor")
+
+
+def gate_fwd(h, r, gate):
+    _chk_flat(h, "h"); _chk_flat(r, "r"); _chk_flat(gate, "gate", F32)
+    if h.shape != r.shape or gate.numel() != 1:
+        raise RuntimeError("gate_fwd: shape mismatch")
+    out = torch.empty_like(h)
+    _lib.check(_lib.lib().stg_gate_fwd(_p(h), _p(r), _p(gate), _p(out), h.numel(), _stream()), "stg_gate_fwd")
+    return out
+
+
+def gate_bwd(dout, r, gate, dgate):
+    _chk_flat(dout, "dout"); _chk_flat(r, "r"); _chk_flat(gate, "gate", F32); _chk_flat(dgate, "dgate", F32)
+    if dout.shape != r.shape or gate.numel() != 1 or dgate.numel() != 1:
+        raise RuntimeError("gate_bwd: shape mismatch")
+    dr = torch.empty_like(dout)
+    _lib.check(_lib.lib().stg_gate_bwd(_p(dout), _p(r), _p(gate), _p(dr), _p(dgate), dout.numel(), _stream()), "stg_gate_bwd")
+    return dr
+
+
+def add(a, b):
+    _chk_flat(a, "a"); _chk_flat(b, "b")
+    if a.shape != b.shape:
+        raise RuntimeError("add: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().stg_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "stg_add")
+    return out
+
+
+def mul_mask(a, mask):
+    _chk_flat(a, "a"); _chk_flat(mask, "mask", F32)
+    if a.numel() != mask.numel():
+        raise RuntimeError("mul_mask: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().stg_mul_mask(_p(a), _p(mask), _p(out), a.numel(), _stream()), "stg_mul_mask")
+    return out
+
+
+def im2col_patch(x, p, Kpad):
+    """x: [B, Cin, T, H, W] fp32/bf16 contiguous -> [B*T*(H/p)*(W/p), Kpad] bf16."""
+    if x.dim() != 5 or not x.is_contiguous() or not x.is_cuda or x.dtype not in (BF16, F32):
+        raise RuntimeError("im2col_patch: expected contiguous 5-D fp32/bf16 GPU tensor")
+    B, Cin, T, H, W = x.shape
+    out = torch.empty((B * T * (H // p) * (W // p), Kpad), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_im2col_patch(_p(x), STG_BF16 if x.dtype == BF16 else STG_F32, _p(out), B, Cin, T, H, W, p, Kpad,
+                                           _stream()), "stg_im2col_patch")
+    return out
+
+
+def cast_bf16(w, transpose=False):
+    """fp32 [R, C] -> bf16 [R, C] or [C, R]."""
+    _chk_flat(w, "w", F32)
+    w2 = w.reshape(w.shape[0], -1) if w.dim() > 1 else w.reshape(1, -1)
+    R, Cc = w2.shape
+    out = torch.empty((Cc, R) if transpose else (R, Cc), dtype=BF16, device=w.device)
+    _lib.check(_lib.lib().stg_cast_bf16(_p(w2), _p(out), R, Cc, 1 if transpose else 0, _stream()), "stg_cast_bf16")
+    return out
+
+
+def cast_f32(x):
+    _chk_flat(x, "x")
+    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    _lib.check(_lib.lib().stg_cast_f32(_p(x), _p(out), x.numel(), _stream()), "stg_cast_f32")
+    return out
+
+
+def meanpool_fwd(x, G, n, out=None, out_dtype=BF16):
+    """x: [G*n, C] bf16 contiguous -> [G, C]; `out` may be a column slice of a wider row-major buffer."""
+    _chk_flat(x, "x")
+    Cc = x.shape[-1]
+    if x.numel() != G * n * Cc:
+        raise RuntimeError("meanpool_fwd: shape mismatch")
+    if out is None:
+        out = torch.empty((G, Cc), dtype=out_dtype, device=x.device)
+    _chk2d(out, "out", out.dtype, cols=Cc, rows=G)
+    _lib.check(_lib.lib().stg_meanpool_fwd(_p(x), _p(out), STG_BF16 if out.dtype == BF16 else STG_F32, _ld(out), G, n, Cc,
+                                           _stream()), "stg_meanpool_fwd")
+    return out
+
+
+def meanpool_bwd(dout, G, n):
+    _chk2d(dout, "dout", BF16, rows=G)
+    Cc = dout.shape[1]
+    din = torch.empty((G * n, Cc), dtype=BF16, device=dout.device)
+    _lib.check(_lib.lib().stg_meanpool_bwd(_p(dout), _ld(dout), _p(din), G, n, Cc, _stream()), "stg_meanpool_bwd")
+    return din
+
+
+def bias_gather(table, index):
+    """table fp32 [L, H], index int64 [nn] -> fp32 [H, nn]."""
+    _chk_flat(table, "table", F32); _chk_flat(index, "index", torch.int64)
+    L, H = table.shape
+    nn = index.numel()
+    out = torch.empty((H, nn), dtype=F32, device=table.device)
+    _lib.check(_lib.lib().stg_bias_gather(_p(table), _p(index), _p(out), L, H, nn, _stream()), "stg_bias_gather")
+    return out
+
+
+def bias_scatter(dbias, index, dtable):
+    _chk_flat(dbias, "dbias", F32); _chk_flat(index, "index", torch.int64); _chk_flat(dtable, "dtable", F32)
+    L, H = dtable.shape
+    nn = index.numel()
+    if dbias.numel() != H * nn:
+        raise RuntimeError("bias_scatter: shape mismatch")
+    _lib.check(_lib.lib().stg_bias_scatter(_p(dbias), _p(index), _p(dtable), L, H, nn, _stream()), "stg_bias_scatter")

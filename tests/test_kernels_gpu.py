@@ -1,0 +1,228 @@
+"""-m gpu: each HIP kernel, called through the C ABI, against a plain fp32 PyTorch-CPU statement of the same op.
+
+Tolerances: bf16 storage carries 8 significand bits, so an output of magnitude s is expected within ~s*2^-8 of the fp32
+result; tests use |err| <= 1e-2 * max(1, |ref|) (the north-star's bf16 tolerance) unless a tighter bound is natural.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _bf(x):
+    return x.to(BF16)
+
+
+def _close(got, ref, tol=1e-2, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    bound = tol * torch.clamp(ref.abs(), min=1.0)
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} elements off; first at {idx}: got "
+                             f"{got[tuple(idx)].item()} ref {ref[tuple(idx)].item()}; max err {err.max().item():.4g}")
+
+
+def _gelu_grad(z):
+    return 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (130, 72, 16), (1000, 384, 128), (257, 29, 512), (4096, 512, 2048),
+                                   (300, 16, 48), (64, 2048, 512), (1, 128, 128)])
+def test_gemm_plain(stg, gpu, M, N, K):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.1)
+    b = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + b
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu))
+    _close(out, ref, what=f"gemm {M}x{N}x{K}")
+    out32 = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), out_dtype=F32)
+    _close(out32, ref, tol=2e-3, what=f"gemm f32 out {M}x{N}x{K}")
+
+
+def test_gemm_identity_asymmetric(stg, gpu):
+    """A = I with an asymmetric W catches a transposed accumulator mapping."""
+    from stgcma import kernels as k
+    n = 128
+    A = torch.eye(n).to(BF16)
+    W = (torch.arange(n * n, dtype=F32).reshape(n, n) % 251 - 125.0).to(BF16)
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), out_dtype=F32)
+    assert torch.equal(out.cpu(), W.float().t())
+
+
+def test_gemm_epilogues(stg, gpu):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 390, 256, 128
+    A = _bf(torch.randn(M, K, generator=g)); W = _bf(torch.randn(N, K, generator=g) * 0.1)
+    b = torch.randn(N, generator=g)
+    r1 = _bf(torch.randn(M, N, generator=g)); r2 = _bf(torch.randn(M, N, generator=g))
+    z = A.float() @ W.float().t() + b
+    # GELU + preact
+    out, pre = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_GELU, want_preact=True)
+    _close(pre, z, what="preact")
+    _close(out, torch.nn.functional.gelu(z), what="gelu")
+    # QuickGELU
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_QUICKGELU)
+    _close(out, z * torch.sigmoid(1.702 * z), what="quickgelu")
+    # residuals + alpha
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), alpha=0.5, res1=r1.to(gpu), res2=r2.to(gpu))
+    _close(out, 0.5 * (A.float() @ W.float().t()) + b + r1.float() + r2.float(), what="residuals")
+    # activation backward: t * gelu'(src)
+    src = _bf(torch.randn(M, N, generator=g))
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), None, dact_src=src.to(gpu), act_bwd=k.ACT_GELU)
+    _close(out, (A.float() @ W.float().t()) * _gelu_grad(src.float()), what="dgelu")
+    s = src.float(); sg = torch.sigmoid(1.702 * s)
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), None, dact_src=src.to(gpu), act_bwd=k.ACT_QUICKGELU)
+    _close(out, (A.float() @ W.float().t()) * (sg * (1 + 1.702 * s * (1 - sg))), what="dquickgelu")
+    # DropPath row scale: rows are (b t) n ; mask per (b, n): idx = (m // (T*n)) * n + m % n
+    T, n = 3, 13
+    Bc = M // (T * n)
+    scale = torch.rand(Bc * n, generator=g)
+    Mm = Bc * T * n
+    out = k.gemm_nt(A[:Mm].to(gpu), W.to(gpu), b.to(gpu), row_scale=scale.to(gpu), rs_outer=T * n, rs_inner=n,
+                    res1=r1[:Mm].to(gpu))
+    m = torch.arange(Mm)
+    idx = (m // (T * n)) * n + m % n
+    _close(out, z[:Mm] * scale[idx][:, None] + r1[:Mm].float(), what="row_scale")
+
+
+def test_gemm_strided_views(stg, gpu):
+    """Operands / outputs that are column slices of wider buffers (how the fused a/v tensors are addressed)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 200, 64, 128
+    Abig = _bf(torch.randn(M, 3 * K, generator=g)).to(gpu)
+    W = _bf(torch.randn(N, K, generator=g) * 0.1).to(gpu)
+    Cbig = torch.zeros(M, 4 * N, dtype=BF16, device=gpu)
+    k.gemm_nt(Abig[:, K:2 * K], W, out=Cbig[:, N:2 * N])
+    ref = Abig[:, K:2 * K].float().cpu() @ W.float().cpu().t()
+    _close(Cbig[:, N:2 * N], ref, what="strided")
+    assert float(Cbig[:, :N].abs().max()) == 0 and float(Cbig[:, 2 * N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 16, 128), (1000, 32, 256), (333, 128, 16), (320, 29, 512), (5000, 64, 1024),
+                                     (100, 512, 2048)])
+def test_wgrad(stg, gpu, M, N1, N2):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    dY = _bf(torch.randn(M, N1, generator=g)); X = _bf(torch.randn(M, N2, generator=g))
+    dW = torch.zeros(N1, N2, device=gpu); db = torch.zeros(N1, device=gpu)
+    k.wgrad_tn(dY.to(gpu), X.to(gpu), dW, db)
+    ref = dY.float().t() @ X.float()
+    scale = math.sqrt(M)
+    _close(dW / scale, ref / scale, tol=2e-3, what="dW")
+    _close(db / scale, dY.float().sum(0) / scale, tol=2e-3, what="db")
+    # accumulates
+    k.wgrad_tn(dY.to(gpu), X.to(gpu), dW, None)
+    _close(dW / scale, 2 * ref / scale, tol=2e-3, what="dW accumulate")
+
+
+@pytest.mark.parametrize("rows,C", [(7, 128), (1000, 256), (513, 512), (100, 1024), (50, 2048), (33, 768), (20, 3072),
+                                    (9, 4096), (64, 48)])
+@pytest.mark.parametrize("xdt", [BF16, F32])
+def test_layernorm(stg, gpu, rows, C, xdt):
+    from stgcma import kernels as k
+    if C % 8:
+        pytest.skip("C % 8")
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(xdt)
+    gamma = torch.randn(C, generator=g) * 0.2 + 1; beta = torch.randn(C, generator=g) * 0.1
+    xr = x.float().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    y, mean, rstd = k.layernorm_fwd(x.to(gpu), gamma.to(gpu), beta.to(gpu))
+    _close(y, y_ref, what="ln fwd")
+    _close(mean, x.float().mean(1), tol=1e-4, what="mean")
+    dy = _bf(torch.randn(rows, C, generator=g))
+    add = _bf(torch.randn(rows, C, generator=g))
+    y_ref.backward(dy.float())
+    dgam = torch.zeros(C, device=gpu); dbet = torch.zeros(C, device=gpu)
+    dx = k.layernorm_bwd(dy.to(gpu), x.to(gpu), gamma.to(gpu), mean, rstd, add_to=add.to(gpu), dgamma=dgam, dbeta=dbet)
+    _close(dx, xr.grad + add.float(), tol=2e-2, what="ln bwd")
+    xh = (x.float() - x.float().mean(1, keepdim=True)) * torch.rsqrt(x.float().var(1, unbiased=False, keepdim=True) + 1e-5)
+    _close(dgam / math.sqrt(rows), (dy.float() * xh).sum(0) / math.sqrt(rows), tol=1e-2, what="dgamma")
+    _close(dbet / math.sqrt(rows), dy.float().sum(0) / math.sqrt(rows), tol=1e-2, what="dbeta")
+
+
+def test_layernorm_patch_merge(stg, gpu):
+    """gather4 == PatchMerging's x0..x3 strided gather + cat + LayerNorm(4C) (reference Swin_AVE.py:967-976)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(3)
+    F_, H, W, C = 3, 6, 8, 32
+    x = _bf(torch.randn(F_ * H * W, C, generator=g))
+    gamma = torch.randn(4 * C, generator=g) * 0.2 + 1; beta = torch.randn(4 * C, generator=g) * 0.1
+    xr = x.float().requires_grad_(True)
+    xv = xr.view(F_, H, W, C)
+    cat = torch.cat([xv[:, 0::2, 0::2], xv[:, 1::2, 0::2], xv[:, 0::2, 1::2], xv[:, 1::2, 1::2]], -1).reshape(-1, 4 * C)
+    y_ref = torch.nn.functional.layer_norm(cat, (4 * C,), gamma, beta, 1e-5)
+    y, mean, rstd = k.layernorm_fwd(x.to(gpu), gamma.to(gpu), beta.to(gpu), gather4=(H, W))
+    _close(y, y_ref, what="merge ln fwd")
+    dy = _bf(torch.randn(F_ * H * W // 4, 4 * C, generator=g))
+    y_ref.backward(dy.float())
+    dx = k.layernorm_bwd(dy.to(gpu), x.to(gpu), gamma.to(gpu), mean, rstd, gather4=(H, W))
+    _close(dx, xr.grad, tol=2e-2, what="merge ln bwd")
+
+
+def test_elementwise(stg, gpu):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(11)
+    for numel_shape in [(1000, 16), (77, 24), (3, 5)]:
+        h = _bf(torch.randn(*numel_shape, generator=g)); r = _bf(torch.randn(*numel_shape, generator=g))
+        gate = torch.tensor([0.37])
+        out = k.gate_fwd(h.to(gpu), r.to(gpu), gate.to(gpu))
+        _close(out, h.float() + 0.37 * r.float(), what="gate fwd")
+        dgate = torch.zeros(1, device=gpu)
+        dr = k.gate_bwd(h.to(gpu), r.to(gpu), gate.to(gpu), dgate)
+        _close(dr, 0.37 * h.float(), what="gate bwd dr")
+        ref = (h.float() * r.float()).sum()
+        assert abs(float(dgate) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref))) + 1e-2
+        _close(k.add(h.to(gpu), r.to(gpu)), h.float() + r.float(), what="add")
+        mask = (torch.rand(*numel_shape, generator=g) > 0.5).float() * 2
+        _close(k.mul_mask(h.to(gpu), mask.to(gpu)), h.float() * mask, what="mul_mask")
+    w = torch.randn(48, 100, generator=g)
+    _close(k.cast_bf16(w.to(gpu)), w, what="cast")
+    _close(k.cast_bf16(w.to(gpu), transpose=True), w.t(), what="cast T")
+    _close(k.cast_f32(_bf(w).to(gpu)), _bf(w).float(), tol=0, what="cast f32")
+    # meanpool
+    G, n, C = 6, 49, 64
+    x = _bf(torch.randn(G * n, C, generator=g))
+    big = torch.zeros(G, 2 * C, dtype=F32, device=gpu)
+    k.meanpool_fwd(x.to(gpu), G, n, out=big[:, C:])
+    _close(big[:, C:], x.float().view(G, n, C).mean(1), tol=1e-3, what="meanpool")
+    d = _bf(torch.randn(G, C, generator=g))
+    _close(k.meanpool_bwd(d.to(gpu), G, n), (d.float() / n)[:, None, :].expand(G, n, C).reshape(G * n, C), what="meanpool bwd")
+    # bias gather / scatter
+    L, H, nn_ = 13, 4, 49
+    table = torch.randn(L, H, generator=g); index = torch.randint(0, L, (nn_,), generator=g)
+    out = k.bias_gather(table.to(gpu), index.to(gpu))
+    assert torch.equal(out.cpu(), table[index].t().contiguous())
+    dtab = torch.zeros(L, H, device=gpu)
+    k.bias_scatter(out, index.to(gpu), dtab)
+    ref = torch.zeros(L, H).index_add_(0, index, table[index])
+    _close(dtab, ref, tol=1e-5, what="bias scatter")
+
+
+def test_im2col_patch_embed(stg, gpu):
+    """Conv3d(k=s=(1,4,4)) == im2col gather + GEMM (reference Swin_AVE.py:1097,1115)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(2)
+    for Cin, Kpad in [(3, 48), (1, 16)]:
+        B, T, H, W, p, E = 2, 3, 16, 24, 4, 32
+        x = torch.randn(B, Cin, T, H, W, generator=g)
+        w = torch.randn(E, Cin, 1, p, p, generator=g) * 0.2; b = torch.randn(E, generator=g)
+        ref = torch.nn.functional.conv3d(_bf(x).float(), _bf(w).float(), b, stride=(1, p, p))
+        ref = ref.permute(0, 2, 3, 4, 1).reshape(-1, E)  # (b t h w) c
+        cols = k.im2col_patch(x.to(gpu), p, Kpad)
+        wb = _bf(w.reshape(E, -1)).to(gpu)
+        out = k.gemm_nt(cols, wb, b.to(gpu))
+        _close(out, ref, what=f"patch embed Cin={Cin}")
