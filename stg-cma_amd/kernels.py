@@ -267,3 +267,106 @@ def bias_scatter(dbias, index, dtable):
     if dbias.numel() != H * nn:
         raise RuntimeError("bias_scatter: shape mismatch")
     _lib.check(_lib.lib().stg_bias_scatter(_p(dbias), _p(index), _p(dtable), L, H, nn, _stream()), "stg_bias_scatter")
+
+
+class AttnGeom:
+    """Addressing of one attention call: row(p, i) = (p // G) * outer + map[(p % G) * n + i] (map None = identity)."""
+
+    def __init__(self, P, H, n, D, G=1, outer=None, map_q=None, n_kv=None, outer_kv=None, map_kv=None, scale=1.0,
+                 bias=None, bias_div=1, bias_mod=1, mask=None):
+        self.P, self.H, self.n, self.D, self.G = int(P), int(H), int(n), int(D), int(G)
+        self.n_kv = int(n if n_kv is None else n_kv)
+        self.outer = int(G * n if outer is None else outer)
+        self.outer_kv = int((self.outer if n_kv is None else G * self.n_kv) if outer_kv is None else outer_kv)
+        self.map_q = map_q
+        self.map_kv = map_q if (map_kv is None and n_kv is None) else map_kv
+        self.scale = float(scale)
+        self.bias, self.bias_div, self.bias_mod, self.mask = bias, int(bias_div), int(bias_mod), mask
+
+
+def _attn_check_rows(t, name, g, n_tok, outer, amap, dev):
+    _chk2d(t, name, BF16)
+    if t.shape[1] < g.H * g.D:
+        raise RuntimeError(f"{name}: needs >= H*D = {g.H * g.D} columns, got {t.shape[1]}")
+    if g.P % g.G != 0:
+        raise RuntimeError(f"{name}: P={g.P} must be a multiple of G={g.G}")
+    need_rows = (g.P // g.G) * outer
+    if amap is not None:
+        if amap.dtype != torch.int32 or not amap.is_cuda or not amap.is_contiguous() or amap.numel() != g.G * n_tok:
+            raise RuntimeError(f"{name}: map must be a contiguous int32 GPU tensor of {g.G * n_tok} entries")
+    elif outer < g.G * n_tok:
+        raise RuntimeError(f"{name}: outer too small")
+    if t.shape[0] < need_rows:
+        raise RuntimeError(f"{name}: needs >= {need_rows} rows, got {t.shape[0]}")
+
+
+def _attn_fill(a, g, Q, K, V, O, lse):
+    a.Q, a.ldq = _p(Q), _ld(Q)
+    a.K, a.ldk = _p(K), _ld(K)
+    a.V, a.ldv = _p(V), _ld(V)
+    a.O, a.ldo = _p(O), _ld(O)
+    a.lse = _p(lse)
+    a.map_q, a.map_kv = _p(g.map_q), _p(g.map_kv)
+    a.outer_q, a.outer_kv, a.G = g.outer, g.outer_kv, g.G
+    a.P, a.H, a.n, a.n_kv, a.D = g.P, g.H, g.n, g.n_kv, g.D
+    a.scale = g.scale
+    if g.bias is not None:
+        if g.bias.dtype != F32 or not g.bias.is_contiguous() or g.bias.numel() != g.bias_mod * g.H * g.n * g.n_kv:
+            raise RuntimeError("attention: bias must be contiguous fp32 [bias_mod, H, n, n_kv]")
+        a.bias, a.bias_div, a.bias_mod = _p(g.bias), g.bias_div, g.bias_mod
+    if g.mask is not None:
+        if g.mask.dtype != F32 or not g.mask.is_contiguous() or g.mask.numel() != g.G * g.n * g.n_kv:
+            raise RuntimeError("attention: mask must be contiguous fp32 [G, n, n_kv]")
+        a.mask = _p(g.mask)
+
+
+def attn_fwd(g, Q, K, V, out=None, want_lse=True):
+    """Q/K/V: 2-D bf16 (possibly column-slice views of a fused qkv buffer).  Returns (O, lse)."""
+    dev = Q.device
+    _attn_check_rows(Q, "Q", g, g.n, g.outer, g.map_q, dev)
+    _attn_check_rows(K, "K", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+    _attn_check_rows(V, "V", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+    if out is None:
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=dev)
+    _attn_check_rows(out, "O", g, g.n, g.outer, g.map_q, dev)
+    lse = torch.empty((g.P, g.H, g.n), dtype=F32, device=dev) if want_lse else None
+    a = _lib.AttnArgs()
+    _attn_fill(a, g, Q, K, V, out, lse)
+    _lib.check(_lib.lib().stg_attn_fwd(C.byref(a), _stream()), "stg_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(g, Q, K, V, O, lse, dO, *, dQ=None, dK=None, dV=None, shared_kv=False, dbias=None):
+    """Returns (dQ, dK, dV).  shared_kv: K and V are the same tensor -> dV is None and dK holds dK + dV."""
+    dev = Q.device
+    for t, name, nt, outer, mp in ((Q, "Q", g.n, g.outer, g.map_q), (K, "K", g.n_kv, g.outer_kv, g.map_kv),
+                                   (V, "V", g.n_kv, g.outer_kv, g.map_kv), (O, "O", g.n, g.outer, g.map_q),
+                                   (dO, "dO", g.n, g.outer, g.map_q)):
+        _attn_check_rows(t, name, g, nt, outer, mp, dev)
+    if lse.dtype != F32 or lse.numel() != g.P * g.H * g.n:
+        raise RuntimeError("attn_bwd: bad lse")
+    if dQ is None:
+        dQ = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=dev)
+    if dK is None:
+        dK = torch.empty((K.shape[0], g.H * g.D), dtype=BF16, device=dev)
+    if dV is None and not shared_kv:
+        dV = torch.empty((V.shape[0], g.H * g.D), dtype=BF16, device=dev)
+    _attn_check_rows(dQ, "dQ", g, g.n, g.outer, g.map_q, dev)
+    _attn_check_rows(dK, "dK", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+    if dV is not None:
+        _attn_check_rows(dV, "dV", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+    delta = torch.empty((g.P, g.H, g.n), dtype=F32, device=dev)
+    b = _lib.AttnBwdArgs()
+    _attn_fill(b.f, g, Q, K, V, O, lse)
+    b.dO, b.lddo = _p(dO), _ld(dO)
+    b.dQ, b.lddq = _p(dQ), _ld(dQ)
+    b.dK, b.lddk = _p(dK), _ld(dK)
+    if dV is not None:
+        b.dV, b.lddv = _p(dV), _ld(dV)
+    b.delta = _p(delta)
+    if dbias is not None:
+        if dbias.dtype != F32 or not dbias.is_contiguous() or g.bias is None or dbias.numel() != g.bias.numel():
+            raise RuntimeError("attn_bwd: dbias must match bias")
+        b.dbias = _p(dbias)
+    _lib.check(_lib.lib().stg_attn_bwd(C.byref(b), _stream()), "stg_attn_bwd")
+    return dQ, dK, dV

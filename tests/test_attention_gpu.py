@@ -1,0 +1,187 @@
+"""-m gpu: the gather-mapped flash attention kernels (fwd, dQ, dK/dV, dbias) against an fp32 PyTorch-CPU statement
+of softmax(scale*QK^T + bias + mask)V, for every addressing mode the model uses."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _close(got, ref, tol=1e-2, what=""):
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    err = (got - ref).abs(); bound = tol * torch.clamp(ref.abs(), min=1.0)
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} off; first {idx}: got {got[tuple(idx)].item()} "
+                             f"ref {ref[tuple(idx)].item()}; max err {err.max().item():.4g}")
+
+
+def _rows(P, G, n, outer, amap):
+    p = torch.arange(P)
+    base = (p // G) * outer
+    g = p % G
+    i = torch.arange(n)
+    idx = g[:, None] * n + i[None, :]
+    off = amap.long()[idx] if amap is not None else idx
+    return base[:, None] + off  # [P, n]
+
+
+def _ref(Q, K, V, rq, rk, H, D, scale, bias, bias_div, bias_mod, mask, G):
+    """fp32 reference with autograd.  Q,K,V: [rows, H*D] fp32 leaf tensors."""
+    P = rq.shape[0]
+    q = Q[rq].view(P, -1, H, D).permute(0, 2, 1, 3)
+    k = K[rk].view(P, -1, H, D).permute(0, 2, 1, 3)
+    v = V[rk].view(P, -1, H, D).permute(0, 2, 1, 3)
+    s = scale * (q @ k.transpose(-1, -2))
+    if bias is not None:
+        bg = (torch.arange(P) // bias_div) % bias_mod
+        s = s + bias[bg]
+    if mask is not None:
+        s = s + mask[torch.arange(P) % G][:, None]
+    pr = torch.softmax(s, -1)
+    o = (pr @ v).permute(0, 2, 1, 3).reshape(P, -1, H * D)
+    lse = torch.logsumexp(s, -1)
+    return o, lse
+
+
+def _run_case(gpu, *, P, H, n, D, G=1, n_kv=None, mapped=False, scale=1.0, with_bias=False, bias_mod=1, with_mask=False,
+              shared_kv=False, want_dbias=False, seed=0, mag=1.0):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(seed)
+    nk = n if n_kv is None else n_kv
+    assert P % G == 0
+    outer_q = G * n + (3 if mapped else 0)
+    outer_k = G * nk + (3 if mapped else 0)
+    if n_kv is None:
+        outer_k = outer_q
+    map_q = map_k = None
+    if mapped:
+        map_q = torch.randperm(outer_q, generator=g)[:G * n].to(torch.int32)
+        map_k = map_q if n_kv is None else torch.randperm(outer_k, generator=g)[:G * nk].to(torch.int32)
+    rows_q = (P // G) * outer_q
+    rows_k = (P // G) * outer_k
+    C = H * D
+    # fused qkv buffer with column slices, like the model
+    if shared_kv:
+        Qb = (torch.randn(rows_q, C, generator=g) * mag).to(BF16)
+        KVb = (torch.randn(rows_k, C, generator=g) * mag).to(BF16)
+        Q, K, V = Qb, KVb, KVb
+    elif n_kv is None:
+        qkv = (torch.randn(rows_q, 3 * C, generator=g) * mag).to(BF16)
+        Q, K, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        Q = (torch.randn(rows_q, C, generator=g) * mag).to(BF16)
+        K = (torch.randn(rows_k, C, generator=g) * mag).to(BF16)
+        V = (torch.randn(rows_k, C, generator=g) * mag).to(BF16)
+    bias = (torch.randn(bias_mod, H, n, nk, generator=g)) if with_bias else None
+    bias_div = max(1, P // bias_mod)
+    mask = None
+    if with_mask:
+        mask = torch.where(torch.rand(G, n, nk, generator=g) < 0.3, torch.tensor(-100.0), torch.tensor(0.0))
+        mask[:, :, 0] = 0.0
+    rq = _rows(P, G, n, outer_q, map_q)
+    rk = _rows(P, G, nk, outer_k, map_k)
+
+    Qr = Q.float().clone().requires_grad_(True)
+    Kr = K.float().clone().requires_grad_(True)
+    Vr = Kr if shared_kv else V.float().clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True) if bias is not None else None
+    o_ref, lse_ref = _ref(Qr, Kr, Vr, rq, rk, H, D, scale, br, bias_div, bias_mod, mask, G)
+
+    geom = k.AttnGeom(P, H, n, D, G=G, outer=outer_q, map_q=None if map_q is None else map_q.to(gpu),
+                      n_kv=n_kv, outer_kv=outer_k if n_kv is not None else None,
+                      map_kv=None if (map_k is None or n_kv is None) else map_k.to(gpu), scale=scale,
+                      bias=None if bias is None else bias.to(gpu), bias_div=bias_div, bias_mod=bias_mod,
+                      mask=None if mask is None else mask.to(gpu))
+    Qg, Kg = Q.to(gpu), K.to(gpu)
+    if shared_kv:
+        Vg = Kg
+    elif n_kv is None:
+        qg = qkv.to(gpu)
+        Qg, Kg, Vg = qg[:, :C], qg[:, C:2 * C], qg[:, 2 * C:]
+    else:
+        Vg = V.to(gpu)
+    O = torch.zeros(rows_q, C, dtype=BF16, device=gpu)
+    O, lse = k.attn_fwd(geom, Qg, Kg, Vg, out=O)
+    tag = f"P{P} H{H} n{n} nk{nk} D{D} G{G} mapped{mapped}"
+    _close(O[rq.to(gpu)], o_ref, what=f"O {tag}")
+    _close(lse, lse_ref, tol=2e-2, what=f"lse {tag}")
+
+    dO_full = torch.zeros(rows_q, C)
+    dO_full[rq.reshape(-1)] = torch.randn(P * n, C, generator=g)
+    dO = dO_full.to(BF16)
+    o_ref.backward(dO.float()[rq])
+    dbias = torch.zeros_like(bias).to(gpu) if want_dbias else None
+    dQ = torch.zeros(rows_q, C, dtype=BF16, device=gpu)
+    dK = torch.zeros(rows_k, C, dtype=BF16, device=gpu)
+    dV = None if shared_kv else torch.zeros(rows_k, C, dtype=BF16, device=gpu)
+    k.attn_bwd(geom, Qg, Kg, Vg, O, lse, dO.to(gpu), dQ=dQ, dK=dK, dV=dV, shared_kv=shared_kv, dbias=dbias)
+    gs = max(1.0, float(Qr.grad.abs().max()))
+    _close(dQ / gs, Qr.grad / gs, tol=2e-2, what=f"dQ {tag}")
+    ks = max(1.0, float(Kr.grad.abs().max()))
+    _close(dK / ks, Kr.grad / ks, tol=2e-2, what=f"dK {tag}")
+    if not shared_kv:
+        vs = max(1.0, float(Vr.grad.abs().max()))
+        _close(dV / vs, Vr.grad / vs, tol=2e-2, what=f"dV {tag}")
+    if want_dbias:
+        bs = max(1.0, float(br.grad.abs().max()))
+        _close(dbias / bs, br.grad / bs, tol=2e-2, what=f"dbias {tag}")
+
+
+def test_window_attention_shapes(stg, gpu):
+    # W-MSA: 49-token windows, head dim 32, rel-pos bias, shift mask, roll/partition as a map (Swin_AVE.py:256-276)
+    _run_case(gpu, P=8, H=4, n=49, D=32, G=4, mapped=True, scale=32 ** -0.5, with_bias=True, with_mask=True, seed=1)
+    _run_case(gpu, P=6, H=2, n=49, D=32, G=1, mapped=False, scale=32 ** -0.5, with_bias=True, seed=2)
+
+
+def test_temporal_attention_shapes(stg, gpu):
+    # temporal: T=10 tokens, two bias groups (video / audio tables), dbias needed (Swin_AVE.py:244-255)
+    _run_case(gpu, P=128, H=4, n=10, D=32, G=32, mapped=True, scale=32 ** -0.5, with_bias=True, bias_mod=2,
+              want_dbias=True, seed=3)
+    _run_case(gpu, P=6, H=2, n=5, D=32, G=3, mapped=True, scale=32 ** -0.5, with_bias=True, bias_mod=2,
+              want_dbias=True, seed=4)
+
+
+@pytest.mark.parametrize("D", [16, 32, 48, 64, 96, 128])
+def test_cross_modal_head_dims(stg, gpu, D):
+    # cross-modal adapter attention: single head, no scale, K = V = other modality (Swin_AVE.py:753-757,801-805)
+    _run_case(gpu, P=3, H=1, n=49, D=D, G=1, n_kv=49, shared_kv=True, seed=10 + D, mag=0.5)
+
+
+def test_cross_modal_global_long(stg, gpu):
+    # frame-global variant: N = 196 / 784-ish lengths exercise the multi-tile online softmax
+    _run_case(gpu, P=2, H=1, n=196, D=32, n_kv=196, shared_kv=True, seed=20, mag=0.7)
+    _run_case(gpu, P=1, H=1, n=800, D=16, n_kv=800, shared_kv=True, seed=21, mag=0.7)
+    _run_case(gpu, P=2, H=1, n=70, D=64, n_kv=33, shared_kv=True, seed=22, mag=0.5)
+
+
+def test_cross_modal_window_mapped(stg, gpu):
+    _run_case(gpu, P=12, H=1, n=49, D=16, G=4, n_kv=49, mapped=True, shared_kv=True, seed=23, mag=0.7)
+
+
+def test_vit_mha_shapes(stg, gpu):
+    # CLIP ViT-B/16 with heads=8 => head dim 96, 197 tokens; temporal T=10 (CLIP_AVE.py:106-108)
+    _run_case(gpu, P=2, H=8, n=197, D=96, scale=96 ** -0.5, seed=30)
+    _run_case(gpu, P=5, H=8, n=10, D=96, G=5, mapped=True, scale=96 ** -0.5, seed=31)
+    _run_case(gpu, P=2, H=4, n=49, D=64, scale=0.125, seed=32)
+
+
+def test_online_softmax_rescale_spike(stg, gpu):
+    """Force the running max to jump in a late KV tile (the rescale branch)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(5)
+    n, D = 128, 32
+    Q = (torch.randn(n, D, generator=g) * 0.3); KV = (torch.randn(n, D, generator=g) * 0.3)
+    KV[100] = Q[7] * 40  # huge score for query 7 at key 100 (4th tile)
+    Qb, KVb = Q.to(BF16), KV.to(BF16)
+    s = Qb.float() @ KVb.float().t()
+    ref = torch.softmax(s, -1) @ KVb.float()
+    geom = k.AttnGeom(1, 1, n, D, n_kv=n)
+    O, lse = k.attn_fwd(geom, Qb.to(gpu), KVb.to(gpu), KVb.to(gpu))
+    _close(O, ref, what="spike O")
+    _close(lse.view(-1), torch.logsumexp(s, -1), tol=2e-2, what="spike lse")
