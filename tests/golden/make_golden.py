@@ -1,0 +1,271 @@
+"""Generate the golden vectors in tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference with a
+timm shim) on seeded parameters and inputs.  Runs only in the build container (the reference never travels); the .npz
+files and this script are committed.  Usage:  python tests/golden/make_golden.py [case ...]
+
+Each fixture stores: `shapes_json` (state_dict float keys + shapes = the naming contract), seeds, outputs, and gradients
+of the trainable tensors (the reference's name filter, traintest_adapt_ave29.py:38-61) for a seeded upstream gradient.
+Parameters / inputs are regenerated from the seeds by tests/golden/params.py.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import params as GP  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_shims():
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
+        return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+    class DropPath(nn.Module):  # timm 0.4.5 semantics
+        def __init__(self, p=0.):
+            super().__init__()
+            self.drop_prob = p
+
+        def forward(self, x):
+            if self.drop_prob == 0. or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep).div_(keep)
+            return x * m
+
+    timm, tm, tl = types.ModuleType("timm"), types.ModuleType("timm.models"), types.ModuleType("timm.models.layers")
+    tl.DropPath, tl.to_2tuple, tl.trunc_normal_ = DropPath, to_2tuple, trunc_normal_
+    timm.models, tm.layers = tm, tl
+    ipdb = types.ModuleType("ipdb")
+    ipdb.set_trace = lambda *a, **k: None
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "clip": types.ModuleType("clip"),
+                        "loratorch": types.ModuleType("loratorch"), "ipdb": ipdb, "torchvision": tv,
+                        "torchvision.models": tvm})
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def seed_module(mod, seed):
+    sd = mod.state_dict()
+    shapes = GP.float_shapes(sd)
+    new = GP.seeded_state(shapes, seed)
+    sd.update(new)
+    mod.load_state_dict(sd, strict=True)
+    return shapes
+
+
+def apply_freeze(mod):
+    names = []
+    for n, p in mod.named_parameters():
+        p.requires_grad = GP.is_trainable(n)
+        if p.requires_grad:
+            names.append(n)
+    return names
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else v) for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def flat_grads(mod, names):
+    d = dict(mod.named_parameters())
+    return torch.cat([(d[n].grad if d[n].grad is not None else torch.zeros_like(d[n])).reshape(-1) for n in names])
+
+
+# --------------------------------------------------------------------------------------------------- Swin blocks
+def swin_block_case(S, tag, *, dim, res, T, B, heads, shift, t_attn, ratio, mode, seed):
+    blk = S.SwinTransformerBlock(dim=dim, input_resolution=(res, res), num_frames=T, num_heads=heads, window_size=7,
+                                 shift_size=shift, t_attn=t_attn, adapter_mlp_ratio=ratio, mode=mode).eval()
+    shapes = seed_module(blk, seed)
+    names = apply_freeze(blk)
+    BT, N = B * T, res * res
+    v = GP.seeded_tensor((BT, N, dim), seed + 1).requires_grad_(True)
+    a = GP.seeded_tensor((BT, N, dim), seed + 2).requires_grad_(True)
+    gv, ga = GP.seeded_tensor((BT, N, dim), seed + 3), GP.seeded_tensor((BT, N, dim), seed + 4)
+    if mode in ("fusion_adapt", "multimodal_adapt_no_fusion"):
+        ov, oa = blk((v, a))
+        ((ov * gv).sum() + (oa * ga).sum()).backward()
+        extra = dict(out_v=ov, out_a=oa, din_v=v.grad, din_a=a.grad)
+    else:
+        x = v if mode == "video_adapt" else a
+        o = blk(x)
+        (o * gv).sum().backward()
+        extra = dict(out=o, din=x.grad)
+    # structural known-answers: the reference's integer buffers
+    bufs = {k: val for k, val in blk.state_dict().items() if not val.is_floating_point()}
+    mask = blk.attn_mask if blk.attn_mask is not None else torch.zeros(0)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(dim=dim, res=res, T=T, B=B, heads=heads, shift=shift,
+         t_attn=t_attn, ratio=ratio, mode=mode, seed=seed)), grad_names_json=json.dumps(names), grads=flat_grads(blk, names),
+         attn_mask=mask, rel_index=bufs["attn.relative_position_index"], **extra)
+
+
+# --------------------------------------------------------------------------------------------------- Swin models
+def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True):
+    m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
+                                        embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                                        window_size=7, pretrained=None, ftmode=mode,
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    shapes = seed_module(m, seed)
+    names = apply_freeze(m)
+    T = cfg["num_frames"]
+    a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, 3, T, 224, 224), seed + 2)
+    logits = m(a, v, mode)
+    tgt = torch.softmax(GP.seeded_tensor((B * T, cfg["label_dim"]), seed + 3, 2.0), -1)
+    loss = nn.CrossEntropyLoss()(logits, tgt)
+    loss.backward()
+    g = flat_grads(m, names)
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    n_head = sum(p.numel() for n, p in m.named_parameters() if n in GP.MLP_HEAD)
+    arrs = dict(shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, mode=mode, seed=seed)),
+                grad_names_json=json.dumps(names), logits=logits, loss=loss.reshape(1),
+                n_params=np.array([sum(p.numel() for p in m.parameters()), n_train, n_head]))
+    if store_all_grads:
+        arrs["grads"] = g
+    else:  # big model: per-tensor L2 norms + a strided sample
+        d = dict(m.named_parameters())
+        arrs["grad_norms"] = torch.stack([d[n].grad.norm() for n in names])
+        arrs["grads_sample"] = g[::97].clone()
+    save(tag, **arrs)
+
+
+# --------------------------------------------------------------------------------------------------- ViT (CLIP) path
+def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"):
+    blk = Cm.ResidualAttentionBlock(d, heads, None, 0.5, 1, T, 0.0, mode=mode).eval()
+    shapes = seed_module(blk, seed)
+    names = apply_freeze(blk)
+    BT = B * T
+    v = GP.seeded_tensor((nv, BT, d), seed + 1).requires_grad_(True)
+    a = GP.seeded_tensor((na, BT, d), seed + 2).requires_grad_(True)
+    gv, ga = GP.seeded_tensor((nv, BT, d), seed + 3), GP.seeded_tensor((na, BT, d), seed + 4)
+    ov, oa = blk((v, a))
+    ((ov * gv).sum() + (oa * ga).sum()).backward()
+    st = max(1, nv // 25)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(d=d, heads=heads, T=T, B=B, nv=nv, na=na, seed=seed,
+         mode=mode, stride=st)), grad_names_json=json.dumps(names), grads=flat_grads(blk, names),
+         out_v=ov[::st], out_a=oa[::st], din_v=v.grad[::st], din_a=a.grad[::st],
+         stats=torch.stack([ov.sum(), ov.abs().sum(), oa.sum(), oa.abs().sum()]))
+
+
+def vit_model_case(Cm, tag, *, layers, heads, d, B, T, seed, mode="fusion"):
+    m = Cm.MM_CLIP_AVE(label_dim=29, layers=layers, num_video_frames=T, embed_dim=d, patch_size=16, heads=heads,
+                       pretrained=None, ftmode=mode).eval()
+    shapes = seed_module(m, seed)
+    names = apply_freeze(m)
+    a = GP.seeded_tensor((B, T, 102, 128), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, 3, T, 224, 224), seed + 2)
+    logits = m(a, v, mode)
+    tgt = torch.softmax(GP.seeded_tensor((B * T, 29), seed + 3, 2.0), -1)
+    loss = nn.CrossEntropyLoss()(logits, tgt)
+    loss.backward()
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    n_head = sum(p.numel() for n, p in m.named_parameters() if n in GP.MLP_HEAD)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(layers=layers, heads=heads, d=d, B=B, T=T, seed=seed,
+         mode=mode)), grad_names_json=json.dumps(names), logits=logits, loss=loss.reshape(1), grads=flat_grads(m, names),
+         n_params=np.array([sum(p.numel() for p in m.parameters()), n_train, n_head]))
+
+
+def structure_case(S, Cm):
+    """Naming / counting contract of the full-size models (no forward)."""
+    out = {}
+    for tag, ctor in {
+        "swin_b_fusion": lambda: S.SwinTransformer2D_Adapter_New(label_dim=29, patch_size=[1, 4, 4], num_frames=10, embed_dim=128,
+                                                                  depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7,
+                                                                  pretrained=None, ftmode="fusion",
+                                                                  adapter_mlp_ratio=[.125, .125, .0625, .0625]),
+        "swin_l_fusion": lambda: S.SwinTransformer2D_Adapter_New(label_dim=29, patch_size=[1, 4, 4], img_size=224, num_frames=10,
+                                                                  embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48],
+                                                                  window_size=7, pretrained=None, ftmode="fusion",
+                                                                  adapter_mlp_ratio=[.5, .25, .125, .0625]),
+        "vit_b_fusion": lambda: Cm.MM_CLIP_AVE(label_dim=29, layers=12, num_video_frames=10, embed_dim=768, patch_size=16,
+                                                heads=8, pretrained=None, ftmode="fusion"),
+    }.items():
+        m = ctor()
+        sd = m.state_dict()
+        keys = [(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+        n_total = sum(p.numel() for p in m.parameters())
+        n_train = sum(p.numel() for n, p in m.named_parameters() if GP.is_trainable(n))
+        n_head = sum(p.numel() for n, p in m.named_parameters() if n in GP.MLP_HEAD)
+        out[tag] = dict(keys=keys, n_total=n_total, n_trainable=n_train, n_head=n_head)
+        print(tag, n_total, n_train, n_head)
+    with open(os.path.join(HERE, "structure.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote structure.json")
+
+
+def scheduler_case():
+    sch = load(os.path.join(REF, "utilities/scheduler.py"), "ref_sched")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        t1 = sch.cosine_scheduler(5e-5, 2e-6, 20, 3339, warmup_epochs=2, start_warmup_value=0, warmup_steps=-1)
+        t2 = sch.cosine_scheduler(5e-5 * 0.1, 2e-6, 20, 3339, warmup_epochs=2, start_warmup_value=0, warmup_steps=-1)
+        t3 = sch.cosine_scheduler(1e-4, 2e-6, 3, 7, warmup_epochs=1)
+    save("cosine_scheduler", t1=t1, t2=t2, t3=t3)
+
+
+SWIN_TINY = dict(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2,
+                 adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
+SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
+              adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
+
+
+def main(argv):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_shims()
+    S = load(os.path.join(REF, "AVE/model/Swin_AVE.py"), "ref_swin_ave")
+    Cm = load(os.path.join(REF, "AVE/model/CLIP_AVE.py"), "ref_clip_ave")
+    cases = {
+        "swin_block_even": lambda: swin_block_case(S, "swin_block_even", dim=128, res=14, T=5, B=1, heads=4, shift=0, t_attn=True,
+                                                   ratio=0.125, mode="fusion_adapt", seed=100),
+        "swin_block_odd": lambda: swin_block_case(S, "swin_block_odd", dim=128, res=14, T=5, B=1, heads=4, shift=3, t_attn=False,
+                                                  ratio=0.125, mode="fusion_adapt", seed=110),
+        "swin_block_s0": lambda: swin_block_case(S, "swin_block_s0", dim=32, res=56, T=1, B=1, heads=1, shift=3, t_attn=False,
+                                                 ratio=0.5, mode="fusion_adapt", seed=120),
+        "swin_block_s3": lambda: swin_block_case(S, "swin_block_s3", dim=256, res=7, T=2, B=2, heads=8, shift=3, t_attn=True,
+                                                 ratio=0.0625, mode="fusion_adapt", seed=130),
+        "swin_block_nofusion": lambda: swin_block_case(S, "swin_block_nofusion", dim=64, res=14, T=2, B=2, heads=2, shift=3,
+                                                       t_attn=True, ratio=0.25, mode="multimodal_adapt_no_fusion", seed=140),
+        "swin_block_video": lambda: swin_block_case(S, "swin_block_video", dim=64, res=14, T=2, B=2, heads=2, shift=0, t_attn=True,
+                                                    ratio=0.25, mode="video_adapt", seed=150),
+        "swin_block_audio": lambda: swin_block_case(S, "swin_block_audio", dim=64, res=14, T=2, B=2, heads=2, shift=3, t_attn=False,
+                                                    ratio=0.25, mode="audio_adapt", seed=160),
+        "swin_tiny_fusion": lambda: swin_model_case(S, "swin_tiny_fusion", cfg=SWIN_TINY, B=1, mode="fusion", seed=200),
+        "swin_tiny_multimodal": lambda: swin_model_case(S, "swin_tiny_multimodal", cfg=SWIN_TINY, B=1, mode="multimodal", seed=210),
+        "swin_tiny_videoonly": lambda: swin_model_case(S, "swin_tiny_videoonly", cfg=SWIN_TINY, B=1, mode="videoonly", seed=220),
+        "swin_b_fusion": lambda: swin_model_case(S, "swin_b_fusion", cfg=SWIN_B, B=1, mode="fusion", seed=300, store_all_grads=False),
+        "vit_block_cfg1": lambda: vit_block_case(Cm, "vit_block_cfg1", d=768, heads=8, T=10, B=1, nv=196, na=196, seed=400),
+        "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=192, heads=2, T=2, B=2, nv=50, na=13, seed=410),
+        "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
+        "structure": lambda: structure_case(S, Cm),
+        "cosine_scheduler": scheduler_case,
+    }
+    todo = argv or list(cases)
+    for c in todo:
+        print("==", c)
+        cases[c]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,120 @@
+"""CPU: pin the oracle (oracle/*.py, fp32 restatement) to the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Tolerance 1e-3 (north-star's fp32 bound); observed deviations are ~1e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLD, build_state, load_case
+
+import oracle.swin as OS
+
+
+def _close(got, ref, tol=1e-3, what=""):
+    got = got.detach().float(); ref = torch.as_tensor(ref).float()
+    assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3g})"
+
+
+def _grads(P, names):
+    return torch.cat([(P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])).reshape(-1) for n in names])
+
+
+@pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3",
+                                 "swin_block_nofusion", "swin_block_video", "swin_block_audio"])
+def test_swin_block_matches_reference(tag):
+    z, cfg, shapes, names = load_case(tag)
+    P = build_state(shapes, cfg["seed"], kind="swin_block", T=cfg["T"], res=cfg["res"])
+    for n in names:
+        P["blk." + n].requires_grad_(True)
+    # structural known-answers from the reference's integer buffers
+    ws, shift = OS.block_geometry(cfg["res"], cfg["res"], 7, cfg["shift"])
+    assert torch.equal(OS.relative_position_index(ws), torch.as_tensor(z["rel_index"]))
+    m = OS.shift_attn_mask(cfg["res"], cfg["res"], ws, shift)
+    if m is None:
+        assert z["attn_mask"].size == 0
+    else:
+        assert torch.equal(m, torch.as_tensor(z["attn_mask"]))
+    from params import seeded_tensor
+    BT, N, C = cfg["B"] * cfg["T"], cfg["res"] ** 2, cfg["dim"]
+    v = seeded_tensor((BT, N, C), cfg["seed"] + 1).requires_grad_(True)
+    a = seeded_tensor((BT, N, C), cfg["seed"] + 2).requires_grad_(True)
+    gv, ga = seeded_tensor((BT, N, C), cfg["seed"] + 3), seeded_tensor((BT, N, C), cfg["seed"] + 4)
+    kw = dict(H=cfg["res"], W=cfg["res"], T=cfg["T"], heads=cfg["heads"], window_size=7, shift_size=cfg["shift"],
+              t_attn=cfg["t_attn"], mode=cfg["mode"])
+    if cfg["mode"] in ("fusion_adapt", "multimodal_adapt_no_fusion"):
+        ov, oa = OS.swin_block(P, "blk", (v, a), **kw)
+        ((ov * gv).sum() + (oa * ga).sum()).backward()
+        _close(ov, z["out_v"], what="out_v"); _close(oa, z["out_a"], what="out_a")
+        _close(v.grad, z["din_v"], what="din_v"); _close(a.grad, z["din_a"], what="din_a")
+    else:
+        x = v if cfg["mode"] == "video_adapt" else a
+        o = OS.swin_block(P, "blk", x, **kw)
+        (o * gv).sum().backward()
+        _close(o, z["out"], what="out"); _close(x.grad, z["din"], what="din")
+    _close(_grads(P, ["blk." + n for n in names]), z["grads"], what="param grads")
+
+
+@pytest.mark.parametrize("tag", ["swin_tiny_fusion", "swin_tiny_multimodal", "swin_tiny_videoonly"])
+def test_swin_tiny_model_matches_reference(tag):
+    z, cfg, shapes, names = load_case(tag)
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for n in names:
+        P[n].requires_grad_(True)
+    from params import seeded_tensor
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2)
+    logits = OS.swin_forward(P, a, v, cfg, cfg["mode"])
+    tgt = torch.softmax(seeded_tensor((B * T, cfg["label_dim"]), cfg["seed"] + 3, 2.0), -1)
+    loss = OS.soft_target_cross_entropy(logits, tgt)
+    loss.backward()
+    _close(logits, z["logits"], what="logits")
+    _close(loss.reshape(1), z["loss"], tol=1e-4, what="loss")
+    _close(_grads(P, names), z["grads"], what="grads")
+
+
+def test_swin_b_full_model_matches_reference():
+    """The headline configuration (Swin-B + STG-CMA, ftmode='fusion', AVE shape, B=1): logits, loss, per-tensor grad norms."""
+    z, cfg, shapes, names = load_case("swin_b_fusion")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for n in names:
+        P[n].requires_grad_(True)
+    from params import seeded_tensor
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2)
+    logits = OS.swin_forward(P, a, v, cfg, "fusion")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1)
+    loss = OS.soft_target_cross_entropy(logits, tgt)
+    loss.backward()
+    _close(logits, z["logits"], what="logits")
+    _close(loss.reshape(1), z["loss"], tol=1e-4, what="loss")
+    norms = torch.stack([P[n].grad.norm() if P[n].grad is not None else torch.zeros(()) for n in names])
+    _close(norms, z["grad_norms"], what="grad norms")
+    _close(_grads(P, names)[::97], z["grads_sample"], what="grad sample")
+    # known answers quoted by the reference's launcher comment (AVE/run_swin_adapt_ave29.sh:55 "5.6M")
+    assert list(z["n_params"]) == [92345613, 5599957, 1063965]
+
+
+def test_structure_contract():
+    with open(os.path.join(GOLD, "structure.json")) as f:
+        st = json.load(f)
+    assert st["swin_b_fusion"]["n_trainable"] == 5599957 and st["swin_b_fusion"]["n_head"] == 1063965
+    assert st["swin_l_fusion"]["n_trainable"] == 19026857
+    assert st["vit_b_fusion"]["n_trainable"] == 6185909
+    keys = [k for k, _, _ in st["swin_b_fusion"]["keys"]]
+    assert "layers.0.blocks.0.attn.temporal_position_bias_table_audio" in keys
+    assert "layers.0.blocks.1.attn_mask" in keys and "layers.0.blocks.0.attn_mask" not in keys
+    assert "layers.2.blocks.17.S_Adapter2_Audio.D_fc2.weight" in keys
+
+
+def test_cosine_scheduler_matches_reference():
+    z = np.load(os.path.join(GOLD, "cosine_scheduler.npz"))
+    np.testing.assert_allclose(OS.cosine_scheduler(5e-5, 2e-6, 20, 3339, warmup_epochs=2).numpy(), z["t1"], rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(OS.cosine_scheduler(5e-6, 2e-6, 20, 3339, warmup_epochs=2).numpy(), z["t2"], rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(OS.cosine_scheduler(1e-4, 2e-6, 3, 7, warmup_epochs=1).numpy(), z["t3"], rtol=1e-12, atol=1e-18)
