@@ -66,7 +66,9 @@ int stg_gemm_nt(const stg_gemm_args* args, void* stream);
  *   db[N1]    (+)= sum_m dY[m,N1]                (optional)
  */
 int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx,
-                 float* dW, int64_t lddw, float* db, int64_t M, int N1, int N2, void* stream);
+                 float* dW, int64_t lddw, float* db, int64_t M, int N1, int N2,
+                 const float* row_scale, int64_t rs_outer, int64_t rs_inner,   /* optional DropPath scale on dY rows */
+                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm; Swin_AVE.py:341,352 norm1/norm2, :960,976 PatchMerging.norm,
@@ -142,8 +144,9 @@ int stg_gate_bwd(const void* dout, const void* r, const float* gate, void* dr, f
 int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B, int Cin, int T, int Hin, int Win, int p, int Kpad,
                      void* stream);
 
-/* fp32 -> bf16 cast (optionally transposed: in [R,Cc] -> out [Cc,R]) for weight shadows */
-int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, void* stream);
+/* fp32 -> bf16 cast for weight shadows / gradient hand-over: in [R,Cc] contiguous -> out [R, ld_out] (or, transposed,
+ * out [Cc, ld_out]); columns beyond the data are zero-filled up to ld_out (GEMM needs K % 8 == 0). */
+int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, int64_t ld_out, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 
@@ -151,8 +154,10 @@ int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 int stg_meanpool_fwd(const void* in, void* out, int out_dtype, int64_t ldo, int64_t G, int n, int C, void* stream);
 int stg_meanpool_bwd(const void* dout, int64_t lddo, void* din, int64_t G, int n, int C, void* stream);
 
-/* out = a + b (bf16), used to join gradient branches */
-int stg_add(const void* a, const void* b, void* out, int64_t numel, void* stream);
+/* out = a + b (+ c) (bf16), joins gradient branches; c may be NULL */
+int stg_add(const void* a, const void* b, const void* c, void* out, int64_t numel, void* stream);
+/* dz = dh * act'(z)  (bf16), backward of the adapter activation (Swin_AVE.py:21, GELU; CLIP QuickGELU) */
+int stg_act_bwd(const void* dh, const void* z, void* dz, int act, int64_t numel, void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

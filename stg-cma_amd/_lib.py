@@ -69,7 +69,7 @@ SIGNATURES = {
     "stg_version": (C.c_int, []),
     "stg_last_error": (C.c_char_p, []),
     "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
-    "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64, c_vp]),
     "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp,
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
@@ -79,11 +79,12 @@ SIGNATURES = {
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
-    "stg_cast_bf16": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp]),
+    "stg_cast_bf16": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp]),
     "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
-    "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_act_bwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),

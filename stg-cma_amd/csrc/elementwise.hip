@@ -73,19 +73,40 @@ __global__ void gate_bwd_kernel(const bf16_t* dout, const bf16_t* r, const float
     }
 }
 
-// ---- out = a + b
-__global__ void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n8, int64_t numel) {
+// ---- out = a + b (+ c)
+__global__ void add_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* c, bf16_t* out, int64_t n8, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         float x[8], y[8];
         unpack8(reinterpret_cast<const uint4*>(a)[i], x);
         unpack8(reinterpret_cast<const uint4*>(b)[i], y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] += y[j];
+        if (c) {
+            unpack8(reinterpret_cast<const uint4*>(c)[i], y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] += y[j];
+        }
         reinterpret_cast<uint4*>(out)[i] = pack8(x);
     }
     if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
         const int64_t i = (n8 << 3) + threadIdx.x;
-        out[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+        out[i] = f2bf(bf2f(a[i]) + bf2f(b[i]) + (c ? bf2f(c[i]) : 0.f));
+    }
+}
+
+// ---- dz = dh * act'(z)
+__global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int act, int64_t n8, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        unpack8(reinterpret_cast<const uint4*>(dh)[i], x);
+        unpack8(reinterpret_cast<const uint4*>(z)[i], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= act_grad(act, y[j]);
+        reinterpret_cast<uint4*>(dz)[i] = pack8(x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        dz[i] = f2bf(bf2f(dh[i]) * act_grad(act, bf2f(z[i])));
     }
 }
 
@@ -131,11 +152,15 @@ __global__ void im2col_kernel(const void* x, int x_f32, bf16_t* out, int64_t B, 
 }
 
 // ---- casts
-__global__ void cast_bf16_kernel(const float* in, bf16_t* out, int64_t numel) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = f2bf(in[i]);
+__global__ void cast_bf16_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc, int64_t ld) {
+    const int64_t total = R * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld, c = i - r * ld;
+        out[i] = c < Cc ? f2bf(in[r * Cc + c]) : (bf16_t)0;
+    }
 }
-__global__ void cast_bf16_t_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc) {
+// out [Cc, ld] = in[R, Cc]^T, columns R..ld-1 zero
+__global__ void cast_bf16_t_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc, int64_t ld) {
     __shared__ float tile[32][33];
     const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
@@ -146,7 +171,7 @@ __global__ void cast_bf16_t_kernel(const float* in, bf16_t* out, int64_t R, int6
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int64_t c = bx + j, r = by + tx;  // out[c][r]
-        if (c < Cc && r < R) out[c * R + r] = f2bf(tile[tx][j]);
+        if (c < Cc && r < ld) out[c * ld + r] = (r < R) ? f2bf(tile[tx][j]) : (bf16_t)0;
     }
 }
 __global__ void cast_f32_kernel(const bf16_t* in, float* out, int64_t numel) {
@@ -242,13 +267,24 @@ extern "C" int stg_gate_bwd(const void* dout, const void* r, const float* gate, 
     STG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int stg_add(const void* a, const void* b, void* out, int64_t numel, void* stream) {
+extern "C" int stg_add(const void* a, const void* b, const void* c, void* out, int64_t numel, void* stream) {
     STG_CHECK(a && b && out, -1, "stg_add: null pointer");
-    STG_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, -2, "stg_add: pointers must be 16-byte aligned");
+    STG_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0, -2, "stg_add: pointers must be 16-byte aligned");
     if (numel <= 0) return 0;
     const int64_t n8 = numel >> 3;
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out,
-                       n8, numel);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b,
+                       (const bf16_t*)c, (bf16_t*)out, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_act_bwd(const void* dh, const void* z, void* dz, int act, int64_t numel, void* stream) {
+    STG_CHECK(dh && z && dz, -1, "stg_act_bwd: null pointer");
+    STG_CHECK(act >= 0 && act <= 2, -3, "stg_act_bwd: bad act");
+    STG_CHECK((((uintptr_t)dh | (uintptr_t)z | (uintptr_t)dz) & 15) == 0, -2, "stg_act_bwd: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)dh, (const bf16_t*)z,
+                       (bf16_t*)dz, act, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -272,15 +308,17 @@ extern "C" int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B
     STG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, void* stream) {
+extern "C" int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, int64_t ld_out, void* stream) {
     STG_CHECK(in && out, -1, "stg_cast_bf16: null pointer");
     if (R <= 0 || Cc <= 0) return 0;
     if (!transpose) {
-        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(R * Cc, 256)), dim3(256), 0, ST, in, (bf16_t*)out, R * Cc);
+        STG_CHECK(ld_out >= Cc, -2, "stg_cast_bf16: ld_out < columns");
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(R * ld_out, 256)), dim3(256), 0, ST, in, (bf16_t*)out, R, Cc, ld_out);
     } else {
-        const int64_t gx = (Cc + 31) / 32, gy = (R + 31) / 32;
+        STG_CHECK(ld_out >= R, -2, "stg_cast_bf16: ld_out < rows (transpose)");
+        const int64_t gx = (Cc + 31) / 32, gy = (ld_out + 31) / 32;
         STG_CHECK(gy < 65536, -2, "stg_cast_bf16: too many rows for transpose");
-        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ST, in, (bf16_t*)out, R, Cc);
+        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ST, in, (bf16_t*)out, R, Cc, ld_out);
     }
     STG_LAUNCH_CHECK();
     return 0;

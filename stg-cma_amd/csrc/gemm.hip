@@ -212,6 +212,7 @@ struct WgradParams {
     int nt1, nt2, msplit;
     int64_t rows_per_split;
     int vec_y, vec_x;
+    const float* row_scale; int64_t rs_outer, rs_inner;
 };
 
 __global__ void __launch_bounds__(256, 2) wgrad_tn_kernel(WgradParams p) {
@@ -252,6 +253,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_kernel(WgradParams p) {
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v.v[j] = (gm < mend && gn + j < p.N1) ? p.dY[gm * p.lddy + gn + j] : 0;
+            }
+            if (p.row_scale && gm < mend) {
+                const float rs = p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v.v[j] = f2bf(bf2f(v.v[j]) * rs);
             }
             *reinterpret_cast<u16x8*>(sY + row * T1 + c * 8) = v;
         }
@@ -349,7 +355,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
 }
 
 extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw,
-                            float* db, int64_t M, int N1, int N2, void* stream) {
+                            float* db, int64_t M, int N1, int N2, const float* row_scale, int64_t rs_outer,
+                            int64_t rs_inner, void* stream) {
     STG_CHECK(dY && X && dW, -1, "stg_wgrad_tn: null pointer");
     STG_CHECK(M >= 0 && N1 > 0 && N2 > 0, -2, "stg_wgrad_tn: bad shape");
     STG_CHECK(lddy >= N1 && ldx >= N2 && lddw >= N2, -2, "stg_wgrad_tn: leading dimension too small");
@@ -367,6 +374,8 @@ extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t
     int64_t cps = (kchunks + msplit - 1) / msplit;  // 64-row chunks per split
     msplit = (kchunks + cps - 1) / cps;
     p.msplit = (int)msplit; p.rows_per_split = cps * TK;
+    if (row_scale) STG_CHECK(rs_outer > 0 && rs_inner > 0, -2, "stg_wgrad_tn: bad row_scale params");
+    p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
     p.vec_y = (lddy % 8 == 0) && (((uintptr_t)dY & 15) == 0);
     p.vec_x = (ldx % 8 == 0) && (((uintptr_t)X & 15) == 0);
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3(ntiles, (unsigned)msplit), dim3(256), 0, (hipStream_t)stream, p);

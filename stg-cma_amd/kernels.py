@@ -92,20 +92,30 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     return (out, pre) if want_preact else out
 
 
-def wgrad_tn(dY, X, dW, db=None):
-    """dW[N1,N2] += dY.T @ X ; db[N1] += dY.sum(0)   (fp32 accumulate into existing buffers)."""
-    M, N1 = dY.shape
+def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inner=1):
+    """dW[N1,N2] += (s * dY).T @ X ; db[N1] += (s * dY).sum(0)   (fp32 accumulate into existing buffers).
+    n1: use only the first n1 columns of dY (dY may be zero-padded to a multiple of 8 columns)."""
+    M = dY.shape[0]
+    N1 = dY.shape[1] if n1 is None else int(n1)
     N2 = X.shape[1]
     _chk2d(dY, "dY", BF16)
+    if N1 > dY.shape[1]:
+        raise RuntimeError("wgrad_tn: n1 exceeds dY columns")
     _chk2d(X, "X", BF16, rows=M)
     _chk2d(dW, "dW", F32, cols=N2, rows=N1)
     if db is not None:
         _chk1d(db, "db", F32, N1)
-    _lib.check(_lib.lib().stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2, _stream()),
-               "stg_wgrad_tn")
+    if row_scale is not None:
+        if not row_scale.is_cuda or row_scale.dtype != F32 or not row_scale.is_contiguous():
+            raise RuntimeError("row_scale: expected contiguous fp32 GPU tensor")
+        need = ((M - 1) // rs_outer) * rs_inner + rs_inner if M > 0 else 0
+        if row_scale.numel() < need:
+            raise RuntimeError(f"row_scale: needs >= {need} entries, got {row_scale.numel()}")
+    _lib.check(_lib.lib().stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
+                                       _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None):
     """x: [rows, C] bf16/fp32 -> y bf16 (+ mean, rstd).  gather4=(H, W): PatchMerging gather, x is [F*H*W, C] -> y [F*H*W/4, 4C]."""
     if x.dtype not in (BF16, F32):
         raise RuntimeError("layernorm: x must be bf16 or fp32")
@@ -123,7 +133,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True):
         g4 = 0
     _chk1d(gamma, "gamma", F32, Cl)
     _chk1d(beta, "beta", F32, Cl)
-    y = torch.empty((rows, Cl), dtype=BF16, device=x.device)
+    y = torch.empty((rows, Cl), dtype=BF16, device=x.device) if out is None else out
+    _chk2d(y, "y", BF16, cols=Cl, rows=rows)
     mean = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
     rstd = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
     _lib.check(_lib.lib().stg_layernorm_fwd(_p(x), STG_BF16 if x.dtype == BF16 else STG_F32, _ld(x), _p(gamma), _p(beta),
@@ -182,13 +193,26 @@ def gate_bwd(dout, r, gate, dgate):
     return dr
 
 
-def add(a, b):
+def add(a, b, c=None):
     _chk_flat(a, "a"); _chk_flat(b, "b")
     if a.shape != b.shape:
         raise RuntimeError("add: shape mismatch")
+    if c is not None:
+        _chk_flat(c, "c")
+        if c.shape != a.shape:
+            raise RuntimeError("add: shape mismatch")
     out = torch.empty_like(a)
-    _lib.check(_lib.lib().stg_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "stg_add")
+    _lib.check(_lib.lib().stg_add(_p(a), _p(b), _p(c), _p(out), a.numel(), _stream()), "stg_add")
     return out
+
+
+def act_bwd(dh, z, act):
+    _chk_flat(dh, "dh"); _chk_flat(z, "z")
+    if dh.shape != z.shape:
+        raise RuntimeError("act_bwd: shape mismatch")
+    dz = torch.empty_like(dh)
+    _lib.check(_lib.lib().stg_act_bwd(_p(dh), _p(z), _p(dz), int(act), dh.numel(), _stream()), "stg_act_bwd")
+    return dz
 
 
 def mul_mask(a, mask):
@@ -211,13 +235,15 @@ def im2col_patch(x, p, Kpad):
     return out
 
 
-def cast_bf16(w, transpose=False):
-    """fp32 [R, C] -> bf16 [R, C] or [C, R]."""
+def cast_bf16(w, transpose=False, pad_to=8):
+    """fp32 [R, C] -> bf16 [R, C'] or (transpose) [C, R'], trailing dim zero-padded to a multiple of `pad_to`."""
     _chk_flat(w, "w", F32)
     w2 = w.reshape(w.shape[0], -1) if w.dim() > 1 else w.reshape(1, -1)
     R, Cc = w2.shape
-    out = torch.empty((Cc, R) if transpose else (R, Cc), dtype=BF16, device=w.device)
-    _lib.check(_lib.lib().stg_cast_bf16(_p(w2), _p(out), R, Cc, 1 if transpose else 0, _stream()), "stg_cast_bf16")
+    inner = R if transpose else Cc
+    ld = (inner + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((Cc, ld) if transpose else (R, ld), dtype=BF16, device=w.device)
+    _lib.check(_lib.lib().stg_cast_bf16(_p(w2), _p(out), R, Cc, 1 if transpose else 0, ld, _stream()), "stg_cast_bf16")
     return out
 
 
@@ -242,20 +268,27 @@ def meanpool_fwd(x, G, n, out=None, out_dtype=BF16):
     return out
 
 
-def meanpool_bwd(dout, G, n):
+def meanpool_bwd(dout, G, n, out=None):
     _chk2d(dout, "dout", BF16, rows=G)
     Cc = dout.shape[1]
-    din = torch.empty((G * n, Cc), dtype=BF16, device=dout.device)
+    din = torch.empty((G * n, Cc), dtype=BF16, device=dout.device) if out is None else out
+    _chk_flat(din, "din")
+    if din.numel() != G * n * Cc:
+        raise RuntimeError("meanpool_bwd: bad out")
     _lib.check(_lib.lib().stg_meanpool_bwd(_p(dout), _ld(dout), _p(din), G, n, Cc, _stream()), "stg_meanpool_bwd")
     return din
 
 
-def bias_gather(table, index):
+def bias_gather(table, index, out=None):
     """table fp32 [L, H], index int64 [nn] -> fp32 [H, nn]."""
     _chk_flat(table, "table", F32); _chk_flat(index, "index", torch.int64)
     L, H = table.shape
     nn = index.numel()
-    out = torch.empty((H, nn), dtype=F32, device=table.device)
+    if out is None:
+        out = torch.empty((H, nn), dtype=F32, device=table.device)
+    _chk_flat(out, "out", F32)
+    if out.numel() != H * nn:
+        raise RuntimeError("bias_gather: bad out")
     _lib.check(_lib.lib().stg_bias_gather(_p(table), _p(index), _p(out), L, H, nn, _stream()), "stg_bias_gather")
     return out
 

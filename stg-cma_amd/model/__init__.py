@@ -1,0 +1,4 @@
+"""`model` package with the reference's module paths: the runners do `import model` and then `model.Swin_AVE.<Class>`
+(AVE/run_adapt_ave29.py:12,156) -- the reference forgot the __init__.py that makes that work; this one exports the
+submodules.  Put the directory that contains this package (stg-cma_amd/) on sys.path ahead of the reference's AVE/ dir."""
+from . import Swin_AVE  # noqa: F401

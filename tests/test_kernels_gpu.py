@@ -190,8 +190,18 @@ def test_elementwise(stg, gpu):
         mask = (torch.rand(*numel_shape, generator=g) > 0.5).float() * 2
         _close(k.mul_mask(h.to(gpu), mask.to(gpu)), h.float() * mask, what="mul_mask")
     w = torch.randn(48, 100, generator=g)
-    _close(k.cast_bf16(w.to(gpu)), w, what="cast")
-    _close(k.cast_bf16(w.to(gpu), transpose=True), w.t(), what="cast T")
+    c = k.cast_bf16(w.to(gpu))                       # [48, 100 -> padded to 104]
+    assert tuple(c.shape) == (48, 104) and float(c[:, 100:].abs().max()) == 0
+    _close(c[:, :100], w, what="cast")
+    ct = k.cast_bf16(w.to(gpu), transpose=True)       # [100, 48]
+    _close(ct, w.t(), what="cast T")
+    w2 = torch.randn(29, 512, generator=g)
+    ct2 = k.cast_bf16(w2.to(gpu), transpose=True)     # [512, 29 -> 32]
+    assert tuple(ct2.shape) == (512, 32) and float(ct2[:, 29:].abs().max()) == 0
+    _close(ct2[:, :29], w2.t(), what="cast T pad")
+    z = _bf(torch.randn(33, 24, generator=g)); dh = _bf(torch.randn(33, 24, generator=g))
+    _close(k.act_bwd(dh.to(gpu), z.to(gpu), k.ACT_GELU), dh.float() * _gelu_grad(z.float()), what="act_bwd")
+    _close(k.add(h.to(gpu), r.to(gpu), h.to(gpu)), 2 * h.float() + r.float(), what="add3")
     _close(k.cast_f32(_bf(w).to(gpu)), _bf(w).float(), tol=0, what="cast f32")
     # meanpool
     G, n, C = 6, 49, 64

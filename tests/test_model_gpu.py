@@ -1,0 +1,193 @@
+"""-m gpu: the HIP-backed nn.Modules (stg-cma_amd/model) against the golden vectors generated from the reference
+(tests/golden/make_golden.py) and against the fp32 oracle on the same seeded inputs.
+
+Tolerances (bf16 activations, fp32 accumulate): logits |err| <= 1e-2 (the north-star's bf16 bound); tensors are compared
+by max-abs error relative to the reference tensor's max-abs value (<= 2e-2) and by relative L2 error (<= 1e-2).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLD, build_state, load_case
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+_report = []
+
+
+def _cmp(got, ref, what, max_rel=2e-2, l2_rel=1e-2):
+    got = got.detach().float().cpu().reshape(-1)
+    ref = torch.as_tensor(np.asarray(ref)).float().reshape(-1)
+    assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    scale = max(float(ref.abs().max()), 1e-6)
+    e_max = float((got - ref).abs().max()) / scale
+    e_l2 = float((got - ref).norm() / max(float(ref.norm()), 1e-12))
+    _report.append(f"{what}: max/scale={e_max:.3e} relL2={e_l2:.3e} scale={scale:.3g}")
+    assert e_max <= max_rel and e_l2 <= l2_rel, f"{what}: max/scale={e_max:.3e} relL2={e_l2:.3e} (scale {scale:.3g})"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_report():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/model_parity_report.txt", "a") as f:
+        f.write("\n".join(_report) + "\n")
+
+
+def _load_into(module, P, prefix=""):
+    sd = module.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point() and not k.endswith("attn_mask"):
+            sd[k] = P[prefix + k]
+    module.load_state_dict(sd, strict=True)
+
+
+def _apply_freeze(module):
+    from params import is_trainable
+    names = []
+    for n, p in module.named_parameters():
+        p.requires_grad = is_trainable(n)
+        if p.requires_grad:
+            names.append(n)
+    return names
+
+
+def _flat_grads(module, names):
+    d = dict(module.named_parameters())
+    return torch.cat([(d[n].grad if d[n].grad is not None else torch.zeros_like(d[n])).reshape(-1).float().cpu() for n in names])
+
+
+@pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3"])
+def test_fusion_block_matches_reference(stg, gpu, tag):
+    from stgcma.model import Swin_AVE as S
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case(tag)
+    P = build_state(shapes, cfg["seed"], kind="swin_block", T=cfg["T"], res=cfg["res"])
+    blk = S.SwinTransformerBlock(dim=cfg["dim"], input_resolution=(cfg["res"], cfg["res"]), num_frames=cfg["T"],
+                                 num_heads=cfg["heads"], window_size=7, shift_size=cfg["shift"], t_attn=cfg["t_attn"],
+                                 adapter_mlp_ratio=cfg["ratio"], mode=cfg["mode"]).eval()
+    _load_into(blk, P, "blk.")
+    # structural: the block's own integer buffers equal the reference's
+    assert torch.equal(blk.attn.relative_position_index, torch.as_tensor(z["rel_index"]))
+    if blk.attn_mask is not None:
+        assert torch.equal(blk.attn_mask, torch.as_tensor(z["attn_mask"]))
+    blk = blk.to(gpu)
+    mine = _apply_freeze(blk)
+    assert mine == names
+    BT, N, C = cfg["B"] * cfg["T"], cfg["res"] ** 2, cfg["dim"]
+    v = seeded_tensor((BT, N, C), cfg["seed"] + 1); a = seeded_tensor((BT, N, C), cfg["seed"] + 2)
+    gv = seeded_tensor((BT, N, C), cfg["seed"] + 3); ga = seeded_tensor((BT, N, C), cfg["seed"] + 4)
+    X = torch.cat([v.reshape(-1, C), a.reshape(-1, C)]).to(BF16).to(gpu).requires_grad_(True)
+    out = blk(X)
+    _cmp(out[:BT * N], z["out_v"], f"{tag} out_v")
+    _cmp(out[BT * N:], z["out_a"], f"{tag} out_a")
+    dO = torch.cat([gv.reshape(-1, C), ga.reshape(-1, C)]).to(BF16).to(gpu)
+    out.backward(dO)
+    _cmp(X.grad[:BT * N], z["din_v"], f"{tag} din_v", max_rel=3e-2, l2_rel=2e-2)
+    _cmp(X.grad[BT * N:], z["din_a"], f"{tag} din_a", max_rel=3e-2, l2_rel=2e-2)
+    _cmp(_flat_grads(blk, names), z["grads"], f"{tag} param grads", max_rel=3e-2, l2_rel=2e-2)
+    # per-tensor view of the same gradients (a small tensor must not hide behind a large one)
+    d = dict(blk.named_parameters())
+    off = 0
+    for n in names:
+        k = d[n].numel()
+        ref = z["grads"][off:off + k]
+        off += k
+        if np.abs(ref).max() > 0:
+            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=4e-2, l2_rel=3e-2)
+
+
+def _build_model(S, cfg, P, gpu, train=False):
+    m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
+                                        embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                                        window_size=7, pretrained=None, ftmode=cfg["mode"],
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
+    _load_into(m, P)
+    m = m.to(gpu)
+    m.train(train)
+    return m
+
+
+def test_swin_tiny_fusion_model_matches_reference(stg, gpu):
+    from stgcma.model import Swin_AVE as S
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("swin_tiny_fusion")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    m = _build_model(S, cfg, P, gpu)
+    assert _apply_freeze(m) == names
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2).to(gpu)
+    logits = m(a, v, "fusion")
+    assert logits.dtype == F32 and tuple(logits.shape) == (B * T, 29)
+    err = float((logits.cpu() - torch.as_tensor(z["logits"])).abs().max())
+    _report.append(f"swin_tiny logits max abs err {err:.3e} (|logits| max {float(np.abs(z['logits']).max()):.3g})")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1).to(gpu)
+    loss = torch.nn.CrossEntropyLoss()(logits, tgt)
+    loss.backward()
+    _cmp(logits, z["logits"], "swin_tiny logits")
+    assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
+    _cmp(_flat_grads(m, names), z["grads"], "swin_tiny grads", max_rel=5e-2, l2_rel=3e-2)
+    assert err <= 1e-2 * max(1.0, float(np.abs(z["logits"]).max())), f"logit deviation {err}"
+
+
+def test_swin_b_fusion_full_model_matches_reference(stg, gpu):
+    """Headline configuration, B=1: logits within 1e-2 of the reference's fp32 CPU path; adapter-gradient norms agree."""
+    from stgcma.model import Swin_AVE as S
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("swin_b_fusion")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    m = _build_model(S, cfg, P, gpu)
+    del P
+    assert _apply_freeze(m) == names
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert [sum(p.numel() for p in m.parameters()), n_train] == list(z["n_params"][:2])
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2).to(gpu)
+    logits = m(a, v, "fusion")
+    err = float((logits.cpu() - torch.as_tensor(z["logits"])).abs().max())
+    _report.append(f"swin_b logits max abs err {err:.3e} (|logits| max {float(np.abs(z['logits']).max()):.3g})")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1).to(gpu)
+    loss = torch.nn.CrossEntropyLoss()(logits, tgt)
+    loss.backward()
+    d = dict(m.named_parameters())
+    norms = torch.stack([d[n].grad.float().norm().cpu() for n in names])
+    _cmp(norms, z["grad_norms"], "swin_b grad norms", max_rel=5e-2, l2_rel=3e-2)
+    _cmp(_flat_grads(m, names)[::97], z["grads_sample"], "swin_b grad sample", max_rel=8e-2, l2_rel=5e-2)
+    assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
+    assert err <= 1e-2 * max(1.0, float(np.abs(z["logits"]).max())), f"logit deviation {err}"
+
+
+def test_train_mode_droppath_and_dropout_run(stg, gpu):
+    """DropPath (temporal residual) and head Dropout are active in train mode: outputs differ between calls, stay finite,
+    and every trainable tensor receives a finite gradient."""
+    from stgcma.model import Swin_AVE as S
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("swin_tiny_fusion")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    m = _build_model(S, cfg, P, gpu, train=True)
+    _apply_freeze(m)
+    B, T = 2, cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), 1, 0.5).to(gpu); v = seeded_tensor((B, 3, T, 224, 224), 2).to(gpu)
+    torch.manual_seed(0)
+    l1 = m(a, v, "fusion")
+    l2 = m(a, v, "fusion")
+    assert torch.isfinite(l1).all() and torch.isfinite(l2).all()
+    assert float((l1 - l2).abs().max()) > 0
+    l1.sum().backward()
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_product_path_has_no_cpu_fallback(stg):
+    from stgcma.model import Swin_AVE as S
+    m = S.SwinTransformer2D_Adapter_New(label_dim=29, embed_dim=32, depths=[2, 2], num_heads=[1, 2], num_frames=2,
+                                        ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25])
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 224, 224), torch.zeros(1, 3, 2, 224, 224), "fusion")
