@@ -55,8 +55,8 @@ typedef struct {
     void* preact; int64_t ldp;
     const void* dact_src; int64_t ldd; int act_bwd;
     const float* row_scale; int64_t rs_outer; int64_t rs_inner;
-    const void* res1; int64_t ldr1;
-    const void* res2; int64_t ldr2;
+    const void* res1; int64_t ldr1; int res1_dtype;   /* STG_BF16 (branch tensors) or STG_F32 (the residual stream) */
+    const void* res2; int64_t ldr2; int res2_dtype;
     int64_t M; int N; int K;
 } stg_gemm_args;
 int stg_gemm_nt(const stg_gemm_args* args, void* stream);
@@ -75,10 +75,11 @@ int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx,
  * :1099,1117-1119 PatchEmbed3D.norm, :1312 final norm; CLIP_AVE.py:33-39).
  * gather4 != 0 folds PatchMerging's 2x2 strided gather + cat (Swin_AVE.py:967-972): logical row r of width 4*C is
  * [x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)] of frame r / (H/2*W/2); C is then the width of one source row.
- * x_dtype: STG_BF16 or STG_F32 input; y is bf16; mean/rstd fp32 per logical row (may be NULL in inference).
+ * x_dtype / y_dtype: STG_BF16 or STG_F32 (the residual stream is fp32, branch inputs bf16); mean/rstd fp32 per logical
+ * row (may be NULL in inference).
  */
 int stg_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
-                      void* y, int64_t ldy, float* mean, float* rstd,
+                      void* y, int y_dtype, int64_t ldy, float* mean, float* rstd,
                       int64_t rows, int C, int gather4, int H, int W, void* stream);
 /* dx (bf16) = LN backward wrt input; if add_to != NULL, dx = add_to + LN_bwd (fuses the residual-branch join).
  * dgamma/dbeta (fp32, atomically accumulated) optional -- only CLIP ln_post is trainable (traintest_adapt_ave29.py:52). */

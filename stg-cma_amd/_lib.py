@@ -29,8 +29,8 @@ class GemmArgs(C.Structure):
         ("preact", c_vp), ("ldp", c_i64),
         ("dact_src", c_vp), ("ldd", c_i64), ("act_bwd", C.c_int),
         ("row_scale", c_vp), ("rs_outer", c_i64), ("rs_inner", c_i64),
-        ("res1", c_vp), ("ldr1", c_i64),
-        ("res2", c_vp), ("ldr2", c_i64),
+        ("res1", c_vp), ("ldr1", c_i64), ("res1_dtype", C.c_int),
+        ("res2", c_vp), ("ldr2", c_i64), ("res2_dtype", C.c_int),
         ("M", c_i64), ("N", C.c_int), ("K", C.c_int),
     ]
 
@@ -70,7 +70,7 @@ SIGNATURES = {
     "stg_last_error": (C.c_char_p, []),
     "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
     "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64, c_vp]),
-    "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp,
+    "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, C.c_int, c_i64, c_vp, c_vp,
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
                                     c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),

@@ -30,12 +30,26 @@ struct GemmParams {
     bf16_t* preact; int64_t ldp;
     const bf16_t* dact_src; int64_t ldd; int act_bwd;
     const float* row_scale; int64_t rs_outer; int64_t rs_inner;
-    const bf16_t* res1; int64_t ldr1;
-    const bf16_t* res2; int64_t ldr2;
+    const void* res1; int64_t ldr1; int res1_f32;
+    const void* res2; int64_t ldr2; int res2_f32;
     int64_t M; int N; int K;
     int nbm, nbn;
     int vec_ok;
 };
+
+__device__ __forceinline__ void add_res4(const void* res, int f32, int64_t off, float* t) {
+    if (f32) {
+        const float4 z = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(res) + off);
+        t[0] += z.x; t[1] += z.y; t[2] += z.z; t[3] += z.w;
+    } else {
+        const u16x4 z = *reinterpret_cast<const u16x4*>(reinterpret_cast<const bf16_t*>(res) + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
+    }
+}
+__device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) {
+    return f32 ? reinterpret_cast<const float*>(res)[off] : bf2f(reinterpret_cast<const bf16_t*>(res)[off]);
+}
 
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
 
@@ -159,16 +173,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) t[r] *= rs;
                 }
-                if (p.res1) {
-                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.res1 + m * p.ldr1 + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
-                }
-                if (p.res2) {
-                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.res2 + m * p.ldr2 + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
-                }
+                if (p.res1) add_res4(p.res1, p.res1_f32, m * p.ldr1 + n, t);
+                if (p.res2) add_res4(p.res2, p.res2_f32, m * p.ldr2 + n, t);
                 if (p.c_f32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) =
                         make_float4(t[0], t[1], t[2], t[3]);
@@ -186,8 +192,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
                     v = act_apply(p.act, v);
                     if (p.dact_src) v *= act_grad(p.act_bwd, bf2f(p.dact_src[m * p.ldd + nn]));
                     v *= rs;
-                    if (p.res1) v += bf2f(p.res1[m * p.ldr1 + nn]);
-                    if (p.res2) v += bf2f(p.res2[m * p.ldr2 + nn]);
+                    if (p.res1) v += ld_res1(p.res1, p.res1_f32, m * p.ldr1 + nn);
+                    if (p.res2) v += ld_res1(p.res2, p.res2_f32, m * p.ldr2 + nn);
                     if (p.c_f32) reinterpret_cast<float*>(p.C)[m * p.ldc + nn] = v;
                     else reinterpret_cast<bf16_t*>(p.C)[m * p.ldc + nn] = f2bf(v);
                 }
@@ -327,6 +333,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     STG_CHECK(a->c_dtype == STG_BF16 || a->c_dtype == STG_F32, -3, "stg_gemm_nt: unsupported c_dtype %d", a->c_dtype);
     STG_CHECK(a->act >= 0 && a->act <= 2 && a->act_bwd >= 0 && a->act_bwd <= 2, -3, "stg_gemm_nt: bad act");
     if (a->row_scale) STG_CHECK(a->rs_outer > 0 && a->rs_inner > 0, -2, "stg_gemm_nt: bad row_scale params");
+    if (a->res1) STG_CHECK(a->res1_dtype == STG_BF16 || a->res1_dtype == STG_F32, -3, "stg_gemm_nt: bad res1 dtype");
+    if (a->res2) STG_CHECK(a->res2_dtype == STG_BF16 || a->res2_dtype == STG_F32, -3, "stg_gemm_nt: bad res2 dtype");
     if (a->M == 0) return 0;
     GemmParams p;
     p.A = (const bf16_t*)a->A; p.lda = a->lda;
@@ -336,8 +344,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     p.preact = (bf16_t*)a->preact; p.ldp = a->ldp;
     p.dact_src = (const bf16_t*)a->dact_src; p.ldd = a->ldd; p.act_bwd = a->act_bwd;
     p.row_scale = a->row_scale; p.rs_outer = a->rs_outer; p.rs_inner = a->rs_inner;
-    p.res1 = (const bf16_t*)a->res1; p.ldr1 = a->ldr1;
-    p.res2 = (const bf16_t*)a->res2; p.ldr2 = a->ldr2;
+    p.res1 = a->res1; p.ldr1 = a->ldr1; p.res1_f32 = (a->res1_dtype == STG_F32);
+    p.res2 = a->res2; p.ldr2 = a->ldr2; p.res2_f32 = (a->res2_dtype == STG_F32);
     p.M = a->M; p.N = a->N; p.K = a->K;
     const int64_t nbm = (a->M + BM - 1) / BM;
     const int64_t nbn = (a->N + BN - 1) / BN;
@@ -347,8 +355,9 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         return ptr == nullptr || ((((uintptr_t)ptr) % need) == 0 && (ld * bytes_per) % need == 0);
     };
     p.vec_ok = al(a->C, a->ldc, p.c_f32 ? 4 : 2, p.c_f32 ? 16 : 8) && al(a->bias, 4, 4, 16) &&
-               al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) && al(a->res1, a->ldr1, 2, 8) &&
-               al(a->res2, a->ldr2, 2, 8);
+               al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) &&
+               al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, p.res1_f32 ? 16 : 8) &&
+               al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, p.res2_f32 ? 16 : 8);
     hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

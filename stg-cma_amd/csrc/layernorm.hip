@@ -12,7 +12,7 @@ constexpr int MAXCH = 8;  // 16-byte chunks per lane  => C <= 64 * 8 * 8 = 4096
 struct LnParams {
     const void* x; int64_t ldx; int x_f32;
     const float* gamma; const float* beta; float eps;
-    bf16_t* y; int64_t ldy;
+    void* y; int64_t ldy; int y_f32;
     float* mean; float* rstd;
     int64_t rows; int C;   // C = logical row width (4*Csrc when gather4)
     int gather4; int Csrc; int H, W;
@@ -106,7 +106,13 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnParams p) {
             const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mu) * rs * g[j] + b[j];
-            store8(p.y + row * p.ldy + ch * 8, o);
+            if (p.y_f32) {
+                float* yp = reinterpret_cast<float*>(p.y) + row * p.ldy + ch * 8;
+                *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+                store8(reinterpret_cast<bf16_t*>(p.y) + row * p.ldy + ch * 8, o);
+            }
         }
     }
 }
@@ -210,7 +216,7 @@ int check_common(const char* who, int64_t rows, int C, int gather4, int H, int W
 }  // namespace
 
 extern "C" int stg_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
-                                 void* y, int64_t ldy, float* mean, float* rstd, int64_t rows, int C, int gather4,
+                                 void* y, int y_dtype, int64_t ldy, float* mean, float* rstd, int64_t rows, int C, int gather4,
                                  int H, int W, void* stream) {
     STG_CHECK(x && gamma && beta && y, -1, "stg_layernorm_fwd: null pointer");
     int rc = check_common("stg_layernorm_fwd", rows, C, gather4, H, W, ldx, x_dtype);
@@ -220,7 +226,8 @@ extern "C" int stg_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const 
     LnParams p = {};
     p.x = x; p.ldx = ldx; p.x_f32 = (x_dtype == STG_F32);
     p.gamma = gamma; p.beta = beta; p.eps = eps;
-    p.y = (bf16_t*)y; p.ldy = ldy; p.mean = mean; p.rstd = rstd;
+    STG_CHECK(y_dtype == STG_BF16 || y_dtype == STG_F32, -3, "stg_layernorm_fwd: unsupported y dtype");
+    p.y = y; p.ldy = ldy; p.y_f32 = (y_dtype == STG_F32); p.mean = mean; p.rstd = rstd;
     p.rows = rows; p.C = C; p.gather4 = gather4; p.Csrc = gather4 ? C / 4 : C; p.H = H; p.W = W;
     return dispatch_ln(false, p, (hipStream_t)stream);
 }

@@ -41,6 +41,14 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
 
 
+def _dt(t):
+    if t.dtype == BF16:
+        return STG_BF16
+    if t.dtype == F32:
+        return STG_F32
+    raise RuntimeError(f"unsupported dtype {t.dtype} (bf16 / fp32 only)")
+
+
 def _chk1d(t, name, dtype, n):
     if not t.is_cuda or t.dtype != dtype or t.dim() != 1 or t.shape[0] != n or not t.is_contiguous():
         raise RuntimeError(f"{name}: expected contiguous {dtype} GPU vector of length {n}")
@@ -82,11 +90,11 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             raise RuntimeError(f"row_scale: needs >= {need} entries, got {row_scale.numel()}")
         a.row_scale, a.rs_outer, a.rs_inner = _p(row_scale), int(rs_outer), int(rs_inner)
     if res1 is not None:
-        _chk2d(res1, "res1", BF16, cols=N, rows=M)
-        a.res1, a.ldr1 = _p(res1), _ld(res1)
+        _chk2d(res1, "res1", res1.dtype, cols=N, rows=M)
+        a.res1, a.ldr1, a.res1_dtype = _p(res1), _ld(res1), _dt(res1)
     if res2 is not None:
-        _chk2d(res2, "res2", BF16, cols=N, rows=M)
-        a.res2, a.ldr2 = _p(res2), _ld(res2)
+        _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
+        a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
     _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_preact else out
@@ -115,7 +123,7 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
                                        _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None, out_dtype=BF16):
     """x: [rows, C] bf16/fp32 -> y bf16 (+ mean, rstd).  gather4=(H, W): PatchMerging gather, x is [F*H*W, C] -> y [F*H*W/4, 4C]."""
     if x.dtype not in (BF16, F32):
         raise RuntimeError("layernorm: x must be bf16 or fp32")
@@ -133,12 +141,12 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, ou
         g4 = 0
     _chk1d(gamma, "gamma", F32, Cl)
     _chk1d(beta, "beta", F32, Cl)
-    y = torch.empty((rows, Cl), dtype=BF16, device=x.device) if out is None else out
-    _chk2d(y, "y", BF16, cols=Cl, rows=rows)
+    y = torch.empty((rows, Cl), dtype=out_dtype, device=x.device) if out is None else out
+    _chk2d(y, "y", y.dtype, cols=Cl, rows=rows)
     mean = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
     rstd = torch.empty((rows,), dtype=F32, device=x.device) if want_stats else None
     _lib.check(_lib.lib().stg_layernorm_fwd(_p(x), STG_BF16 if x.dtype == BF16 else STG_F32, _ld(x), _p(gamma), _p(beta),
-                                            float(eps), _p(y), _ld(y), _p(mean), _p(rstd), rows, Cl, g4, H, W, _stream()),
+                                            float(eps), _p(y), _dt(y), _ld(y), _p(mean), _p(rstd), rows, Cl, g4, H, W, _stream()),
                "stg_layernorm_fwd")
     return y, mean, rstd
 

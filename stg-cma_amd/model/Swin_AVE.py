@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import FusionBlockSpec, FusionHeadFn, PatchMergeFn, SwinFusionBlockFn, fusion_param_names, patch_embed_into
+from ..ops import BlockSpec, SwinBlockFn, SwinModelFn, block_buffer_names, block_param_names
 from ._common import DropPath, to_2tuple, trunc_normal_
 
 BF16 = torch.bfloat16
@@ -137,36 +137,19 @@ class SwinTransformerBlock(nn.Module):
             attn_mask = None
         self.register_buffer("attn_mask", attn_mask)
         H, W = self.input_resolution
-        self._spec = FusionBlockSpec(dim, H, W, num_frames, num_heads, self.window_size, self.shift_size, t_attn)
+        self._spec = BlockSpec(dim, H, W, num_frames, num_heads, self.window_size, self.shift_size, t_attn, mode=mode,
+                               drop_path=float(drop_path))
 
-    def _drop_scale(self, n_rows, device):
-        """timm DropPath mask for a tensor whose dim 0 has n_rows entries (scaled by 1/keep), or None in eval / p == 0."""
-        p = getattr(self.drop_path, "drop_prob", 0.)
-        if not self.training or p == 0.:
-            return None
-        keep = 1.0 - p
-        return torch.empty(n_rows, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+    def tensor_names(self):
+        return block_param_names(self._spec) + block_buffer_names(self._spec)
 
     def forward(self, X):
-        """X: fused bf16 token tensor [2*BT*N, C] (video rows first, then audio) for the two-stream modes."""
-        if self.mode != 'fusion_adapt':
-            raise NotImplementedError(f"block mode '{self.mode}' is routed by the model (see SwinTransformer2D_Adapter_New)")
-        spec = self._spec
-        R = X.shape[0]
-        assert R % (2 * spec.N * spec.T) == 0, "input feature has wrong size"
-        B = R // (2 * spec.N * spec.T)
-        names = fusion_param_names(self.t_attn)
-        params = [self.get_parameter(n) for n in names]
-        names = names + ["_rel_index"]
-        params.append(self.attn.relative_position_index.reshape(-1))
-        dp_v = dp_a = None
-        if self.t_attn:
-            names = names + ["_t_index", "_t_index_a"]
-            params += [self.attn.t_relative_coords, self.attn.t_relative_coords_a]
-            # DropPath on the temporal residual is drawn per (b, n) row of the '(b n) t c' layout (Swin_AVE.py:706-715)
-            dp_v = self._drop_scale(B * spec.N, X.device)
-            dp_a = self._drop_scale(B * spec.N, X.device)
-        return SwinFusionBlockFn.apply(X, spec, tuple(names), dp_v, dp_a, *params)
+        """X: fused token tensor [M*BT*N, C] (video rows first, then audio, for the two-stream modes; one modality for
+        'video_adapt' / 'audio_adapt').  fp32 (the residual-stream dtype) or bf16."""
+        names = self.tensor_names()
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        return SwinBlockFn.apply(X, self._spec, tuple(names), self.training, torch.is_grad_enabled(), *[sd[n] for n in names])
 
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, " \
@@ -181,12 +164,6 @@ class PatchMerging(nn.Module):
         self.input_resolution, self.dim = input_resolution, dim
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
-
-    def forward(self, X):
-        H, W = self.input_resolution
-        assert X.shape[0] % (H * W) == 0, "input feature has wrong size"
-        assert H % 2 == 0 and W % 2 == 0, f"x size ({H}*{W}) are not even."
-        return PatchMergeFn.apply(X, H, W, self.norm.weight, self.norm.bias, self.reduction.weight)
 
     def extra_repr(self):
         return f"input_resolution={self.input_resolution}, dim={self.dim}"
@@ -210,17 +187,6 @@ class BasicLayer(nn.Module):
             for i in range(depth)])
         self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
-    def forward(self, X):
-        for blk in self.blocks:
-            if self.use_checkpoint:
-                import torch.utils.checkpoint as checkpoint
-                X = checkpoint.checkpoint(blk, X, use_reentrant=False)
-            else:
-                X = blk(X)
-        if self.downsample is not None:
-            X = self.downsample(X)
-        return X
-
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, depth={self.depth}"
 
@@ -237,16 +203,6 @@ class PatchEmbed3D(nn.Module):
         self.num_patches = self.patches_resolution[0] * self.patches_resolution[1]
         self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
-
-    def embed_into(self, x, out_rows):
-        B, _, D, H, W = x.shape
-        if W % self.patch_size[2] or H % self.patch_size[1] or D % self.patch_size[0]:
-            raise NotImplementedError("input size must be divisible by the patch size (the reference's padding path never "
-                                      "triggers at 224, Swin_AVE.py:1108-1113)")
-        nw = self.norm.weight if self.norm is not None else None
-        nb = self.norm.bias if self.norm is not None else None
-        patch_embed_into(x, self.proj.weight, self.proj.bias, nw, nb, out_rows)
-        return B, D
 
 
 class SwinTransformer2D_Adapter_New(nn.Module):
@@ -368,29 +324,57 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         return {'relative_position_bias_table', 'temporal_position_bias_table'}
 
     # ------------------------------------------------------------------ forward
+    def _plan(self):
+        """Static launch plan of the whole network for ops.SwinModelFn (rebuilt lazily; cheap)."""
+        plan = getattr(self, "_plan_cache", None)
+        if plan is not None:
+            return plan
+
+        class Plan:
+            pass
+
+        plan = Plan()
+        first = self.layers[0].blocks[0]._spec
+        plan.mods = first.mods
+        plan.n_patches = self.patch_embed.num_patches
+        plan.embed_dim = self.embed_dim
+        plan.stages = []
+        for s_i, layer in enumerate(self.layers):
+            st = {"blocks": [], "names": {}, "merge": None}
+            for b_i, blk in enumerate(layer.blocks):
+                pre = f"layers.{s_i}.blocks.{b_i}."
+                st["blocks"].append((blk._spec, pre))
+                st["names"][pre] = blk.tensor_names()
+            if layer.downsample is not None:
+                H, W = layer.input_resolution
+                st["merge"] = (H, W, f"layers.{s_i}.downsample.")
+            plan.stages.append(st)
+        last = self.layers[-1].input_resolution
+        plan.n_tok_last = last[0] * last[1]
+        plan.head_drop = self.mlp_head[1].p if len(plan.mods) == 2 else 0.
+        train_ok = ("Adapter", "gate_", "temporal_position_bias_table", "mlp_head.")
+        plan.trainable_ok = lambda n: any(t in n for t in train_ok)
+        self._plan_cache = plan
+        return plan
+
     def forward(self, a, v, mode):
-        if mode not in ('fusion',):
-            raise NotImplementedError(f"forward mode '{mode}': only 'fusion' runs on the HIP path in this build")
-        if mode != self.ftmode:
+        """a: [B, T, H, W] spectrogram segments, v: [B, 3, T, H, W] frames -> fp32 logits [(B*T), label_dim]
+        (Swin_AVE.py:1479-1599).  Runs entirely on the HIP path; raises when inputs / parameters are not on a GPU."""
+        if mode not in ('audioonly', 'videoonly', 'multimodal', 'fusion') or mode != self.ftmode:
             raise TypeError('ftmode is not expected !!!')
         if not self.t_relative:
             raise NotImplementedError("t_relative=False (absolute temporal embedding) is not on the HIP path yet")
-        if not v.is_cuda:
+        ref = v if mode != 'audioonly' else a
+        if not ref.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
-        B, _, T, Hh, Ww = v.shape
-        N = self.patch_embed.num_patches
-        C = self.embed_dim
-        Rm = B * T * N
-        X = torch.empty((2 * Rm, C), dtype=BF16, device=v.device)
-        self.patch_embed.embed_into(v, X[:Rm])
-        self.patch_embed_audio.embed_into(a.unsqueeze(1), X[Rm:])
-        for layer in self.layers:
-            X = layer(X)
-        n_tok = self.layers[-1].input_resolution[0] * self.layers[-1].input_resolution[1]
-        lin0, drop, lin2 = self.mlp_head[0], self.mlp_head[1], self.mlp_head[2]
-        drop_mask = None
-        if self.training and drop.p > 0:
-            keep = 1.0 - drop.p
-            drop_mask = torch.empty((B * T, lin0.out_features), dtype=torch.float32, device=v.device).bernoulli_(keep).div_(keep)
-        return FusionHeadFn.apply(X, n_tok, drop_mask, self.norm.weight, self.norm.bias, lin0.weight, lin0.bias,
-                                  lin2.weight, lin2.bias)
+        if self.layers[0].use_checkpoint:
+            raise NotImplementedError("use_checkpoint=True: activation recompute is not wired into the fused model node yet")
+        names, tensors = [], []
+        for n, p in self.named_parameters():
+            names.append(n)
+            tensors.append(p)
+        for n, b in self.named_buffers():
+            if not n.endswith("attn_mask"):
+                names.append(n)
+                tensors.append(b)
+        return SwinModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)

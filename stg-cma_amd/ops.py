@@ -1,23 +1,29 @@
-"""Autograd glue for the Swin + STG-CMA hot path: block-level torch.autograd.Functions whose forward AND backward are
-explicit sequences of libstgcma_hip.so launches (kernels.py).  No ATen compute kernel runs on the hot path: residual
-joins, activation gradients, DropPath scaling, window (un)partitioning and the temporal rearranges are all fused into GEMM
-epilogues, LayerNorm-backward `add_to`, or attention addressing.
+"""Forward / backward orchestration of the Swin + STG-CMA hot path as explicit sequences of libstgcma_hip.so launches
+(kernels.py), wrapped in torch.autograd.Functions.  No ATen compute kernel runs on the hot path: residual joins,
+activation gradients, DropPath scaling, window (un)partitioning and the temporal rearranges are fused into GEMM epilogues,
+LayerNorm-backward `add_to`, or attention addressing.
 
-Data layout: one fused token tensor X[2*BT*N, C] bf16 -- rows [0, BT*N) are video tokens, rows [BT*N, 2*BT*N) audio tokens,
-each in the reference's '(b t) n c' order -- so every frozen (shared) weight runs ONE GEMM over both modalities
-(Swin_AVE.py:743-745 calls self.attn twice with the same weights) while per-modality adapters address row slices.
+Data layout.  One fused token tensor X[M*BT*N, C]: rows of modality 0 (video) first, then modality 1 (audio), each in the
+reference's '(b t) n c' order, so every frozen (shared) weight runs ONE GEMM over both modalities (Swin_AVE.py:743-745
+calls self.attn twice with the same weights) while per-modality adapters address row slices.  The residual stream X is
+fp32 (what the reference's autocast loop effectively keeps: LayerNorm outputs / residual adds promote to fp32), every
+branch tensor (LN output, qkv, attention output, MLP hidden, adapter hidden) is bf16, and the gradient stream dX is bf16.
 
-Backward computes dgrad through the frozen backbone and wgrad only for tensors with requires_grad (adapters, gates,
-temporal bias tables, head), mirroring what autograd does for the reference under its freeze filter
-(traintest_adapt_ave29.py:38-61).
+Backward computes dgrad through the frozen backbone and wgrad only for tensors whose gradient autograd asks for
+(adapters, gates, temporal bias tables, head) -- what autograd does for the reference under its freeze filter
+(traintest_adapt_ave29.py:38-61).  Asking for a backbone weight gradient raises NotImplementedError.
 """
+import weakref
+
 import torch
 
 from . import kernels as K
 from .kernels import ACT_GELU, ACT_NONE, BF16, F32
 
+RESIDUAL_DTYPE = F32
+
 # ------------------------------------------------------------------------------------------------ weight shadows
-_shadow_cache = {}
+_shadow_cache = {}   # id(parameter) -> (weakref to it, {transpose: ((data_ptr, version), bf16 tensor)})
 
 
 def shadow(p, transpose=False):
@@ -28,13 +34,20 @@ def shadow(p, transpose=False):
         raise RuntimeError("stg-cma_amd: parameters must live on the GPU (the HIP path has no CPU fallback)")
     if t.dtype != F32:
         raise RuntimeError(f"stg-cma_amd: parameters are expected in fp32 (got {t.dtype}); bf16 shadows are made internally")
-    key = (t.data_ptr(), bool(transpose), tuple(t.shape))
-    hit = _shadow_cache.get(key)
-    ver = p._version
-    if hit is not None and hit[0] == ver:
+    # keyed by the parameter OBJECT (weakly): a freed model's storage may be recycled for a new parameter of the same shape
+    # and version, so the address alone does not identify the values
+    ent = _shadow_cache.get(id(p))
+    if ent is None or ent[0]() is not p:
+        key = id(p)
+        ent = (weakref.ref(p, lambda _r, k=key: _shadow_cache.pop(k, None)), {})
+        _shadow_cache[key] = ent
+    slot = ent[1]
+    tag = (t.data_ptr(), p._version)
+    hit = slot.get(bool(transpose))
+    if hit is not None and hit[0] == tag:
         return hit[1]
     s = K.cast_bf16(t.contiguous(), transpose=transpose)
-    _shadow_cache[key] = (ver, s)
+    slot[bool(transpose)] = (tag, s)
     return s
 
 
@@ -110,29 +123,63 @@ def _check_frozen(need, names, who):
                 f"traintest_adapt_ave29.py:52-61). Freeze the backbone before calling forward.")
 
 
-# ------------------------------------------------------------------------------------------------ fusion block
-class FusionBlockSpec:
-    """Static description of one SwinTransformerBlock in 'fusion_adapt' mode (Swin_AVE.py:317-391)."""
+def drop_scale(p, n_rows, device, training):
+    """timm DropPath mask over n_rows leading entries, scaled by 1/keep; None in eval or when p == 0."""
+    if not training or p == 0.:
+        return None
+    keep = 1.0 - p
+    return torch.empty(n_rows, dtype=F32, device=device).bernoulli_(keep).div_(keep)
 
-    def __init__(self, C, H, W, T, heads, ws, shift, t_attn):
+
+# ------------------------------------------------------------------------------------------------ Swin block
+class BlockSpec:
+    """Static description of one SwinTransformerBlock (Swin_AVE.py:317-391).
+
+    mods: modality ids present in the fused tensor ((0, 1) two-stream, (0,) video only, (1,) audio only);
+    fuse: gated cross-modal attention inside the S-adapters ('fusion_adapt');
+    parallel: FFN adapter parallel to the MLP on norm2(x), scaled 0.5 with DropPath ('video_adapt' / 'audio_adapt'),
+              otherwise serial on the MLP output."""
+
+    def __init__(self, C, H, W, T, heads, ws, shift, t_attn, mode="fusion_adapt", drop_path=0.):
         self.C, self.H, self.W, self.T, self.heads, self.ws, self.shift, self.t_attn = C, H, W, T, heads, ws, shift, t_attn
         self.N = H * W
         self.nW = (H // ws) * (W // ws)
         self.hd = C // heads
+        self.mode = mode
+        self.drop_path = drop_path
+        self.mods = {"fusion_adapt": (0, 1), "multimodal_adapt_no_fusion": (0, 1), "video_adapt": (0,), "audio_adapt": (1,)}[mode]
+        self.fuse = mode == "fusion_adapt"
+        self.parallel = mode in ("video_adapt", "audio_adapt")
+        if self.hd not in (16, 32, 48, 64, 96, 128):
+            raise NotImplementedError(f"attention head dim {self.hd} unsupported (need 16/32/48/64/96/128)")
 
 
-# Order of the parameter tensors handed to SwinFusionBlockFn (names relative to the block module)
-def fusion_param_names(t_attn):
+FusionBlockSpec = BlockSpec
+_SFX = ("", "_Audio")
+
+
+def block_param_names(spec):
+    """Parameter names (relative to the block module) the block functions read, in a fixed order."""
     names = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
              "attn.relative_position_bias_table", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
              "mlp.fc2.weight", "mlp.fc2.bias", "gate_v", "gate_a"]
-    ad = ["S_Adapter", "S_Adapter2", "S_Adapter_Audio", "S_Adapter2_Audio"]
-    if t_attn:
+    ad = []
+    for m in spec.mods:
+        ad += ["S_Adapter" + _SFX[m], "S_Adapter2" + _SFX[m]]
+    if spec.t_attn:
         names += ["attn.temporal_position_bias_table", "attn.temporal_position_bias_table_audio"]
-        ad += ["T_Adapter", "T_Adapter_Audio"]
+        ad += ["T_Adapter" + _SFX[m] for m in spec.mods]
     for a in ad:
         names += [f"{a}.D_fc1.weight", f"{a}.D_fc1.bias", f"{a}.D_fc2.weight", f"{a}.D_fc2.bias"]
     return names
+
+
+def block_buffer_names(spec):
+    return ["attn.relative_position_index"] + (["attn.t_relative_coords", "attn.t_relative_coords_a"] if spec.t_attn else [])
+
+
+def fusion_param_names(t_attn):
+    return block_param_names(BlockSpec(32, 7, 7, 1, 1, 7, 0, t_attn))
 
 
 FROZEN_ONLY = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
@@ -144,6 +191,7 @@ class _Adapter:
     """Shadows + parameter handles of one Adapter (D_fc1 -> GELU -> D_fc2)."""
 
     def __init__(self, P, name):
+        self.name = name
         self.w1p, self.b1p = P[name + ".D_fc1.weight"], P[name + ".D_fc1.bias"]
         self.w2p, self.b2p = P[name + ".D_fc2.weight"], P[name + ".D_fc2.bias"]
         self.dh = self.w1p.shape[0]
@@ -165,22 +213,20 @@ def _zeros_like_f32(p):
 class _Grads:
     """fp32 gradient buffers for the trainable tensors of a call, keyed by parameter name."""
 
-    def __init__(self, P, need):
-        self.P = P
-        self.need = need
+    def __init__(self, P, need, prefix=""):
+        self.P, self.need, self.prefix = P, need, prefix
         self.g = {}
 
     def buf(self, name):
-        p = self.P[name]
-        if not self.need.get(name, False):
+        if not self.need.get(self.prefix + name, False):
             return None
         if name not in self.g:
-            self.g[name] = _zeros_like_f32(p)
+            self.g[name] = _zeros_like_f32(self.P[name])
         return self.g[name]
 
 
 def _adapter_wgrad(G, name, dZ, X, dY2, H2, *, rs=None, rs_outer=1, rs_inner=1):
-    """Accumulate dW/db of D_fc1 (dZ^T X) and D_fc2 (dY2^T H2) when they train."""
+    """Accumulate dW/db of D_fc1 (dZ^T X) and D_fc2 ((s*dY2)^T H2) when they train."""
     w1, b1 = G.buf(name + ".D_fc1.weight"), G.buf(name + ".D_fc1.bias")
     if w1 is not None or b1 is not None:
         if w1 is None or b1 is None:
@@ -226,226 +272,250 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
 
 
-class SwinFusionBlockFn(torch.autograd.Function):
-    """SwinTransformerBlock.forward, mode 'fusion_adapt' (Swin_AVE.py:693-813), on the fused token tensor."""
+def _slices(spec, R):
+    nm = len(spec.mods)
+    Rm = R // nm
+    return Rm, [slice(i * Rm, (i + 1) * Rm) for i in range(nm)]
 
-    @staticmethod
-    def forward(ctx, X, spec, names, dp_v, dp_a, *params):
-        P = dict(zip(names, params))
-        need = dict(zip(names, ctx.needs_input_grad[5:]))
-        _check_frozen(need, FROZEN_ONLY, "SwinFusionBlock")
-        save = any(ctx.needs_input_grad)
-        R, C = X.shape
-        Rm = R // 2
-        BT = Rm // spec.N
-        B = BT // spec.T
-        T, N, H = spec.T, spec.N, spec.heads
-        g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, T)
-        S = {}
-        n1g, n1b = f32c(P["norm1.weight"]), f32c(P["norm1.bias"])
-        wqkv, bqkv = shadow(P["attn.qkv.weight"]), f32c(P["attn.qkv.bias"])
-        wproj, bproj = shadow(P["attn.proj.weight"]), f32c(P["attn.proj.bias"])
-        gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
-        sl = (slice(0, Rm), slice(Rm, R))
-        dps = (dp_v, dp_a)
 
-        # ---------------- temporal attention + T_Adapter (even blocks; :705-716)
-        if spec.t_attn:
-            Y, mean, rstd = K.layernorm_fwd(X, n1g, n1b, want_stats=save)
-            QKV = K.gemm_nt(Y, wqkv, bqkv)
-            del Y
-            tbias = torch.empty((2, H, T * T), dtype=F32, device=X.device)
-            K.bias_gather(f32c(P["attn.temporal_position_bias_table"]), P["_t_index"], out=tbias[0])
-            K.bias_gather(f32c(P["attn.temporal_position_bias_table_audio"]), P["_t_index_a"], out=tbias[1])
-            tg = K.AttnGeom(2 * B * N, H, T, spec.hd, G=N, outer=T * N, map_q=g["tmap"], scale=spec.hd ** -0.5,
-                            bias=tbias, bias_div=B * N, bias_mod=2)
-            AO, lse = K.attn_fwd(tg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
-            PO = K.gemm_nt(AO, wproj, bproj)
-            X1 = torch.empty_like(X)
-            hz = []
-            for m, an in enumerate(("T_Adapter", "T_Adapter_Audio")):
-                A = _Adapter(P, an)
-                Ht, Zt = K.gemm_nt(PO[sl[m]], A.w1, A.b1, act=ACT_GELU, want_preact=True)
-                K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[m]], res1=X[sl[m]], row_scale=dps[m], rs_outer=T * N, rs_inner=N)
-                hz.append((Ht, Zt))
-            if save:
-                S["t"] = (X, mean, rstd, QKV, AO, lse, PO, hz, tbias)
-            del QKV, AO, PO
-        else:
-            X1 = X
+def _temporal_geom(spec, B, g, tbias, nm):
+    return K.AttnGeom(nm * B * spec.N, spec.heads, spec.T, spec.hd, G=spec.N, outer=spec.T * spec.N, map_q=g["tmap"],
+                      scale=spec.hd ** -0.5, bias=tbias, bias_div=B * spec.N, bias_mod=nm)
 
-        # ---------------- (shifted-)window attention + window-level cross-modal adapter (:718-787)
-        Y, mean, rstd = K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
+
+def _window_geom(spec, BT, g, sbias, nm):
+    P = nm * BT * spec.nW
+    return K.AttnGeom(P, spec.heads, spec.ws * spec.ws, spec.hd, G=spec.nW, outer=spec.N, map_q=g["wmap"],
+                      scale=spec.hd ** -0.5, bias=sbias, bias_div=P, bias_mod=1, mask=g["mask"])
+
+
+def block_forward(X, spec, P, training, save):
+    """SwinTransformerBlock.forward for every mode (Swin_AVE.py:393-813) on the fused fp32 token tensor.
+    P: {name: tensor} (block_param_names + block_buffer_names).  Returns (X_out, saved-state dict or None)."""
+    R, C = X.shape
+    assert C == spec.C and X.dtype == RESIDUAL_DTYPE
+    Rm, sl = _slices(spec, R)
+    nm = len(spec.mods)
+    BT = Rm // spec.N
+    B = BT // spec.T
+    assert B * spec.T * spec.N == Rm, "input feature has wrong size"
+    T, N, H = spec.T, spec.N, spec.heads
+    g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, T)
+    S = {}
+    n1g, n1b = f32c(P["norm1.weight"]), f32c(P["norm1.bias"])
+    wqkv, bqkv = shadow(P["attn.qkv.weight"]), f32c(P["attn.qkv.bias"])
+    wproj, bproj = shadow(P["attn.proj.weight"]), f32c(P["attn.proj.bias"])
+    gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
+
+    # ---------------- temporal attention + T_Adapter (even blocks; :705-716).  DropPath per (b, n) row.
+    if spec.t_attn:
+        dps = [drop_scale(spec.drop_path, B * N, X.device, training) for _ in spec.mods]
+        Y, mean, rstd = K.layernorm_fwd(X, n1g, n1b, want_stats=save)
         QKV = K.gemm_nt(Y, wqkv, bqkv)
         del Y
-        nn_ = spec.ws * spec.ws
-        sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["_rel_index"])
-        wg = K.AttnGeom(2 * BT * spec.nW, H, nn_, spec.hd, G=spec.nW, outer=N, map_q=g["wmap"], scale=spec.hd ** -0.5,
-                        bias=sbias, bias_div=2 * BT * spec.nW, bias_mod=1, mask=g["mask"])
-        AO, lse = K.attn_fwd(wg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
+        tbias = torch.empty((nm, H, T * T), dtype=F32, device=X.device)
+        for i, m in enumerate(spec.mods):
+            tab = "attn.temporal_position_bias_table" + ("_audio" if m else "")
+            K.bias_gather(f32c(P[tab]), P["attn.t_relative_coords" + ("_a" if m else "")], out=tbias[i])
+        AO, lse = K.attn_fwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
         PO = K.gemm_nt(AO, wproj, bproj)
-        Av, Aa = _Adapter(P, "S_Adapter2"), _Adapter(P, "S_Adapter2_Audio")
-        Hv, Zv = K.gemm_nt(PO[sl[0]], Av.w1, Av.b1, act=ACT_GELU, want_preact=True)
-        Ha, Za = K.gemm_nt(PO[sl[1]], Aa.w1, Aa.b1, act=ACT_GELU, want_preact=True)
-        Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, Hv, Ha, gate_v, gate_a, True, g, save)
-        X2 = torch.empty_like(X)
-        K.gemm_nt(Hv2, Av.w2, Av.b2, out=X2[sl[0]], res1=PO[sl[0]], res2=X1[sl[0]])
-        K.gemm_nt(Ha2, Aa.w2, Aa.b2, out=X2[sl[1]], res1=PO[sl[1]], res2=X1[sl[1]])
+        X1 = torch.empty_like(X)
+        hz = []
+        for i, m in enumerate(spec.mods):
+            A = _Adapter(P, "T_Adapter" + _SFX[m])
+            Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True)
+            K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[i]], res1=X[sl[i]], row_scale=dps[i], rs_outer=T * N, rs_inner=N)
+            hz.append((Ht, Zt))
         if save:
-            S["s"] = (X1, mean, rstd, QKV, AO, lse, PO, Hv, Zv, Ha, Za, Hv2, Ha2, xs, sbias)
+            S["t"] = (X, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
         del QKV, AO, PO
+    else:
+        X1 = X
 
-        # ---------------- FFN + frame-global cross-modal adapter on the MLP output (:790-811)
-        Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
-        Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_preact=True)
-        del Y
-        M = K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
-        del Hm
-        Av, Aa = _Adapter(P, "S_Adapter"), _Adapter(P, "S_Adapter_Audio")
-        Hv, Zv = K.gemm_nt(M[sl[0]], Av.w1, Av.b1, act=ACT_GELU, want_preact=True)
-        Ha, Za = K.gemm_nt(M[sl[1]], Aa.w1, Aa.b1, act=ACT_GELU, want_preact=True)
-        Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, Hv, Ha, gate_v, gate_a, False, g, save)
-        X3 = torch.empty_like(X)
-        K.gemm_nt(Hv2, Av.w2, Av.b2, out=X3[sl[0]], res1=M[sl[0]], res2=X2[sl[0]])
-        K.gemm_nt(Ha2, Aa.w2, Aa.b2, out=X3[sl[1]], res1=M[sl[1]], res2=X2[sl[1]])
+    # ---------------- (shifted-)window attention + S_Adapter2 (window-level cross-modal when fusing) (:718-787)
+    Y, mean, rstd = K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
+    QKV = K.gemm_nt(Y, wqkv, bqkv)
+    del Y
+    sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
+    AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
+    PO = K.gemm_nt(AO, wproj, bproj)
+    ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
+    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+    xs = None
+    if spec.fuse:
+        Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, save)
+        H2 = [Hv2, Ha2]
+    else:
+        H2 = [hz_[0] for hz_ in HZ]
+    X2 = torch.empty_like(X)
+    for i, A in enumerate(ads):
+        K.gemm_nt(H2[i], A.w2, A.b2, out=X2[sl[i]], res1=PO[sl[i]], res2=X1[sl[i]])
+    if save:
+        S["s"] = (X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias)
+    del QKV, AO, PO, HZ, H2
+
+    # ---------------- FFN + S_Adapter (:790-811; parallel variant :438-440)
+    Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
+    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_preact=True)
+    M = K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
+    del Hm
+    ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
+    X3 = torch.empty_like(X)
+    if spec.parallel:
+        # x + mlp(xn) + drop_path(0.5 * S_Adapter(xn)): DropPath per frame (dim 0 of the (BT, N, C) tensor)
+        dpf = drop_scale(spec.drop_path, BT, X.device, training)
+        rs = (0.5 * dpf) if dpf is not None else torch.full((BT,), 0.5, dtype=F32, device=X.device)
+        A = ads[0]
+        Ha_, Za_ = K.gemm_nt(Y, A.w1, A.b1, act=ACT_GELU, want_preact=True)
+        K.gemm_nt(Ha_, A.w2, A.b2, out=X3, row_scale=rs, rs_outer=N, rs_inner=1, res1=M, res2=X2)
         if save:
-            S["f"] = (X2, mean, rstd, Zm, M, Hv, Zv, Ha, Za, Hv2, Ha2, xs)
-            ctx.S, ctx.P, ctx.spec, ctx.names, ctx.dps, ctx.need = S, P, spec, names, dps, need
-            ctx.dims = (R, C, Rm, BT, B)
-        return X3
+            S["f"] = (X2, mean, rstd, Zm, Y, Ha_, Za_, rs)
+    else:
+        del Y
+        HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+        xs = None
+        if spec.fuse:
+            Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, save)
+            H2 = [Hv2, Ha2]
+        else:
+            H2 = [hz_[0] for hz_ in HZ]
+        for i, A in enumerate(ads):
+            K.gemm_nt(H2[i], A.w2, A.b2, out=X3[sl[i]], res1=M[sl[i]], res2=X2[sl[i]])
+        if save:
+            S["f"] = (X2, mean, rstd, Zm, M, HZ, H2, xs)
+    return X3, (S if save else None)
 
-    @staticmethod
-    def backward(ctx, dX3):
-        S, P, spec, names, dps = ctx.S, ctx.P, ctx.spec, ctx.names, ctx.dps
-        R, C, Rm, BT, B = ctx.dims
-        T, N, H = spec.T, spec.N, spec.heads
-        g = geom(dX3.device, spec.H, spec.W, spec.ws, spec.shift, T)
-        dX3 = dX3.contiguous()
-        G = _Grads(P, ctx.need)
-        sl = (slice(0, Rm), slice(Rm, R))
-        gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
-        dgv, dga = G.buf("gate_v"), G.buf("gate_a")
-        n1g = f32c(P["norm1.weight"])
-        wqkv_t, wproj_t = shadow(P["attn.qkv.weight"], True), shadow(P["attn.proj.weight"], True)
 
-        # ---------------- FFN + global cross-modal
-        X2, mean, rstd, Zm, M, Hv, Zv, Ha, Za, Hv2, Ha2, xs = S.pop("f")
-        Av, Aa = _Adapter(P, "S_Adapter"), _Adapter(P, "S_Adapter_Audio")
-        dHv2 = K.gemm_nt(dX3[sl[0]], Av.w2t)
-        dHa2 = K.gemm_nt(dX3[sl[1]], Aa.w2t)
-        dHv, dHa = _cross_modal_bwd(spec, BT, Hv, Ha, gate_v, gate_a, False, g, xs, dHv2, dHa2, dgv, dga)
-        dZv, dZa = K.act_bwd(dHv, Zv, ACT_GELU), K.act_bwd(dHa, Za, ACT_GELU)
-        _adapter_wgrad(G, "S_Adapter", dZv, M[sl[0]], dX3[sl[0]], Hv2)
-        _adapter_wgrad(G, "S_Adapter_Audio", dZa, M[sl[1]], dX3[sl[1]], Ha2)
+def block_backward(S, spec, P, need, prefix, dX3):
+    """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad})."""
+    R, C = dX3.shape
+    Rm, sl = _slices(spec, R)
+    nm = len(spec.mods)
+    BT = Rm // spec.N
+    B = BT // spec.T
+    T, N, H = spec.T, spec.N, spec.heads
+    g = geom(dX3.device, spec.H, spec.W, spec.ws, spec.shift, T)
+    G = _Grads(P, need, prefix)
+    gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
+    dgv, dga = G.buf("gate_v"), G.buf("gate_a")
+    n1g = f32c(P["norm1.weight"])
+    wqkv_t, wproj_t = shadow(P["attn.qkv.weight"], True), shadow(P["attn.proj.weight"], True)
+
+    # ---------------- FFN + S_Adapter
+    ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
+    if spec.parallel:
+        X2, mean, rstd, Zm, Y, Ha_, Za_, rs = S.pop("f")
+        A = ads[0]
+        dHa = K.gemm_nt(dX3, A.w2t, row_scale=rs, rs_outer=N, rs_inner=1)
+        dZa = K.act_bwd(dHa, Za_, ACT_GELU)
+        _adapter_wgrad(G, A.name, dZa, Y, dX3, Ha_, rs=rs, rs_outer=N, rs_inner=1)
+        dYa = K.gemm_nt(dZa, A.w1t)
+        dZm = K.gemm_nt(dX3, shadow(P["mlp.fc2.weight"], True), dact_src=Zm, act_bwd=ACT_GELU)
+        dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True), res1=dYa)
+        del Y, Ha_, Za_, dHa, dZa, dYa, dZm, Zm
+    else:
+        X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
+        dH2 = [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
+        if spec.fuse:
+            dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, xs, dH2[0], dH2[1], dgv, dga)
+            dHh = [dHv, dHa]
+        else:
+            dHh = dH2
         dM = torch.empty_like(dX3)
-        K.gemm_nt(dZv, Av.w1t, out=dM[sl[0]], res1=dX3[sl[0]])
-        K.gemm_nt(dZa, Aa.w1t, out=dM[sl[1]], res1=dX3[sl[1]])
-        del Hv, Zv, Ha, Za, Hv2, Ha2, xs, dHv2, dHa2, dHv, dHa, dZv, dZa, M
+        for i, A in enumerate(ads):
+            dZ = K.act_bwd(dHh[i], HZ[i][1], ACT_GELU)
+            _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
+            K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
+        del HZ, H2, xs, dH2, dHh, M
         dZm = K.gemm_nt(dM, shadow(P["mlp.fc2.weight"], True), dact_src=Zm, act_bwd=ACT_GELU)
         del dM, Zm
         dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True))
         del dZm
-        dX2 = K.layernorm_bwd(dY, X2, f32c(P["norm2.weight"]), mean, rstd, add_to=dX3)
-        del dY, X2, dX3
+    dX2 = K.layernorm_bwd(dY, X2, f32c(P["norm2.weight"]), mean, rstd, add_to=dX3)
+    del dY, X2, dX3
 
-        # ---------------- window attention + window-level cross-modal
-        X1, mean, rstd, QKV, AO, lse, PO, Hv, Zv, Ha, Za, Hv2, Ha2, xs, sbias = S.pop("s")
-        Av, Aa = _Adapter(P, "S_Adapter2"), _Adapter(P, "S_Adapter2_Audio")
-        dHv2 = K.gemm_nt(dX2[sl[0]], Av.w2t)
-        dHa2 = K.gemm_nt(dX2[sl[1]], Aa.w2t)
-        dHv, dHa = _cross_modal_bwd(spec, BT, Hv, Ha, gate_v, gate_a, True, g, xs, dHv2, dHa2, dgv, dga)
-        dZv, dZa = K.act_bwd(dHv, Zv, ACT_GELU), K.act_bwd(dHa, Za, ACT_GELU)
-        _adapter_wgrad(G, "S_Adapter2", dZv, PO[sl[0]], dX2[sl[0]], Hv2)
-        _adapter_wgrad(G, "S_Adapter2_Audio", dZa, PO[sl[1]], dX2[sl[1]], Ha2)
-        dPO = torch.empty_like(dX2)
-        K.gemm_nt(dZv, Av.w1t, out=dPO[sl[0]], res1=dX2[sl[0]])
-        K.gemm_nt(dZa, Aa.w1t, out=dPO[sl[1]], res1=dX2[sl[1]])
-        del Hv, Zv, Ha, Za, Hv2, Ha2, xs, dHv2, dHa2, dHv, dHa, dZv, dZa, PO
+    # ---------------- window attention + S_Adapter2
+    X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias = S.pop("s")
+    ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
+    dH2 = [K.gemm_nt(dX2[sl[i]], A.w2t) for i, A in enumerate(ads)]
+    if spec.fuse:
+        dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, xs, dH2[0], dH2[1], dgv, dga)
+        dHh = [dHv, dHa]
+    else:
+        dHh = dH2
+    dPO = torch.empty_like(dX2)
+    for i, A in enumerate(ads):
+        dZ = K.act_bwd(dHh[i], HZ[i][1], ACT_GELU)
+        _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
+        K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
+    del HZ, H2, xs, dH2, dHh, PO
+    dAO = K.gemm_nt(dPO, wproj_t)
+    del dPO
+    dQKV = torch.empty_like(QKV)
+    K.attn_bwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
+               dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+    del QKV, AO, dAO
+    dY = K.gemm_nt(dQKV, wqkv_t)
+    del dQKV
+    dX1 = K.layernorm_bwd(dY, X1, n1g, mean, rstd, add_to=dX2)
+    del dY, dX2, X1
+
+    # ---------------- temporal attention + T_Adapter
+    if spec.t_attn:
+        X0, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps = S.pop("t")
+        dPO = torch.empty_like(dX1)
+        for i, m in enumerate(spec.mods):
+            A = _Adapter(P, "T_Adapter" + _SFX[m])
+            Ht, Zt = hz[i]
+            dHt = K.gemm_nt(dX1[sl[i]], A.w2t, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
+            dZt = K.act_bwd(dHt, Zt, ACT_GELU)
+            _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
+            K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
+        del hz, PO
         dAO = K.gemm_nt(dPO, wproj_t)
         del dPO
-        nn_ = spec.ws * spec.ws
-        wg = K.AttnGeom(2 * BT * spec.nW, H, nn_, spec.hd, G=spec.nW, outer=N, map_q=g["wmap"], scale=spec.hd ** -0.5,
-                        bias=sbias, bias_div=2 * BT * spec.nW, bias_mod=1, mask=g["mask"])
+        tabs = [G.buf("attn.temporal_position_bias_table" + ("_audio" if m else "")) for m in spec.mods]
+        dtb = torch.zeros_like(tbias) if any(t is not None for t in tabs) else None
         dQKV = torch.empty_like(QKV)
-        K.attn_bwd(wg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
-                   dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+        K.attn_bwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
+                   dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:], dbias=dtb)
+        for i, m in enumerate(spec.mods):
+            if tabs[i] is not None:
+                K.bias_scatter(dtb[i], P["attn.t_relative_coords" + ("_a" if m else "")], tabs[i])
         del QKV, AO, dAO
         dY = K.gemm_nt(dQKV, wqkv_t)
         del dQKV
-        dX1 = K.layernorm_bwd(dY, X1, n1g, mean, rstd, add_to=dX2)
-        del dY, dX2, X1
-
-        # ---------------- temporal attention + T_Adapter
-        if spec.t_attn:
-            X0, mean, rstd, QKV, AO, lse, PO, hz, tbias = S.pop("t")
-            dPO = torch.empty_like(dX1)
-            for m, an in enumerate(("T_Adapter", "T_Adapter_Audio")):
-                A = _Adapter(P, an)
-                Ht, Zt = hz[m]
-                dHt = K.gemm_nt(dX1[sl[m]], A.w2t, row_scale=dps[m], rs_outer=T * N, rs_inner=N)
-                dZt = K.act_bwd(dHt, Zt, ACT_GELU)
-                _adapter_wgrad(G, an, dZt, PO[sl[m]], dX1[sl[m]], Ht, rs=dps[m], rs_outer=T * N, rs_inner=N)
-                K.gemm_nt(dZt, A.w1t, out=dPO[sl[m]])
-            del hz, PO
-            dAO = K.gemm_nt(dPO, wproj_t)
-            del dPO
-            tg = K.AttnGeom(2 * B * N, H, T, spec.hd, G=N, outer=T * N, map_q=g["tmap"], scale=spec.hd ** -0.5,
-                            bias=tbias, bias_div=B * N, bias_mod=2)
-            tv, ta = G.buf("attn.temporal_position_bias_table"), G.buf("attn.temporal_position_bias_table_audio")
-            dtb = torch.zeros_like(tbias) if (tv is not None or ta is not None) else None
-            dQKV = torch.empty_like(QKV)
-            K.attn_bwd(tg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
-                       dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:], dbias=dtb)
-            if tv is not None:
-                K.bias_scatter(dtb[0], P["_t_index"], tv)
-            if ta is not None:
-                K.bias_scatter(dtb[1], P["_t_index_a"], ta)
-            del QKV, AO, dAO
-            dY = K.gemm_nt(dQKV, wqkv_t)
-            del dQKV
-            dX0 = K.layernorm_bwd(dY, X0, n1g, mean, rstd, add_to=dX1)
-        else:
-            dX0 = dX1
-        grads = tuple(G.g.get(n) for n in names)
-        return (dX0, None, None, None, None) + grads
+        dX0 = K.layernorm_bwd(dY, X0, n1g, mean, rstd, add_to=dX1)
+    else:
+        dX0 = dX1
+    return dX0, G.g
 
 
-# ------------------------------------------------------------------------------------------------ patch merging
-class PatchMergeFn(torch.autograd.Function):
-    """PatchMerging.forward on every frame of both modalities (Swin_AVE.py:958-981): 2x2 gather + LN(4C) + Linear(4C->2C)."""
-
-    @staticmethod
-    def forward(ctx, X, H, W, norm_w, norm_b, red_w):
-        if any(ctx.needs_input_grad[3:]):
-            raise NotImplementedError("PatchMerging: norm / reduction must be frozen (backbone weights get no wgrad in this build)")
-        save = ctx.needs_input_grad[0]
-        Y, mean, rstd = K.layernorm_fwd(X, f32c(norm_w), f32c(norm_b), gather4=(H, W), want_stats=save)
-        out = K.gemm_nt(Y, shadow(red_w))
-        if save:
-            ctx.saved = (X, mean, rstd, norm_w, red_w, H, W)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        X, mean, rstd, norm_w, red_w, H, W = ctx.saved
-        dY = K.gemm_nt(dout.contiguous(), shadow(red_w, True))
-        dX = K.layernorm_bwd(dY, X, f32c(norm_w), mean, rstd, gather4=(H, W))
-        return dX, None, None, None, None, None
+# ------------------------------------------------------------------------------------------------ patch merging / embedding / heads
+def merge_forward(X, H, W, P, save):
+    """PatchMerging.forward on every frame of the fused tensor (Swin_AVE.py:958-981): 2x2 gather + LN(4C) + Linear(4C->2C)."""
+    Y, mean, rstd = K.layernorm_fwd(X, f32c(P["norm.weight"]), f32c(P["norm.bias"]), gather4=(H, W), want_stats=save)
+    out = K.gemm_nt(Y, shadow(P["reduction.weight"]), out_dtype=RESIDUAL_DTYPE)
+    return out, ((X, mean, rstd) if save else None)
 
 
-# ------------------------------------------------------------------------------------------------ patch embedding (frozen, forward only)
+def merge_backward(S, H, W, P, dout):
+    X, mean, rstd = S
+    dY = K.gemm_nt(dout, shadow(P["reduction.weight"], True))
+    return K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd, gather4=(H, W))
+
+
 def patch_embed_into(x5, proj_w, proj_b, norm_w, norm_b, out_rows):
     """PatchEmbed3D (Swin_AVE.py:1104-1124) for kernel == stride == (1,p,p): im2col gather -> GEMM(+bias) -> LayerNorm,
-    written into `out_rows` ([B*T*Hp*Wp, E] slice of the fused token tensor).  Frozen in the reference recipe; inputs carry
-    no gradient, so there is no backward."""
-    for p in (proj_w, proj_b, norm_w, norm_b):
-        if p is not None and p.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("patch embedding must be frozen (traintest_adapt_ave29.py:52-61)")
+    written into `out_rows` ([B*T*Hp*Wp, E] slice of the fused fp32 token tensor).  Frozen in the reference recipe and the
+    inputs carry no gradient, so there is no backward."""
     E, Cin, pd, ph, pw = proj_w.shape
     if pd != 1 or ph != pw:
         raise NotImplementedError("patch embedding supports patch_size (1, p, p) only")
     Kd = Cin * ph * pw
     Kpad = (Kd + 7) // 8 * 8
+    if x5.dtype not in (F32, BF16):
+        x5 = x5.float()
     cols = K.im2col_patch(x5.contiguous(), ph, Kpad)
     if norm_w is None:
         K.gemm_nt(cols, shadow(proj_w), f32c(proj_b), out=out_rows)
@@ -454,56 +524,178 @@ def patch_embed_into(x5, proj_w, proj_b, norm_w, norm_b, out_rows):
     K.layernorm_fwd(Y, f32c(norm_w), f32c(norm_b), want_stats=False, out=out_rows)
 
 
-# ------------------------------------------------------------------------------------------------ head
-class FusionHeadFn(torch.autograd.Function):
+def head_fusion_forward(X, n_tok, P, training, drop_p, save):
     """final norm -> token mean -> cat((a, v)) -> Linear -> Dropout -> Linear (Swin_AVE.py:1585-1599), fp32 logits."""
+    R, C = X.shape
+    Rm = R // 2
+    BT = Rm // n_tok
+    Y, mean, rstd = K.layernorm_fwd(X, f32c(P["norm.weight"]), f32c(P["norm.bias"]), want_stats=save)
+    pooled = torch.empty((BT, 2 * C), dtype=BF16, device=X.device)
+    K.meanpool_fwd(Y[Rm:], BT, n_tok, out=pooled[:, :C])      # audio first: torch.cat((a, v)) (:1596)
+    K.meanpool_fwd(Y[:Rm], BT, n_tok, out=pooled[:, C:])
+    del Y
+    h0 = K.gemm_nt(pooled, shadow(P["mlp_head.0.weight"]), f32c(P["mlp_head.0.bias"]))
+    mask = None
+    if training and drop_p > 0:
+        keep = 1.0 - drop_p
+        mask = torch.empty(h0.shape, dtype=F32, device=X.device).bernoulli_(keep).div_(keep)
+    h0d = K.mul_mask(h0, mask) if mask is not None else h0
+    logits = K.gemm_nt(h0d, shadow(P["mlp_head.2.weight"]), f32c(P["mlp_head.2.bias"]), out_dtype=F32)
+    return logits, ((X, mean, rstd, pooled, h0d, mask, n_tok) if save else None)
+
+
+def head_fusion_backward(S, P, need, dlogits, need_dx):
+    X, mean, rstd, pooled, h0d, mask, n_tok = S
+    R, C = X.shape
+    Rm = R // 2
+    BT = Rm // n_tok
+    w0, w2 = P["mlp_head.0.weight"], P["mlp_head.2.weight"]
+    L = w2.shape[0]
+    G = _Grads(P, need)
+    dl = K.cast_bf16(dlogits.float().contiguous())                   # [BT, L padded to 8]
+    gw2, gb2 = G.buf("mlp_head.2.weight"), G.buf("mlp_head.2.bias")
+    if gw2 is not None:
+        K.wgrad_tn(dl, h0d, gw2, gb2, n1=L)
+    dh0 = K.gemm_nt(dl, shadow(w2, True))                            # [BT, 512]; K = L padded
+    if mask is not None:
+        dh0 = K.mul_mask(dh0, mask)
+    gw0, gb0 = G.buf("mlp_head.0.weight"), G.buf("mlp_head.0.bias")
+    if gw0 is not None:
+        K.wgrad_tn(dh0, pooled, gw0, gb0)
+    dX = None
+    if need_dx:
+        dpool = K.gemm_nt(dh0, shadow(w0, True))                     # [BT, 2C]
+        dY = torch.empty((R, C), dtype=BF16, device=X.device)
+        K.meanpool_bwd(dpool[:, :C], BT, n_tok, out=dY[Rm:])
+        K.meanpool_bwd(dpool[:, C:], BT, n_tok, out=dY[:Rm])
+        dX = K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd)
+    return dX, G.g
+
+
+def head_single_forward(X, n_tok, P, save):
+    """final norm -> token mean -> mlp_head = LayerNorm + Linear (Swin_AVE.py:1494-1503, :1324-1325)."""
+    R, C = X.shape
+    BT = R // n_tok
+    Y, mean, rstd = K.layernorm_fwd(X, f32c(P["norm.weight"]), f32c(P["norm.bias"]), want_stats=save)
+    pooled = K.meanpool_fwd(Y, BT, n_tok)
+    del Y
+    Z, m2, r2 = K.layernorm_fwd(pooled, f32c(P["mlp_head.0.weight"]), f32c(P["mlp_head.0.bias"]), want_stats=save)
+    logits = K.gemm_nt(Z, shadow(P["mlp_head.1.weight"]), f32c(P["mlp_head.1.bias"]), out_dtype=F32)
+    return logits, ((X, mean, rstd, pooled, m2, r2, Z, n_tok) if save else None)
+
+
+def head_single_backward(S, P, need, dlogits, need_dx):
+    X, mean, rstd, pooled, m2, r2, Z, n_tok = S
+    R, C = X.shape
+    BT = R // n_tok
+    w1 = P["mlp_head.1.weight"]
+    L = w1.shape[0]
+    G = _Grads(P, need)
+    dl = K.cast_bf16(dlogits.float().contiguous())
+    gw, gb = G.buf("mlp_head.1.weight"), G.buf("mlp_head.1.bias")
+    if gw is not None:
+        K.wgrad_tn(dl, Z, gw, gb, n1=L)
+    dZ = K.gemm_nt(dl, shadow(w1, True))
+    gg, gbeta = G.buf("mlp_head.0.weight"), G.buf("mlp_head.0.bias")
+    if (gg is None) != (gbeta is None):
+        raise NotImplementedError("mlp_head.0 weight and bias must be frozen/trained together")
+    dpool = K.layernorm_bwd(dZ, pooled, f32c(P["mlp_head.0.weight"]), m2, r2, dgamma=gg, dbeta=gbeta)
+    dX = None
+    if need_dx:
+        dY = K.meanpool_bwd(dpool, BT, n_tok)
+        dX = K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd)
+    return dX, G.g
+
+
+# ------------------------------------------------------------------------------------------------ autograd wrappers
+class SwinBlockFn(torch.autograd.Function):
+    """One block as its own autograd node (used when a block is called stand-alone).  autograd wants gradients in the
+    dtype of the fp32 residual tensor, so the bf16 gradient stream is cast at the node boundary; the whole-model
+    Function below keeps it in bf16 end to end."""
 
     @staticmethod
-    def forward(ctx, X, n_tok, drop_mask, norm_w, norm_b, w0, b0, w2, b2):
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-            raise NotImplementedError("final norm must be frozen (it is in the reference recipe: 'norm' matches no trainable substring)")
-        save = any(ctx.needs_input_grad)
-        ctx.need = ctx.needs_input_grad
-        R, C = X.shape
-        Rm = R // 2
-        BT = Rm // n_tok
-        Y, mean, rstd = K.layernorm_fwd(X, f32c(norm_w), f32c(norm_b), want_stats=save)
-        pooled = torch.empty((BT, 2 * C), dtype=BF16, device=X.device)
-        K.meanpool_fwd(Y[Rm:], BT, n_tok, out=pooled[:, :C])      # audio first: torch.cat((a, v)) (:1596)
-        K.meanpool_fwd(Y[:Rm], BT, n_tok, out=pooled[:, C:])
-        del Y
-        h0 = K.gemm_nt(pooled, shadow(w0), f32c(b0))
-        h0d = K.mul_mask(h0, drop_mask) if drop_mask is not None else h0
-        logits = K.gemm_nt(h0d, shadow(w2), f32c(b2), out_dtype=F32)
-        if save:
-            ctx.saved = (X, mean, rstd, pooled, h0d, drop_mask, norm_w, w0, b0, w2, b2, n_tok)
+    def forward(ctx, X, spec, names, training, grad_on, *params):
+        P = dict(zip(names, params))
+        need = {n: bool(grad_on and f) for n, f in zip(names, ctx.needs_input_grad[5:])}
+        _check_frozen(need, FROZEN_ONLY, "SwinTransformerBlock")
+        save = bool(grad_on) and any(ctx.needs_input_grad)
+        Xr = X if X.dtype == RESIDUAL_DTYPE else (K.cast_f32(X.contiguous()) if X.dtype == BF16 else X.float())
+        out, S = block_forward(Xr.contiguous(), spec, P, training, save)
+        ctx.S, ctx.P, ctx.spec, ctx.names, ctx.need, ctx.in_dtype = S, P, spec, names, need, X.dtype
+        return out if X.dtype == RESIDUAL_DTYPE else out.to(X.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = dout.contiguous()
+        d = K.cast_bf16(d.float().reshape(d.shape[0], -1)) if d.dtype != BF16 else d
+        dX0, g = block_backward(ctx.S, ctx.spec, ctx.P, ctx.need, "", d)
+        ctx.S = None
+        dX0 = dX0 if ctx.in_dtype == BF16 else K.cast_f32(dX0).to(ctx.in_dtype)
+        return (dX0, None, None, None, None) + tuple(g.get(n) for n in ctx.names)
+
+
+SwinFusionBlockFn = SwinBlockFn
+
+
+class SwinModelFn(torch.autograd.Function):
+    """The whole Swin + STG-CMA forward as ONE autograd node: patch embeddings -> stages of blocks / merges -> head.
+    Between blocks the residual stream stays fp32 and the gradient stream bf16 with no autograd bookkeeping or dtype
+    casts; per-block saved state lives in ctx and is released block by block during backward."""
+
+    @staticmethod
+    def forward(ctx, a, v, plan, training, grad_on, names, *params):
+        P = dict(zip(names, params))
+        need = {n: bool(grad_on and f) for n, f in zip(names, ctx.needs_input_grad[6:])}
+        save = any(need.values())
+        for n in names:
+            if need[n] and not plan.trainable_ok(n):
+                _check_frozen({n: True}, [n], "SwinTransformer2D_Adapter_New")
+        mods = plan.mods
+        src = v if 0 in mods else a
+        B, T = src.shape[0], (src.shape[2] if 0 in mods else src.shape[1])
+        N0 = plan.n_patches
+        Rm = B * T * N0
+        X = torch.empty((len(mods) * Rm, plan.embed_dim), dtype=RESIDUAL_DTYPE, device=src.device)
+        for i, m in enumerate(mods):
+            pe = "patch_embed_audio" if m else "patch_embed"
+            x5 = a.unsqueeze(1) if m else v
+            nw = P.get(pe + ".norm.weight")
+            patch_embed_into(x5, P[pe + ".proj.weight"], P[pe + ".proj.bias"], nw, P.get(pe + ".norm.bias"), X[i * Rm:(i + 1) * Rm])
+        tape = []
+        for st in plan.stages:
+            for spec, pre in st["blocks"]:
+                Pb = {n: P[pre + n] for n in st["names"][pre]}
+                X, S = block_forward(X, spec, Pb, training, save)
+                tape.append(("block", spec, pre, Pb, S))
+            if st["merge"] is not None:
+                H, W, pre = st["merge"]
+                Pm = {n: P[pre + n] for n in ("norm.weight", "norm.bias", "reduction.weight")}
+                X, S = merge_forward(X, H, W, Pm, save)
+                tape.append(("merge", (H, W), pre, Pm, S))
+        if len(mods) == 2:
+            logits, S = head_fusion_forward(X, plan.n_tok_last, P, training, plan.head_drop, save)
+        else:
+            logits, S = head_single_forward(X, plan.n_tok_last, P, save)
+        ctx.tape, ctx.head, ctx.P, ctx.need, ctx.names, ctx.two = tape, S, P, need, names, len(mods) == 2
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        X, mean, rstd, pooled, h0d, drop_mask, norm_w, w0, b0, w2, b2, n_tok = ctx.saved
-        R, C = X.shape
-        Rm = R // 2
-        BT = Rm // n_tok
-        L = w2.shape[0]
-        dl = K.cast_bf16(dlogits.float().contiguous())                   # [BT, L padded to 8]
-        need = ctx.need
-        gw2 = _zeros_like_f32(w2) if need[7] else None
-        gb2 = _zeros_like_f32(b2) if need[8] else None
-        if gw2 is not None:
-            K.wgrad_tn(dl, h0d, gw2, gb2, n1=L)
-        dh0 = K.gemm_nt(dl, shadow(w2, True))                            # [BT, 512]; K = L padded
-        if drop_mask is not None:
-            dh0 = K.mul_mask(dh0, drop_mask)
-        gw0 = _zeros_like_f32(w0) if need[5] else None
-        gb0 = _zeros_like_f32(b0) if need[6] else None
-        if gw0 is not None:
-            K.wgrad_tn(dh0, pooled, gw0, gb0)
-        dX = None
-        if need[0]:
-            dpool = K.gemm_nt(dh0, shadow(w0, True))                     # [BT, 2C]
-            dY = torch.empty((R, C), dtype=BF16, device=X.device)
-            K.meanpool_bwd(dpool[:, :C], BT, n_tok, out=dY[Rm:])
-            K.meanpool_bwd(dpool[:, C:], BT, n_tok, out=dY[:Rm])
-            dX = K.layernorm_bwd(dY, X, f32c(norm_w), mean, rstd)
-        return dX, None, None, None, None, gw0, gb0, gw2, gb2
+        P, need = ctx.P, ctx.need
+        grads = {}
+        if ctx.two:
+            dX, g = head_fusion_backward(ctx.head, P, need, dlogits, True)
+        else:
+            dX, g = head_single_backward(ctx.head, P, need, dlogits, True)
+        grads.update(g)
+        ctx.head = None
+        tape = ctx.tape
+        while tape:
+            kind, spec, pre, Pl, S = tape.pop()
+            if kind == "block":
+                dX, g = block_backward(S, spec, Pl, need, pre, dX)
+                for k, val in g.items():
+                    grads[pre + k] = val
+            else:
+                dX = merge_backward(S, spec[0], spec[1], Pl, dX)
+        return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)

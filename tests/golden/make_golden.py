@@ -63,10 +63,10 @@ def load(path, name):
     return m
 
 
-def seed_module(mod, seed):
+def seed_module(mod, seed, state_fn=None):
     sd = mod.state_dict()
     shapes = GP.float_shapes(sd)
-    new = GP.seeded_state(shapes, seed)
+    new = (state_fn or GP.seeded_state)(shapes, seed)
     sd.update(new)
     mod.load_state_dict(sd, strict=True)
     return shapes
@@ -120,12 +120,12 @@ def swin_block_case(S, tag, *, dim, res, T, B, heads, shift, t_attn, ratio, mode
 
 
 # --------------------------------------------------------------------------------------------------- Swin models
-def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True):
+def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True, state_fn=None):
     m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
                                         embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
                                         window_size=7, pretrained=None, ftmode=mode,
                                         adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
-    shapes = seed_module(m, seed)
+    shapes = seed_module(m, seed, state_fn)
     names = apply_freeze(m)
     T = cfg["num_frames"]
     a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
@@ -255,6 +255,8 @@ def main(argv):
         "swin_tiny_multimodal": lambda: swin_model_case(S, "swin_tiny_multimodal", cfg=SWIN_TINY, B=1, mode="multimodal", seed=210),
         "swin_tiny_videoonly": lambda: swin_model_case(S, "swin_tiny_videoonly", cfg=SWIN_TINY, B=1, mode="videoonly", seed=220),
         "swin_b_fusion": lambda: swin_model_case(S, "swin_b_fusion", cfg=SWIN_B, B=1, mode="fusion", seed=300, store_all_grads=False),
+        "swin_b_fusion_refinit": lambda: swin_model_case(S, "swin_b_fusion_refinit", cfg=SWIN_B, B=1, mode="fusion", seed=310,
+                                                         store_all_grads=False, state_fn=GP.refinit_state),
         "vit_block_cfg1": lambda: vit_block_case(Cm, "vit_block_cfg1", d=768, heads=8, T=10, B=1, nv=196, na=196, seed=400),
         "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=192, heads=2, T=2, B=2, nv=50, na=13, seed=410),
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),

@@ -67,3 +67,29 @@ MLP_HEAD = tuple(f"mlp_head.{i}.{w}" for i in range(4) for w in ("weight", "bias
 def is_trainable(name):
     """The reference's name filter (AVE/traintest_adapt_ave29.py:38-55): head params and adapter-ish names train."""
     return name in MLP_HEAD or any(s in name for s in TRAINABLE_SUBSTRINGS)
+
+
+def refinit_state(shapes, seed):
+    """Parameters at the REFERENCE's own initialisation scale (Swin_AVE.py:1353-1361: trunc_normal(.02) Linear weights,
+    zero biases, unit LayerNorms; bias tables trunc_normal(.02)), except that the tensors the reference zero-initialises
+    (adapter D_fc2, gates; :1422-1468, :365-366) get small non-zero values so the adapter path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for key, shape in shapes:
+        shape = tuple(shape)
+        k = key.split(".")[-1]
+        if "gate_" in key:
+            t = torch.tensor([0.5 if key.endswith("gate_v") else -0.5])
+        elif k == "weight" and len(shape) == 1:
+            t = torch.ones(shape)
+        elif k == "bias" and ("norm" in key or key.startswith("mlp_head.0") and len(shape) == 1 and False):
+            t = torch.zeros(shape)
+        elif k == "bias":
+            t = torch.randn(shape, generator=g) * 0.02 if "D_fc2" in key else torch.zeros(shape)
+        elif k == "weight" and "proj.weight" in key and len(shape) == 5:   # patch-embed conv: default kaiming-uniform scale
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        else:
+            t = torch.randn(shape, generator=g).clamp_(-2, 2) * 0.02
+        out[key] = t.reshape(shape)
+    return out

@@ -25,10 +25,10 @@ def load_case(tag):
     return z, cfg, shapes, names
 
 
-def build_state(shapes, seed, kind, T=None, res=None, prefix=None):
+def build_state(shapes, seed, kind, T=None, res=None, prefix=None, state_fn=None):
     """{key: fp32 tensor} regenerated from the seed (+ the integer index buffers the oracle reads)."""
     import oracle.swin as OS
-    P = GP.seeded_state(shapes, seed)
+    P = (state_fn or GP.seeded_state)(shapes, seed)
     if kind == "swin_block":
         P = {"blk." + k: v for k, v in P.items()}
         ws, _ = OS.block_geometry(res, res, 7, 0)
