@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): clips/sec forward+backward(+Adam step on the adapters) of Swin-B + STG-CMA,
+ftmode='fusion', AVE shape (10 frames + 10 one-second spectrogram segments per clip, 224^2), bf16 MFMA compute,
+B = 32 clips per GPU, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 8 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic clips resident in HBM: forward, soft-target cross-entropy
+(the harness's loss, AVE/traintest_adapt_ave29.py:113,159), backward through the frozen backbone with weight gradients for
+the 5.6 M trainable parameters, one RCCL all-reduce of the flat gradient arena (N > 1), Adam step with the reference's
+hyper-parameters (:68).  Rank 0 prints ONE JSON line; `value` is the whole-job clips/s (all ranks), timed between
+barrier + synchronize on both sides and taking the max over ranks.
+
+Extra objects in the line:
+  roofline      dominant kernel = gemm_nt (bf16 MFMA 16x16x32): achieved = algorithmic GEMM FLOPs (2*M*N*K per launch, no
+                padding) / HIP-event time of those launches inside the timed region; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline  the oracle (oracle/swin.py, fp32 PyTorch-CPU restatement, "port") timed on this box's host cores on a bounded
+                sample (B=1 clip, fwd+bwd), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+GFLOP_PER_CLIP = 1587.5      # fwd+bwd algorithmic GEMM FLOPs per clip, Swin-B AVE fusion
+PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+SWIN_B = dict(label_dim=29, patch_size=[1, 4, 4], num_frames=10, embed_dim=128, depths=[2, 2, 18, 2],
+              num_heads=[4, 8, 16, 32], window_size=7, pretrained=None, ftmode="fusion",
+              adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
+
+
+def build_model(torch, device):
+    import stgcma  # noqa: F401
+    from stgcma.model import Swin_AVE as S
+    from stgcma.recipe import is_trainable
+    torch.manual_seed(0)
+    m = S.SwinTransformer2D_Adapter_New(**SWIN_B)
+    # de-zero what the reference zero-initialises, so no kernel can shortcut zeros
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "D_fc2" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif "gate_" in n:
+                p.fill_(0.1)
+    for n, p in m.named_parameters():                       # the reference's freeze filter
+        p.requires_grad = is_trainable(n)
+    return m.to(device).train()
+
+
+def synth_batch(torch, B, device, rank):
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    v = torch.randn((B, 3, 10, 224, 224), generator=g, device=device)
+    a = torch.randn((B, 10, 224, 224), generator=g, device=device) * 0.5
+    cls = torch.randint(0, 29, (B * 10,), generator=g, device=device)
+    labels = torch.nn.functional.one_hot(cls, 29).float()   # float one-hot rows, '(b t) c'
+    return a, v, labels
+
+
+def cpu_baseline(torch, model, reps=3):
+    """oracle fwd+bwd at B=1 on the host cores (bounded sample)."""
+    import oracle.swin as OS
+    from params import seeded_tensor
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    for n in names:
+        P[n].requires_grad_(True)
+    cfg = dict(SWIN_B, img_size=224)
+    a = seeded_tensor((1, 10, 224, 224), 7, 0.5)
+    v = seeded_tensor((1, 3, 10, 224, 224), 8)
+    tgt = torch.nn.functional.one_hot(torch.arange(10) % 29, 29).float()
+    times = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        logits = OS.swin_forward(P, a, v, cfg, "fusion")
+        OS.soft_target_cross_entropy(logits, tgt).backward()
+        times.append(time.perf_counter() - t0)
+        for n in names:
+            P[n].grad = None
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/swin.py fp32 fwd+bwd, B=1 clip, 1 warm-up + median of {reps}, torch {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import stgcma  # noqa: F401
+    from stgcma import ddp, kernels
+
+    rank, local_rank, world = ddp.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    model = build_model(torch, device)
+    if world > 1:
+        ddp.broadcast_parameters(model)
+        ddp.attach(model)
+    head = [p for n, p in model.named_parameters() if n.startswith("mlp_head.")]
+    adapt = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("mlp_head.")]
+    opt = torch.optim.Adam([{"params": adapt, "lr": 1e-4}, {"params": head, "lr": 1e-5}], weight_decay=5e-7, betas=(0.95, 0.999))
+    loss_fn = torch.nn.CrossEntropyLoss()
+    a, v, labels = synth_batch(torch, args.batch, device, rank)
+
+    def step():
+        logits = model(a, v, "fusion")
+        loss = loss_fn(logits, labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernels.gemm_profile_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    n_gemm, gemm_ms, gemm_flops = kernels.gemm_profile_stop()
+    final_loss = float(loss)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "clips/sec fwd+bwd, Swin-B+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Swin-B + STG-CMA ftmode=fusion, AVE shape (10 frames + 10 spectrogram segments, 224^2), "
+                                   "fwd+bwd+Adam on 5.6M adapter/head params", "clips_per_gpu": args.batch,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": "fp32"},
+            "model_tflops": round(value * GFLOP_PER_CLIP / 1e3, 2),
+            "mfma_frac_whole_step": round(value * GFLOP_PER_CLIP / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_gemm // max(args.steps, 1),
+                         "avg_launch_us": round(gemm_ms * 1e3 / max(n_gemm, 1), 2),
+                         "gemm_ms_per_step": round(gemm_ms / max(args.steps, 1), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(torch, model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,8 @@
 // Block tile 128x128x64, 256 threads = 2x2 waves of 64x64, LDS double buffered (64 KiB => 2 blocks / CU),
 // global prefetch of tile k+1 into registers while tile k is in the MFMA loop (one barrier per k-tile).
 // Block ids are remapped so that the N-tiles sharing one A row-panel run on the same XCD (its L2 holds the panel).
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/stgcma.h"
 
@@ -35,6 +37,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int nbm, nbn;
     int vec_ok;
+    int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work
 };
 
 __device__ __forceinline__ void add_res4(const void* res, int f32, int64_t off, float* t) {
@@ -53,105 +56,27 @@ __device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) 
 
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
 
-__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+struct AccTile { f32x4_t v[4][4]; };   // passed BY VALUE: a by-reference accumulator array ends up mirrored in scratch
 
-    // XCD-aware bijective remap: consecutive logical tiles (same A panel) land on one XCD.
-    const int nblk = p.nbm * p.nbn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / p.nbn, bn = bid % p.nbn;
-    const int64_t m0 = (int64_t)bm * BM;
-    const int n0 = bn * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = lane & 15, lk = lane >> 4;
-
-    constexpr int ITERS = BM * CPR / 256;  // 4 chunks of A and 4 of W per thread per k-tile
-    uint4 ra[ITERS], rb[ITERS];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / CPR, c = id % CPR;
-            const int gk = kt * BK + c * 8;
-            const int64_t gm = m0 + row;
-            const int gn = n0 + row;
-            ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const uint4*>(p.A + gm * p.lda + gk) : zero4;
-            rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const uint4*>(p.W + (int64_t)gn * p.ldw + gk) : zero4;
-        }
-    };
-    auto swrite = [&](int stage) {
-        bf16_t* sA = smem + stage * (BM + BN) * BK;
-        bf16_t* sW = sA + BM * BK;
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int id = tid + i * 256;
-            const int row = id / CPR, c = id % CPR;
-            *reinterpret_cast<uint4*>(sA + row * BK + swz(row, c) * 8) = ra[i];
-            *reinterpret_cast<uint4*>(sW + row * BK + swz(row, c) * 8) = rb[i];
-        }
-    };
-
-    f32x4_t acc[4][4];  // [n tile][m tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const bf16_t* sA = smem + stage * (BM + BN) * BK;
-        const bf16_t* sW = sA + BM * BK;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8_t af[4], wf[4];
-            const int c = 4 * s + lk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ar = wm * 64 + i * 16 + lrow;
-                const int wr = wn * 64 + i * 16 + lrow;
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + ar * BK + swz(ar, c) * 8);
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + wr * BK + swz(wr, c) * 8);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
-        if (kt + 1 < nk) swrite(stage ^ 1);
-        __syncthreads();
-    }
-
-    // ---------------- epilogue: lane owns row m, 4 consecutive columns n per (ni, mi) tile ----------------
+// Epilogue shared by both GEMM kernels: lane owns row m, 4 consecutive columns n per (ni, mi) accumulator tile.
+// FULL tiles (the overwhelming majority) run a straight-line vector path with only kernel-uniform option branches.
+template <bool FULL>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
+                                              int lrow, int lk) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int64_t m = m0 + wm * 64 + mi * 16 + lrow;
-        if (m >= p.M) continue;
+        if (!FULL && m >= p.M) continue;
         float rs = 1.0f;
         if (p.row_scale) rs = p.row_scale[(m / p.rs_outer) * p.rs_inner + (m % p.rs_inner)];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + 4 * lk;
-            if (n >= p.N) continue;
+            if (!FULL && n >= p.N) continue;
             float t[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = acc[ni][mi][r] * p.alpha;
-            if (p.vec_ok && n + 3 < p.N) {
+            for (int r = 0; r < 4; ++r) t[r] = accs.v[ni][mi][r] * p.alpha;
+            if (FULL || (p.vec_ok && n + 3 < p.N)) {
                 if (p.bias) {
                     const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
                     t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
@@ -200,6 +125,212 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
             }
         }
     }
+}
+
+__device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm,
+                                                       int wn, int lrow, int lk) {
+    const bool full = p.vec_ok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if (full) gemm_epilogue<true>(p, accs, m0, n0, wm, wn, lrow, lk);
+    else gemm_epilogue<false>(p, accs, m0, n0, wm, wn, lrow, lk);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+
+    // XCD-aware bijective remap: consecutive logical tiles (same A panel) land on one XCD.
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int64_t m0 = (int64_t)bm * BM;
+    const int n0 = bn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, lk = lane >> 4;
+
+    constexpr int ITERS = BM * CPR / 256;  // 4 chunks of A and 4 of W per thread per k-tile
+    uint4 ra[ITERS], rb[ITERS];
+
+    // Loads are UNCONDITIONAL from clamped (always in-bounds) addresses; out-of-range rows of A / W only feed output
+    // rows / columns that are never stored, and the K tail (K % 64 != 0) is zeroed by a value select AFTER the load.
+    // (A `cond ? load : 0` makes hipcc branch around every load and wait vmcnt(0) each: 8 dependent HBM round trips
+    // per k-tile -- measured 10x slower.)
+    const bf16_t* pa[ITERS];
+    const bf16_t* pw[ITERS];
+    const int kc = (tid % CPR) * 8;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int row = (tid + i * 256) / CPR;
+        int64_t gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        pa[i] = p.A + gm * p.lda;
+        pw[i] = p.W + (int64_t)gn * p.ldw;
+    }
+    const bool kfull = (p.K % BK) == 0;
+
+    auto gload = [&](int kt) {
+        int gk = kt * BK + kc;
+        const bool kok = kfull || gk < p.K;
+        gk = kok ? gk : 0;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            ra[i] = *reinterpret_cast<const uint4*>(pa[i] + gk);
+            rb[i] = *reinterpret_cast<const uint4*>(pw[i] + gk);
+        }
+        if (!kfull) {
+            const unsigned msk = kok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                ra[i].x &= msk; ra[i].y &= msk; ra[i].z &= msk; ra[i].w &= msk;
+                rb[i].x &= msk; rb[i].y &= msk; rb[i].z &= msk; rb[i].w &= msk;
+            }
+        }
+    };
+    auto swrite = [&](int stage) {
+        bf16_t* sA = smem + stage * (BM + BN) * BK;
+        bf16_t* sW = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / CPR, c = id % CPR;
+            *reinterpret_cast<uint4*>(sA + row * BK + swz(row, c) * 8) = ra[i];
+            *reinterpret_cast<uint4*>(sW + row * BK + swz(row, c) * 8) = rb[i];
+        }
+    };
+
+    AccTile accs;  // [n tile][m tile]
+    auto& acc = accs.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const bf16_t* sA = smem + stage * (BM + BN) * BK;
+        const bf16_t* sW = sA + BM * BK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t af[4], wf[4];
+            const int c = 4 * s + lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ar = wm * 64 + i * 16 + lrow;
+                const int wr = wn * 64 + i * 16 + lrow;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + ar * BK + swz(ar, c) * 8);
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + wr * BK + swz(wr, c) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite(stage ^ 1);
+        __syncthreads();
+    }
+
+    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lrow, lk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (K % 64 == 0): tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write --
+// the register-staged variant above is LDS-WRITE bound: 32 KB of ds_write_b128 per k-tile at ~79 B/clk/CU).
+// One wave-instruction writes 1 KiB = 8 rows x 128 B linearly (LDS dest = wave-uniform base + lane*16), so the XOR
+// swizzle lives on the per-lane SOURCE address: LDS position `pos` of row r receives global chunk pos ^ (r & 7), and the
+// fragment reads apply the same involution.  Rows beyond M / N are clamped (their products are never stored).
+// 2-stage pipeline: issue tile t+1's DMA, run tile t's MFMAs, then vmcnt(0) + barrier.
+__global__ void __launch_bounds__(256, 2) gemm_nt_glds_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int64_t m0 = (int64_t)bm * BM;
+    const int n0 = bn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, lk = lane >> 4;
+
+    // this lane's 4 + 4 DMA pieces per k-tile: LDS chunk q = (wave*4 + j)*64 + lane  ->  row q>>3, position q&7
+    const bf16_t* pa[4];
+    const bf16_t* pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = (wave * 4 + j) * 64 + lane;
+        const int row = q >> 3, c = (q & 7) ^ (row & 7);
+        int64_t gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        pa[j] = p.A + gm * p.lda + c * 8;
+        pw[j] = p.W + (int64_t)gn * p.ldw + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        bf16_t* sA = smem + buf * (BM + BN) * BK;
+        bf16_t* sW = sA + BM * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[j] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 512), 16, 0, 0);
+        }
+    };
+
+    AccTile accs;
+    auto& acc = accs.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk && p.dbg != 1) stage(cur ^ 1, kt + 1);
+        const bf16_t* sA = smem + cur * (BM + BN) * BK;
+        const bf16_t* sW = sA + BM * BK;
+        if (p.dbg != 2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t af[4], wf[4];
+            const int c = 4 * s + lk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ar = wm * 64 + i * 16 + lrow;
+                const int wr = wn * 64 + i * 16 + lrow;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + ar * BK + swz(ar, c) * 8);
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + wr * BK + swz(wr, c) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lrow, lk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,6 +478,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     p.res1 = a->res1; p.ldr1 = a->ldr1; p.res1_f32 = (a->res1_dtype == STG_F32);
     p.res2 = a->res2; p.ldr2 = a->ldr2; p.res2_f32 = (a->res2_dtype == STG_F32);
     p.M = a->M; p.N = a->N; p.K = a->K;
+    { const char* e = getenv("STG_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int64_t nbm = (a->M + BM - 1) / BM;
     const int64_t nbn = (a->N + BN - 1) / BN;
     STG_CHECK(nbm * nbn < (1ll << 31), -2, "stg_gemm_nt: grid too large");
@@ -358,7 +490,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
                al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) &&
                al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, p.res1_f32 ? 16 : 8) &&
                al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, p.res2_f32 ? 16 : 8);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -96,8 +96,33 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
-    _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+    if _gemm_prof is not None:          # bench.py: HIP events around every GEMM launch, on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+        e1.record()
+        _gemm_prof.append((e0, e1, 2.0 * M * N * K))
+    else:
+        _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_preact else out
+
+
+_gemm_prof = None
+
+
+def gemm_profile_start():
+    """Start recording (start event, end event, algorithmic FLOPs) per stg_gemm_nt launch."""
+    global _gemm_prof
+    _gemm_prof = []
+
+
+def gemm_profile_stop():
+    """Stop recording; returns (launches, total_ms, total_flops) after synchronising."""
+    global _gemm_prof
+    rec, _gemm_prof = _gemm_prof, None
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+    return len(rec), ms, sum(f for _, _, f in rec)
 
 
 def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inner=1):

@@ -213,16 +213,37 @@ def _zeros_like_f32(p):
 class _Grads:
     """fp32 gradient buffers for the trainable tensors of a call, keyed by parameter name."""
 
-    def __init__(self, P, need, prefix=""):
-        self.P, self.need, self.prefix = P, need, prefix
+    def __init__(self, P, need, prefix="", arena=None):
+        self.P, self.need, self.prefix, self.arena = P, need, prefix, arena
         self.g = {}
 
     def buf(self, name):
         if not self.need.get(self.prefix + name, False):
             return None
         if name not in self.g:
-            self.g[name] = _zeros_like_f32(self.P[name])
+            if self.arena is not None:
+                self.g[name] = self.arena.view(self.prefix + name, self.P[name])
+            else:
+                self.g[name] = _zeros_like_f32(self.P[name])
         return self.g[name]
+
+
+class GradArena:
+    """One flat zero-initialised fp32 buffer holding every trainable gradient of a backward pass: a single memset instead
+    of one per tensor, and the whole payload of the data-parallel exchange (ONE RCCL all-reduce over xGMI, ddp.py)."""
+
+    def __init__(self, names, P, need, device):
+        self.off = {}
+        total = 0
+        for n in names:
+            if need.get(n, False):
+                self.off[n] = total
+                total += (P[n].numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+        self.flat = torch.zeros(total, dtype=F32, device=device)
+
+    def view(self, name, like):
+        o = self.off[name]
+        return self.flat[o:o + like.numel()].view(like.shape)
 
 
 def _adapter_wgrad(G, name, dZ, X, dY2, H2, *, rs=None, rs_outer=1, rs_inner=1):
@@ -386,7 +407,7 @@ def block_forward(X, spec, P, training, save):
     return X3, (S if save else None)
 
 
-def block_backward(S, spec, P, need, prefix, dX3):
+def block_backward(S, spec, P, need, prefix, dX3, arena=None):
     """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad})."""
     R, C = dX3.shape
     Rm, sl = _slices(spec, R)
@@ -395,7 +416,7 @@ def block_backward(S, spec, P, need, prefix, dX3):
     B = BT // spec.T
     T, N, H = spec.T, spec.N, spec.heads
     g = geom(dX3.device, spec.H, spec.W, spec.ws, spec.shift, T)
-    G = _Grads(P, need, prefix)
+    G = _Grads(P, need, prefix, arena)
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
     dgv, dga = G.buf("gate_v"), G.buf("gate_a")
     n1g = f32c(P["norm1.weight"])
@@ -544,14 +565,14 @@ def head_fusion_forward(X, n_tok, P, training, drop_p, save):
     return logits, ((X, mean, rstd, pooled, h0d, mask, n_tok) if save else None)
 
 
-def head_fusion_backward(S, P, need, dlogits, need_dx):
+def head_fusion_backward(S, P, need, dlogits, need_dx, arena=None):
     X, mean, rstd, pooled, h0d, mask, n_tok = S
     R, C = X.shape
     Rm = R // 2
     BT = Rm // n_tok
     w0, w2 = P["mlp_head.0.weight"], P["mlp_head.2.weight"]
     L = w2.shape[0]
-    G = _Grads(P, need)
+    G = _Grads(P, need, "", arena)
     dl = K.cast_bf16(dlogits.float().contiguous())                   # [BT, L padded to 8]
     gw2, gb2 = G.buf("mlp_head.2.weight"), G.buf("mlp_head.2.bias")
     if gw2 is not None:
@@ -584,13 +605,13 @@ def head_single_forward(X, n_tok, P, save):
     return logits, ((X, mean, rstd, pooled, m2, r2, Z, n_tok) if save else None)
 
 
-def head_single_backward(S, P, need, dlogits, need_dx):
+def head_single_backward(S, P, need, dlogits, need_dx, arena=None):
     X, mean, rstd, pooled, m2, r2, Z, n_tok = S
     R, C = X.shape
     BT = R // n_tok
     w1 = P["mlp_head.1.weight"]
     L = w1.shape[0]
-    G = _Grads(P, need)
+    G = _Grads(P, need, "", arena)
     dl = K.cast_bf16(dlogits.float().contiguous())
     gw, gb = G.buf("mlp_head.1.weight"), G.buf("mlp_head.1.bias")
     if gw is not None:
@@ -677,25 +698,29 @@ class SwinModelFn(torch.autograd.Function):
         else:
             logits, S = head_single_forward(X, plan.n_tok_last, P, save)
         ctx.tape, ctx.head, ctx.P, ctx.need, ctx.names, ctx.two = tape, S, P, need, names, len(mods) == 2
+        ctx.ddp = getattr(plan, "ddp", None)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         P, need = ctx.P, ctx.need
         grads = {}
+        arena = GradArena(ctx.names, P, need, dlogits.device)
         if ctx.two:
-            dX, g = head_fusion_backward(ctx.head, P, need, dlogits, True)
+            dX, g = head_fusion_backward(ctx.head, P, need, dlogits, True, arena)
         else:
-            dX, g = head_single_backward(ctx.head, P, need, dlogits, True)
+            dX, g = head_single_backward(ctx.head, P, need, dlogits, True, arena)
         grads.update(g)
         ctx.head = None
         tape = ctx.tape
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g = block_backward(S, spec, Pl, need, pre, dX)
+                dX, g = block_backward(S, spec, Pl, need, pre, dX, arena)
                 for k, val in g.items():
                     grads[pre + k] = val
             else:
                 dX = merge_backward(S, spec[0], spec[1], Pl, dX)
+        if ctx.ddp is not None:
+            ctx.ddp.allreduce_(arena.flat)      # one collective for every trainable gradient of the step
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
