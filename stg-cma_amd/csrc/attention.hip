@@ -64,19 +64,24 @@ __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpr
 template <int D>
 __device__ __forceinline__ void stage_tile(bf16_t* s, const bf16_t* src, int64_t ld, const int32_t* map, int64_t outer,
                                            int G, int nt, int64_t p, int h, int t0, int lane) {
-    constexpr int CPR = D / 8;
+    constexpr int CPR = D / 8;                    // 32 * CPR is a multiple of 64 for every supported D
+    uint4 v[(32 * CPR) / 64];
+    // loads are unconditional from clamped rows (a `cond ? load : 0` serialises every load behind a branch + vmcnt(0));
+    // rows beyond nt are zeroed by a select after the loads have been issued back to back
 #pragma unroll
-    for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+    for (int i = 0; i < (32 * CPR) / 64; ++i) {
         const int idx = lane + 64 * i;
-        if ((32 * CPR) % 64 != 0 && idx >= 32 * CPR) break;
         const int tr = idx / CPR, ch = idx - tr * CPR;
         const int t = t0 + tr;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t < nt) {
-            const int64_t row = tok_row(map, outer, G, nt, p, t);
-            v = *reinterpret_cast<const uint4*>(src + row * ld + h * D + ch * 8);
-        }
-        *reinterpret_cast<uint4*>(s + tr * D + ch * 8) = v;
+        const int64_t row = tok_row(map, outer, G, nt, p, t < nt ? t : nt - 1);
+        v[i] = *reinterpret_cast<const uint4*>(src + row * ld + h * D + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int tr = idx / CPR, ch = idx - tr * CPR;
+        if (t0 + tr >= nt) v[i] = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(s + tr * D + ch * 8) = v[i];
     }
 }
 
@@ -160,16 +165,28 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnP a) {
         for (int s = 0; s < KS; ++s) st = MFMA32(ld_frag(kp + 16 * s), qf[s], st);
         float x[16];
         float mt = -INFINITY;
+        float add[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) add[reg] = 0.f;
+        if (bias_q) {                                  // wave-uniform branches around blocks of independent loads
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                add[reg] += bias_q[kr < a.n_kv ? kr : a.n_kv - 1];
+            }
+        }
+        if (mask_q) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                add[reg] += mask_q[kr < a.n_kv ? kr : a.n_kv - 1];
+            }
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            float v = st[reg] * a.scale;
-            if (kr < a.n_kv) {
-                if (bias_q) v += bias_q[kr];
-                if (mask_q) v += mask_q[kr];
-            } else {
-                v = -INFINITY;
-            }
+            float v = st[reg] * a.scale + add[reg];
+            v = kr < a.n_kv ? v : -INFINITY;
             x[reg] = v;
             mt = fmaxf(mt, v);
         }
@@ -282,16 +299,28 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnP a) {
             dpt = MFMA32(ld_frag(vp + 16 * s), dof[s], dpt);
         }
         float ds[16];
+        float add[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) add[reg] = 0.f;
+        if (bias_q) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                add[reg] += bias_q[kr < a.n_kv ? kr : a.n_kv - 1];
+            }
+        }
+        if (mask_q) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                add[reg] += mask_q[kr < a.n_kv ? kr : a.n_kv - 1];
+            }
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            float v = st[reg] * a.scale;
-            float pr = 0.f;
-            if (kr < a.n_kv) {
-                if (bias_q) v += bias_q[kr];
-                if (mask_q) v += mask_q[kr];
-                pr = __expf(v - lse_q);
-            }
+            const float v = st[reg] * a.scale + add[reg];
+            const float pr = kr < a.n_kv ? __expf(v - lse_q) : 0.f;
             ds[reg] = pr * (dpt[reg] - delta);
         }
         bf16x8_t dsf[2];
@@ -383,18 +412,36 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
                 sc = MFMA32(ld_frag(sQ + r * D + 16 * s + 8 * hh), kf[s], sc);
                 dp = MFMA32(ld_frag(sDO + r * D + 16 * s + 8 * hh), vf[s], dp);
             }
-            float pr[16], ds[16];
+            float pr[16], ds[16], add[16], lse_r[16], del_r[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {               // independent loads, clamped rows, issued back to back
+                const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                const int qc = qr < a.n ? qr : a.n - 1;
+                lse_r[reg] = lse_p[qc];
+                del_r[reg] = del_p[qc];
+                add[reg] = 0.f;
+            }
+            if (bias_k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    add[reg] += bias_k[(int64_t)(qr < a.n ? qr : a.n - 1) * a.n_kv];
+                }
+            }
+            if (mask_k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    add[reg] += mask_k[(int64_t)(qr < a.n ? qr : a.n - 1) * a.n_kv];
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                float pv = 0.f, dsv = 0.f;
-                if (qr < a.n && key < a.n_kv) {
-                    float v = sc[reg] * a.scale;
-                    if (bias_k) v += bias_k[(int64_t)qr * a.n_kv];
-                    if (mask_k) v += mask_k[(int64_t)qr * a.n_kv];
-                    pv = __expf(v - lse_p[qr]);
-                    dsv = pv * (dp[reg] - del_p[qr]);
-                }
+                const bool ok = qr < a.n && key < a.n_kv;
+                const float v = sc[reg] * a.scale + add[reg];
+                const float pv = ok ? __expf(v - lse_r[reg]) : 0.f;
+                const float dsv = pv * (dp[reg] - del_r[reg]);
                 pr[reg] = pv;
                 ds[reg] = dsv;
                 dbacc[reg] += dsv;

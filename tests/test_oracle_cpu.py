@@ -101,6 +101,24 @@ def test_swin_b_full_model_matches_reference():
     assert list(z["n_params"]) == [92345613, 5599957, 1063965]
 
 
+def test_swin_b_refinit_model_matches_reference():
+    """Same model at the reference's own initialisation scale (the fixture behind the GPU test's absolute 1e-2 logit bound)."""
+    from params import refinit_state, seeded_tensor
+    z, cfg, shapes, names = load_case("swin_b_fusion_refinit")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=refinit_state)
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2)
+    logits = OS.swin_forward(P, a, v, cfg, "fusion")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1)
+    OS.soft_target_cross_entropy(logits, tgt).backward()
+    assert float((logits.detach() - torch.as_tensor(z["logits"])).abs().max()) <= 1e-4
+    norms = torch.stack([P[n].grad.norm() if P[n].grad is not None else torch.zeros(()) for n in names])
+    _close(norms, z["grad_norms"], what="grad norms")
+
+
 def test_structure_contract():
     with open(os.path.join(GOLD, "structure.json")) as f:
         st = json.load(f)
