@@ -110,6 +110,10 @@ typedef struct {
     const int32_t* map_q; const int32_t* map_kv;
     int64_t outer_q, outer_kv;
     int G;
+    /* map_kind 0: tables above (NULL = identity).  Arithmetic maps (no lookup in front of the operand loads), same map for
+     * queries and keys:  1 = cyclic shift + window partition, map_a/b = image H/W in tokens, map_c = window size,
+     * map_d = shift (G = windows per image, n = ws*ws);  2 = temporal regrouping, map_a = tokens per frame (= G), n = T. */
+    int map_kind; int map_a, map_b, map_c, map_d;
     int64_t P; int H; int n; int n_kv; int D;
     float scale;
     const float* bias; int64_t bias_div; int bias_mod;

@@ -45,6 +45,7 @@ class AttnArgs(C.Structure):
         ("map_q", c_vp), ("map_kv", c_vp),
         ("outer_q", c_i64), ("outer_kv", c_i64),
         ("G", C.c_int),
+        ("map_kind", C.c_int), ("map_a", C.c_int), ("map_b", C.c_int), ("map_c", C.c_int), ("map_d", C.c_int),
         ("P", c_i64), ("H", C.c_int), ("n", C.c_int), ("n_kv", C.c_int), ("D", C.c_int),
         ("scale", C.c_float),
         ("bias", c_vp), ("bias_div", c_i64), ("bias_mod", C.c_int),

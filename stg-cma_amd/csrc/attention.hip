@@ -7,6 +7,12 @@
 //
 // Work decomposition: ONE WAVE per (problem, head, 32-row tile); waves never synchronise with each other
 // (LDS regions are wave-private, ordered by wavefront-scope fences), so a launch is just a flat list of waves.
+// Short sequences (n <= 16: temporal attention, T = 10 / 5) are PACKED: floor(32 / n) problems share one 32-row tile with
+// a block-diagonal validity mask, so a wave's MFMA tile carries 3 (T = 10) or 6 (T = 5) sequences instead of one.
+//
+// Addressing is arithmetic wherever the model's maps are (map_kind 1: cyclic-shift + window partition, 2: temporal
+// regrouping) -- a table lookup would put a dependent HBM/L2 round trip in front of every operand load.  Operand loads of
+// tile t+1 are issued into registers before tile t is computed (these kernels are latency-, not FLOP-bound).
 //
 // MFMA: v_mfma_f32_32x32x16_bf16.  Lane l = (r = l & 31, hh = l >> 5):
 //   A operand: A[row r][k = 8*hh + j],  B operand: B[k = 8*hh + j][col r],  j = 0..7
@@ -32,9 +38,11 @@ struct AttnP {
     const int32_t* map_q; const int32_t* map_kv;
     int64_t outer_q, outer_kv;
     int G;
-    int64_t P; int H; int n; int n_kv;
+    int map_kind, ma, mb, mc, md;     // 1: window (Himg, Wimg, ws, shift)   2: temporal (N tokens per frame)
+    int P; int H; int n; int n_kv;
+    int pack;                          // problems per 32-row tile (1 unless n == n_kv <= 16)
     float scale;
-    const float* bias; int64_t bias_div; int bias_mod;
+    const float* bias; int bias_div; int bias_mod;
     const float* mask;
     // backward
     const bf16_t* dO; int64_t lddo;
@@ -43,15 +51,9 @@ struct AttnP {
     bf16_t* dV; int64_t lddv;
     float* delta;
     float* dbias;
-    int pchunk;            // problems per wave in the dK/dV kernel (dbias reduction)
-    int64_t total_items;
+    int pchunk;                        // tile-groups per wave in the dK/dV kernel (dbias reduction)
+    int total_items;
 };
-
-__device__ __forceinline__ int64_t tok_row(const int32_t* map, int64_t outer, int G, int n, int64_t p, int i) {
-    const int64_t pg = p / G;
-    const int idx = (int)(p - pg * G) * n + i;
-    return pg * outer + (map ? (int64_t)map[idx] : (int64_t)idx);
-}
 
 __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -60,30 +62,80 @@ __device__ __forceinline__ void lds_fence() {
 
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 
-// stage a 32 x D tile (rows t0..t0+31 of `src` for problem p, head h) into wave-private LDS, zero-filling rows >= nt
-template <int D>
-__device__ __forceinline__ void stage_tile(bf16_t* s, const bf16_t* src, int64_t ld, const int32_t* map, int64_t outer,
-                                           int G, int nt, int64_t p, int h, int t0, int lane) {
-    constexpr int CPR = D / 8;                    // 32 * CPR is a multiple of 64 for every supported D
-    uint4 v[(32 * CPR) / 64];
-    // loads are unconditional from clamped rows (a `cond ? load : 0` serialises every load behind a branch + vmcnt(0));
-    // rows beyond nt are zeroed by a select after the loads have been issued back to back
-#pragma unroll
-    for (int i = 0; i < (32 * CPR) / 64; ++i) {
-        const int idx = lane + 64 * i;
-        const int tr = idx / CPR, ch = idx - tr * CPR;
-        const int t = t0 + tr;
-        const int64_t row = tok_row(map, outer, G, nt, p, t < nt ? t : nt - 1);
-        v[i] = *reinterpret_cast<const uint4*>(src + row * ld + h * D + ch * 8);
+// token offset of (group g, token i) inside its outer block
+__device__ __forceinline__ int tok_off(const AttnP& a, bool kv, int g, int i) {
+    if (a.map_kind == 1) {
+        const int nww = a.mb / a.mc;
+        const int wi = g / nww, wj = g - wi * nww;
+        const int ti = i / a.mc, tj = i - ti * a.mc;
+        int h = wi * a.mc + ti + a.md;
+        h = h >= a.ma ? h - a.ma : h;
+        int w = wj * a.mc + tj + a.md;
+        w = w >= a.mb ? w - a.mb : w;
+        return h * a.mb + w;
     }
-#pragma unroll
-    for (int i = 0; i < (32 * CPR) / 64; ++i) {
-        const int idx = lane + 64 * i;
-        const int tr = idx / CPR, ch = idx - tr * CPR;
-        if (t0 + tr >= nt) v[i] = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(s + tr * D + ch * 8) = v[i];
-    }
+    if (a.map_kind == 2) return i * a.ma + g;
+    const int32_t* m = kv ? a.map_kv : a.map_q;
+    const int idx = g * (kv ? a.n_kv : a.n) + i;
+    return m ? m[idx] : idx;
 }
+
+// tile row x (0..31) of the tile that starts at token t0 of problem(-group) p0 -> (problem, token, valid); invalid rows are
+// clamped to an in-bounds (problem, token) so that every load stays unconditional
+template <bool PK>
+__device__ __forceinline__ bool locate(const AttnP& a, int p0, int t0, int x, int nt, int& p, int& i) {
+    bool ok;
+    if (PK) {
+        const int sub = x / nt;
+        i = x - sub * nt;
+        p = p0 + sub;
+        ok = sub < a.pack && p < a.P;
+        if (!ok) { p = p0; i = 0; }
+    } else {
+        p = p0;
+        i = t0 + x;
+        ok = i < nt;
+        if (!ok) i = nt - 1;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int64_t row_of(const AttnP& a, bool kv, int p, int i) {
+    const unsigned pg = (unsigned)p / (unsigned)a.G;
+    const int g = p - (int)pg * a.G;
+    return (int64_t)pg * (kv ? a.outer_kv : a.outer_q) + tok_off(a, kv, g, i);
+}
+
+// ---- 32 x D tile staging through registers (so the loads of the NEXT tile can be in flight during compute)
+template <int D>
+struct TileRegs {
+    static constexpr int CPR = D / 8;
+    static constexpr int NV = (32 * CPR) / 64;     // 16-byte chunks per lane (32*CPR is a multiple of 64 for every D)
+    uint4 v[NV];
+    template <bool PK>
+    __device__ __forceinline__ void load(const AttnP& a, const bf16_t* src, int64_t ld, bool kv, int nt, int p0, int h, int t0,
+                                         int lane) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            const int tr = idx / CPR, ch = idx - tr * CPR;
+            int p, t;
+            locate<PK>(a, p0, t0, tr, nt, p, t);
+            v[i] = *reinterpret_cast<const uint4*>(src + row_of(a, kv, p, t) * ld + h * D + ch * 8);
+        }
+    }
+    template <bool PK>
+    __device__ __forceinline__ void store(const AttnP& a, bf16_t* s, int nt, int p0, int t0, int lane) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            const int tr = idx / CPR, ch = idx - tr * CPR;
+            int p, t;
+            const bool ok = locate<PK>(a, p0, t0, tr, nt, p, t);
+            *reinterpret_cast<uint4*>(s + tr * D + ch * 8) = ok ? v[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
+};
 
 // A-operand fragment of the TRANSPOSED tile: A[i = d][k slot j] = tile[kappa(s2, hh, j)][d]; rows d >= D are zero
 template <int D>
@@ -100,11 +152,10 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int s2, int hh, int
     return f;
 }
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8_t pack_frag(const float* x) {
-    bf16x8_t f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(x[j]);
-    return f;
+    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8_t, w);
 }
 
 __device__ __forceinline__ f32x16_t zero16() {
@@ -115,26 +166,40 @@ __device__ __forceinline__ f32x16_t zero16() {
 }
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define ACC_ROW(reg, hh) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hh))
+
+__device__ __forceinline__ void decode_item(const AttnP& a, int item, int tiles, int& t, int& h, int& p0) {
+    t = item % tiles;
+    const int rest = item / tiles;
+    h = rest % a.H;
+    p0 = (rest / a.H) * a.pack;
+}
+
+// additive score terms (bias + mask) and validity of the 16 accumulator rows a lane holds, for "other side" rows of a tile
+// fixed = this lane's own token (query for fwd/dq, key for dkv); the bias/mask element is [q token][k token].
+struct RowTerms {
+    float add[16];
+    unsigned okmask;
+};
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int D>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnP a) {
+template <int D, bool PK>
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int item = blockIdx.x * 4 + wave;
     if (item >= a.total_items) return;
-    const int QT = (a.n + 31) >> 5;
-    const int qt = (int)(item % QT);
-    const int h = (int)((item / QT) % a.H);
-    const int64_t p = item / ((int64_t)QT * a.H);
+    const int QT = PK ? 1 : (a.n + 31) >> 5;
+    int qt, h, p0;
+    decode_item(a, item, QT, qt, h, p0);
     bf16_t* sV = smem + wave * 32 * D;
 
-    const int q = qt * 32 + r;
-    const int qc = q < a.n ? q : a.n - 1;
-    const int64_t rowq = tok_row(a.map_q, a.outer_q, a.G, a.n, p, qc);
+    int pq, iq;
+    const bool okq = locate<PK>(a, p0, qt * 32, r, a.n, pq, iq);
+    const int64_t rowq = row_of(a, false, pq, iq);
     bf16x8_t qf[KS];
     {
         const bf16_t* qp = a.Q + rowq * a.ldq + h * D + 8 * hh;
@@ -142,61 +207,75 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnP a) {
         for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
     }
     const float* bias_q = nullptr;
-    if (a.bias) {
-        const int64_t bg = (p / a.bias_div) % a.bias_mod;
-        bias_q = a.bias + ((bg * a.H + h) * a.n + qc) * (int64_t)a.n_kv;
-    }
-    const float* mask_q = a.mask ? a.mask + ((p % a.G) * a.n + qc) * (int64_t)a.n_kv : nullptr;
+    if (a.bias) bias_q = a.bias + ((int64_t)(((pq / a.bias_div) % a.bias_mod) * a.H + h) * a.n + iq) * a.n_kv;
+    const float* mask_q = a.mask ? a.mask + ((int64_t)(pq % a.G) * a.n + iq) * a.n_kv : nullptr;
 
     f32x16_t o[DB];
 #pragma unroll
     for (int b = 0; b < DB; ++b) o[b] = zero16();
     float m = -INFINITY, l = 0.f;
 
+    // prefetch tile 0
+    TileRegs<D> vt;
+    bf16x8_t kf[KS];
+    {
+        vt.template load<PK>(a, a.V, a.ldv, true, a.n_kv, p0, h, 0, lane);
+        int pk, jk;
+        locate<PK>(a, p0, 0, r, a.n_kv, pk, jk);
+        const bf16_t* kp = a.K + row_of(a, true, pk, jk) * a.ldk + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[s] = ld_frag(kp + 16 * s);
+    }
+
     for (int kv0 = 0; kv0 < a.n_kv; kv0 += 32) {
         lds_fence();
-        stage_tile<D>(sV, a.V, a.ldv, a.map_kv, a.outer_kv, a.G, a.n_kv, p, h, kv0, lane);
-        const int key = kv0 + r;
-        const int kc = key < a.n_kv ? key : a.n_kv - 1;
-        const int64_t rowk = tok_row(a.map_kv, a.outer_kv, a.G, a.n_kv, p, kc);
-        const bf16_t* kp = a.K + rowk * a.ldk + h * D + 8 * hh;
+        vt.template store<PK>(a, sV, a.n_kv, p0, kv0, lane);
         f32x16_t st = zero16();
 #pragma unroll
-        for (int s = 0; s < KS; ++s) st = MFMA32(ld_frag(kp + 16 * s), qf[s], st);
-        float x[16];
-        float mt = -INFINITY;
-        float add[16];
+        for (int s = 0; s < KS; ++s) st = MFMA32(kf[s], qf[s], st);
+        if (kv0 + 32 < a.n_kv) {                       // wave-uniform: next tile's operands go in flight now
+            vt.template load<PK>(a, a.V, a.ldv, true, a.n_kv, p0, h, kv0 + 32, lane);
+            int pk, jk;
+            locate<PK>(a, p0, kv0 + 32, r, a.n_kv, pk, jk);
+            const bf16_t* kp = a.K + row_of(a, true, pk, jk) * a.ldk + h * D + 8 * hh;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) add[reg] = 0.f;
+            for (int s = 0; s < KS; ++s) kf[s] = ld_frag(kp + 16 * s);
+        }
+        float x[16], add[16];
+        unsigned okm = 0;
+        int jcol[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int pk, jk;
+            const bool ok = locate<PK>(a, p0, kv0, ACC_ROW(reg, hh), a.n_kv, pk, jk) && pk == pq;
+            okm |= ok ? (1u << reg) : 0u;
+            jcol[reg] = jk;
+            add[reg] = 0.f;
+        }
         if (bias_q) {                                  // wave-uniform branches around blocks of independent loads
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                add[reg] += bias_q[kr < a.n_kv ? kr : a.n_kv - 1];
-            }
+            for (int reg = 0; reg < 16; ++reg) add[reg] += bias_q[jcol[reg]];
         }
         if (mask_q) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                add[reg] += mask_q[kr < a.n_kv ? kr : a.n_kv - 1];
-            }
+            for (int reg = 0; reg < 16; ++reg) add[reg] += mask_q[jcol[reg]];
         }
+        float mt = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
             float v = st[reg] * a.scale + add[reg];
-            v = kr < a.n_kv ? v : -INFINITY;
+            v = ((okm >> reg) & 1u) ? v : -INFINITY;
             x[reg] = v;
             mt = fmaxf(mt, v);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float mn = fmaxf(m, mt);
-        const float alpha = __expf(m - mn);
+        const float msafe = mn == -INFINITY ? 0.f : mn;   // a padded query row of a packed tile sees no valid key
+        const float alpha = __expf(m - msafe);
         float ps = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            x[reg] = __expf(x[reg] - mn);
+            x[reg] = __expf(x[reg] - msafe);
             ps += x[reg];
         }
         ps += __shfl_xor(ps, 32, 64);
@@ -216,7 +295,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnP a) {
             for (int b = 0; b < DB; ++b) o[b] = MFMA32(tr_frag<D>(sV, s2, hh, 32 * b + r), pf[s2], o[b]);
     }
 
-    if (q < a.n) {
+    if (okq) {
         const float inv = 1.0f / l;
         bf16_t* op = a.O + rowq * a.ldo + h * D;
 #pragma unroll
@@ -231,29 +310,28 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnP a) {
                     *reinterpret_cast<uint2*>(op + d) = w;
                 }
             }
-        if (a.lse && hh == 0) a.lse[(p * a.H + h) * a.n + q] = m + __logf(l);
+        if (a.lse && hh == 0) a.lse[((int64_t)pq * a.H + h) * a.n + iq] = m + __logf(l);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int D>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnP a) {
+template <int D, bool PK>
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int item = blockIdx.x * 4 + wave;
     if (item >= a.total_items) return;
-    const int QT = (a.n + 31) >> 5;
-    const int qt = (int)(item % QT);
-    const int h = (int)((item / QT) % a.H);
-    const int64_t p = item / ((int64_t)QT * a.H);
+    const int QT = PK ? 1 : (a.n + 31) >> 5;
+    int qt, h, p0;
+    decode_item(a, item, QT, qt, h, p0);
     bf16_t* sK = smem + wave * 32 * D;
 
-    const int q = qt * 32 + r;
-    const int qc = q < a.n ? q : a.n - 1;
-    const int64_t rowq = tok_row(a.map_q, a.outer_q, a.G, a.n, p, qc);
+    int pq, iq;
+    const bool okq = locate<PK>(a, p0, qt * 32, r, a.n, pq, iq);
+    const int64_t rowq = row_of(a, false, pq, iq);
     bf16x8_t qf[KS], dof[KS];
     float delta = 0.f;
     {
@@ -270,69 +348,80 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnP a) {
         }
     }
     delta += __shfl_xor(delta, 32, 64);
-    const int64_t stat_idx = (p * a.H + h) * a.n + qc;
-    if (q < a.n && hh == 0) a.delta[stat_idx] = delta;
+    const int64_t stat_idx = ((int64_t)pq * a.H + h) * a.n + iq;
+    if (okq && hh == 0) a.delta[stat_idx] = delta;
     const float lse_q = a.lse[stat_idx];
     const float* bias_q = nullptr;
-    if (a.bias) {
-        const int64_t bg = (p / a.bias_div) % a.bias_mod;
-        bias_q = a.bias + ((bg * a.H + h) * a.n + qc) * (int64_t)a.n_kv;
-    }
-    const float* mask_q = a.mask ? a.mask + ((p % a.G) * a.n + qc) * (int64_t)a.n_kv : nullptr;
+    if (a.bias) bias_q = a.bias + ((int64_t)(((pq / a.bias_div) % a.bias_mod) * a.H + h) * a.n + iq) * a.n_kv;
+    const float* mask_q = a.mask ? a.mask + ((int64_t)(pq % a.G) * a.n + iq) * a.n_kv : nullptr;
 
     f32x16_t dq[DB];
 #pragma unroll
     for (int b = 0; b < DB; ++b) dq[b] = zero16();
 
+    TileRegs<D> kt;
+    bf16x8_t vf[KS];
+    {
+        kt.template load<PK>(a, a.K, a.ldk, true, a.n_kv, p0, h, 0, lane);
+        int pk, jk;
+        locate<PK>(a, p0, 0, r, a.n_kv, pk, jk);
+        const bf16_t* vp = a.V + row_of(a, true, pk, jk) * a.ldv + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) vf[s] = ld_frag(vp + 16 * s);
+    }
+
     for (int kv0 = 0; kv0 < a.n_kv; kv0 += 32) {
         lds_fence();
-        stage_tile<D>(sK, a.K, a.ldk, a.map_kv, a.outer_kv, a.G, a.n_kv, p, h, kv0, lane);
-        const int key = kv0 + r;
-        const int kc = key < a.n_kv ? key : a.n_kv - 1;
-        const int64_t rowk = tok_row(a.map_kv, a.outer_kv, a.G, a.n_kv, p, kc);
-        const bf16_t* kp = a.K + rowk * a.ldk + h * D + 8 * hh;
-        const bf16_t* vp = a.V + rowk * a.ldv + h * D + 8 * hh;
-        f32x16_t st = zero16(), dpt = zero16();
+        kt.template store<PK>(a, sK, a.n_kv, p0, kv0, lane);
+        f32x16_t dpt = zero16();
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            st = MFMA32(ld_frag(kp + 16 * s), qf[s], st);
-            dpt = MFMA32(ld_frag(vp + 16 * s), dof[s], dpt);
+        for (int s = 0; s < KS; ++s) dpt = MFMA32(vf[s], dof[s], dpt);
+        if (kv0 + 32 < a.n_kv) {
+            kt.template load<PK>(a, a.K, a.ldk, true, a.n_kv, p0, h, kv0 + 32, lane);
+            int pk, jk;
+            locate<PK>(a, p0, kv0 + 32, r, a.n_kv, pk, jk);
+            const bf16_t* vp = a.V + row_of(a, true, pk, jk) * a.ldv + h * D + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) vf[s] = ld_frag(vp + 16 * s);
         }
-        float ds[16];
-        float add[16];
+        lds_fence();
+        f32x16_t st = zero16();
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) add[reg] = 0.f;
+        for (int s = 0; s < KS; ++s) st = MFMA32(ld_frag(sK + r * D + 16 * s + 8 * hh), qf[s], st);
+        float ds[16], add[16];
+        unsigned okm = 0;
+        int jcol[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int pk, jk;
+            const bool ok = locate<PK>(a, p0, kv0, ACC_ROW(reg, hh), a.n_kv, pk, jk) && pk == pq;
+            okm |= ok ? (1u << reg) : 0u;
+            jcol[reg] = jk;
+            add[reg] = 0.f;
+        }
         if (bias_q) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                add[reg] += bias_q[kr < a.n_kv ? kr : a.n_kv - 1];
-            }
+            for (int reg = 0; reg < 16; ++reg) add[reg] += bias_q[jcol[reg]];
         }
         if (mask_q) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                add[reg] += mask_q[kr < a.n_kv ? kr : a.n_kv - 1];
-            }
+            for (int reg = 0; reg < 16; ++reg) add[reg] += mask_q[jcol[reg]];
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int kr = kv0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
             const float v = st[reg] * a.scale + add[reg];
-            const float pr = kr < a.n_kv ? __expf(v - lse_q) : 0.f;
+            const float pr = ((okm >> reg) & 1u) ? __expf(v - lse_q) : 0.f;
             ds[reg] = pr * (dpt[reg] - delta);
         }
         bf16x8_t dsf[2];
         dsf[0] = pack_frag(ds);
         dsf[1] = pack_frag(ds + 8);
-        lds_fence();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int b = 0; b < DB; ++b) dq[b] = MFMA32(tr_frag<D>(sK, s2, hh, 32 * b + r), dsf[s2], dq[b]);
     }
-    if (q < a.n) {
+    if (okq) {
         bf16_t* op = a.dQ + rowq * a.lddq + h * D;
 #pragma unroll
         for (int b = 0; b < DB; ++b)
@@ -349,35 +438,66 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnP a) {
     }
 }
 
+// dbias[bg][h][i][j] += dS accumulated in the dK/dV kernel.  Entry [i][j] sits on the lane of key j (sub-problem s) and the
+// register of query i of the SAME sub-problem (block diagonal when packed).  The bias group is taken per lane from the
+// lane's own problem of tile-group `gi` (host guarantees n <= 32 and that a flush never mixes bias groups on one lane).
+template <bool PK>
+__device__ __forceinline__ void flush_dbias(const AttnP& a, f32x16_t& dbacc, int gi, int kv0, int r, int hh, int h) {
+    const int subk = PK ? r / a.n_kv : 0;
+    const int jk = PK ? r - subk * a.n_kv : kv0 + r;
+    const int pk = gi * a.pack + subk;
+    const bool lane_ok = PK ? (subk < a.pack) : (jk < a.n_kv);
+    if (lane_ok) {
+        const int pkc = pk < a.P ? pk : a.P - 1;
+        const int bg = (pkc / a.bias_div) % a.bias_mod;
+        float* db = a.dbias + ((int64_t)(bg * a.H + h) * a.n) * a.n_kv + jk;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int x = ACC_ROW(reg, hh);
+            int subq, iq;
+            if (PK) { subq = x / a.n; iq = x - subq * a.n; } else { subq = 0; iq = x; }
+            if (subq == subk && iq < a.n) atomicAdd(db + iq * a.n_kv, dbacc[reg]);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) dbacc[reg] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dK, dV (+ dbias)
 // The wave owns 32 keys (key on the lane): S[q][key] = Q . K^T and dP[q][key] = dO . V^T come out with the query in
 // registers; P and dS are then the B operands of dV^T[d][key] = dO^T . P and dK^T[d][key] = Q^T . dS.
-template <int D>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
+template <int D, bool PK>
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
+    constexpr bool PREFETCH = D <= 64;                 // register budget: two extra tiles in flight only for small D
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 2 * 32 * D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int item = blockIdx.x * 4 + wave;
     if (item >= a.total_items) return;
-    const int KT = (a.n_kv + 31) >> 5;
-    const int kt = (int)(item % KT);
-    const int h = (int)((item / KT) % a.H);
-    const int64_t pc = item / ((int64_t)KT * a.H);
+    const int KT = PK ? 1 : (a.n_kv + 31) >> 5;
+    const int kt = item % KT;
+    const int rest = item / KT;
+    const int h = rest % a.H;
+    const int gc = rest / a.H;                          // chunk of tile-groups
     bf16_t* sQ = smem + wave * 2 * 32 * D;
     bf16_t* sDO = sQ + 32 * D;
-
     const int kv0 = kt * 32;
-    const int key = kv0 + r;
-    const int kc = key < a.n_kv ? key : a.n_kv - 1;
     f32x16_t dbacc = zero16();
+    const int ngroups = (a.P + a.pack - 1) / a.pack;
+    const int gbeg = gc * a.pchunk;
+    const int gend = gbeg + a.pchunk < ngroups ? gbeg + a.pchunk : ngroups;
 
-    const int64_t pbeg = pc * a.pchunk;
-    int64_t pend = pbeg + a.pchunk;
-    if (pend > a.P) pend = a.P;
-    for (int64_t p = pbeg; p < pend; ++p) {
-        const int64_t rowk = tok_row(a.map_kv, a.outer_kv, a.G, a.n_kv, p, kc);
+    // a chunk whose problems span two bias groups (only at a group boundary) flushes after every tile-group instead of once
+    const bool straddle = a.dbias != nullptr &&
+        ((gbeg * a.pack) / a.bias_div) != (((gend * a.pack < a.P ? gend * a.pack : a.P) - 1) / a.bias_div);
+    for (int gi = gbeg; gi < gend; ++gi) {
+        if (straddle && gi > gbeg) flush_dbias<PK>(a, dbacc, gi - 1, kv0, r, hh, h);
+        const int p0 = gi * a.pack;
+        int pk, jk;
+        const bool okk = locate<PK>(a, p0, kv0, r, a.n_kv, pk, jk);
+        const int64_t rowk = row_of(a, true, pk, jk);
         bf16x8_t kf[KS], vf[KS];
         {
             const bf16_t* kp = a.K + rowk * a.ldk + h * D + 8 * hh;
@@ -389,22 +509,48 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
             }
         }
         const float* bias_k = nullptr;
-        if (a.bias) {
-            const int64_t bg = (p / a.bias_div) % a.bias_mod;
-            bias_k = a.bias + ((bg * a.H + h) * a.n) * (int64_t)a.n_kv + kc;
-        }
-        const float* mask_k = a.mask ? a.mask + ((p % a.G) * a.n) * (int64_t)a.n_kv + kc : nullptr;
-        const float* lse_p = a.lse + (p * a.H + h) * a.n;
-        const float* del_p = a.delta + (p * a.H + h) * a.n;
+        if (a.bias) bias_k = a.bias + ((int64_t)(((pk / a.bias_div) % a.bias_mod) * a.H + h) * a.n) * a.n_kv + jk;
+        const float* mask_k = a.mask ? a.mask + ((int64_t)(pk % a.G) * a.n) * a.n_kv + jk : nullptr;
 
         f32x16_t dk[DB], dv[DB];
 #pragma unroll
         for (int b = 0; b < DB; ++b) { dk[b] = zero16(); dv[b] = zero16(); }
 
-        for (int q0 = 0; q0 < a.n; q0 += 32) {
+        TileRegs<D> tq, tdo;
+        tq.template load<PK>(a, a.Q, a.ldq, false, a.n, p0, h, 0, lane);
+        tdo.template load<PK>(a, a.dO, a.lddo, false, a.n, p0, h, 0, lane);
+        const int qend = PK ? 32 : a.n;
+        for (int q0 = 0; q0 < qend; q0 += 32) {
             lds_fence();
-            stage_tile<D>(sQ, a.Q, a.ldq, a.map_q, a.outer_q, a.G, a.n, p, h, q0, lane);
-            stage_tile<D>(sDO, a.dO, a.lddo, a.map_q, a.outer_q, a.G, a.n, p, h, q0, lane);
+            tq.template store<PK>(a, sQ, a.n, p0, q0, lane);
+            tdo.template store<PK>(a, sDO, a.n, p0, q0, lane);
+            if (PREFETCH && q0 + 32 < qend) {
+                tq.template load<PK>(a, a.Q, a.ldq, false, a.n, p0, h, q0 + 32, lane);
+                tdo.template load<PK>(a, a.dO, a.lddo, false, a.n, p0, h, q0 + 32, lane);
+            }
+            // per accumulator row (= query): statistics + additive terms, independent loads from clamped addresses
+            float lse_r[16], del_r[16], add[16];
+            unsigned okm = 0;
+            int qoff[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int pqr, iqr;
+                const bool ok = locate<PK>(a, p0, q0, ACC_ROW(reg, hh), a.n, pqr, iqr) && pqr == pk && okk;
+                okm |= ok ? (1u << reg) : 0u;
+                const int64_t si = ((int64_t)pqr * a.H + h) * a.n + iqr;
+                lse_r[reg] = a.lse[si];
+                del_r[reg] = a.delta[si];
+                qoff[reg] = iqr * a.n_kv;
+                add[reg] = 0.f;
+            }
+            if (bias_k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) add[reg] += bias_k[qoff[reg]];
+            }
+            if (mask_k) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) add[reg] += mask_k[qoff[reg]];
+            }
             lds_fence();
             f32x16_t sc = zero16(), dp = zero16();
 #pragma unroll
@@ -412,35 +558,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
                 sc = MFMA32(ld_frag(sQ + r * D + 16 * s + 8 * hh), kf[s], sc);
                 dp = MFMA32(ld_frag(sDO + r * D + 16 * s + 8 * hh), vf[s], dp);
             }
-            float pr[16], ds[16], add[16], lse_r[16], del_r[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {               // independent loads, clamped rows, issued back to back
-                const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                const int qc = qr < a.n ? qr : a.n - 1;
-                lse_r[reg] = lse_p[qc];
-                del_r[reg] = del_p[qc];
-                add[reg] = 0.f;
-            }
-            if (bias_k) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    add[reg] += bias_k[(int64_t)(qr < a.n ? qr : a.n - 1) * a.n_kv];
-                }
-            }
-            if (mask_k) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    add[reg] += mask_k[(int64_t)(qr < a.n ? qr : a.n - 1) * a.n_kv];
-                }
-            }
+            float pr[16], ds[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int qr = q0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                const bool ok = qr < a.n && key < a.n_kv;
                 const float v = sc[reg] * a.scale + add[reg];
-                const float pv = ok ? __expf(v - lse_r[reg]) : 0.f;
+                const float pv = ((okm >> reg) & 1u) ? __expf(v - lse_r[reg]) : 0.f;
                 const float dsv = pv * (dp[reg] - del_r[reg]);
                 pr[reg] = pv;
                 ds[reg] = dsv;
@@ -456,8 +578,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
                     dv[b] = MFMA32(tr_frag<D>(sDO, s2, hh, 32 * b + r), pf[s2], dv[b]);
                     dk[b] = MFMA32(tr_frag<D>(sQ, s2, hh, 32 * b + r), dsf[s2], dk[b]);
                 }
+            if (!PREFETCH && q0 + 32 < qend) {
+                tq.template load<PK>(a, a.Q, a.ldq, false, a.n, p0, h, q0 + 32, lane);
+                tdo.template load<PK>(a, a.dO, a.lddo, false, a.n, p0, h, q0 + 32, lane);
+            }
         }
-        if (key < a.n_kv) {
+        if (okk) {
             bf16_t* kp = a.dK + rowk * a.lddk + h * D;
             bf16_t* vp = a.dV ? a.dV + rowk * a.lddv + h * D : nullptr;
 #pragma unroll
@@ -482,84 +608,96 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnP a) {
                 }
         }
     }
-    if (a.dbias && key < a.n_kv) {
-        // host guarantees n <= 32 (one query tile) and a single bias group per problem chunk
-        const int64_t bg = (pbeg / a.bias_div) % a.bias_mod;
-        float* db = a.dbias + ((bg * a.H + h) * a.n) * (int64_t)a.n_kv + key;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int qr = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            if (qr < a.n) atomicAdd(db + (int64_t)qr * a.n_kv, dbacc[reg]);
-        }
-    }
+    if (a.dbias) flush_dbias<PK>(a, dbacc, gend - 1, kv0, r, hh, h);
 }
 
 int fill(const stg_attn_args* f, AttnP& p, const char* who) {
     STG_CHECK(f->Q && f->K && f->V, -1, "%s: null Q/K/V", who);
     STG_CHECK(f->P >= 0 && f->H > 0 && f->n > 0 && f->n_kv > 0 && f->G > 0, -2, "%s: bad shape", who);
+    STG_CHECK(f->P < (1ll << 30) && f->P * f->H < (1ll << 30), -2, "%s: too many problems", who);
     STG_CHECK(f->D == 16 || f->D == 32 || f->D == 48 || f->D == 64 || f->D == 96 || f->D == 128, -2,
               "%s: unsupported head dim %d", who, f->D);
-    STG_CHECK(f->ldq % 4 == 0 && f->ldk % 8 == 0 && f->ldv % 8 == 0, -2, "%s: leading dims must be multiples of 8", who);
-    STG_CHECK(f->ldq % 8 == 0, -2, "%s: ldq must be a multiple of 8", who);
+    STG_CHECK(f->ldq % 8 == 0 && f->ldk % 8 == 0 && f->ldv % 8 == 0, -2, "%s: leading dims must be multiples of 8", who);
     STG_CHECK((((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V) & 15) == 0, -2, "%s: Q/K/V must be 16-byte aligned", who);
-    STG_CHECK(f->map_q != nullptr || f->outer_q >= (int64_t)f->G * f->n, -2, "%s: outer_q too small for identity map", who);
-    STG_CHECK(f->map_kv != nullptr || f->outer_kv >= (int64_t)f->G * f->n_kv, -2, "%s: outer_kv too small for identity map", who);
-    if (f->bias) STG_CHECK(f->bias_div > 0 && f->bias_mod > 0, -2, "%s: bad bias grouping", who);
+    STG_CHECK(f->map_kind >= 0 && f->map_kind <= 2, -2, "%s: bad map_kind", who);
+    if (f->map_kind == 0) {
+        STG_CHECK(f->map_q != nullptr || f->outer_q >= (int64_t)f->G * f->n, -2, "%s: outer_q too small for identity map", who);
+        STG_CHECK(f->map_kv != nullptr || f->outer_kv >= (int64_t)f->G * f->n_kv, -2, "%s: outer_kv too small for identity map", who);
+    } else if (f->map_kind == 1) {       // window: (Himg, Wimg, ws, shift); G windows of ws*ws tokens tile the image
+        STG_CHECK(f->map_c > 0 && f->map_a % f->map_c == 0 && f->map_b % f->map_c == 0 && f->map_d >= 0 && f->map_d < f->map_c,
+                  -2, "%s: bad window map", who);
+        STG_CHECK(f->n == f->map_c * f->map_c && f->n_kv == f->n && f->G == (f->map_a / f->map_c) * (f->map_b / f->map_c), -2,
+                  "%s: window map does not match n / G", who);
+        STG_CHECK(f->outer_q >= (int64_t)f->map_a * f->map_b && f->outer_kv >= (int64_t)f->map_a * f->map_b, -2,
+                  "%s: outer too small for window map", who);
+    } else {                              // temporal: map_a = tokens per frame (= G), n = T frames
+        STG_CHECK(f->map_a == f->G && f->n_kv == f->n, -2, "%s: temporal map needs map_a == G and n_kv == n", who);
+        STG_CHECK(f->outer_q >= (int64_t)f->n * f->map_a && f->outer_kv >= (int64_t)f->n * f->map_a, -2,
+                  "%s: outer too small for temporal map", who);
+    }
+    if (f->bias) STG_CHECK(f->bias_div > 0 && f->bias_mod > 0 && f->bias_div < (1ll << 31), -2, "%s: bad bias grouping", who);
     p.Q = (const bf16_t*)f->Q; p.ldq = f->ldq; p.K = (const bf16_t*)f->K; p.ldk = f->ldk;
     p.V = (const bf16_t*)f->V; p.ldv = f->ldv; p.O = (bf16_t*)f->O; p.ldo = f->ldo; p.lse = f->lse;
     p.map_q = f->map_q; p.map_kv = f->map_kv; p.outer_q = f->outer_q; p.outer_kv = f->outer_kv; p.G = f->G;
-    p.P = f->P; p.H = f->H; p.n = f->n; p.n_kv = f->n_kv; p.scale = f->scale;
-    p.bias = f->bias; p.bias_div = f->bias ? f->bias_div : 1; p.bias_mod = f->bias ? f->bias_mod : 1; p.mask = f->mask;
+    p.map_kind = f->map_kind; p.ma = f->map_a; p.mb = f->map_b; p.mc = f->map_c; p.md = f->map_d;
+    p.P = (int)f->P; p.H = f->H; p.n = f->n; p.n_kv = f->n_kv; p.scale = f->scale;
+    p.pack = (f->n == f->n_kv && f->n <= 16) ? 32 / f->n : 1;
+    p.bias = f->bias; p.bias_div = f->bias ? (int)f->bias_div : 1; p.bias_mod = f->bias ? f->bias_mod : 1; p.mask = f->mask;
     return 0;
 }
 
-template <template <int> class Launcher>
+template <template <int, bool> class Launcher>
 int dispatch_d(int D, const AttnP& p, hipStream_t st) {
+    const bool pk = p.pack > 1;
     switch (D) {
-        case 16: return Launcher<16>::run(p, st);
-        case 32: return Launcher<32>::run(p, st);
-        case 48: return Launcher<48>::run(p, st);
-        case 64: return Launcher<64>::run(p, st);
-        case 96: return Launcher<96>::run(p, st);
-        case 128: return Launcher<128>::run(p, st);
+        case 16: return pk ? Launcher<16, true>::run(p, st) : Launcher<16, false>::run(p, st);
+        case 32: return pk ? Launcher<32, true>::run(p, st) : Launcher<32, false>::run(p, st);
+        case 48: return pk ? Launcher<48, true>::run(p, st) : Launcher<48, false>::run(p, st);
+        case 64: return pk ? Launcher<64, true>::run(p, st) : Launcher<64, false>::run(p, st);
+        case 96: return pk ? Launcher<96, true>::run(p, st) : Launcher<96, false>::run(p, st);
+        case 128: return pk ? Launcher<128, true>::run(p, st) : Launcher<128, false>::run(p, st);
     }
     return -2;
 }
 
 inline int grid_of(int64_t items, unsigned& g) {
     const int64_t blocks = (items + 3) / 4;
-    if (blocks <= 0 || blocks >= (1ll << 31)) return -2;
+    if (blocks <= 0 || items >= (1ll << 31)) return -2;
     g = (unsigned)blocks;
     return 0;
 }
 
-template <int D> struct FwdL {
+template <int D, bool PK> struct FwdL {
     static int run(const AttnP& p, hipStream_t st) {
         unsigned g;
         STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(attn_fwd_kernel<D>, dim3(g), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
         STG_LAUNCH_CHECK();
         return 0;
     }
 };
-template <int D> struct DqL {
+template <int D, bool PK> struct DqL {
     static int run(const AttnP& p, hipStream_t st) {
         unsigned g;
         STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3(g), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dq_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
         STG_LAUNCH_CHECK();
         return 0;
     }
 };
-template <int D> struct DkvL {
+template <int D, bool PK> struct DkvL {
     static int run(const AttnP& p, hipStream_t st) {
         unsigned g;
         STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3(g), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dkv_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
         STG_LAUNCH_CHECK();
         return 0;
     }
 };
+
+inline int64_t tiles_q(const AttnP& p) { return p.pack > 1 ? 1 : (p.n + 31) / 32; }
+inline int64_t tiles_kv(const AttnP& p) { return p.pack > 1 ? 1 : (p.n_kv + 31) / 32; }
+inline int64_t groups(const AttnP& p) { return ((int64_t)p.P + p.pack - 1) / p.pack; }
 
 }  // namespace
 
@@ -570,7 +708,9 @@ extern "C" int stg_attn_fwd(const stg_attn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O != nullptr && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_attn_fwd: bad O");
     if (f->P == 0) return 0;
-    p.total_items = f->P * f->H * (int64_t)((f->n + 31) / 32);
+    const int64_t items = groups(p) * f->H * tiles_q(p);
+    STG_CHECK(items < (1ll << 31), -2, "stg_attn_fwd: too many work items");
+    p.total_items = (int)items;
     return dispatch_d<FwdL>(f->D, p, (hipStream_t)stream);
 }
 
@@ -590,19 +730,21 @@ extern "C" int stg_attn_bwd(const stg_attn_bwd_args* b, void* stream) {
     p.dQ = (bf16_t*)b->dQ; p.lddq = b->lddq; p.dK = (bf16_t*)b->dK; p.lddk = b->lddk;
     p.dV = (bf16_t*)b->dV; p.lddv = b->lddv; p.delta = b->delta; p.dbias = b->dbias;
     p.pchunk = 1;
-    p.total_items = f->P * f->H * (int64_t)((f->n + 31) / 32);
+    int64_t items = groups(p) * f->H * tiles_q(p);
+    STG_CHECK(items < (1ll << 31), -2, "stg_attn_bwd: too many work items");
+    p.total_items = (int)items;
     rc = dispatch_d<DqL>(f->D, p, (hipStream_t)stream);
     if (rc) return rc;
-    int64_t nchunks = f->P;
+    int64_t nchunks = groups(p);
     if (b->dbias) {
         STG_CHECK(f->bias != nullptr, -2, "stg_attn_bwd: dbias without bias");
-        STG_CHECK(f->n <= 32, -2, "stg_attn_bwd: dbias needs n <= 32 (temporal attention), got %d", f->n);
-        // problems of one chunk must share a bias group: chunk size divides bias_div
-        int64_t ch = 64;
-        while (ch > 1 && (f->bias_div % ch) != 0) ch >>= 1;
+        STG_CHECK(f->n <= 32 && f->n_kv <= 32, -2, "stg_attn_bwd: dbias needs n <= 32 (temporal attention), got %d", f->n);
+        const int64_t ch = 32;             // tile-groups per wave: 32x fewer dbias atomics
         p.pchunk = (int)ch;
-        nchunks = (f->P + ch - 1) / ch;
+        nchunks = (groups(p) + ch - 1) / ch;
     }
-    p.total_items = nchunks * f->H * (int64_t)((f->n_kv + 31) / 32);
+    items = nchunks * f->H * tiles_kv(p);
+    STG_CHECK(items < (1ll << 31), -2, "stg_attn_bwd: too many work items");
+    p.total_items = (int)items;
     return dispatch_d<DkvL>(f->D, p, (hipStream_t)stream);
 }

@@ -17,17 +17,17 @@ struct __attribute__((aligned(8))) u16x4 { uint16_t v[4]; };
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (plain integer rounding would turn some NaNs into inf/0)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: a plain vector cast lowers to ONE v_cvt_pk_bf16_f32 per pair on
+// gfx950 (integer-arithmetic rounding costs ~6 VALU per element and dominated the attention kernels' issue slots)
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_hw_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -339,7 +339,13 @@ class AttnGeom:
     """Addressing of one attention call: row(p, i) = (p // G) * outer + map[(p % G) * n + i] (map None = identity)."""
 
     def __init__(self, P, H, n, D, G=1, outer=None, map_q=None, n_kv=None, outer_kv=None, map_kv=None, scale=1.0,
-                 bias=None, bias_div=1, bias_mod=1, mask=None):
+                 bias=None, bias_div=1, bias_mod=1, mask=None, window=None, temporal=None):
+        """window=(Himg, Wimg, ws, shift) / temporal=N select the arithmetic maps (no table); else map_q/map_kv tables."""
+        self.kind, self.mp = 0, (0, 0, 0, 0)
+        if window is not None:
+            self.kind, self.mp = 1, tuple(int(x) for x in window)
+        elif temporal is not None:
+            self.kind, self.mp = 2, (int(temporal), 0, 0, 0)
         self.P, self.H, self.n, self.D, self.G = int(P), int(H), int(n), int(D), int(G)
         self.n_kv = int(n if n_kv is None else n_kv)
         self.outer = int(G * n if outer is None else outer)
@@ -374,6 +380,7 @@ def _attn_fill(a, g, Q, K, V, O, lse):
     a.lse = _p(lse)
     a.map_q, a.map_kv = _p(g.map_q), _p(g.map_kv)
     a.outer_q, a.outer_kv, a.G = g.outer, g.outer_kv, g.G
+    a.map_kind, (a.map_a, a.map_b, a.map_c, a.map_d) = g.kind, g.mp
     a.P, a.H, a.n, a.n_kv, a.D = g.P, g.H, g.n, g.n_kv, g.D
     a.scale = g.scale
     if g.bias is not None:

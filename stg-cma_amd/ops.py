@@ -263,8 +263,8 @@ def _adapter_wgrad(G, name, dZ, X, dY2, H2, *, rs=None, rs_outer=1, rs_inner=1):
 def _xattn_geom(spec, BT, dh, window, g):
     if window:
         n = spec.ws * spec.ws
-        return K.AttnGeom(BT * spec.nW, 1, n, dh, G=spec.nW, outer=spec.N, map_q=g["wmap"], n_kv=n, outer_kv=spec.N,
-                          map_kv=g["wmap"], scale=1.0)
+        return K.AttnGeom(BT * spec.nW, 1, n, dh, G=spec.nW, outer=spec.N, n_kv=n, outer_kv=spec.N, scale=1.0,
+                          window=(spec.H, spec.W, spec.ws, spec.shift))
     return K.AttnGeom(BT, 1, spec.N, dh, G=1, outer=spec.N, n_kv=spec.N, outer_kv=spec.N, scale=1.0)
 
 
@@ -300,13 +300,13 @@ def _slices(spec, R):
 
 
 def _temporal_geom(spec, B, g, tbias, nm):
-    return K.AttnGeom(nm * B * spec.N, spec.heads, spec.T, spec.hd, G=spec.N, outer=spec.T * spec.N, map_q=g["tmap"],
+    return K.AttnGeom(nm * B * spec.N, spec.heads, spec.T, spec.hd, G=spec.N, outer=spec.T * spec.N, temporal=spec.N,
                       scale=spec.hd ** -0.5, bias=tbias, bias_div=B * spec.N, bias_mod=nm)
 
 
 def _window_geom(spec, BT, g, sbias, nm):
     P = nm * BT * spec.nW
-    return K.AttnGeom(P, spec.heads, spec.ws * spec.ws, spec.hd, G=spec.nW, outer=spec.N, map_q=g["wmap"],
+    return K.AttnGeom(P, spec.heads, spec.ws * spec.ws, spec.hd, G=spec.nW, outer=spec.N, window=(spec.H, spec.W, spec.ws, spec.shift),
                       scale=spec.hd ** -0.5, bias=sbias, bias_div=P, bias_mod=1, mask=g["mask"])
 
 

@@ -50,8 +50,8 @@ def _ref(Q, K, V, rq, rk, H, D, scale, bias, bias_div, bias_mod, mask, G):
 
 
 def _run_case(gpu, *, P, H, n, D, G=1, n_kv=None, mapped=False, scale=1.0, with_bias=False, bias_mod=1, with_mask=False,
-              shared_kv=False, want_dbias=False, seed=0, mag=1.0):
-    from stgcma import kernels as k
+              shared_kv=False, want_dbias=False, seed=0, mag=1.0, window=None, temporal=None):
+    from stgcma import kernels as k, ops
     g = torch.Generator().manual_seed(seed)
     nk = n if n_kv is None else n_kv
     assert P % G == 0
@@ -63,6 +63,12 @@ def _run_case(gpu, *, P, H, n, D, G=1, n_kv=None, mapped=False, scale=1.0, with_
     if mapped:
         map_q = torch.randperm(outer_q, generator=g)[:G * n].to(torch.int32)
         map_k = map_q if n_kv is None else torch.randperm(outer_k, generator=g)[:G * nk].to(torch.int32)
+    if window is not None:                      # arithmetic map, checked against the table form of the same map
+        map_q = map_k = ops.window_token_map(*window)
+        outer_q = outer_k = window[0] * window[1]
+    if temporal is not None:
+        map_q = map_k = ops.temporal_token_map(temporal, n)
+        outer_q = outer_k = temporal * n
     rows_q = (P // G) * outer_q
     rows_k = (P // G) * outer_k
     C = H * D
@@ -93,9 +99,11 @@ def _run_case(gpu, *, P, H, n, D, G=1, n_kv=None, mapped=False, scale=1.0, with_
     br = bias.clone().requires_grad_(True) if bias is not None else None
     o_ref, lse_ref = _ref(Qr, Kr, Vr, rq, rk, H, D, scale, br, bias_div, bias_mod, mask, G)
 
-    geom = k.AttnGeom(P, H, n, D, G=G, outer=outer_q, map_q=None if map_q is None else map_q.to(gpu),
+    arith = window is not None or temporal is not None
+    geom = k.AttnGeom(P, H, n, D, G=G, outer=outer_q, map_q=None if (map_q is None or arith) else map_q.to(gpu),
                       n_kv=n_kv, outer_kv=outer_k if n_kv is not None else None,
-                      map_kv=None if (map_k is None or n_kv is None) else map_k.to(gpu), scale=scale,
+                      map_kv=None if (map_k is None or n_kv is None or arith) else map_k.to(gpu), scale=scale,
+                      window=window, temporal=temporal,
                       bias=None if bias is None else bias.to(gpu), bias_div=bias_div, bias_mod=bias_mod,
                       mask=None if mask is None else mask.to(gpu))
     Qg, Kg = Q.to(gpu), K.to(gpu)
@@ -137,6 +145,18 @@ def test_window_attention_shapes(stg, gpu):
     # W-MSA: 49-token windows, head dim 32, rel-pos bias, shift mask, roll/partition as a map (Swin_AVE.py:256-276)
     _run_case(gpu, P=8, H=4, n=49, D=32, G=4, mapped=True, scale=32 ** -0.5, with_bias=True, with_mask=True, seed=1)
     _run_case(gpu, P=6, H=2, n=49, D=32, G=1, mapped=False, scale=32 ** -0.5, with_bias=True, seed=2)
+
+
+def test_arithmetic_maps_and_packing(stg, gpu):
+    """map_kind 1 (shift + window partition) and 2 (temporal regrouping) computed in-kernel; short sequences packed 3 / 6
+    per tile, including tile-groups that straddle the video/audio bias-table boundary and a ragged last group."""
+    _run_case(gpu, P=8, H=4, n=49, D=32, G=4, scale=32 ** -0.5, with_bias=True, with_mask=True, seed=41, window=(14, 14, 7, 3))
+    _run_case(gpu, P=18, H=2, n=49, D=32, G=9, scale=32 ** -0.5, with_bias=True, seed=42, window=(21, 21, 7, 0))
+    _run_case(gpu, P=4, H=1, n=49, D=16, G=4, n_kv=49, shared_kv=True, seed=43, mag=0.7, window=(14, 14, 7, 3))
+    _run_case(gpu, P=20, H=4, n=10, D=32, G=10, scale=32 ** -0.5, with_bias=True, bias_mod=2, want_dbias=True, seed=44, temporal=10)
+    _run_case(gpu, P=200, H=2, n=10, D=32, G=50, scale=32 ** -0.5, with_bias=True, bias_mod=2, want_dbias=True, seed=45, temporal=50)
+    _run_case(gpu, P=14, H=2, n=5, D=32, G=7, scale=32 ** -0.5, with_bias=True, bias_mod=2, want_dbias=True, seed=46, temporal=7)
+    _run_case(gpu, P=7, H=2, n=16, D=64, G=7, scale=0.125, seed=47, temporal=7)
 
 
 def test_temporal_attention_shapes(stg, gpu):

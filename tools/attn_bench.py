@@ -27,13 +27,13 @@ for s, (C, res, H, dh) in enumerate(stages):
     nW = (res // 7) ** 2
     qkv = torch.randn(R, 3 * C, device="cuda").bfloat16()
     bias = torch.randn(1, H, 49, 49, device="cuda")
-    g = K.AttnGeom(2 * BT * nW, H, 49, hd, G=nW, outer=N, map_q=ge["wmap"], scale=hd ** -0.5, bias=bias, bias_div=2 * BT * nW, bias_mod=1, mask=ge["mask"])
+    g = K.AttnGeom(2 * BT * nW, H, 49, hd, G=nW, outer=N, window=(res, res, 7, 3 if res > 7 else 0), scale=hd ** -0.5, bias=bias, bias_div=2 * BT * nW, bias_mod=1, mask=ge["mask"])
     run(f"s{s} window", g, qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:])
     tb = torch.randn(2, H, T, T, device="cuda")
-    g = K.AttnGeom(2 * B * N, H, T, hd, G=N, outer=T * N, map_q=ge["tmap"], scale=hd ** -0.5, bias=tb, bias_div=B * N, bias_mod=2)
+    g = K.AttnGeom(2 * B * N, H, T, hd, G=N, outer=T * N, temporal=N, scale=hd ** -0.5, bias=tb, bias_div=B * N, bias_mod=2)
     run(f"s{s} temporal", g, qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:], dbias=True)
     hv = torch.randn(BT * N, dh, device="cuda").bfloat16(); ha = torch.randn(BT * N, dh, device="cuda").bfloat16()
-    g = K.AttnGeom(BT * nW, 1, 49, dh, G=nW, outer=N, map_q=ge["wmap"], n_kv=49, outer_kv=N, map_kv=ge["wmap"], scale=1.0)
+    g = K.AttnGeom(BT * nW, 1, 49, dh, G=nW, outer=N, n_kv=49, outer_kv=N, scale=1.0, window=(res, res, 7, 3 if res > 7 else 0))
     run(f"s{s} xmodal window", g, hv, ha, ha, shared=True)
     g = K.AttnGeom(BT, 1, N, dh, G=1, outer=N, n_kv=N, outer_kv=N, scale=1.0)
     run(f"s{s} xmodal global", g, hv, ha, ha, shared=True)
