@@ -253,8 +253,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
 // swizzle lives on the per-lane SOURCE address: LDS position `pos` of row r receives global chunk pos ^ (r & 7), and the
 // fragment reads apply the same involution.  Rows beyond M / N are clamped (their products are never stored).
 // 2-stage pipeline: issue tile t+1's DMA, run tile t's MFMAs, then vmcnt(0) + barrier.
-__global__ void __launch_bounds__(256, 2) gemm_nt_glds_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+template <int NST>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
+__global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
     const int nblk = p.nbm * p.nbn;
     int bid = blockIdx.x;
     {
@@ -306,8 +307,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_glds_kernel(GemmParams p) {
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk && p.dbg != 1) stage(cur ^ 1, kt + 1);
+        const int cur = NST == 2 ? (kt & 1) : 0;
+        if (NST == 2 && kt + 1 < nk && p.dbg != 1) stage(cur ^ 1, kt + 1);
         const bf16_t* sA = smem + cur * (BM + BN) * BK;
         const bf16_t* sW = sA + BM * BK;
         if (p.dbg != 2)
@@ -329,6 +330,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_glds_kernel(GemmParams p) {
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
         __syncthreads();
+        if (NST == 1 && kt + 1 < nk) {      // single buffer: refill after every wave is done reading, then wait for the DMA
+            stage(0, kt + 1);
+            __syncthreads();
+        }
     }
     gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lrow, lk);
 }
@@ -490,7 +495,9 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
                al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) &&
                al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, p.res1_f32 ? 16 : 8) &&
                al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, p.res2_f32 ? 16 : 8);
-    if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    static const int nst = [] { const char* e = getenv("STG_GEMM_NST"); return e ? atoi(e) : 1; }();
+    if (a->K % BK == 0 && nst == 1) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<2>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
