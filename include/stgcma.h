@@ -169,6 +169,10 @@ int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, voi
 int stg_bias_gather(const float* table, const int64_t* index, float* out, int L, int H, int nn, void* stream);
 /* dtable[index[ij], h] += dbias[h, ij] */
 int stg_bias_scatter(const float* dbias, const int64_t* index, float* dtable, int L, int H, int nn, void* stream);
+/* ViT token assembly (CLIP_AVE.py:1091-1103): out[bt,0] = class_embedding + pos[0] + temb[t], out[bt,1+i] = patch[bt,i] +
+ * pos[1+i] + temb[t]; patch bf16 [BT*np, D] (conv-as-GEMM output), pos fp32 [np+1, D], temb fp32 [T, D], out fp32. */
+int stg_vit_embed(const void* patch, const float* cls, const float* pos, const float* temb, float* out, int64_t BT, int T,
+                  int np, int D, void* stream);
 
 #ifdef __cplusplus
 }

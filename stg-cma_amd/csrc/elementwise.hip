@@ -242,9 +242,45 @@ __global__ void bias_scatter_kernel(const float* dbias, const int64_t* index, fl
     }
 }
 
+// ---- ViT token assembly: out[bt, 0] = cls + pos[0] + temb[t]; out[bt, 1+i] = patch[bt, i] + pos[1+i] + temb[t]   (fp32)
+__global__ void vit_embed_kernel(const bf16_t* patch, const float* cls, const float* pos, const float* temb, float* out,
+                                 int64_t BT, int T, int np, int D) {
+    const int d4 = D / 4;
+    const int64_t total = BT * (np + 1) * d4;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(id % d4) * 4;
+        const int64_t row = id / d4;
+        const int n = (int)(row % (np + 1));
+        const int64_t bt = row / (np + 1);
+        const int t = (int)(bt % T);
+        const float4 pe = *reinterpret_cast<const float4*>(pos + (int64_t)n * D + c);
+        const float4 te = *reinterpret_cast<const float4*>(temb + (int64_t)t * D + c);
+        float4 v;
+        if (n == 0) {
+            v = *reinterpret_cast<const float4*>(cls + c);
+        } else {
+            const u16x4 q = *reinterpret_cast<const u16x4*>(patch + (bt * np + (n - 1)) * D + c);
+            v = make_float4(bf2f(q.v[0]), bf2f(q.v[1]), bf2f(q.v[2]), bf2f(q.v[3]));
+        }
+        v.x += pe.x + te.x; v.y += pe.y + te.y; v.z += pe.z + te.z; v.w += pe.w + te.w;
+        *reinterpret_cast<float4*>(out + row * D + c) = v;
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int stg_vit_embed(const void* patch, const float* cls, const float* pos, const float* temb, float* out, int64_t BT,
+                             int T, int np, int D, void* stream) {
+    STG_CHECK(patch && cls && pos && temb && out, -1, "stg_vit_embed: null pointer");
+    STG_CHECK(BT >= 0 && T > 0 && np > 0 && D > 0 && D % 4 == 0 && BT % T == 0, -2, "stg_vit_embed: bad shape");
+    if (BT == 0) return 0;
+    hipLaunchKernelGGL(vit_embed_kernel, dim3(grid_for(BT * (np + 1) * (D / 4), 256)), dim3(256), 0, ST, (const bf16_t*)patch,
+                       cls, pos, temb, out, BT, T, np, D);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int stg_gate_fwd(const void* h, const void* r, const float* gate, void* out, int64_t numel, void* stream) {
     STG_CHECK(h && r && gate && out, -1, "stg_gate_fwd: null pointer");
@@ -299,7 +335,7 @@ extern "C" int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B
                                 int Kpad, void* stream) {
     STG_CHECK(x && out, -1, "stg_im2col_patch: null pointer");
     STG_CHECK(x_dtype == STG_F32 || x_dtype == STG_BF16, -3, "stg_im2col_patch: unsupported dtype");
-    STG_CHECK(B >= 0 && Cin > 0 && T > 0 && p > 0 && Hin % p == 0 && Win % p == 0, -2, "stg_im2col_patch: bad shape");
+    STG_CHECK(B >= 0 && Cin > 0 && T > 0 && p > 0 && Hin >= p && Win >= p, -2, "stg_im2col_patch: bad shape");
     STG_CHECK(Kpad % 8 == 0 && Kpad >= Cin * p * p, -2, "stg_im2col_patch: Kpad must be a multiple of 8 and >= Cin*p*p");
     const int64_t nrows = B * T * (Hin / p) * (Win / p);
     if (nrows == 0) return 0;

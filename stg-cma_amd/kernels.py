@@ -443,3 +443,16 @@ def attn_bwd(g, Q, K, V, O, lse, dO, *, dQ=None, dK=None, dV=None, shared_kv=Fal
         b.dbias = _p(dbias)
     _lib.check(_lib.lib().stg_attn_bwd(C.byref(b), _stream()), "stg_attn_bwd")
     return dQ, dK, dV
+
+
+def vit_embed(patch, cls, pos, temb, BT, T):
+    """ViT token assembly -> fp32 [BT*(np+1), D]; see stg_vit_embed."""
+    _chk_flat(patch, "patch"); _chk_flat(cls, "cls", F32); _chk_flat(pos, "pos", F32); _chk_flat(temb, "temb", F32)
+    D = cls.numel()
+    n = pos.shape[0]
+    np_ = n - 1
+    if patch.numel() != BT * np_ * D or pos.numel() != n * D or temb.numel() != T * D:
+        raise RuntimeError("vit_embed: shape mismatch")
+    out = torch.empty((BT * n, D), dtype=F32, device=patch.device)
+    _lib.check(_lib.lib().stg_vit_embed(_p(patch), _p(cls), _p(pos), _p(temb), _p(out), BT, T, np_, D, _stream()), "stg_vit_embed")
+    return out

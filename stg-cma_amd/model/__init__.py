@@ -2,3 +2,4 @@
 (AVE/run_adapt_ave29.py:12,156) -- the reference forgot the __init__.py that makes that work; this one exports the
 submodules.  Put the directory that contains this package (stg-cma_amd/) on sys.path ahead of the reference's AVE/ dir."""
 from . import Swin_AVE  # noqa: F401
+from . import CLIP_AVE  # noqa: F401,E402

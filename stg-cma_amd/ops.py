@@ -268,28 +268,29 @@ def _xattn_geom(spec, BT, dh, window, g):
     return K.AttnGeom(BT, 1, spec.N, dh, G=1, outer=spec.N, n_kv=spec.N, outer_kv=spec.N, scale=1.0)
 
 
-def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save):
-    """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808)."""
-    ag = _xattn_geom(spec, BT, hv.shape[1], window, g)
-    rv, lse_v = K.attn_fwd(ag, hv, ha, ha, want_lse=save)
-    ra, lse_a = K.attn_fwd(ag, ha, hv, hv, want_lse=save)
+def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=None):
+    """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808).
+    geoms = (video-queries geometry, audio-queries geometry) when the two token counts differ (ViT)."""
+    ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
+    rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
+    ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
     hv2 = K.gate_fwd(hv, rv, gate_v)
     ha2 = K.gate_fwd(ha, ra, gate_a)
     return hv2, ha2, (rv, ra, lse_v, lse_a)
 
 
-def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a):
+def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None):
     """Returns (dhv, dha) = gradients wrt the pre-fusion hidden states."""
     rv, ra, lse_v, lse_a = saved
-    ag = _xattn_geom(spec, BT, hv.shape[1], window, g)
+    ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     if dgate_v is None:
         dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
     if dgate_a is None:
         dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
     drv = K.gate_bwd(dhv2, rv, gate_v, dgate_v)
     dra = K.gate_bwd(dha2, ra, gate_a, dgate_a)
-    dq_v, dkv_a, _ = K.attn_bwd(ag, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
-    dq_a, dkv_v, _ = K.attn_bwd(ag, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
+    dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
+    dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
     return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
 
 

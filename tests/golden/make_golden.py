@@ -258,7 +258,7 @@ def main(argv):
         "swin_b_fusion_refinit": lambda: swin_model_case(S, "swin_b_fusion_refinit", cfg=SWIN_B, B=1, mode="fusion", seed=310,
                                                          store_all_grads=False, state_fn=GP.refinit_state),
         "vit_block_cfg1": lambda: vit_block_case(Cm, "vit_block_cfg1", d=768, heads=8, T=10, B=1, nv=196, na=196, seed=400),
-        "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=192, heads=2, T=2, B=2, nv=50, na=13, seed=410),
+        "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=256, heads=4, T=2, B=2, nv=50, na=13, seed=410),
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,

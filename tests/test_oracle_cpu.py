@@ -136,3 +136,50 @@ def test_cosine_scheduler_matches_reference():
     np.testing.assert_allclose(OS.cosine_scheduler(5e-5, 2e-6, 20, 3339, warmup_epochs=2).numpy(), z["t1"], rtol=1e-12, atol=1e-18)
     np.testing.assert_allclose(OS.cosine_scheduler(5e-6, 2e-6, 20, 3339, warmup_epochs=2).numpy(), z["t2"], rtol=1e-12, atol=1e-18)
     np.testing.assert_allclose(OS.cosine_scheduler(1e-4, 2e-6, 3, 7, warmup_epochs=1).numpy(), z["t3"], rtol=1e-12, atol=1e-18)
+
+
+# ----------------------------------------------------------------------------------------------- ViT (CLIP) path
+import oracle.vit as OV  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", ["vit_block_cfg1", "vit_block_small"])
+def test_vit_block_matches_reference(tag):
+    """BASELINE.json config 1: single ViT-B/16 block + cross-modal adapters, 196 audio + 196 video tokens, fp32 CPU."""
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case(tag)
+    P = build_state(shapes, cfg["seed"], kind="vit_block")
+    for n in names:
+        P["blk." + n].requires_grad_(True)
+    BT, d, nv, na, st = cfg["B"] * cfg["T"], cfg["d"], cfg["nv"], cfg["na"], cfg["stride"]
+    v = seeded_tensor((nv, BT, d), cfg["seed"] + 1).permute(1, 0, 2).contiguous().requires_grad_(True)
+    a = seeded_tensor((na, BT, d), cfg["seed"] + 2).permute(1, 0, 2).contiguous().requires_grad_(True)
+    gv = seeded_tensor((nv, BT, d), cfg["seed"] + 3).permute(1, 0, 2)
+    ga = seeded_tensor((na, BT, d), cfg["seed"] + 4).permute(1, 0, 2)
+    ov, oa = OV.vit_block(P, "blk", (v, a), T=cfg["T"], heads=cfg["heads"], mode=cfg["mode"])
+    ((ov * gv).sum() + (oa * ga).sum()).backward()
+    _close(ov.permute(1, 0, 2)[::st], z["out_v"], what="out_v")
+    _close(oa.permute(1, 0, 2)[::st], z["out_a"], what="out_a")
+    _close(v.grad.permute(1, 0, 2)[::st], z["din_v"], what="din_v")
+    _close(a.grad.permute(1, 0, 2)[::st], z["din_a"], what="din_a")
+    stats = torch.stack([ov.sum(), ov.abs().sum(), oa.sum(), oa.abs().sum()])
+    _close(stats / stats.abs().max(), torch.as_tensor(z["stats"]) / float(np.abs(z["stats"]).max()), tol=1e-4, what="stats")
+    _close(_grads(P, ["blk." + n for n in names]), z["grads"], what="param grads")
+
+
+def test_vit_tiny_model_matches_reference():
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("vit_tiny_fusion")
+    P = build_state(shapes, cfg["seed"], kind="vit")
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T = cfg["B"], cfg["T"]
+    a = seeded_tensor((B, T, 102, 128), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2)
+    logits = OV.vit_forward(P, a, v, cfg, "fusion")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1)
+    loss = OS.soft_target_cross_entropy(logits, tgt)
+    loss.backward()
+    _close(logits, z["logits"], what="logits")
+    _close(loss.reshape(1), z["loss"], tol=1e-4, what="loss")
+    _close(_grads(P, names), z["grads"], what="grads")
+    assert list(z["n_params"][1:]) == [sum(P[n].numel() for n in names), sum(P[n].numel() for n in names if n.startswith("mlp_head"))]
