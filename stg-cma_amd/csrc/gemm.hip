@@ -357,7 +357,7 @@ struct WgradParams {
     const float* row_scale; int64_t rs_outer, rs_inner;
 };
 
-__global__ void __launch_bounds__(256, 2) wgrad_tn_kernel(WgradParams p) {
+__global__ void __launch_bounds__(256, 2) wgrad_tn_generic_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t sY[TK * T1];
     __shared__ __attribute__((aligned(16))) bf16_t sX[TK * T2];
     const int tile = blockIdx.x;
@@ -456,6 +456,157 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_kernel(WgradParams p) {
     }
 }
 
+
+// Fast path (both leading dims multiples of 8, 16-byte aligned): A = the NARROW operand (<= 64 columns per block: adapter
+// hidden width / head classes), B = the wide one; unconditional clamped loads (rows beyond the split are zeroed by a select),
+// only the NT1 valid 16-column tiles of A are ever read / multiplied, output optionally transposed so that the narrow
+// operand can be either dY (D_fc1: dW[d_h, C]) or X (D_fc2: dW[C, d_h] = (X^T dY)^T).
+struct WgradFast {
+    const bf16_t* A; int64_t lda; int NA;      // narrow
+    const bf16_t* B; int64_t ldb; int NB;      // wide
+    float* dW; int64_t lddw; int transpose_out;
+    float* db; int bias_on;                    // 1: column sums of A, 2: column sums of B
+    const float* row_scale; int64_t rs_outer, rs_inner; int scale_on;   // 1: scale A rows, 2: scale B rows
+    int64_t M; int64_t rows_per_split;
+    int nta;                                   // column tiles of A (each 16*NT1 wide)
+};
+
+template <int NT1>
+__global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
+    constexpr int TA = 16 * NT1;
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TK * TA];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TK * T2];
+    const int ta = blockIdx.x % p.nta, tb = blockIdx.x / p.nta;
+    const int a0 = ta * TA, b0 = tb * T2;
+    const int64_t mbeg = (int64_t)blockIdx.y * p.rows_per_split;
+    int64_t mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    f32x4_t acc[NT1][2];
+    f32x4_t accba[NT1], accbb[2];
+#pragma unroll
+    for (int i = 0; i < NT1; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NT1; ++i) accba[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    accbb[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    accbb[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool bias_a = p.db != nullptr && p.bias_on == 1 && tb == 0 && wave == 0;
+    const bool bias_b = p.db != nullptr && p.bias_on == 2 && ta == 0;
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
+
+    constexpr int CA = TA / 8;                       // 16-byte chunks per A row
+    constexpr int ITA = (TK * CA + 255) / 256;
+    constexpr int ITB = TK * (T2 / 8) / 256;         // 4
+    const int na8 = (p.NA + 7) & ~7, nb8 = (p.NB + 7) & ~7;
+
+    for (int64_t mb = mbeg; mb < mend; mb += TK) {
+        uint4 va[ITA], vb[ITB];
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            const int id = tid + i * 256;
+            const int row = (id / CA) % TK, c = id % CA;
+            int64_t gm = mb + row;
+            gm = gm < mend ? gm : mend - 1;
+            int gn = a0 + c * 8;
+            gn = gn < na8 ? gn : 0;
+            va[i] = *reinterpret_cast<const uint4*>(p.A + gm * p.lda + gn);
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / (T2 / 8), c = id % (T2 / 8);
+            int64_t gm = mb + row;
+            gm = gm < mend ? gm : mend - 1;
+            int gn = b0 + c * 8;
+            gn = gn < nb8 ? gn : 0;
+            vb[i] = *reinterpret_cast<const uint4*>(p.B + gm * p.ldb + gn);
+        }
+        auto scale8 = [&](uint4& v, int64_t gm) {
+            const float rs = p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)];
+            v.x = pack_bf2(__uint_as_float(v.x << 16) * rs, __uint_as_float(v.x & 0xffff0000u) * rs);
+            v.y = pack_bf2(__uint_as_float(v.y << 16) * rs, __uint_as_float(v.y & 0xffff0000u) * rs);
+            v.z = pack_bf2(__uint_as_float(v.z << 16) * rs, __uint_as_float(v.z & 0xffff0000u) * rs);
+            v.w = pack_bf2(__uint_as_float(v.w << 16) * rs, __uint_as_float(v.w & 0xffff0000u) * rs);
+        };
+#pragma unroll
+        for (int i = 0; i < ITA; ++i) {
+            const int id = tid + i * 256;
+            if (ITA * 256 > TK * CA && id >= TK * CA) continue;
+            const int row = id / CA, c = id % CA;
+            const int64_t gm = mb + row;
+            if (gm >= mend) va[i] = make_uint4(0, 0, 0, 0);
+            else if (p.row_scale && p.scale_on == 1) scale8(va[i], gm);
+            *reinterpret_cast<uint4*>(sA + row * TA + c * 8) = va[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ITB; ++i) {
+            const int id = tid + i * 256;
+            const int row = id / (T2 / 8), c = id % (T2 / 8);
+            const int64_t gm = mb + row;
+            if (gm >= mend) vb[i] = make_uint4(0, 0, 0, 0);
+            else if (p.row_scale && p.scale_on == 2) scale8(vb[i], gm);
+            *reinterpret_cast<uint4*>(sB + row * T2 + c * 8) = vb[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t pf[NT1], qf[2];
+            const int kr = 32 * s + 8 * lg;
+#pragma unroll
+            for (int i = 0; i < NT1; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[i][j] = (short)sA[(kr + j) * TA + i * 16 + li];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[q][j] = (short)sB[(kr + j) * T2 + (wave * 2 + q) * 16 + li];
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[q], acc[i][q], 0, 0, 0);
+                if (bias_a) accba[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], ones, accba[i], 0, 0, 0);
+            }
+            if (bias_b) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) accbb[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, qf[q], accbb[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = A column (4*lg + r)][col = B column (li)]
+#pragma unroll
+    for (int i = 0; i < NT1; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int na = a0 + i * 16 + 4 * lg + r;
+            if (na >= p.NA) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int nb = b0 + (wave * 2 + q) * 16 + li;
+                if (nb < p.NB) {
+                    float* dst = p.transpose_out ? p.dW + (int64_t)nb * p.lddw + na : p.dW + (int64_t)na * p.lddw + nb;
+                    atomicAdd(dst, acc[i][q][r]);
+                }
+            }
+            if (bias_a && li == 0) atomicAdd(p.db + na, accba[i][r]);
+        }
+    }
+    if (bias_b && lg == 0) {            // every row of accb[q] holds the column sums; take row 0 (lg == 0, r == 0)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nb = b0 + (wave * 2 + q) * 16 + li;
+            if (nb < p.NB) atomicAdd(p.db + nb, accbb[q][0]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
@@ -509,13 +660,45 @@ extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t
     STG_CHECK(dY && X && dW, -1, "stg_wgrad_tn: null pointer");
     STG_CHECK(M >= 0 && N1 > 0 && N2 > 0, -2, "stg_wgrad_tn: bad shape");
     STG_CHECK(lddy >= N1 && ldx >= N2 && lddw >= N2, -2, "stg_wgrad_tn: leading dimension too small");
+    if (row_scale) STG_CHECK(rs_outer > 0 && rs_inner > 0, -2, "stg_wgrad_tn: bad row_scale params");
     if (M == 0) return 0;
+    const int64_t kchunks = (M + TK - 1) / TK;
+    const bool fast = (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY & 15) == 0) && (((uintptr_t)X & 15) == 0) &&
+                      lddy >= ((N1 + 7) & ~7) && ldx >= ((N2 + 7) & ~7);
+    if (fast) {
+        WgradFast p;
+        const bool y_narrow = N1 <= N2;
+        p.A = (const bf16_t*)(y_narrow ? dY : X); p.lda = y_narrow ? lddy : ldx; p.NA = y_narrow ? N1 : N2;
+        p.B = (const bf16_t*)(y_narrow ? X : dY); p.ldb = y_narrow ? ldx : lddy; p.NB = y_narrow ? N2 : N1;
+        p.dW = dW; p.lddw = lddw; p.transpose_out = y_narrow ? 0 : 1;
+        p.db = db; p.bias_on = y_narrow ? 1 : 2;
+        p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
+        p.scale_on = y_narrow ? 1 : 2;
+        p.M = M;
+        const int nt1 = p.NA <= 16 ? 1 : (p.NA <= 32 ? 2 : 4);
+        const int TA = 16 * nt1;
+        p.nta = (p.NA + TA - 1) / TA;
+        const int ntb = (p.NB + T2 - 1) / T2;
+        const int ntiles = p.nta * ntb;
+        int64_t msplit = 2048 / ntiles;
+        if (msplit < 1) msplit = 1;
+        if (msplit > kchunks) msplit = kchunks;
+        if (msplit > 65535) msplit = 65535;
+        const int64_t cps = (kchunks + msplit - 1) / msplit;
+        msplit = (kchunks + cps - 1) / cps;
+        p.rows_per_split = cps * TK;
+        const dim3 grid(ntiles, (unsigned)msplit);
+        if (nt1 == 1) hipLaunchKernelGGL(wgrad_tn_fast_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (nt1 == 2) hipLaunchKernelGGL(wgrad_tn_fast_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(wgrad_tn_fast_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
     WgradParams p;
     p.dY = (const bf16_t*)dY; p.lddy = lddy; p.X = (const bf16_t*)X; p.ldx = ldx;
     p.dW = dW; p.lddw = lddw; p.db = db; p.M = M; p.N1 = N1; p.N2 = N2;
     p.nt1 = (N1 + T1 - 1) / T1; p.nt2 = (N2 + T2 - 1) / T2;
     const int ntiles = p.nt1 * p.nt2;
-    int64_t kchunks = (M + TK - 1) / TK;
     int64_t msplit = 2048 / ntiles;
     if (msplit < 1) msplit = 1;
     if (msplit > kchunks) msplit = kchunks;
@@ -523,11 +706,10 @@ extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t
     int64_t cps = (kchunks + msplit - 1) / msplit;  // 64-row chunks per split
     msplit = (kchunks + cps - 1) / cps;
     p.msplit = (int)msplit; p.rows_per_split = cps * TK;
-    if (row_scale) STG_CHECK(rs_outer > 0 && rs_inner > 0, -2, "stg_wgrad_tn: bad row_scale params");
     p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
     p.vec_y = (lddy % 8 == 0) && (((uintptr_t)dY & 15) == 0);
     p.vec_x = (ldx % 8 == 0) && (((uintptr_t)X & 15) == 0);
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(ntiles, (unsigned)msplit), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(wgrad_tn_generic_kernel, dim3(ntiles, (unsigned)msplit), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -20,7 +20,8 @@ import torch
 from . import kernels as K
 from .kernels import ACT_GELU, ACT_NONE, BF16, F32
 
-RESIDUAL_DTYPE = F32
+import os as _os
+RESIDUAL_DTYPE = BF16 if _os.environ.get("STG_RESIDUAL", "fp32").lower() == "bf16" else F32   # fp32 default; bf16 = A/B knob
 
 # ------------------------------------------------------------------------------------------------ weight shadows
 _shadow_cache = {}   # id(parameter) -> (weakref to it, {transpose: ((data_ptr, version), bf16 tensor)})
