@@ -505,8 +505,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
     constexpr int ITB = TK * (T2 / 8) / 256;         // 4
     const int na8 = (p.NA + 7) & ~7, nb8 = (p.NB + 7) & ~7;
 
-    for (int64_t mb = mbeg; mb < mend; mb += TK) {
-        uint4 va[ITA], vb[ITB];
+    uint4 va[ITA], vb[ITB];
+    auto gload = [&](int64_t mb) {                   // unconditional clamped loads: issued early, consumed one chunk later
 #pragma unroll
         for (int i = 0; i < ITA; ++i) {
             const int id = tid + i * 256;
@@ -527,13 +527,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
             gn = gn < nb8 ? gn : 0;
             vb[i] = *reinterpret_cast<const uint4*>(p.B + gm * p.ldb + gn);
         }
-        auto scale8 = [&](uint4& v, int64_t gm) {
-            const float rs = p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)];
-            v.x = pack_bf2(__uint_as_float(v.x << 16) * rs, __uint_as_float(v.x & 0xffff0000u) * rs);
-            v.y = pack_bf2(__uint_as_float(v.y << 16) * rs, __uint_as_float(v.y & 0xffff0000u) * rs);
-            v.z = pack_bf2(__uint_as_float(v.z << 16) * rs, __uint_as_float(v.z & 0xffff0000u) * rs);
-            v.w = pack_bf2(__uint_as_float(v.w << 16) * rs, __uint_as_float(v.w & 0xffff0000u) * rs);
-        };
+    };
+    auto scale8 = [&](uint4& v, int64_t gm) {
+        const float rs = p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)];
+        v.x = pack_bf2(__uint_as_float(v.x << 16) * rs, __uint_as_float(v.x & 0xffff0000u) * rs);
+        v.y = pack_bf2(__uint_as_float(v.y << 16) * rs, __uint_as_float(v.y & 0xffff0000u) * rs);
+        v.z = pack_bf2(__uint_as_float(v.z << 16) * rs, __uint_as_float(v.z & 0xffff0000u) * rs);
+        v.w = pack_bf2(__uint_as_float(v.w << 16) * rs, __uint_as_float(v.w & 0xffff0000u) * rs);
+    };
+    gload(mbeg);
+    for (int64_t mb = mbeg; mb < mend; mb += TK) {
 #pragma unroll
         for (int i = 0; i < ITA; ++i) {
             const int id = tid + i * 256;
@@ -553,6 +556,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
             else if (p.row_scale && p.scale_on == 2) scale8(vb[i], gm);
             *reinterpret_cast<uint4*>(sB + row * T2 + c * 8) = vb[i];
         }
+        if (mb + TK < mend) gload(mb + TK);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -680,8 +684,8 @@ extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t
         p.nta = (p.NA + TA - 1) / TA;
         const int ntb = (p.NB + T2 - 1) / T2;
         const int ntiles = p.nta * ntb;
-        int64_t msplit = 2048 / ntiles;
-        if (msplit < 1) msplit = 1;
+        int64_t msplit = 640 / ntiles;        // ~2.5 blocks per CU: every block then adds its tile atomically once, and
+        if (msplit < 1) msplit = 1;           // 2048 blocks hammering the same few KB of dW were atomic-contention bound
         if (msplit > kchunks) msplit = kchunks;
         if (msplit > 65535) msplit = 65535;
         const int64_t cps = (kchunks + msplit - 1) / msplit;
