@@ -136,6 +136,38 @@ typedef struct {
 int stg_attn_bwd(const stg_attn_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole-window attention: WindowAttention.forward's spatial branch (Swin_AVE.py:256-276) with roll + window_partition /
+ * window_reverse + roll (:727-740, :765-776) as addressing, specialised for windows of n = ws*ws <= 64 tokens and head
+ * dim 32 (every Swin-T/S/B/L stage).  One wavefront owns one (window, head): the padded 64 x 64 score block stays in
+ * registers, and the backward produces dQ, dK and dV in ONE kernel (no S / dP recompute split, no delta workspace).
+ *
+ * stg_winattn_table builds the additive term once per block (the bias table is frozen, traintest_adapt_ave29.py:52-61):
+ *   bm [g][h][q][k] = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (Swin_AVE.py:262-273; the kernels run the
+ *   softmax on exp2), padded to 64 x 64 with k >= n -> -1e30 (padding keys drop out of the softmax) and q >= n -> 0;
+ *   bmT[g][h][k][q] = bm[g][h][q][k].
+ *   table fp32 [L, H], index int64 [n*n], mask fp32 [Gt, n, n] or NULL (then Gt = 1).
+ * Image pg = p / G occupies rows [pg*outer, pg*outer + Himg*Wimg); Q, K, V share one leading dimension (the fused qkv
+ * buffer), Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*32.  lse: fp32 [P, H, 64] (entries >= n unused).
+ */
+typedef struct {
+    const void* Q; const void* K; const void* V; int64_t ld;
+    void* O; int64_t ldo;
+    float* lse;
+    const float* bm; const float* bmT;
+    int Gt;                           /* tables per image: G (shifted blocks) or 1 */
+    int64_t outer;
+    int Himg, Wimg, ws, shift;        /* image size in tokens, window size, cyclic shift */
+    int G, n;                         /* windows per image, tokens per window (= ws*ws) */
+    int64_t P; int H; int D;
+    float scale;
+} stg_winattn_args;
+int stg_winattn_table(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT,
+                      int L, int H, int n, int Gt, void* stream);
+int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
+int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
+                    int64_t lddqkv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels
  */
 /* out = h + gate[0] * r  (Swin_AVE.py:759-760,807-808); all bf16 [rows, d] contiguous-ld tensors, gate fp32 scalar on device */

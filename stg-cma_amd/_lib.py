@@ -65,6 +65,21 @@ class AttnBwdArgs(C.Structure):
     ]
 
 
+class WinAttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
+        ("O", c_vp), ("ldo", c_i64),
+        ("lse", c_vp),
+        ("bm", c_vp), ("bmT", c_vp),
+        ("Gt", C.c_int),
+        ("outer", c_i64),
+        ("Himg", C.c_int), ("Wimg", C.c_int), ("ws", C.c_int), ("shift", C.c_int),
+        ("G", C.c_int), ("n", C.c_int),
+        ("P", c_i64), ("H", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/stgcma.h declares
 SIGNATURES = {
     "stg_version": (C.c_int, []),
@@ -77,6 +92,9 @@ SIGNATURES = {
                                     c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
+    "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
+    "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),

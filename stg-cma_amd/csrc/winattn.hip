@@ -1,0 +1,418 @@
+// Whole-window attention for Swin W-MSA / SW-MSA (window <= 64 tokens, head dim 32): ONE WAVE computes one (window, head)
+// problem end to end -- forward, and a single backward kernel that produces dQ, dK and dV together.
+//
+// Why a second attention family next to attention.hip: for 49-token windows the generic flash kernels spend their time in
+// VALU bookkeeping (two query-tile waves x two key tiles per problem, online-softmax rescaling, per-element bias and mask
+// loads, and a backward split into two kernels that each recompute S and dP).  Here the 64 x 64 padded score block lives in
+// registers at once (single-pass softmax), bias + shift mask + key padding come from ONE pre-added, padded table read with
+// 16-byte loads, every operand load of the problem is issued up front, and the backward computes both score orientations
+// in the same wave (query-on-lane for dQ, key-on-lane for dK/dV) from the SAME operand registers: an A-operand fragment
+// with rows = tokens is bit-identical to a B-operand fragment with columns = tokens.
+//
+// MFMA v_mfma_f32_32x32x16_bf16, lane l = (r = l & 31, hh = l >> 5); accumulator row (reg, hh) = (reg&3) + 8*(reg>>2) + 4*hh.
+// Addressing: token i of window w of frame f lives at row f*outer + tok(w, i) with the cyclic shift + partition computed
+// arithmetically (Swin_AVE.py:727-740; the inverse scatter :765-776 is the same map).
+#include <math.h>
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+constexpr int WD = 32;             // head dim
+constexpr float NEG_BIG = -1.0e30f;
+
+struct WinP {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; int64_t ld;   // fused qkv rows: Q/K/V at base + row*ld + h*32
+    bf16_t* O; int64_t ldo;
+    float* lse;                    // [P, H, 64]
+    const float* bm;               // [Gt, H, 64(q), 64(key)]  bias + mask, key >= n -> -1e30
+    const float* bmT;              // [Gt, H, 64(key), 64(q)]
+    int Gt;                        // tables per image: nW (shifted blocks) or 1
+    int64_t outer;                 // rows per image
+    int Himg, Wimg, ws, shift, nww, G, n;
+    uint32_t ws_magic, nww_magic;  // ceil(2^20 / ws), ceil(2^20 / nww): x / d == (x * magic) >> 20 for x * d < 2^20
+    int P, H;
+    float scale, scale2;           // scale2 = scale * log2(e): the tables are pre-multiplied by log2(e), softmax runs on exp2
+    // backward
+    const bf16_t* dO; int64_t lddo;
+    bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
+    int total;
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define ACC_ROW(reg, hh) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hh))
+
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t pack8(const float* x) {
+    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// row of token i (clamped to the last valid token) of window g of image pg
+__device__ __forceinline__ int64_t tok_row(const WinP& a, int pg, int g, int i) {
+    i = i < a.n ? i : a.n - 1;
+    const int wi = (int)(((uint32_t)g * a.nww_magic) >> 20), wj = g - wi * a.nww;
+    const int ti = (int)(((uint32_t)i * a.ws_magic) >> 20), tj = i - ti * a.ws;
+    int h = wi * a.ws + ti + a.shift;
+    h = h >= a.Himg ? h - a.Himg : h;
+    int w = wj * a.ws + tj + a.shift;
+    w = w >= a.Wimg ? w - a.Wimg : w;
+    return (int64_t)pg * a.outer + h * a.Wimg + w;
+}
+
+// transposed fragment of a [64 x 32] LDS tile: A[i = d][k slot j] = tile[32*kt + kappa(s2, hh, j)][d]
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int kt, int s2, int hh, int d) {
+    bf16x8_t f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)s[(32 * kt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3)) * WD + d];
+    return f;
+}
+
+// stage rows (tokens 0..63, clamped) of one of Q/K/V/dO for head h into a [64][32] LDS tile (zeros beyond n)
+__device__ __forceinline__ void stage64(const WinP& a, bf16_t* s, const bf16_t* src, int64_t ld, int pg, int g, int h, int lane) {
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;           // 64 rows x 4 chunks
+        const int tr = idx >> 2, ch = idx & 3;
+        v[i] = *reinterpret_cast<const uint4*>(src + tok_row(a, pg, g, tr) * ld + h * WD + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        const int tr = idx >> 2, ch = idx & 3;
+        *reinterpret_cast<uint4*>(s + tr * WD + ch * 8) = tr < a.n ? v[i] : make_uint4(0, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 64 * WD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int h = item % a.H;
+    const int p = item / a.H;
+    const int pg = p / a.G, g = p - pg * a.G;
+    bf16_t* sV = smem + wave * 64 * WD;
+
+    // operand fragments straight from HBM/L2 (token on the row / column index, head dims contiguous): all issued up front
+    bf16x8_t qf[2][2], kf[2][2];
+    int64_t rowq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowq[t] = tok_row(a, pg, g, 32 * t + r);
+        const bf16_t* qp = a.Q + rowq[t] * a.ld + h * WD + 8 * hh;
+        const bf16_t* kp = a.K + rowq[t] * a.ld + h * WD + 8 * hh;
+        qf[t][0] = ld_frag(qp); qf[t][1] = ld_frag(qp + 16);
+        kf[t][0] = ld_frag(kp); kf[t][1] = ld_frag(kp + 16);
+    }
+    stage64(a, sV, a.V, a.ld, pg, g, h, lane);
+    const float* bmq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        bmq[t] = a.bm + (((int64_t)(g % a.Gt) * a.H + h) * 64 + (32 * t + r)) * 64;
+    float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 32 * kt + 8 * g4 + 4 * hh);
+
+    // St[key][q] for the 2 x 2 tiles
+    f32x16_t st[2][2];               // [q tile][key tile]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[qt][kt] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st[qt][kt] = MFMA32(kf[kt][s], qf[qt][s], st[qt][kt]);
+        }
+    lds_fence();
+    f32x16_t o[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float x[2][16];
+        float m = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float4 ad = add[qt][kt][reg >> 2];
+                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
+                x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
+                m = fmaxf(m, x[kt][reg]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
+                l += x[kt][reg];
+            }
+        l += __shfl_xor(l, 32, 64);
+        o[qt] = zero16();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) o[qt] = MFMA32(tr_frag(sV, kt, s2, hh, r), pack8(x[kt] + 8 * s2), o[qt]);
+        const int q = 32 * qt + r;
+        if (q < a.n) {
+            const float inv = 1.0f / l;
+            bf16_t* op = a.O + rowq[qt] * a.ldo + h * WD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(o[qt][4 * g4 + 0] * inv, o[qt][4 * g4 + 1] * inv);
+                w.y = pack_bf2(o[qt][4 * g4 + 2] * inv, o[qt][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
+            }
+            if (a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (dQ, dK, dV)
+__global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
+    // per wave: K tile, Q tile, dO tile ([64][32] bf16 each) + lse[64] + delta[64]
+    constexpr int PER_WAVE = 3 * 64 * WD + 256;     // in bf16 units (2 * 64 floats = 256 bf16 slots)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int h = item % a.H;
+    const int p = item / a.H;
+    const int pg = p / a.G, g = p - pg * a.G;
+    bf16_t* sK = smem + wave * PER_WAVE;
+    bf16_t* sQ = sK + 64 * WD;
+    bf16_t* sD = sQ + 64 * WD;
+    float* sLse = reinterpret_cast<float*>(sD + 64 * WD);
+    float* sDel = sLse + 64;
+
+    bf16x8_t qf[2][2], kf[2][2], vf[2][2], dof[2][2];
+    int64_t row[2];
+    float delta[2], lse_q[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        row[t] = tok_row(a, pg, g, 32 * t + r);
+        const int64_t off = row[t] * a.ld + h * WD + 8 * hh;
+        qf[t][0] = ld_frag(a.Q + off); qf[t][1] = ld_frag(a.Q + off + 16);
+        kf[t][0] = ld_frag(a.K + off); kf[t][1] = ld_frag(a.K + off + 16);
+        vf[t][0] = ld_frag(a.V + off); vf[t][1] = ld_frag(a.V + off + 16);
+        const bf16_t* dp = a.dO + row[t] * a.lddo + h * WD + 8 * hh;
+        const bf16_t* op = a.O + row[t] * a.ldo + h * WD + 8 * hh;
+        dof[t][0] = ld_frag(dp); dof[t][1] = ld_frag(dp + 16);
+        const bf16x8_t o0 = ld_frag(op), o1 = ld_frag(op + 16);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            d += bf2f((bf16_t)dof[t][0][j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)dof[t][1][j]) * bf2f((bf16_t)o1[j]);
+        d += __shfl_xor(d, 32, 64);
+        delta[t] = d;
+        const int q = 32 * t + r;
+        lse_q[t] = a.lse[((int64_t)p * a.H + h) * 64 + (q < a.n ? q : a.n - 1)] * 1.4426950408889634f;
+    }
+    stage64(a, sK, a.K, a.ld, pg, g, h, lane);
+    stage64(a, sQ, a.Q, a.ld, pg, g, h, lane);
+    stage64(a, sD, a.dO, a.lddo, pg, g, h, lane);
+    if (hh == 0) {
+        sLse[r] = lse_q[0]; sLse[32 + r] = lse_q[1];
+        sDel[r] = delta[0]; sDel[32 + r] = delta[1];
+    }
+    const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
+    lds_fence();
+
+    // ---------------- phase A: query on the lane -> dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float* bmq = a.bm + tb + (int64_t)(32 * qt + r) * 64;
+        f32x16_t dq = zero16();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float4 add[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 32 * kt + 8 * g4 + 4 * hh);
+            f32x16_t st = zero16(), dpt = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st = MFMA32(kf[kt][s], qf[qt][s], st);
+                dpt = MFMA32(vf[kt][s], dof[qt][s], dpt);
+            }
+            float ds[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float4 ad = add[reg >> 2];
+                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
+                const float pr = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + av - lse_q[qt]);      // padded keys: av = -1e30 -> 0
+                ds[reg] = pr * (dpt[reg] - delta[qt]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dq = MFMA32(tr_frag(sK, kt, s2, hh, r), pack8(ds + 8 * s2), dq);
+        }
+        if (32 * qt + r < a.n) {
+            bf16_t* op = a.dQ + row[qt] * a.lddqkv + h * WD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
+                w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
+                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
+            }
+        }
+    }
+
+    // ---------------- phase B: key on the lane -> dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T = sum_q Q^T[d][q] dS[q][key]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const float* bmk = a.bmT + tb + (int64_t)(32 * kt + r) * 64;       // [key][q]
+        f32x16_t dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float4 add[4], ls[4], de[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int q4 = 32 * qt + 8 * g4 + 4 * hh;
+                add[g4] = *reinterpret_cast<const float4*>(bmk + q4);
+                ls[g4] = *reinterpret_cast<const float4*>(sLse + q4);
+                de[g4] = *reinterpret_cast<const float4*>(sDel + q4);
+            }
+            f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {          // rows = queries (A = Q / dO fragments), columns = keys (B = K / V fragments)
+                sc = MFMA32(qf[qt][s], kf[kt][s], sc);
+                dp = MFMA32(dof[qt][s], vf[kt][s], dp);
+            }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int c = reg & 3;
+                const float av = c == 0 ? add[reg >> 2].x : c == 1 ? add[reg >> 2].y : c == 2 ? add[reg >> 2].z : add[reg >> 2].w;
+                const float lv = c == 0 ? ls[reg >> 2].x : c == 1 ? ls[reg >> 2].y : c == 2 ? ls[reg >> 2].z : ls[reg >> 2].w;
+                const float dl = c == 0 ? de[reg >> 2].x : c == 1 ? de[reg >> 2].y : c == 2 ? de[reg >> 2].z : de[reg >> 2].w;
+                const bool okq = 32 * qt + ACC_ROW(reg, hh) < a.n;                 // padded query rows contribute nothing
+                const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 + av - lv) : 0.f;
+                pr[reg] = pv;
+                ds[reg] = pv * (dp[reg] - dl);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dv = MFMA32(tr_frag(sD, qt, s2, hh, r), pack8(pr + 8 * s2), dv);
+                dk = MFMA32(tr_frag(sQ, qt, s2, hh, r), pack8(ds + 8 * s2), dk);
+            }
+        }
+        if (32 * kt + r < a.n) {
+            bf16_t* kp = a.dK + row[kt] * a.lddqkv + h * WD;
+            bf16_t* vp = a.dV + row[kt] * a.lddqkv + h * WD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
+                w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
+                *reinterpret_cast<uint2*>(kp + 8 * g4 + 4 * hh) = w;
+                w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
+                w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(vp + 8 * g4 + 4 * hh) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bias + mask table
+// bm[g][h][q][k] = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to 64 x 64;
+// bmT = transposed
+__global__ void win_table_kernel(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT, int L, int H,
+                                 int n, int Gt) {
+    const int total = Gt * H * 64 * 64;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        const int k = id & 63, q = (id >> 6) & 63;
+        const int h = (id >> 12) % H, g = (id >> 12) / H;
+        float v = 0.f;
+        if (k >= n) v = NEG_BIG;
+        else if (q < n) {
+            int64_t ix = index[q * n + k];
+            ix = ix < 0 ? 0 : (ix >= L ? L - 1 : ix);
+            v = (table[ix * H + h] + (mask ? mask[((int64_t)g * n + q) * n + k] : 0.f)) * 1.4426950408889634f;
+        }
+        bm[id] = v;
+        bmT[(((int64_t)g * H + h) * 64 + k) * 64 + q] = v;
+    }
+}
+
+int fill(const stg_winattn_args* f, WinP& p, const char* who) {
+    STG_CHECK(f->Q && f->K && f->V && f->bm && f->bmT, -1, "%s: null pointer", who);
+    STG_CHECK(f->D == WD, -2, "%s: head dim must be 32", who);
+    STG_CHECK(f->ws > 0 && f->n == f->ws * f->ws && f->n <= 64, -2, "%s: window must hold <= 64 tokens", who);
+    STG_CHECK(f->Himg % f->ws == 0 && f->Wimg % f->ws == 0 && f->shift >= 0 && f->shift < f->ws, -2, "%s: bad window geometry", who);
+    STG_CHECK(f->G == (f->Himg / f->ws) * (f->Wimg / f->ws) && (f->Gt == 1 || f->Gt == f->G), -2, "%s: bad G / Gt", who);
+    STG_CHECK(f->P >= 0 && f->P % f->G == 0 && f->H > 0 && f->P * (int64_t)f->H < (1ll << 30), -2, "%s: bad problem count", who);
+    STG_CHECK(f->outer >= (int64_t)f->Himg * f->Wimg, -2, "%s: outer too small", who);
+    STG_CHECK(f->ld % 8 == 0 && (((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V) & 15) == 0, -2, "%s: misaligned qkv", who);
+    p.Q = (const bf16_t*)f->Q; p.K = (const bf16_t*)f->K; p.V = (const bf16_t*)f->V; p.ld = f->ld;
+    p.O = (bf16_t*)f->O; p.ldo = f->ldo; p.lse = f->lse; p.bm = f->bm; p.bmT = f->bmT; p.Gt = f->Gt; p.outer = f->outer;
+    p.Himg = f->Himg; p.Wimg = f->Wimg; p.ws = f->ws; p.shift = f->shift; p.nww = f->Wimg / f->ws; p.G = f->G; p.n = f->n;
+    STG_CHECK(f->G < 4096 && (int64_t)f->G * p.nww < (1 << 20) && 64 * f->ws < (1 << 20), -2, "%s: window grid too large", who);
+    p.ws_magic = ((1u << 20) + f->ws - 1) / f->ws; p.nww_magic = ((1u << 20) + p.nww - 1) / p.nww;
+    p.P = (int)f->P; p.H = f->H; p.scale = f->scale; p.scale2 = f->scale * 1.4426950408889634f; p.total = (int)(f->P * f->H);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int stg_winattn_table(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT, int L, int H,
+                                 int n, int Gt, void* stream) {
+    STG_CHECK(table && index && bm && bmT, -1, "stg_winattn_table: null pointer");
+    STG_CHECK(L > 0 && H > 0 && n > 0 && n <= 64 && Gt > 0, -2, "stg_winattn_table: bad shape");
+    const int total = Gt * H * 64 * 64;
+    int blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(win_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, index, mask, bm, bmT, L, H, n, Gt);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_winattn_fwd: null args");
+    WinP p = {};
+    int rc = fill(f, p, "stg_winattn_fwd");
+    if (rc) return rc;
+    STG_CHECK(f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_winattn_fwd: bad O");
+    if (p.total == 0) return 0;
+    hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
+                               int64_t lddqkv, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_winattn_bwd: null args");
+    WinP p = {};
+    int rc = fill(f, p, "stg_winattn_bwd");
+    if (rc) return rc;
+    STG_CHECK(f->O && f->lse && dO && dQ && dK && dV, -1, "stg_winattn_bwd: null pointer");
+    STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_winattn_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+              "stg_winattn_bwd: misaligned pointers");
+    if (p.total == 0) return 0;
+    p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
+    hipLaunchKernelGGL(winattn_bwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -445,6 +445,96 @@ def attn_bwd(g, Q, K, V, O, lse, dO, *, dQ=None, dK=None, dV=None, shared_kv=Fal
     return dQ, dK, dV
 
 
+class WinGeom:
+    """One W-MSA / SW-MSA call over the fused qkv buffer: P = images * nW windows of n = ws*ws <= 64 tokens, head dim 32.
+    bm / bmT come from winattn_table (bias + shift mask, padded to 64 x 64, times log2 e)."""
+
+    def __init__(self, images, H, Himg, Wimg, ws, shift, scale, bm, bmT):
+        self.Himg, self.Wimg, self.ws, self.shift = int(Himg), int(Wimg), int(ws), int(shift)
+        self.G = (self.Himg // self.ws) * (self.Wimg // self.ws)
+        self.n = self.ws * self.ws
+        self.P, self.H, self.scale = int(images) * self.G, int(H), float(scale)
+        self.outer = self.Himg * self.Wimg
+        self.bm, self.bmT = bm, bmT
+        for t in (bm, bmT):
+            if t.dtype != F32 or not t.is_cuda or not t.is_contiguous() or t.dim() != 4 or tuple(t.shape[1:]) != (self.H, 64, 64) \
+                    or t.shape[0] not in (1, self.G):
+                raise RuntimeError("winattn: bm / bmT must be contiguous fp32 [1 or nW, H, 64, 64] GPU tensors")
+        if bm.shape != bmT.shape:
+            raise RuntimeError("winattn: bm and bmT differ in shape")
+        self.Gt = int(bm.shape[0])
+        if self.n > 64 or self.Himg % self.ws or self.Wimg % self.ws or not 0 <= self.shift < self.ws:
+            raise RuntimeError("winattn: unsupported window geometry")
+
+
+def winattn_supported(n, hd):
+    return n <= 64 and hd == 32
+
+
+def winattn_table(table, index, mask, n):
+    """table fp32 [L, H], index int64 [n*n], mask fp32 [nW, n, n] or None -> (bm, bmT) fp32 [Gt, H, 64, 64]."""
+    _chk_flat(table, "table", F32); _chk_flat(index, "index", torch.int64)
+    L, H = table.shape
+    if index.numel() != n * n or n > 64:
+        raise RuntimeError("winattn_table: index must hold n*n entries, n <= 64")
+    Gt = 1
+    if mask is not None:
+        _chk_flat(mask, "mask", F32)
+        Gt = mask.shape[0]
+        if mask.numel() != Gt * n * n:
+            raise RuntimeError("winattn_table: mask must be [nW, n, n]")
+    bm = torch.empty((Gt, H, 64, 64), dtype=F32, device=table.device)
+    bmT = torch.empty_like(bm)
+    _lib.check(_lib.lib().stg_winattn_table(_p(table), _p(index), _p(mask), _p(bm), _p(bmT), L, H, n, Gt, _stream()),
+               "stg_winattn_table")
+    return bm, bmT
+
+
+def _win_fill(g, Q, K, V, O, lse):
+    for t, name in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
+        _chk2d(t, name, BF16)
+        if t.shape[1] < g.H * 32 or t.shape[0] < (g.P // g.G) * g.outer:
+            raise RuntimeError(f"winattn {name}: needs >= {(g.P // g.G) * g.outer} rows x {g.H * 32} columns, got {tuple(t.shape)}")
+    if not (_ld(Q) == _ld(K) == _ld(V)):
+        raise RuntimeError("winattn: Q, K, V must share one leading dimension (slices of the fused qkv buffer)")
+    a = _lib.WinAttnArgs()
+    a.Q, a.K, a.V, a.ld = _p(Q), _p(K), _p(V), _ld(Q)
+    a.O, a.ldo = _p(O), _ld(O)
+    a.lse = _p(lse)
+    a.bm, a.bmT, a.Gt = _p(g.bm), _p(g.bmT), g.Gt
+    a.outer = g.outer
+    a.Himg, a.Wimg, a.ws, a.shift, a.G, a.n = g.Himg, g.Wimg, g.ws, g.shift, g.G, g.n
+    a.P, a.H, a.D, a.scale = g.P, g.H, 32, g.scale
+    return a
+
+
+def winattn_fwd(g, Q, K, V, out=None, want_lse=True):
+    """Returns (O bf16 [rows, H*32], lse fp32 [P, H, 64] or None)."""
+    if out is None:
+        out = torch.empty((Q.shape[0], g.H * 32), dtype=BF16, device=Q.device)
+    lse = torch.empty((g.P, g.H, 64), dtype=F32, device=Q.device) if want_lse else None
+    a = _win_fill(g, Q, K, V, out, lse)
+    _lib.check(_lib.lib().stg_winattn_fwd(C.byref(a), _stream()), "stg_winattn_fwd")
+    return out, lse
+
+
+def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
+    """dQ / dK / dV: column slices of one bf16 buffer (same leading dimension), written in place."""
+    if lse is None or lse.dtype != F32 or lse.numel() != g.P * g.H * 64:
+        raise RuntimeError("winattn_bwd: bad lse")
+    rows = (g.P // g.G) * g.outer
+    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+        _chk2d(t, name, BF16)
+        if t.shape[1] < g.H * 32 or t.shape[0] < rows:
+            raise RuntimeError(f"winattn_bwd {name}: needs >= {rows} rows x {g.H * 32} columns")
+    if not (_ld(dQ) == _ld(dK) == _ld(dV)):
+        raise RuntimeError("winattn_bwd: dQ, dK, dV must share one leading dimension")
+    a = _win_fill(g, Q, K, V, O, lse)
+    _lib.check(_lib.lib().stg_winattn_bwd(C.byref(a), _p(dO), _ld(dO), _p(dQ), _p(dK), _p(dV), _ld(dQ), _stream()),
+               "stg_winattn_bwd")
+    return dQ, dK, dV
+
+
 def vit_embed(patch, cls, pos, temb, BT, T):
     """ViT token assembly -> fp32 [BT*(np+1), D]; see stg_vit_embed."""
     _chk_flat(patch, "patch"); _chk_flat(cls, "cls", F32); _chk_flat(pos, "pos", F32); _chk_flat(temb, "temb", F32)

@@ -61,6 +61,7 @@ def f32c(p):
 
 def clear_shadow_cache():
     _shadow_cache.clear()
+    _wintab_cache.clear()
 
 
 # ------------------------------------------------------------------------------------------------ geometry caches
@@ -112,6 +113,24 @@ def geom(device, H, W, ws, shift, T):
         }
         _geom_cache[key] = g
     return g
+
+
+_wintab_cache = {}   # id(bias-table parameter) -> (weakref, tag, (bm, bmT))
+USE_WINATTN = _os.environ.get("STG_WINATTN", "1") != "0"     # 0 = route W-MSA through the generic attention kernels (A/B knob)
+
+
+def win_tables(tab_p, index, mask, n):
+    """Padded bias + shift-mask tables of one block for the whole-window attention kernels, rebuilt only when the (frozen)
+    relative_position_bias_table changes (Swin_AVE.py:262-273)."""
+    t = tab_p.detach()
+    tag = (t.data_ptr(), tab_p._version, None if mask is None else mask.data_ptr())
+    ent = _wintab_cache.get(id(tab_p))
+    if ent is not None and ent[0]() is tab_p and ent[1] == tag:
+        return ent[2]
+    tabs = K.winattn_table(f32c(tab_p), index.reshape(-1), mask, n)
+    key = id(tab_p)
+    _wintab_cache[key] = (weakref.ref(tab_p, lambda _r, k=key: _wintab_cache.pop(k, None)), tag, tabs)
+    return tabs
 
 
 def _check_frozen(need, names, who):
@@ -359,8 +378,13 @@ def block_forward(X, spec, P, training, save):
     Y, mean, rstd = K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
     QKV = K.gemm_nt(Y, wqkv, bqkv)
     del Y
-    sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
-    AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
+    if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
+        bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
+        sbias = K.WinGeom(nm * BT, H, spec.H, spec.W, spec.ws, spec.shift, spec.hd ** -0.5, bm, bmT)
+        AO, lse = K.winattn_fwd(sbias, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
+    else:
+        sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
+        AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
     PO = K.gemm_nt(AO, wproj, bproj)
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
     HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
@@ -475,8 +499,12 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
     dAO = K.gemm_nt(dPO, wproj_t)
     del dPO
     dQKV = torch.empty_like(QKV)
-    K.attn_bwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
-               dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+    if isinstance(sbias, K.WinGeom):
+        K.winattn_bwd(sbias, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
+                      dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+    else:
+        K.attn_bwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
+                   dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
     del QKV, AO, dAO
     dY = K.gemm_nt(dQKV, wqkv_t)
     del dQKV

@@ -1,0 +1,112 @@
+"""-m gpu: the whole-window attention kernels (stg_winattn_table / _fwd / _bwd) against an fp32 PyTorch-CPU statement of
+WindowAttention's spatial branch with roll + window_partition as addressing (Swin_AVE.py:256-276, :727-740, :765-776).
+Tolerance 1e-2 (bf16 operands, fp32 accumulate), relative to max(1, |ref|)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _close(got, ref, tol=1e-2, what=""):
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    err = (got - ref).abs(); bound = tol * torch.clamp(ref.abs(), min=1.0)
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} off; first {idx}: got {got[tuple(idx)].item()} "
+                             f"ref {ref[tuple(idx)].item()}; max err {err.max().item():.4g}")
+
+
+def _case(gpu, *, images, heads, Himg, ws, shift, seed=0, mag=1.0):
+    from stgcma import kernels as k, ops
+    import oracle.swin as OS
+    g = torch.Generator().manual_seed(seed)
+    n, N, C = ws * ws, Himg * Himg, heads * 32
+    nW = (Himg // ws) ** 2
+    rows = images * N
+    qkv = (torch.randn(rows, 3 * C, generator=g) * mag).to(BF16)
+    dO = torch.randn(rows, C, generator=g).to(BF16)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    index = OS.relative_position_index(ws)
+    mask = ops.shift_mask(Himg, Himg, ws, shift) if shift > 0 else None
+    scale = 32 ** -0.5
+
+    # ---- fp32 reference on the CPU (autograd)
+    x = qkv.float().requires_grad_(True)
+    wmap = ops.window_token_map(Himg, Himg, ws, shift).long()
+    rq = (torch.arange(images)[:, None] * N + wmap[None, :]).reshape(images * nW, n)            # [P, n] rows
+    def split(j):
+        return x[:, j * C:(j + 1) * C][rq].view(-1, n, heads, 32).permute(0, 2, 1, 3)
+    s = scale * (split(0) @ split(1).transpose(-1, -2)) + table[index.reshape(-1)].view(n, n, heads).permute(2, 0, 1)[None]
+    if mask is not None:
+        s = s + mask.repeat(images, 1, 1)[:, None]
+    o = (torch.softmax(s, -1) @ split(2)).permute(0, 2, 1, 3).reshape(-1, C)
+    o_nat = torch.zeros(rows, C).index_add(0, rq.reshape(-1), o)
+    lse_ref = torch.logsumexp(s, -1)
+    (o_nat * dO.float()).sum().backward()
+
+    # ---- HIP
+    d = lambda t: None if t is None else t.to(gpu)
+    bm, bmT = k.winattn_table(d(table), d(index.reshape(-1)), d(mask), n)
+    assert torch.equal(bm.transpose(-1, -2), bmT)
+    assert float(bm[..., :n, n:].max()) < -1e29 if n < 64 else True
+    wg = k.WinGeom(images, heads, Himg, Himg, ws, shift, scale, bm, bmT)
+    Q = d(qkv)
+    O, lse = k.winattn_fwd(wg, Q[:, :C], Q[:, C:2 * C], Q[:, 2 * C:])
+    _close(O.float() / mag, o_nat / mag, what="O")          # |V| ~ mag: the bf16 rounding of P and O scales with it
+    _close(lse[..., :n], lse_ref, tol=2e-2, what="lse")
+    dQKV = torch.full_like(Q, float("nan"))
+    k.winattn_bwd(wg, Q[:, :C], Q[:, C:2 * C], Q[:, 2 * C:], O, lse, d(dO), dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+    gscale = max(1.0, float(x.grad.abs().max()))
+    _close(dQKV[:, :C] / gscale, x.grad[:, :C] / gscale, tol=1.5e-2, what="dQ")
+    _close(dQKV[:, C:2 * C] / gscale, x.grad[:, C:2 * C] / gscale, tol=1.5e-2, what="dK")
+    _close(dQKV[:, 2 * C:] / gscale, x.grad[:, 2 * C:] / gscale, tol=1.5e-2, what="dV")
+
+    # ---- and against the generic gather-mapped kernels (same inputs, both HIP)
+    sb = k.bias_gather(d(table), d(index.reshape(-1)))
+    ag = k.AttnGeom(images * nW, heads, n, 32, G=nW, outer=N, window=(Himg, Himg, ws, shift), scale=scale, bias=sb,
+                    bias_div=images * nW, bias_mod=1, mask=d(mask))
+    O2, lse2 = k.attn_fwd(ag, Q[:, :C], Q[:, C:2 * C], Q[:, 2 * C:])
+    _close(O.float() / mag, O2.float() / mag, what="O vs generic")
+
+
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_7x7_stage1_like(stg, gpu, shift):
+    """Swin stage-1 geometry: 56 x 56 tokens, 64 windows of 49 tokens (15 padding keys / queries per tile)."""
+    _case(gpu, images=2, heads=4, Himg=56, ws=7, shift=shift, seed=1)
+
+
+def test_window_single_window_stage4(stg, gpu):
+    """Stage 4: the 7 x 7 image is one window (window_size clamps, shift 0; Swin_AVE.py:354-358)."""
+    _case(gpu, images=5, heads=32, Himg=7, ws=7, shift=0, seed=2)
+
+
+def test_window_stage3_shifted_large_scores(stg, gpu):
+    """14 x 14, 4 windows, shifted, |q k| large enough that softmax saturates in places."""
+    _case(gpu, images=3, heads=16, Himg=14, ws=7, shift=3, seed=3, mag=3.0)
+
+
+def test_window_full_tile_8x8(stg, gpu):
+    """n = 64 exactly: no padding lanes at all."""
+    _case(gpu, images=2, heads=2, Himg=16, ws=8, shift=4, seed=4)
+
+
+def test_window_small_4x4(stg, gpu):
+    """n = 16: the second 32-row tile is all padding."""
+    _case(gpu, images=3, heads=1, Himg=8, ws=4, shift=1, seed=5)
+
+
+def test_winattn_rejects_bad_geometry(stg, gpu):
+    from stgcma import kernels as k
+    bm = torch.zeros(1, 2, 64, 64, device=gpu)
+    with pytest.raises(RuntimeError):
+        k.WinGeom(1, 2, 14, 14, 5, 0, 1.0, bm, bm)                      # 14 % 5
+    with pytest.raises(RuntimeError):
+        k.WinGeom(1, 2, 27, 27, 9, 0, 1.0, bm, bm)                      # 81 tokens
+    wg = k.WinGeom(1, 2, 14, 14, 7, 0, 1.0, bm, bm)
+    q = torch.zeros(14 * 14 - 1, 192, dtype=BF16, device=gpu)
+    with pytest.raises(RuntimeError):
+        k.winattn_fwd(wg, q[:, :64], q[:, 64:128], q[:, 128:])          # too few rows
