@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 100
+#define STG_VERSION 101
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -37,9 +37,9 @@ const char* stg_last_error(void);
  * :973-979 (PatchMerging.reduction), :1319-1322 (mlp_head); CLIP_AVE.py:56-60,106-108 (c_fc/c_proj/in_proj/out_proj).
  * The same entry serves dgrad (W := pre-transposed weight) -- frozen weights never get a wgrad.
  *   t = acc*alpha + bias[n]
- *   if preact:   preact[m,n] = bf16(t)                       (saved for the activation's backward)
+ *   if dact:     dact[m,n] = bf16(act'(t))                   (saved for the activation's backward; needs act != NONE)
  *   t = act(t)
- *   if dact_src: t *= act'(dact_src[m,n])                    (backward through GELU/QuickGELU, act_bwd selects)
+ *   if dact_src: t *= dact_src[m,n]                          (backward through GELU/QuickGELU: the saved derivative)
  *   if row_scale: t *= row_scale[(m / rs_outer) * rs_inner + (m % rs_inner)]   (DropPath mask, Swin_AVE.py:709,715)
  *   if res1: t += res1[m,n];  if res2: t += res2[m,n]        (residual adds, Swin_AVE.py:780-787,810-811)
  *   C[m,n] = (c_dtype == STG_BF16) ? bf16(t) : t
@@ -52,8 +52,8 @@ typedef struct {
     const float* bias;
     float alpha;
     int act;
-    void* preact; int64_t ldp;
-    const void* dact_src; int64_t ldd; int act_bwd;
+    void* dact; int64_t ldp;
+    const void* dact_src; int64_t ldd;
     const float* row_scale; int64_t rs_outer; int64_t rs_inner;
     const void* res1; int64_t ldr1; int res1_dtype;   /* STG_BF16 (branch tensors) or STG_F32 (the residual stream) */
     const void* res2; int64_t ldr2; int res2_dtype;
@@ -193,8 +193,9 @@ int stg_meanpool_bwd(const void* dout, int64_t lddo, void* din, int64_t G, int n
 
 /* out = a + b (+ c) (bf16), joins gradient branches; c may be NULL */
 int stg_add(const void* a, const void* b, const void* c, void* out, int64_t numel, void* stream);
-/* dz = dh * act'(z)  (bf16), backward of the adapter activation (Swin_AVE.py:21, GELU; CLIP QuickGELU) */
-int stg_act_bwd(const void* dh, const void* z, void* dz, int act, int64_t numel, void* stream);
+/* dz = dh * dact  (bf16), backward of the adapter activation (Swin_AVE.py:21 GELU; CLIP QuickGELU) given the derivative
+ * act'(pre-activation) that stg_gemm_nt saved in its `dact` output */
+int stg_act_bwd(const void* dh, const void* dact, void* dz, int64_t numel, void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

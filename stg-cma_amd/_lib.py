@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstgcma_hip.so")
+LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so")   # env: an alternative build (kernel A/B runs)
 
 STG_F32, STG_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
@@ -26,8 +26,8 @@ class GemmArgs(C.Structure):
         ("bias", c_vp),
         ("alpha", C.c_float),
         ("act", C.c_int),
-        ("preact", c_vp), ("ldp", c_i64),
-        ("dact_src", c_vp), ("ldd", c_i64), ("act_bwd", C.c_int),
+        ("dact", c_vp), ("ldp", c_i64),
+        ("dact_src", c_vp), ("ldd", c_i64),
         ("row_scale", c_vp), ("rs_outer", c_i64), ("rs_inner", c_i64),
         ("res1", c_vp), ("ldr1", c_i64), ("res1_dtype", C.c_int),
         ("res2", c_vp), ("ldr2", c_i64), ("res2_dtype", C.c_int),
@@ -103,7 +103,7 @@ SIGNATURES = {
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "stg_act_bwd": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, c_i64, c_vp]),
+    "stg_act_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -131,8 +131,8 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if handle.stg_version() != 100:
-        raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version 100")
+    if handle.stg_version() != 101:
+        raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version 101")
     _lib = handle
     return _lib
 

@@ -95,18 +95,18 @@ __global__ void add_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* c, bf
 }
 
 // ---- dz = dh * act'(z)
-__global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int act, int64_t n8, int64_t numel) {
+__global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int64_t n8, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         float x[8], y[8];
         unpack8(reinterpret_cast<const uint4*>(dh)[i], x);
         unpack8(reinterpret_cast<const uint4*>(z)[i], y);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] *= act_grad(act, y[j]);
+        for (int j = 0; j < 8; ++j) x[j] *= y[j];
         reinterpret_cast<uint4*>(dz)[i] = pack8(x);
     }
     if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
         const int64_t i = (n8 << 3) + threadIdx.x;
-        dz[i] = f2bf(bf2f(dh[i]) * act_grad(act, bf2f(z[i])));
+        dz[i] = f2bf(bf2f(dh[i]) * bf2f(z[i]));
     }
 }
 
@@ -313,14 +313,13 @@ extern "C" int stg_add(const void* a, const void* b, const void* c, void* out, i
     STG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int stg_act_bwd(const void* dh, const void* z, void* dz, int act, int64_t numel, void* stream) {
+extern "C" int stg_act_bwd(const void* dh, const void* z, void* dz, int64_t numel, void* stream) {
     STG_CHECK(dh && z && dz, -1, "stg_act_bwd: null pointer");
-    STG_CHECK(act >= 0 && act <= 2, -3, "stg_act_bwd: bad act");
     STG_CHECK((((uintptr_t)dh | (uintptr_t)z | (uintptr_t)dz) & 15) == 0, -2, "stg_act_bwd: pointers must be 16-byte aligned");
     if (numel <= 0) return 0;
     const int64_t n8 = numel >> 3;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)dh, (const bf16_t*)z,
-                       (bf16_t*)dz, act, n8, numel);
+                       (bf16_t*)dz, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -29,27 +29,18 @@ struct GemmParams {
     const float* bias;
     float alpha;
     int act;
-    bf16_t* preact; int64_t ldp;
-    const bf16_t* dact_src; int64_t ldd; int act_bwd;
+    bf16_t* dact; int64_t ldp;
+    const bf16_t* dact_src; int64_t ldd;
     const float* row_scale; int64_t rs_outer; int64_t rs_inner;
     const void* res1; int64_t ldr1; int res1_f32;
     const void* res2; int64_t ldr2; int res2_f32;
     int64_t M; int N; int K;
     int nbm, nbn;
     int vec_ok;
-    int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work
+    int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
+    int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work, 3 = no epilogue
 };
 
-__device__ __forceinline__ void add_res4(const void* res, int f32, int64_t off, float* t) {
-    if (f32) {
-        const float4 z = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(res) + off);
-        t[0] += z.x; t[1] += z.y; t[2] += z.z; t[3] += z.w;
-    } else {
-        const u16x4 z = *reinterpret_cast<const u16x4*>(reinterpret_cast<const bf16_t*>(res) + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] += bf2f(z.v[r]);
-    }
-}
 __device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) {
     return f32 ? reinterpret_cast<const float*>(res)[off] : bf2f(reinterpret_cast<const bf16_t*>(res)[off]);
 }
@@ -58,80 +49,208 @@ __device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
 
 struct AccTile { f32x4_t v[4][4]; };   // passed BY VALUE: a by-reference accumulator array ends up mirrored in scratch
 
-// Epilogue shared by both GEMM kernels: lane owns row m, 4 consecutive columns n per (ni, mi) accumulator tile.
-// FULL tiles (the overwhelming majority) run a straight-line vector path with only kernel-uniform option branches.
-template <bool FULL>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
-                                              int lrow, int lk) {
+// Element-wise fallback epilogue (N % 8 != 0 or unaligned operands: the 29-column classifier head): lane owns row m and
+// 4 consecutive columns n per (ni, mi) accumulator tile; scalar, bounds-checked, every option a run-time test.
+__device__ __forceinline__ void gemm_epilogue_elems(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
+                                                    int lrow, int lk) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int64_t m = m0 + wm * 64 + mi * 16 + lrow;
-        if (!FULL && m >= p.M) continue;
+        if (m >= p.M) continue;
         float rs = 1.0f;
         if (p.row_scale) rs = p.row_scale[(m / p.rs_outer) * p.rs_inner + (m % p.rs_inner)];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + 4 * lk;
-            if (!FULL && n >= p.N) continue;
-            float t[4];
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                if (nn >= p.N) break;
+                float v = accs.v[ni][mi][r] * p.alpha;
+                if (p.bias) v += p.bias[nn];
+                float dv = 1.0f;
+                act_both(p.act, v, v, dv);
+                if (p.dact && p.act) p.dact[m * p.ldp + nn] = f2bf(dv);
+                if (p.dact_src) v *= bf2f(p.dact_src[m * p.ldd + nn]);
+                v *= rs;
+                if (p.res1) v += ld_res1(p.res1, p.res1_f32, m * p.ldr1 + nn);
+                if (p.res2) v += ld_res1(p.res2, p.res2_f32, m * p.ldr2 + nn);
+                if (p.c_f32) reinterpret_cast<float*>(p.C)[m * p.ldc + nn] = v;
+                else reinterpret_cast<bf16_t*>(p.C)[m * p.ldc + nn] = f2bf(v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-layout epilogue (every 8-aligned call, i.e. everything but the 29-column head).
+// In the accumulator layout a wave-wide store touches 16 rows x 32 bytes: measured, the bare C store of a K = 512 GEMM
+// cost as much as its whole MFMA loop, and the residual-add variants ran at ~2.6 TB/s.  So each wave transposes its
+// 64 x 64 fp32 sub-tile through a private 8 KiB LDS region (32 rows at a time, 16-byte chunks XOR-swizzled by row so both
+// the accumulator-layout writes and the row-layout reads are conflict-free) and then owns, per instruction, 8 rows x 64
+// columns with 8 consecutive columns per lane: every global access of the epilogue (C, saved derivative, derivative
+// source, residuals) is a 16- or 32-byte piece of a 128/256-byte contiguous row segment.
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+struct Row8 { uint4 lo, hi; };     // 8 values: bf16 in lo, or fp32 in lo (0..3) + hi (4..7)
+
+__device__ __forceinline__ Row8 ld_row8(const void* base, int f32, int64_t off) {
+    Row8 r;
+    if (f32) {
+        const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(base) + off);
+        r.lo = q[0]; r.hi = q[1];
+    } else {
+        r.lo = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(base) + off);
+        r.hi = r.lo;
+    }
+    return r;
+}
+__device__ __forceinline__ void row8_to_f32(const Row8& r, int f32, float* v) {
+    if (f32) {
+        v[0] = __uint_as_float(r.lo.x); v[1] = __uint_as_float(r.lo.y); v[2] = __uint_as_float(r.lo.z); v[3] = __uint_as_float(r.lo.w);
+        v[4] = __uint_as_float(r.hi.x); v[5] = __uint_as_float(r.hi.y); v[6] = __uint_as_float(r.hi.z); v[7] = __uint_as_float(r.hi.w);
+    } else {
+        const uint32_t w[4] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = accs.v[ni][mi][r] * p.alpha;
-            if (FULL || (p.vec_ok && n + 3 < p.N)) {
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                    t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
-                }
-                if (p.preact) {
-                    uint2 o; o.x = pack_bf2(t[0], t[1]); o.y = pack_bf2(t[2], t[3]);
-                    *reinterpret_cast<uint2*>(p.preact + m * p.ldp + n) = o;
-                }
-                if (p.act) {
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = __uint_as_float(w[j] << 16);
+            v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ uint4 pack_row8(const float* t) {
+    return make_uint4(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]), pack_bf2(t[4], t[5]), pack_bf2(t[6], t[7]));
+}
+
+// The option set is a compile-time VARIANT picked on the host (epi_variant): with every option a run-time test, the
+// straight-line code of one 8-row step carried ~10 wave-uniform branches and the register allocation of all paths at once
+// (spills at the 128-VGPR budget of 4 waves / SIMD) -- measured 555 us vs 369 us for the plain store of a
+// 125440 x 2048 x 512 GEMM.  The variants are the signatures that carry the training step (tools/step_gemm_shapes.py);
+// anything else takes EV_GENERIC, which keeps every test at run time.  Partial tiles are predicated, not branched.
+enum { EV_GENERIC = 0, EV_PLAIN, EV_GELU, EV_QGELU, EV_DSRC, EV_R16, EV_BRQ };
+
+template <int V>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
+                                                   int lane, float* stg) {
+    constexpr bool G = V == EV_GENERIC;
+    const bool alpha_on = G ? p.alpha != 1.0f : false;
+    const int act = G ? p.act : (V == EV_GELU ? (int)STG_ACT_GELU : V == EV_QGELU ? (int)STG_ACT_QUICKGELU : (int)STG_ACT_NONE);
+    const bool dsrc_on = G ? p.dact_src != nullptr : V == EV_DSRC;
+    const bool rs_on = G ? p.row_scale != nullptr : false;
+    const bool r1_on = G ? p.res1 != nullptr : (V == EV_R16 || V == EV_BRQ);
+    const int r1_f32 = G ? p.res1_f32 : 0;
+    const bool r2_on = G ? p.res2 != nullptr : V == EV_BRQ;
+    const int r2_f32 = G ? p.res2_f32 : 1;
+    const bool c_f32 = G ? p.c_f32 != 0 : V == EV_BRQ;
+
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int rr = lane >> 3, cc = lane & 7;
+    int n = n0 + wn * 64 + cc * 8;
+    const bool col_ok = n < p.N;
+    if (!col_ok) n = 0;                                // clamped: loads stay unconditional, stores are predicated
+    float bias[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] = act_apply(p.act, t[r]);
-                }
-                if (p.dact_src) {
-                    const u16x4 z = *reinterpret_cast<const u16x4*>(p.dact_src + m * p.ldd + n);
+    for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+        bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] *= act_grad(p.act_bwd, bf2f(z.v[r]));
-                }
-                if (p.row_scale) {
+    for (int half = 0; half < 2; ++half) {
+        if (half) lds_wave_sync();                     // the previous half's reads are done before it is overwritten
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] *= rs;
-                }
-                if (p.res1) add_res4(p.res1, p.res1_f32, m * p.ldr1 + n, t);
-                if (p.res2) add_res4(p.res2, p.res2_f32, m * p.ldr2 + n, t);
-                if (p.c_f32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) =
-                        make_float4(t[0], t[1], t[2], t[3]);
+        for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4_t*>(stg + (mi2 * 16 + lrow) * 64 + (((ni * 4 + lk) ^ lrow) << 2)) = accs.v[ni][half * 2 + mi2];
+        lds_wave_sync();                               // LDS-only fences: the row operands' global loads may be hoisted above
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + rr;
+            int64_t m = m0 + wm * 64 + half * 32 + row;
+            const bool ok = m < p.M && col_ok;
+            m = m < p.M ? m : p.M - 1;
+            Row8 qd, q1, q2;
+            if (dsrc_on) qd = ld_row8(p.dact_src, 0, m * p.ldd + n);
+            if (r1_on) q1 = ld_row8(p.res1, r1_f32, m * p.ldr1 + n);
+            if (r2_on) q2 = ld_row8(p.res2, r2_f32, m * p.ldr2 + n);
+            const float* src = stg + row * 64;
+            const int c0 = (2 * cc) ^ (row & 15);
+            const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(src + (c0 << 2));
+            const f32x4_t u1 = *reinterpret_cast<const f32x4_t*>(src + ((c0 ^ 1) << 2));
+            float t[8] = {u0[0], u0[1], u0[2], u0[3], u1[0], u1[1], u1[2], u1[3]};
+            if (alpha_on) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] *= p.alpha;
+            }
+            if (!G || p.bias) {                        // variants always add (zeros without a bias): no branch
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] += bias[j];
+            }
+            if (act == STG_ACT_GELU) {
+                float d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gelu_fast(t[j], t[j], d[j]);
+                if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
+            } else if (act == STG_ACT_QUICKGELU) {
+                float d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) quick_gelu_fast(t[j], t[j], d[j]);
+                if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
+            }
+            float v[8];
+            if (dsrc_on) {
+                row8_to_f32(qd, 0, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] *= v[j];
+            }
+            if (rs_on) {
+                const float rs = p.row_scale[(m / p.rs_outer) * p.rs_inner + (m % p.rs_inner)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] *= rs;
+            }
+            if (r1_on) {
+                row8_to_f32(q1, r1_f32, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] += v[j];
+            }
+            if (r2_on) {
+                row8_to_f32(q2, r2_f32, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] += v[j];
+            }
+            if (ok) {
+                if (c_f32) {
+                    float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n);
+                    dst[0] = make_float4(t[0], t[1], t[2], t[3]);
+                    dst[1] = make_float4(t[4], t[5], t[6], t[7]);
                 } else {
-                    uint2 o; o.x = pack_bf2(t[0], t[1]); o.y = pack_bf2(t[2], t[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = o;
-                }
-            } else {
-                for (int r = 0; r < 4; ++r) {
-                    const int nn = n + r;
-                    if (nn >= p.N) break;
-                    float v = t[r];
-                    if (p.bias) v += p.bias[nn];
-                    if (p.preact) p.preact[m * p.ldp + nn] = f2bf(v);
-                    v = act_apply(p.act, v);
-                    if (p.dact_src) v *= act_grad(p.act_bwd, bf2f(p.dact_src[m * p.ldd + nn]));
-                    v *= rs;
-                    if (p.res1) v += ld_res1(p.res1, p.res1_f32, m * p.ldr1 + nn);
-                    if (p.res2) v += ld_res1(p.res2, p.res2_f32, m * p.ldr2 + nn);
-                    if (p.c_f32) reinterpret_cast<float*>(p.C)[m * p.ldc + nn] = v;
-                    else reinterpret_cast<bf16_t*>(p.C)[m * p.ldc + nn] = f2bf(v);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + n) = pack_row8(t);
                 }
             }
         }
     }
 }
 
+// smem: the block's tile buffer (>= 32 KiB), free once every wave is past the main loop's final barrier
 __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm,
-                                                       int wn, int lrow, int lk) {
-    const bool full = p.vec_ok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (full) gemm_epilogue<true>(p, accs, m0, n0, wm, wn, lrow, lk);
-    else gemm_epilogue<false>(p, accs, m0, n0, wm, wn, lrow, lk);
+                                                       int wn, int lane, bf16_t* smem) {
+    if (p.dbg == 3 && accs.v[0][0][0] != 12345.678f) return;
+    float* stg = reinterpret_cast<float*>(smem) + (wm * 2 + wn) * 2048;
+    switch (p.epi_variant) {
+        case EV_PLAIN: gemm_epilogue_rows<EV_PLAIN>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_GELU: gemm_epilogue_rows<EV_GELU>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_QGELU: gemm_epilogue_rows<EV_QGELU>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_DSRC: gemm_epilogue_rows<EV_DSRC>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_R16: gemm_epilogue_rows<EV_R16>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_BRQ: gemm_epilogue_rows<EV_BRQ>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_GENERIC: gemm_epilogue_rows<EV_GENERIC>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        default: gemm_epilogue_elems(p, accs, m0, n0, wm, wn, lane & 15, lane >> 4); break;     // unaligned / N % 8 != 0
+    }
 }
 
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
@@ -243,7 +362,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lrow, lk);
+    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,7 +454,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
             __syncthreads();
         }
     }
-    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lrow, lk);
+    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,7 +741,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     STG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, -2, "stg_gemm_nt: A/W must be 16-byte aligned");
     STG_CHECK(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
     STG_CHECK(a->c_dtype == STG_BF16 || a->c_dtype == STG_F32, -3, "stg_gemm_nt: unsupported c_dtype %d", a->c_dtype);
-    STG_CHECK(a->act >= 0 && a->act <= 2 && a->act_bwd >= 0 && a->act_bwd <= 2, -3, "stg_gemm_nt: bad act");
+    STG_CHECK(a->act >= 0 && a->act <= 2, -3, "stg_gemm_nt: bad act");
+    STG_CHECK(!a->dact || a->act != 0, -3, "stg_gemm_nt: dact output needs an activation");
     if (a->row_scale) STG_CHECK(a->rs_outer > 0 && a->rs_inner > 0, -2, "stg_gemm_nt: bad row_scale params");
     if (a->res1) STG_CHECK(a->res1_dtype == STG_BF16 || a->res1_dtype == STG_F32, -3, "stg_gemm_nt: bad res1 dtype");
     if (a->res2) STG_CHECK(a->res2_dtype == STG_BF16 || a->res2_dtype == STG_F32, -3, "stg_gemm_nt: bad res2 dtype");
@@ -632,8 +752,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == STG_F32);
     p.bias = a->bias; p.alpha = a->alpha; p.act = a->act;
-    p.preact = (bf16_t*)a->preact; p.ldp = a->ldp;
-    p.dact_src = (const bf16_t*)a->dact_src; p.ldd = a->ldd; p.act_bwd = a->act_bwd;
+    p.dact = (bf16_t*)a->dact; p.ldp = a->ldp;
+    p.dact_src = (const bf16_t*)a->dact_src; p.ldd = a->ldd;
     p.row_scale = a->row_scale; p.rs_outer = a->rs_outer; p.rs_inner = a->rs_inner;
     p.res1 = a->res1; p.ldr1 = a->ldr1; p.res1_f32 = (a->res1_dtype == STG_F32);
     p.res2 = a->res2; p.ldr2 = a->ldr2; p.res2_f32 = (a->res2_dtype == STG_F32);
@@ -646,13 +766,25 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     auto al = [](const void* ptr, int64_t ld, int bytes_per, int need) {
         return ptr == nullptr || ((((uintptr_t)ptr) % need) == 0 && (ld * bytes_per) % need == 0);
     };
-    p.vec_ok = al(a->C, a->ldc, p.c_f32 ? 4 : 2, p.c_f32 ? 16 : 8) && al(a->bias, 4, 4, 16) &&
-               al(a->preact, a->ldp, 2, 8) && al(a->dact_src, a->ldd, 2, 8) &&
-               al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, p.res1_f32 ? 16 : 8) &&
-               al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, p.res2_f32 ? 16 : 8);
-    static const int nst = [] { const char* e = getenv("STG_GEMM_NST"); return e ? atoi(e) : 1; }();
-    if (a->K % BK == 0 && nst == 1) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<2>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    p.vec_ok = 0;
+    const bool vec8 = a->N % 8 == 0 && al(a->C, a->ldc, p.c_f32 ? 4 : 2, 16) && al(a->bias, 4, 4, 16) &&
+                      al(a->dact, a->ldp, 2, 16) && al(a->dact_src, a->ldd, 2, 16) &&
+                      al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, 16) && al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, 16);
+    p.epi_variant = -1;
+    if (vec8) {
+        p.epi_variant = EV_GENERIC;
+        const bool r1b = a->res1 && !p.res1_f32, r2q = a->res2 && p.res2_f32;
+        if (a->alpha == 1.0f && !a->row_scale) {
+            if (!p.c_f32 && !a->dact_src && !a->res1 && !a->res2)
+                p.epi_variant = a->act == STG_ACT_NONE ? EV_PLAIN : (a->act == STG_ACT_GELU ? EV_GELU : EV_QGELU);
+            else if (!p.c_f32 && !a->act && a->dact_src && !a->res1 && !a->res2) p.epi_variant = EV_DSRC;
+            else if (!p.c_f32 && !a->act && !a->dact_src && r1b && !a->res2) p.epi_variant = EV_R16;
+            else if (p.c_f32 && !a->act && !a->dact_src && r1b && r2q) p.epi_variant = EV_BRQ;
+        }
+        static const int force_generic = [] { const char* e = getenv("STG_GEMM_EPI"); return e && atoi(e) == 0; }();
+        if (force_generic) p.epi_variant = EV_GENERIC;            // A/B knob: every option a run-time test
+    }
+    if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

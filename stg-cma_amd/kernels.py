@@ -54,9 +54,10 @@ def _chk1d(t, name, dtype, n):
         raise RuntimeError(f"{name}: expected contiguous {dtype} GPU vector of length {n}")
 
 
-def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_preact=False, dact_src=None,
-            act_bwd=ACT_NONE, row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None):
-    """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, preact)."""
+def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
+            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None):
+    """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, dact) with dact = bf16(act'(pre-activation)),
+    the tensor a later call takes as dact_src (or act_bwd as its second argument)."""
     M, K = A.shape
     N = W.shape[0]
     _chk2d(A, "A", BF16)
@@ -76,12 +77,14 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     a.alpha = float(alpha)
     a.act = int(act)
     pre = None
-    if want_preact:
+    if want_dact:
+        if act == ACT_NONE:
+            raise RuntimeError("gemm_nt: want_dact needs an activation")
         pre = torch.empty((M, N), dtype=BF16, device=A.device)
-        a.preact, a.ldp = _p(pre), _ld(pre)
+        a.dact, a.ldp = _p(pre), _ld(pre)
     if dact_src is not None:
         _chk2d(dact_src, "dact_src", BF16, cols=N, rows=M)
-        a.dact_src, a.ldd, a.act_bwd = _p(dact_src), _ld(dact_src), int(act_bwd)
+        a.dact_src, a.ldd = _p(dact_src), _ld(dact_src)
     if row_scale is not None:
         if not row_scale.is_cuda or row_scale.dtype != F32 or not row_scale.is_contiguous():
             raise RuntimeError("row_scale: expected contiguous fp32 GPU tensor")
@@ -104,7 +107,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _gemm_prof.append((e0, e1, 2.0 * M * N * K))
     else:
         _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
-    return (out, pre) if want_preact else out
+    return (out, pre) if want_dact else out
 
 
 _gemm_prof = None
@@ -239,12 +242,13 @@ def add(a, b, c=None):
     return out
 
 
-def act_bwd(dh, z, act):
+def act_bwd(dh, z):
+    """dz = dh * z, z = the activation derivative saved by gemm_nt(want_dact=True)."""
     _chk_flat(dh, "dh"); _chk_flat(z, "z")
     if dh.shape != z.shape:
         raise RuntimeError("act_bwd: shape mismatch")
     dz = torch.empty_like(dh)
-    _lib.check(_lib.lib().stg_act_bwd(_p(dh), _p(z), _p(dz), int(act), dh.numel(), _stream()), "stg_act_bwd")
+    _lib.check(_lib.lib().stg_act_bwd(_p(dh), _p(z), _p(dz), dh.numel(), _stream()), "stg_act_bwd")
     return dz
 
 

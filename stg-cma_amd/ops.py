@@ -365,7 +365,7 @@ def block_forward(X, spec, P, training, save):
         hz = []
         for i, m in enumerate(spec.mods):
             A = _Adapter(P, "T_Adapter" + _SFX[m])
-            Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True)
+            Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True)
             K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[i]], res1=X[sl[i]], row_scale=dps[i], rs_outer=T * N, rs_inner=N)
             hz.append((Ht, Zt))
         if save:
@@ -387,7 +387,7 @@ def block_forward(X, spec, P, training, save):
         AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
     PO = K.gemm_nt(AO, wproj, bproj)
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
-    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
     xs = None
     if spec.fuse:
         Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, save)
@@ -403,7 +403,7 @@ def block_forward(X, spec, P, training, save):
 
     # ---------------- FFN + S_Adapter (:790-811; parallel variant :438-440)
     Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
-    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_preact=True)
+    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_dact=True)
     M = K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
     del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
@@ -413,13 +413,13 @@ def block_forward(X, spec, P, training, save):
         dpf = drop_scale(spec.drop_path, BT, X.device, training)
         rs = (0.5 * dpf) if dpf is not None else torch.full((BT,), 0.5, dtype=F32, device=X.device)
         A = ads[0]
-        Ha_, Za_ = K.gemm_nt(Y, A.w1, A.b1, act=ACT_GELU, want_preact=True)
+        Ha_, Za_ = K.gemm_nt(Y, A.w1, A.b1, act=ACT_GELU, want_dact=True)
         K.gemm_nt(Ha_, A.w2, A.b2, out=X3, row_scale=rs, rs_outer=N, rs_inner=1, res1=M, res2=X2)
         if save:
             S["f"] = (X2, mean, rstd, Zm, Y, Ha_, Za_, rs)
     else:
         del Y
-        HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+        HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
         xs = None
         if spec.fuse:
             Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, save)
@@ -454,10 +454,10 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         X2, mean, rstd, Zm, Y, Ha_, Za_, rs = S.pop("f")
         A = ads[0]
         dHa = K.gemm_nt(dX3, A.w2t, row_scale=rs, rs_outer=N, rs_inner=1)
-        dZa = K.act_bwd(dHa, Za_, ACT_GELU)
+        dZa = K.act_bwd(dHa, Za_)
         _adapter_wgrad(G, A.name, dZa, Y, dX3, Ha_, rs=rs, rs_outer=N, rs_inner=1)
         dYa = K.gemm_nt(dZa, A.w1t)
-        dZm = K.gemm_nt(dX3, shadow(P["mlp.fc2.weight"], True), dact_src=Zm, act_bwd=ACT_GELU)
+        dZm = K.gemm_nt(dX3, shadow(P["mlp.fc2.weight"], True), dact_src=Zm)
         dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True), res1=dYa)
         del Y, Ha_, Za_, dHa, dZa, dYa, dZm, Zm
     else:
@@ -470,11 +470,11 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
             dHh = dH2
         dM = torch.empty_like(dX3)
         for i, A in enumerate(ads):
-            dZ = K.act_bwd(dHh[i], HZ[i][1], ACT_GELU)
+            dZ = K.act_bwd(dHh[i], HZ[i][1])
             _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
         del HZ, H2, xs, dH2, dHh, M
-        dZm = K.gemm_nt(dM, shadow(P["mlp.fc2.weight"], True), dact_src=Zm, act_bwd=ACT_GELU)
+        dZm = K.gemm_nt(dM, shadow(P["mlp.fc2.weight"], True), dact_src=Zm)
         del dM, Zm
         dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True))
         del dZm
@@ -492,7 +492,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         dHh = dH2
     dPO = torch.empty_like(dX2)
     for i, A in enumerate(ads):
-        dZ = K.act_bwd(dHh[i], HZ[i][1], ACT_GELU)
+        dZ = K.act_bwd(dHh[i], HZ[i][1])
         _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
         K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
     del HZ, H2, xs, dH2, dHh, PO
@@ -519,7 +519,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
             A = _Adapter(P, "T_Adapter" + _SFX[m])
             Ht, Zt = hz[i]
             dHt = K.gemm_nt(dX1[sl[i]], A.w2t, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
-            dZt = K.act_bwd(dHt, Zt, ACT_GELU)
+            dZt = K.act_bwd(dHt, Zt)
             _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
             K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
         del hz, PO

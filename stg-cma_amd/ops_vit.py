@@ -110,7 +110,7 @@ def vit_block_forward(X, spec, P, training, save):
     hz = []
     for i, m in enumerate(spec.mods):
         A = _Adapter(P, "T_Adapter" + _SFX[m])
-        Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True)
+        Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True)
         K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[i]], res1=X[sl[i]], row_scale=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
         hz.append((Ht, Zt))
     if save:
@@ -125,7 +125,7 @@ def vit_block_forward(X, spec, P, training, save):
     sg, slse = _mha(spec, BT, B, QKV, sl, False, save, AO)
     PO = K.gemm_nt(AO, wout, bout)
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
-    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
     xs = None
     if spec.fuse:
         Hv2, Ha2, xs = _cross_modal_fwd(None, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, None, save,
@@ -142,12 +142,12 @@ def vit_block_forward(X, spec, P, training, save):
 
     # ---- joint adaptation: QuickGELU MLP, then MLP_Adapter on its output (:403-429)
     Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["ln_2.weight"]), f32c(P["ln_2.bias"]), want_stats=save)
-    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.c_fc.weight"]), f32c(P["mlp.c_fc.bias"]), act=ACT_QUICKGELU, want_preact=True)
+    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.c_fc.weight"]), f32c(P["mlp.c_fc.bias"]), act=ACT_QUICKGELU, want_dact=True)
     del Y
     M = K.gemm_nt(Hm, shadow(P["mlp.c_proj.weight"]), f32c(P["mlp.c_proj.bias"]))
     del Hm
     ads = [_Adapter(P, "MLP_Adapter" + _SFX[m]) for m in spec.mods]
-    HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_preact=True) for i, A in enumerate(ads)]
+    HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
     xs = None
     if spec.fuse:
         Hv2, Ha2, xs = _cross_modal_fwd(None, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, None, save,
@@ -184,7 +184,7 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
             dHh = dH2
         dIn = torch.empty_like(dOut)
         for i, A in enumerate(ads):
-            dZ = K.act_bwd(dHh[i], HZ[i][1], ACT_GELU)
+            dZ = K.act_bwd(dHh[i], HZ[i][1])
             _adapter_wgrad(G, A.name, dZ, Xin[sl[i]], dOut[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dIn[sl[i]], res1=dOut[sl[i]])
         return dIn
@@ -193,7 +193,7 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
     X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
     dM = adapters_bwd("MLP_Adapter", HZ, H2, xs, M, dX3)
     del HZ, H2, xs, M
-    dZm = K.gemm_nt(dM, shadow(P["mlp.c_proj.weight"], True), dact_src=Zm, act_bwd=ACT_QUICKGELU)
+    dZm = K.gemm_nt(dM, shadow(P["mlp.c_proj.weight"], True), dact_src=Zm)
     del dM, Zm
     dY = K.gemm_nt(dZm, shadow(P["mlp.c_fc.weight"], True))
     del dZm
@@ -221,7 +221,7 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
         Ht, Zt = hz[i]
         kw = dict(row_scale=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
         dHt = K.gemm_nt(dX1[sl[i]], A.w2t, **kw)
-        dZt = K.act_bwd(dHt, Zt, ACT_GELU)
+        dZt = K.act_bwd(dHt, Zt)
         _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
         K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
     del hz, PO

@@ -17,7 +17,7 @@ import oracle.swin as OS
 def test_library_loads_and_exports_every_declared_symbol(stg):
     from stgcma import _lib
     lib = _lib.lib()
-    assert lib.stg_version() == 100
+    assert lib.stg_version() == 101
     header = open(os.path.join(ROOT, "include", "stgcma.h")).read()
     declared = set(re.findall(r"\b(stg_[a-z0-9_]+)\s*\(", header))
     declared -= {"stg_attn_bwd_prep"}          # mentioned in a comment only
@@ -147,3 +147,17 @@ def test_grad_arena_layout(stg):
     va.fill_(1.0); vc.fill_(2.0)
     assert float(ar.flat.sum()) == 15 + 8
     assert va.data_ptr() % 16 == ar.flat.data_ptr() % 16 and (vc.data_ptr() - ar.flat.data_ptr()) % 16 == 0
+
+
+def test_bench_cpu_baseline_leg_runs_on_host(stg):
+    """bench.py's cpu_baseline leg (the oracle timed on host cores) must work from a model's state_dict, integer buffers
+    included -- it only ever runs on the GPU box otherwise."""
+    import bench
+    from stgcma.model import Swin_AVE as S
+    torch.manual_seed(0)
+    m = S.SwinTransformer2D_Adapter_New(**bench.SWIN_B)
+    from stgcma.recipe import is_trainable
+    for n, p in m.named_parameters():
+        p.requires_grad = is_trainable(n)
+    r = bench.cpu_baseline_measure(torch, m, max_passes=1)
+    assert r["kind"] == "port" and r["unit"] == "clips/s" and r["value"] > 0 and r["cores"] >= 1

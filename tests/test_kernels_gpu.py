@@ -68,23 +68,24 @@ def test_gemm_epilogues(stg, gpu):
     b = torch.randn(N, generator=g)
     r1 = _bf(torch.randn(M, N, generator=g)); r2 = _bf(torch.randn(M, N, generator=g))
     z = A.float() @ W.float().t() + b
-    # GELU + preact
-    out, pre = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_GELU, want_preact=True)
-    _close(pre, z, what="preact")
+    # GELU + saved derivative (the backward's multiplier)
+    out, dact = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_GELU, want_dact=True)
+    _close(dact, _gelu_grad(z), what="gelu'")
     _close(out, torch.nn.functional.gelu(z), what="gelu")
     # QuickGELU
-    out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_QUICKGELU)
-    _close(out, z * torch.sigmoid(1.702 * z), what="quickgelu")
+    out, dact = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_QUICKGELU, want_dact=True)
+    sg = torch.sigmoid(1.702 * z)
+    _close(out, z * sg, what="quickgelu")
+    _close(dact, sg * (1 + 1.702 * z * (1 - sg)), what="quickgelu'")
     # residuals + alpha
     out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), alpha=0.5, res1=r1.to(gpu), res2=r2.to(gpu))
     _close(out, 0.5 * (A.float() @ W.float().t()) + b + r1.float() + r2.float(), what="residuals")
-    # activation backward: t * gelu'(src)
+    # activation backward: t * saved derivative
     src = _bf(torch.randn(M, N, generator=g))
-    out = k.gemm_nt(A.to(gpu), W.to(gpu), None, dact_src=src.to(gpu), act_bwd=k.ACT_GELU)
-    _close(out, (A.float() @ W.float().t()) * _gelu_grad(src.float()), what="dgelu")
-    s = src.float(); sg = torch.sigmoid(1.702 * s)
-    out = k.gemm_nt(A.to(gpu), W.to(gpu), None, dact_src=src.to(gpu), act_bwd=k.ACT_QUICKGELU)
-    _close(out, (A.float() @ W.float().t()) * (sg * (1 + 1.702 * s * (1 - sg))), what="dquickgelu")
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), None, dact_src=src.to(gpu))
+    _close(out, (A.float() @ W.float().t()) * src.float(), what="dact_src")
+    with pytest.raises(RuntimeError):
+        k.gemm_nt(A.to(gpu), W.to(gpu), None, want_dact=True)                  # a derivative needs an activation
     # DropPath row scale: rows are (b t) n ; mask per (b, n): idx = (m // (T*n)) * n + m % n
     T, n = 3, 13
     Bc = M // (T * n)
@@ -96,6 +97,32 @@ def test_gemm_epilogues(stg, gpu):
     idx = (m // (T * n)) * n + m % n
     _close(out, z[:Mm] * scale[idx][:, None] + r1[:Mm].float(), what="row_scale")
 
+
+
+@pytest.mark.parametrize("M,N,K", [(390, 256, 128), (1000, 136, 64), (257, 72, 40), (64, 8, 16), (130, 29, 128), (4099, 384, 512)])
+def test_gemm_epilogue_layouts(stg, gpu, M, N, K):
+    """Row-layout epilogue (N % 8 == 0) and the element fallback (N = 29): partial row / column tiles, fp32 and bf16
+    residuals and outputs, strided views, every option at once."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)); W = _bf(torch.randn(N, K, generator=g) * 0.2)
+    b = torch.randn(N, generator=g)
+    r1 = _bf(torch.randn(M, N, generator=g)); r2 = torch.randn(M, N, generator=g)
+    src = _bf(torch.rand(M, N, generator=g))
+    z = A.float() @ W.float().t()
+    # fp32 output, bf16 + fp32 residuals (the residual-stream update)
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), res1=r1.to(gpu), res2=r2.to(gpu), out_dtype=F32)
+    assert out.dtype == F32
+    _close(out, z + b + r1.float() + r2, tol=4e-3, what="f32 out")
+    # into a row slice of a wider fp32 buffer (column offset => strided rows)
+    big = torch.full((M, N + 16), 7.0, device=gpu)
+    k.gemm_nt(A.to(gpu), W.to(gpu), None, out=big[:, 8:8 + N], res1=r2.to(gpu))
+    _close(big[:, 8:8 + N], z + r2, tol=4e-3, what="strided out")
+    assert float((big[:, :8] - 7).abs().max()) == 0 and float((big[:, 8 + N:] - 7).abs().max()) == 0
+    # gelu + derivative + derivative source + bf16 out
+    out, d = k.gemm_nt(A.to(gpu), W.to(gpu), b.to(gpu), act=k.ACT_GELU, want_dact=True, dact_src=src.to(gpu), res1=r1.to(gpu))
+    _close(out, torch.nn.functional.gelu(z + b) * src.float() + r1.float(), what="gelu*src+res")
+    _close(d, _gelu_grad(z + b), what="gelu' saved")
 
 def test_gemm_strided_views(stg, gpu):
     """Operands / outputs that are column slices of wider buffers (how the fused a/v tensors are addressed)."""
@@ -200,7 +227,7 @@ def test_elementwise(stg, gpu):
     assert tuple(ct2.shape) == (512, 32) and float(ct2[:, 29:].abs().max()) == 0
     _close(ct2[:, :29], w2.t(), what="cast T pad")
     z = _bf(torch.randn(33, 24, generator=g)); dh = _bf(torch.randn(33, 24, generator=g))
-    _close(k.act_bwd(dh.to(gpu), z.to(gpu), k.ACT_GELU), dh.float() * _gelu_grad(z.float()), what="act_bwd")
+    _close(k.act_bwd(dh.to(gpu), z.to(gpu)), dh.float() * z.float(), what="act_bwd")
     _close(k.add(h.to(gpu), r.to(gpu), h.to(gpu)), 2 * h.float() + r.float(), what="add3")
     _close(k.cast_f32(_bf(w).to(gpu)), _bf(w).float(), tol=0, what="cast f32")
     # meanpool

@@ -19,7 +19,9 @@ def wrapped(A, W, bias=None, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = orig(A, W, bias, **kw); e1.record()
     epi = ("b" if bias is not None else "") + ("a" if kw.get("act") else "") + ("d" if kw.get("dact_src") is not None else "") + \
-          ("r" if kw.get("res1") is not None else "") + ("R" if kw.get("res2") is not None else "") + ("s" if kw.get("row_scale") is not None else "")
+          ("" if kw.get("res1") is None else ("r" if kw["res1"].dtype == torch.bfloat16 else "q")) + \
+          ("" if kw.get("res2") is None else ("R" if kw["res2"].dtype == torch.bfloat16 else "Q")) + ("s" if kw.get("row_scale") is not None else "") + \
+          ("p" if kw.get("want_dact") else "") + ("A" if kw.get("alpha", 1.0) != 1.0 else "")
     od = kw["out"].dtype if kw.get("out") is not None else kw.get("out_dtype", torch.bfloat16)
     rec.append((A.shape[0], W.shape[0], A.shape[1], epi, str(od)[-4:], e0, e1)); return r
 K.gemm_nt = wrapped
@@ -30,8 +32,15 @@ for M, N, Kd, epi, od, e0, e1 in rec:
     k = (M, N, Kd, epi, od); agg[k][0] += 1; agg[k][1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
 print(f"total gemm ms {tot:.1f} launches {len(rec)}")
-for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', 40))]:
     M, N, Kd, epi, od = k
     fl = 2.0 * M * N * Kd * c
     by = c * (M * Kd * 2 + M * N * (4 if od == "at32" else 2))
     print(f"M={M:8d} N={N:5d} K={Kd:5d} epi={epi:6s} out={od} x{c:3d}  {ms:7.2f} ms  {fl/ms/1e9:7.1f} TF  ~{by/ms/1e6:7.0f} GB/s(min)")
+
+sig = collections.defaultdict(lambda: [0, 0.0])
+for (M, N, Kd, epi, od), (c, ms) in agg.items():
+    sig[(epi, od)][0] += c; sig[(epi, od)][1] += ms
+print("--- epilogue signatures")
+for k, (c, ms) in sorted(sig.items(), key=lambda kv: -kv[1][1]):
+    print(f"epi={k[0]:8s} out={k[1]} x{c:4d} {ms:7.2f} ms")
