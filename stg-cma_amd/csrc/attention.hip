@@ -24,8 +24,10 @@
 // The other operand of those products (V^T, K^T, Q^T, dO^T) is k-strided in memory; its 32 x D tile is staged
 // row-major in LDS with 16-byte stores and gathered with 16-bit reads (32 lanes read 64 contiguous bytes).
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/stgcma.h"
+#include "xattn.h"
 
 namespace {
 
@@ -701,6 +703,11 @@ inline int64_t groups(const AttnP& p) { return ((int64_t)p.P + p.pack - 1) / p.p
 
 }  // namespace
 
+static bool xattn_on() {          // STG_XATTN=0: keep the frame-global cross-modal attention on the generic kernels (A/B knob)
+    static const bool on = [] { const char* e = getenv("STG_XATTN"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 extern "C" int stg_attn_fwd(const stg_attn_args* f, void* stream) {
     STG_CHECK(f != nullptr, -1, "stg_attn_fwd: null args");
     AttnP p = {};
@@ -708,6 +715,7 @@ extern "C" int stg_attn_fwd(const stg_attn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O != nullptr && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_attn_fwd: bad O");
     if (f->P == 0) return 0;
+    if (xattn_on() && stg_xattn_eligible(f, true)) return stg_xattn_fwd(f, stream);      // frame-global cross-modal attention
     const int64_t items = groups(p) * f->H * tiles_q(p);
     STG_CHECK(items < (1ll << 31), -2, "stg_attn_fwd: too many work items");
     p.total_items = (int)items;
@@ -726,6 +734,7 @@ extern "C" int stg_attn_bwd(const stg_attn_bwd_args* b, void* stream) {
     STG_CHECK((((uintptr_t)f->O | (uintptr_t)b->dO) & 15) == 0, -2, "stg_attn_bwd: O/dO must be 16-byte aligned");
     STG_CHECK((((uintptr_t)b->dQ | (uintptr_t)b->dK | (uintptr_t)b->dV) & 7) == 0, -2, "stg_attn_bwd: dQ/dK/dV must be 8-byte aligned");
     if (f->P == 0) return 0;
+    if (xattn_on() && b->dV == nullptr && b->dbias == nullptr && stg_xattn_eligible(f, true)) return stg_xattn_bwd(b, stream);
     p.dO = (const bf16_t*)b->dO; p.lddo = b->lddo;
     p.dQ = (bf16_t*)b->dQ; p.lddq = b->lddq; p.dK = (bf16_t*)b->dK; p.lddk = b->lddk;
     p.dV = (bf16_t*)b->dV; p.lddv = b->lddv; p.delta = b->delta; p.dbias = b->dbias;

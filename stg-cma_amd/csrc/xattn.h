@@ -1,0 +1,6 @@
+// Internal: fast path of stg_attn_fwd / stg_attn_bwd for long single-head K == V attention (xattn.hip).
+#pragma once
+#include "../../include/stgcma.h"
+bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse);
+int stg_xattn_fwd(const stg_attn_args* f, void* stream);
+int stg_xattn_bwd(const stg_attn_bwd_args* b, void* stream);   // requires b->dV == NULL (dK receives dK + dV)

@@ -1,0 +1,481 @@
+// Long-sequence single-head attention with K == V: the adapters' frame-global cross-modal attention
+//   h_v' = softmax(h_v h_a^T) h_a   and   h_a' = softmax(h_a h_v^T) h_v        (Swin_AVE.py:799-808, CLIP_AVE.py:386-398)
+// with up to 3136 queries x 3136 keys per frame and head dim 16 / 32 (the adapter bottleneck width of stages 1 / 2).
+//
+// At these widths the work is neither MFMA- nor HBM-bound: a 32 x 32 score tile costs 3 MFMAs but 1024 exponentials, so
+// the kernels are built around the VALU instruction count per score (the generic gather-mapped kernels of attention.hip
+// spend ~45 issue slots per score on addressing, bounds and bias/mask plumbing; these spend ~4):
+//   * scores stay transposed (key on the accumulator row, query on the lane): max / LSE / delta are per-lane scalars;
+//   * softmax runs on exp2 with one FMA per score (scale * log2 e folded), the running max is only raised when a tile
+//     exceeds it by more than 2^8 (lazy rescale: the common tile does no accumulator rescaling at all);
+//   * the row sum comes out of the MFMA: for D = 16 the unused A-operand rows 16..31 of the P.V product are fed ones, so
+//     accumulator row 16 IS sum_k p (for D = 32 one extra MFMA with a ones operand does the same);
+//   * K == V, so the K fragment a lane loads for the score MFMA (16 bytes of one key row) is also its piece of the V
+//     tile: it is written once to a wave-private LDS tile and read back transposed with ds_read_b64_tr_b16 (the k-strided
+//     V^T / K^T / Q^T / dO^T operands), 2 reads per fragment instead of 8 16-bit reads + packing;
+//   * two 32-key tiles per loop trip, next trip's fragments prefetched into registers; tails are handled in a separate,
+//     masked instantiation of the loop body so the steady state carries no bounds logic.
+// One wave owns 32 queries (fwd, dQ) or 32 keys (dK+dV); waves never synchronise with each other.
+//
+// MFMA v_mfma_f32_32x32x16_bf16, lane l = (r = l & 31, hh = l >> 5): A[row r][k = 8 hh + j], B[k = 8 hh + j][col r];
+// C/D col = r, row = (reg & 3) + 8 (reg >> 2) + 4 hh.  An accumulator used as the next B operand has k slot (hh, j) of
+// step s2 = row 16 s2 + 8 (j >> 2) + 4 hh + (j & 3); the transposed reads deliver the other operand in that same order.
+#include <math.h>
+#include <type_traits>
+#include "common.h"
+#include "../../include/stgcma.h"
+#include "xattn.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THRESHOLD = 8.0f;       // in log2 units: probabilities stay below 2^8 between rescales
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+__device__ __forceinline__ bf16x8_t pack_frag(const float* x) {
+    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// transposed fragment of a row-major [32 rows][D] LDS tile: element j of lane (r, hh) = tile[16 s2 + 8 (j >> 2) + 4 hh + (j & 3)][r & 15 (+16 if D = 32 and r >= 16)]
+// `base` = this lane's address for (s2 = 0, t = 0): tile + (4 hh + q) * D + col0 + 4 p, lane-in-group i = 4 q + p
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* base, int s2, int D) {
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(base + (16 * s2) * D));
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(base + (16 * s2 + 8) * D));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+struct XP {
+    const bf16_t* Q; int64_t ldq;
+    const bf16_t* KV; int64_t ldk;
+    bf16_t* O; int64_t ldo;
+    float* lse;
+    int64_t outer_q, outer_kv;
+    int P, n, n_kv;
+    float scale, c2;
+    const bf16_t* dO; int64_t lddo;
+    bf16_t* dQ; int64_t lddq;
+    bf16_t* dKV; int64_t lddk;
+    float* delta;
+    int tiles, total;
+};
+
+// per-wave LDS: two [32][D] tiles + 8 bytes of bf16 ones
+template <int D> struct Lds { static constexpr int TILE = 32 * D; static constexpr int PER_WAVE = 2 * TILE + 8; };
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
+    constexpr int KS = D / 16;
+    constexpr int TILE = Lds<D>::TILE;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int p = item / a.tiles, qt = item - p * a.tiles;
+    bf16_t* tA = smem + wave * Lds<D>::PER_WAVE;
+    bf16_t* tB = tA + TILE;
+    bf16_t* ones = tB + TILE;
+    if (lane < 4) ones[lane] = (bf16_t)0x3F80;
+
+    int q = qt * 32 + r;
+    const bool okq = q < a.n;
+    q = okq ? q : a.n - 1;
+    const int64_t rowq = (int64_t)p * a.outer_q + q;
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = ld_frag(a.Q + rowq * a.ldq + 8 * hh + 16 * s);
+
+    // this lane's pieces: LDS write slot of its K fragment(s), and its transposed-read base
+    const bf16_t* kvp = a.KV + (int64_t)p * a.outer_kv * a.ldk + 8 * hh;
+    const int wr_off = r * D + 8 * hh;                           // + 16 s
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
+    // D = 16: lanes r >= 16 (A rows 16..31) read ones -> accumulator rows 16.. hold the row sum
+    const int tr_off = (D == 16) ? (4 * hh + gq) * D + 4 * gp : (4 * hh + gq) * D + 16 * c + 4 * gp;
+    const bool ones_lane = (D == 16) && c == 1;
+    const bf16_t* trA = ones_lane ? ones : tA + tr_off;
+    const bf16_t* trB = ones_lane ? ones : tB + tr_off;
+    const int tr_stride = ones_lane ? 0 : D;                    // rows advance only for real tiles
+
+    f32x16_t o = zero16(), lacc = zero16();
+    float m2 = -INFINITY;
+    bf16x8_t ones_frag;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones_frag[j] = (short)0x3F80;
+
+    bf16x8_t kfA[KS], kfB[KS];
+    auto load_pair = [&](int k0) {                              // clamped: every load in bounds, tails masked by value
+        int ka = k0 + r, kb = k0 + 32 + r;
+        ka = ka < a.n_kv ? ka : a.n_kv - 1;
+        kb = kb < a.n_kv ? kb : a.n_kv - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kfA[s] = ld_frag(kvp + (int64_t)ka * a.ldk + 16 * s);
+            kfB[s] = ld_frag(kvp + (int64_t)kb * a.ldk + 16 * s);
+        }
+    };
+    load_pair(0);
+
+    auto body = [&](int k0, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        lds_sync();                                             // previous trip's transposed reads are done
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(tA + wr_off + 16 * s) = kfA[s];
+            *reinterpret_cast<bf16x8_t*>(tB + wr_off + 16 * s) = kfB[s];
+        }
+        f32x16_t sA = zero16(), sB = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sA = MFMA32(kfA[s], qf[s], sA);
+            sB = MFMA32(kfB[s], qf[s], sB);
+        }
+        if (k0 + 64 < a.n_kv) load_pair(k0 + 64);               // wave-uniform
+        if (MASKED) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = k0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                sA[reg] = key < a.n_kv ? sA[reg] : -INFINITY;
+                sB[reg] = key + 32 < a.n_kv ? sB[reg] : -INFINITY;
+            }
+        }
+        float mt = fmaxf(sA[0], sB[0]);
+#pragma unroll
+        for (int reg = 1; reg < 16; ++reg) mt = fmaxf(mt, fmaxf(sA[reg], sB[reg]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mt2 = mt * a.c2;
+        if (__builtin_amdgcn_ballot_w64(mt2 > m2 + RESCALE_THRESHOLD) != 0) {
+            const float mn = fmaxf(m2, mt2);
+            const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) o[reg] *= alpha;
+            if (D == 32) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) lacc[reg] *= alpha;
+            }
+            m2 = mn;
+        }
+        float pA[16], pB[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            pA[reg] = __builtin_amdgcn_exp2f(fmaf(sA[reg], a.c2, -m2));
+            pB[reg] = __builtin_amdgcn_exp2f(fmaf(sB[reg], a.c2, -m2));
+        }
+        lds_sync();                                             // tile writes visible to the transposed reads
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t fa = pack_frag(pA + 8 * s2), fb = pack_frag(pB + 8 * s2);
+            o = MFMA32(tr_frag(trA, s2, tr_stride), fa, o);
+            o = MFMA32(tr_frag(trB, s2, tr_stride), fb, o);
+            if (D == 32) {
+                lacc = MFMA32(ones_frag, fa, lacc);
+                lacc = MFMA32(ones_frag, fb, lacc);
+            }
+        }
+    };
+
+    const int full = a.n_kv & ~63;
+    int k0 = 0;
+    for (; k0 < full; k0 += 64) body(k0, std::false_type{});
+    if (k0 < a.n_kv) body(k0, std::true_type{});
+
+    if (okq) {
+        const float l = (D == 16) ? o[8] : lacc[0];
+        const float inv = 1.0f / l;
+        bf16_t* op = a.O + rowq * a.ldo;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            uint2 w;
+            w.x = pack_bf2(o[4 * g + 0] * inv, o[4 * g + 1] * inv);
+            w.y = pack_bf2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
+        }
+        if (hh == 0) a.lse[(int64_t)p * a.n + q] = (m2 + __log2f(l)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+template <int D>
+__global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
+    constexpr int KS = D / 16;
+    constexpr int TILE = Lds<D>::TILE;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int p = item / a.tiles, qt = item - p * a.tiles;
+    bf16_t* tA = smem + wave * Lds<D>::PER_WAVE;
+    bf16_t* tB = tA + TILE;
+
+    int q = qt * 32 + r;
+    const bool okq = q < a.n;
+    q = okq ? q : a.n - 1;
+    const int64_t rowq = (int64_t)p * a.outer_q + q;
+    bf16x8_t qf[KS], dof[KS];
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = ld_frag(a.Q + rowq * a.ldq + 8 * hh + 16 * s);
+        dof[s] = ld_frag(a.dO + rowq * a.lddo + 8 * hh + 16 * s);
+        const bf16x8_t of = ld_frag(a.O + rowq * a.ldo + 8 * hh + 16 * s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse2 = a.lse[(int64_t)p * a.n + q] * LOG2E;
+    if (okq && hh == 0) a.delta[(int64_t)p * a.n + q] = delta;
+
+    const bf16_t* kvp = a.KV + (int64_t)p * a.outer_kv * a.ldk + 8 * hh;
+    const int wr_off = r * D + 8 * hh;
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
+    const int tr_off = (D == 16) ? (4 * hh + gq) * D + 4 * gp : (4 * hh + gq) * D + 16 * c + 4 * gp;   // D = 16: rows 16.. duplicate 0..15 (ignored)
+    const bf16_t* trA = tA + tr_off;
+    const bf16_t* trB = tB + tr_off;
+
+    f32x16_t dq = zero16();
+    bf16x8_t kfA[KS], kfB[KS];
+    auto load_pair = [&](int k0) {
+        int ka = k0 + r, kb = k0 + 32 + r;
+        ka = ka < a.n_kv ? ka : a.n_kv - 1;
+        kb = kb < a.n_kv ? kb : a.n_kv - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kfA[s] = ld_frag(kvp + (int64_t)ka * a.ldk + 16 * s);
+            kfB[s] = ld_frag(kvp + (int64_t)kb * a.ldk + 16 * s);
+        }
+    };
+    load_pair(0);
+
+    auto body = [&](int k0, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        lds_sync();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(tA + wr_off + 16 * s) = kfA[s];
+            *reinterpret_cast<bf16x8_t*>(tB + wr_off + 16 * s) = kfB[s];
+        }
+        f32x16_t sA = zero16(), sB = zero16(), dpA = zero16(), dpB = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sA = MFMA32(kfA[s], qf[s], sA);
+            sB = MFMA32(kfB[s], qf[s], sB);
+            dpA = MFMA32(kfA[s], dof[s], dpA);                  // V == K
+            dpB = MFMA32(kfB[s], dof[s], dpB);
+        }
+        if (k0 + 64 < a.n_kv) load_pair(k0 + 64);
+        float dA[16], dB[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float xa = fmaf(sA[reg], a.c2, -lse2), xb = fmaf(sB[reg], a.c2, -lse2);
+            if (MASKED) {
+                const int key = k0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                xa = key < a.n_kv ? xa : -INFINITY;
+                xb = key + 32 < a.n_kv ? xb : -INFINITY;
+            }
+            dA[reg] = __builtin_amdgcn_exp2f(xa) * (dpA[reg] - delta);
+            dB[reg] = __builtin_amdgcn_exp2f(xb) * (dpB[reg] - delta);
+        }
+        lds_sync();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dq = MFMA32(tr_frag(trA, s2, D), pack_frag(dA + 8 * s2), dq);
+            dq = MFMA32(tr_frag(trB, s2, D), pack_frag(dB + 8 * s2), dq);
+        }
+    };
+    const int full = a.n_kv & ~63;
+    int k0 = 0;
+    for (; k0 < full; k0 += 64) body(k0, std::false_type{});
+    if (k0 < a.n_kv) body(k0, std::true_type{});
+
+    if (okq) {
+        bf16_t* op = a.dQ + rowq * a.lddq;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            uint2 w;
+            w.x = pack_bf2(dq[4 * g + 0] * a.scale, dq[4 * g + 1] * a.scale);
+            w.y = pack_bf2(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
+            *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK + dV (K == V)
+template <int D>
+__global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
+    constexpr int KS = D / 16;
+    constexpr int TILE = Lds<D>::TILE;
+    // per wave: Q tile + dO tile (one 32-query tile per trip) + lse2[32] + delta[32]
+    constexpr int PER_WAVE = 2 * TILE + 128;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int p = item / a.tiles, kt = item - p * a.tiles;
+    bf16_t* tQ = smem + wave * PER_WAVE;
+    bf16_t* tD = tQ + TILE;
+    float* sStat = reinterpret_cast<float*>(tD + TILE);         // [0..31] lse2, [32..63] delta
+
+    int key = kt * 32 + r;
+    const bool okk = key < a.n_kv;
+    key = okk ? key : a.n_kv - 1;
+    const int64_t rowk = (int64_t)p * a.outer_kv + key;
+    bf16x8_t kf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf[s] = ld_frag(a.KV + rowk * a.ldk + 8 * hh + 16 * s);
+
+    const bf16_t* qp = a.Q + (int64_t)p * a.outer_q * a.ldq + 8 * hh;
+    const bf16_t* dop = a.dO + (int64_t)p * a.outer_q * a.lddo + 8 * hh;
+    const float* statp = (hh == 0 ? a.lse : a.delta) + (int64_t)p * a.n;
+    const int wr_off = r * D + 8 * hh;
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
+    const int tr_off = (D == 16) ? (4 * hh + gq) * D + 4 * gp : (4 * hh + gq) * D + 16 * c + 4 * gp;
+    const bf16_t* trQ = tQ + tr_off;
+    const bf16_t* trD = tD + tr_off;
+
+    f32x16_t dk = zero16(), dv = zero16();
+    bf16x8_t qf[KS], dof[KS];
+    float stat;
+    auto load_tile = [&](int q0) {
+        int qq = q0 + r;
+        const bool ok = qq < a.n;
+        qq = ok ? qq : a.n - 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = ld_frag(qp + (int64_t)qq * a.ldq + 16 * s);
+            dof[s] = ld_frag(dop + (int64_t)qq * a.lddo + 16 * s);
+        }
+        const float v = statp[qq];
+        // padded queries: lse2 = +inf -> p = 0, delta = 0
+        stat = hh == 0 ? (ok ? v * LOG2E : INFINITY) : (ok ? v : 0.f);
+    };
+    load_tile(0);
+
+    for (int q0 = 0; q0 < a.n; q0 += 32) {
+        lds_sync();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(tQ + wr_off + 16 * s) = qf[s];
+            *reinterpret_cast<bf16x8_t*>(tD + wr_off + 16 * s) = dof[s];
+        }
+        sStat[lane] = stat;
+        f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sc = MFMA32(qf[s], kf[s], sc);                      // S[q][key]: query on the accumulator row, key on the lane
+            dp = MFMA32(dof[s], kf[s], dp);                     // dP[q][key] = dO[q] . V[key],  V == K
+        }
+        if (q0 + 32 < a.n) load_tile(q0 + 32);
+        lds_sync();
+        float pr[16], ds[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4*>(sStat + 8 * g + 4 * hh);
+            const float4 d4 = *reinterpret_cast<const float4*>(sStat + 32 + 8 * g + 4 * hh);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int reg = 4 * g + e;
+                pr[reg] = __builtin_amdgcn_exp2f(fmaf(sc[reg], a.c2, -lv[e]));
+                ds[reg] = pr[reg] * (dp[reg] - dl[e]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dv = MFMA32(tr_frag(trD, s2, D), pack_frag(pr + 8 * s2), dv);
+            dk = MFMA32(tr_frag(trQ, s2, D), pack_frag(ds + 8 * s2), dk);
+        }
+    }
+
+    if (okk) {
+        bf16_t* op = a.dKV + rowk * a.lddk;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            uint2 w;
+            w.x = pack_bf2(fmaf(dk[4 * g + 0], a.scale, dv[4 * g + 0]), fmaf(dk[4 * g + 1], a.scale, dv[4 * g + 1]));
+            w.y = pack_bf2(fmaf(dk[4 * g + 2], a.scale, dv[4 * g + 2]), fmaf(dk[4 * g + 3], a.scale, dv[4 * g + 3]));
+            *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
+        }
+    }
+}
+
+XP make(const stg_attn_args* f) {
+    XP p = {};
+    p.Q = (const bf16_t*)f->Q; p.ldq = f->ldq;
+    p.KV = (const bf16_t*)f->K; p.ldk = f->ldk;
+    p.O = (bf16_t*)f->O; p.ldo = f->ldo;
+    p.lse = f->lse;
+    p.outer_q = f->outer_q; p.outer_kv = f->outer_kv;
+    p.P = (int)f->P; p.n = f->n; p.n_kv = f->n_kv;
+    p.scale = f->scale; p.c2 = f->scale * LOG2E;
+    return p;
+}
+
+}  // namespace
+
+// Eligibility of a generic attention description for these kernels (see xattn.h)
+bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse) {
+    return f->H == 1 && (f->D == 16 || f->D == 32) && f->map_kind == 0 && !f->map_q && !f->map_kv && !f->bias && !f->mask &&
+           f->K == f->V && f->ldk == f->ldv && f->G == 1 && f->n >= 64 && f->n_kv >= 64 && f->scale > 0.f &&
+           f->outer_q >= f->n && f->outer_kv >= f->n_kv && f->P * (int64_t)((f->n + 31) / 32) < (1ll << 30) &&
+           f->P * (int64_t)((f->n_kv + 31) / 32) < (1ll << 30) && (!need_lse || f->lse) &&
+           f->ldq % 8 == 0 && f->ldk % 8 == 0 && f->ldo % 4 == 0 &&
+           (((uintptr_t)f->Q | (uintptr_t)f->K) & 15) == 0 && ((uintptr_t)f->O & 7) == 0;
+}
+
+int stg_xattn_fwd(const stg_attn_args* f, void* stream) {
+    XP p = make(f);
+    if (p.P == 0) return 0;
+    STG_CHECK(p.lse != nullptr, -1, "stg_attn_fwd (cross-modal path): lse is required");
+    p.tiles = (p.n + 31) / 32;
+    p.total = p.P * p.tiles;
+    const dim3 grid((p.total + 3) / 4), block(256);
+    if (f->D == 16) hipLaunchKernelGGL(xattn_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(xattn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+int stg_xattn_bwd(const stg_attn_bwd_args* b, void* stream) {
+    XP p = make(&b->f);
+    if (p.P == 0) return 0;
+    STG_CHECK(b->dO && b->dQ && b->dK && b->delta && p.lse && p.O, -1, "stg_attn_bwd (cross-modal path): null pointer");
+    STG_CHECK(b->lddo % 8 == 0 && b->lddq % 4 == 0 && b->lddk % 4 == 0 && ((uintptr_t)b->dO & 15) == 0 &&
+              (((uintptr_t)b->dQ | (uintptr_t)b->dK) & 7) == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.O & 15) == 0, -2,
+              "stg_attn_bwd (cross-modal path): misaligned operands");
+    p.dO = (const bf16_t*)b->dO; p.lddo = b->lddo;
+    p.dQ = (bf16_t*)b->dQ; p.lddq = b->lddq;
+    p.dKV = (bf16_t*)b->dK; p.lddk = b->lddk;
+    p.delta = b->delta;
+    const dim3 block(256);
+    p.tiles = (p.n + 31) / 32;
+    p.total = p.P * p.tiles;
+    if (b->f.D == 16) hipLaunchKernelGGL(xattn_dq_kernel<16>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(xattn_dq_kernel<32>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    p.tiles = (p.n_kv + 31) / 32;
+    p.total = p.P * p.tiles;
+    if (b->f.D == 16) hipLaunchKernelGGL(xattn_dkv_kernel<16>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(xattn_dkv_kernel<32>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

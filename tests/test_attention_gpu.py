@@ -180,6 +180,17 @@ def test_cross_modal_global_long(stg, gpu):
     _run_case(gpu, P=2, H=1, n=70, D=64, n_kv=33, shared_kv=True, seed=22, mag=0.5)
 
 
+def test_cross_modal_global_fast_path(stg, gpu):
+    """xattn.hip (H = 1, K == V, D in {16, 32}, n >= 64): stage-1 / stage-2 frame sizes, ragged query and key tails
+    (n % 32, n_kv % 64 != 0), n != n_kv, a non-unit scale, and several problems per launch."""
+    _run_case(gpu, P=2, H=1, n=3136, D=16, n_kv=3136, shared_kv=True, seed=50, mag=0.7)
+    _run_case(gpu, P=2, H=1, n=784, D=32, n_kv=784, shared_kv=True, seed=51, mag=0.7)
+    _run_case(gpu, P=3, H=1, n=197, D=32, n_kv=130, shared_kv=True, seed=52, mag=1.0, scale=0.5)
+    _run_case(gpu, P=3, H=1, n=130, D=16, n_kv=197, shared_kv=True, seed=53, mag=1.0, scale=0.7)
+    _run_case(gpu, P=5, H=1, n=64, D=16, n_kv=64, shared_kv=True, seed=54, mag=1.0)
+    _run_case(gpu, P=2, H=1, n=97, D=32, n_kv=65, shared_kv=True, seed=55, mag=0.7)
+
+
 def test_cross_modal_window_mapped(stg, gpu):
     _run_case(gpu, P=12, H=1, n=49, D=16, G=4, n_kv=49, mapped=True, shared_kv=True, seed=23, mag=0.7)
 
@@ -205,3 +216,7 @@ def test_online_softmax_rescale_spike(stg, gpu):
     O, lse = k.attn_fwd(geom, Qb.to(gpu), KVb.to(gpu), KVb.to(gpu))
     _close(O, ref, what="spike O")
     _close(lse.view(-1), torch.logsumexp(s, -1), tol=2e-2, what="spike lse")
+    kv = KVb.to(gpu)                                       # K is V (one tensor): the xattn.hip path and its lazy rescale
+    O, lse = k.attn_fwd(geom, Qb.to(gpu), kv, kv)
+    _close(O, ref, what="spike O (K is V)")
+    _close(lse.view(-1), torch.logsumexp(s, -1), tol=2e-2, what="spike lse (K is V)")
