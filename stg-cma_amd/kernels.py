@@ -99,33 +99,41 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
-    if _gemm_prof is not None:          # bench.py: HIP events around every GEMM launch, on the launch stream
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
-        e1.record()
-        _gemm_prof.append((e0, e1, 2.0 * M * N * K))
-    else:
-        _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+    prof = _gemm_prof
+    if prof is not None and K % 64 == 0 and M > 0:          # bench.py: launches of gemm_nt_glds_kernel (the K % 64 == 0 kernel)
+        prof["launches"] += 1
+        prof["flops"] += 2.0 * M * N * K
+        if prof["launches"] % prof["stride"] == 0:         # HIP events around every stride-th launch, on the launch stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+            e1.record()
+            prof["rec"].append((e0, e1, 2.0 * M * N * K))
+            return (out, pre) if want_dact else out
+    _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_dact else out
 
 
 _gemm_prof = None
 
 
-def gemm_profile_start():
-    """Start recording (start event, end event, algorithmic FLOPs) per stg_gemm_nt launch."""
+def gemm_profile_start(stride=7):
+    """Start sampling launches of the dominant kernel (gemm_nt_glds_kernel): every `stride`-th launch is bracketed by HIP
+    events on its stream.  Events around EVERY launch (1464 per step) cost ~10 % of the step, so the timed region is sampled
+    systematically instead: the launch sequence repeats every step with a period co-prime to 7, so over >= 7 steps every
+    call site is sampled equally often."""
     global _gemm_prof
-    _gemm_prof = []
+    _gemm_prof = {"stride": int(stride), "launches": 0, "flops": 0.0, "rec": []}
 
 
 def gemm_profile_stop():
-    """Stop recording; returns (launches, total_ms, total_flops) after synchronising."""
+    """Stop sampling; returns {launches, flops (all launches), sampled, sampled_ms, sampled_flops} after synchronising."""
     global _gemm_prof
-    rec, _gemm_prof = _gemm_prof, None
+    prof, _gemm_prof = _gemm_prof, None
     torch.cuda.synchronize()
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-    return len(rec), ms, sum(f for _, _, f in rec)
+    rec = prof["rec"]
+    return {"launches": prof["launches"], "flops": prof["flops"], "sampled": len(rec),
+            "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _ in rec), "sampled_flops": sum(f for _, _, f in rec)}
 
 
 def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inner=1):

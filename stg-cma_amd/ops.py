@@ -143,12 +143,53 @@ def _check_frozen(need, names, who):
                 f"traintest_adapt_ave29.py:52-61). Freeze the backbone before calling forward.")
 
 
-def drop_scale(p, n_rows, device, training):
+def drop_scale(p, n_rows, device, training, pool=None):
     """timm DropPath mask over n_rows leading entries, scaled by 1/keep; None in eval or when p == 0."""
     if not training or p == 0.:
         return None
     keep = 1.0 - p
+    if pool is not None:
+        return pool.take(n_rows, keep)
     return torch.empty(n_rows, dtype=F32, device=device).bernoulli_(keep).div_(keep)
+
+
+_keep_cache = {}
+
+
+class DropPool:
+    """Every DropPath / Dropout mask of one forward pass from ONE uniform draw: a bernoulli_ launch per mask (23 per step
+    for Swin-B) costs ~0.4 ms of host time each on ROCm.  requests: [(entries, keep probability)] in the order the forward
+    will take them; same distribution as timm's DropPath / nn.Dropout (Bernoulli(keep) / keep)."""
+
+    def __init__(self, requests, device):
+        self.requests, self.i, self.off = requests, 0, 0
+        key = (tuple(requests), str(device))
+        kv = _keep_cache.get(key)
+        if kv is None:
+            keep = torch.cat([torch.full((n,), float(k)) for n, k in requests]).to(device)
+            kv = (keep, 1.0 / keep)
+            _keep_cache[key] = kv
+        self.mask = (torch.rand(kv[0].shape, device=device) < kv[0]).to(F32).mul_(kv[1])
+
+    def take(self, n, keep):
+        rn, rk = self.requests[self.i]
+        if rn != n or abs(rk - keep) > 1e-12:
+            raise RuntimeError(f"DropPool: request {self.i} is ({rn}, {rk}), forward asked for ({n}, {keep})")
+        out = self.mask[self.off:self.off + n]
+        self.i += 1
+        self.off += n
+        return out
+
+
+def block_drop_requests(spec, B):
+    """The (entries, keep) masks block_forward draws, in order."""
+    if spec.drop_path == 0.:
+        return []
+    keep = 1.0 - spec.drop_path
+    req = [(B * spec.N, keep) for _ in spec.mods] if spec.t_attn else []
+    if spec.parallel:
+        req.append((B * spec.T, keep))
+    return req
 
 
 # ------------------------------------------------------------------------------------------------ Swin block
@@ -331,7 +372,7 @@ def _window_geom(spec, BT, g, sbias, nm):
                       scale=spec.hd ** -0.5, bias=sbias, bias_div=P, bias_mod=1, mask=g["mask"])
 
 
-def block_forward(X, spec, P, training, save):
+def block_forward(X, spec, P, training, save, pool=None):
     """SwinTransformerBlock.forward for every mode (Swin_AVE.py:393-813) on the fused fp32 token tensor.
     P: {name: tensor} (block_param_names + block_buffer_names).  Returns (X_out, saved-state dict or None)."""
     R, C = X.shape
@@ -351,7 +392,7 @@ def block_forward(X, spec, P, training, save):
 
     # ---------------- temporal attention + T_Adapter (even blocks; :705-716).  DropPath per (b, n) row.
     if spec.t_attn:
-        dps = [drop_scale(spec.drop_path, B * N, X.device, training) for _ in spec.mods]
+        dps = [drop_scale(spec.drop_path, B * N, X.device, training, pool) for _ in spec.mods]
         Y, mean, rstd = K.layernorm_fwd(X, n1g, n1b, want_stats=save)
         QKV = K.gemm_nt(Y, wqkv, bqkv)
         del Y
@@ -410,7 +451,7 @@ def block_forward(X, spec, P, training, save):
     X3 = torch.empty_like(X)
     if spec.parallel:
         # x + mlp(xn) + drop_path(0.5 * S_Adapter(xn)): DropPath per frame (dim 0 of the (BT, N, C) tensor)
-        dpf = drop_scale(spec.drop_path, BT, X.device, training)
+        dpf = drop_scale(spec.drop_path, BT, X.device, training, pool)
         rs = (0.5 * dpf) if dpf is not None else torch.full((BT,), 0.5, dtype=F32, device=X.device)
         A = ads[0]
         Ha_, Za_ = K.gemm_nt(Y, A.w1, A.b1, act=ACT_GELU, want_dact=True)
@@ -575,7 +616,7 @@ def patch_embed_into(x5, proj_w, proj_b, norm_w, norm_b, out_rows):
     K.layernorm_fwd(Y, f32c(norm_w), f32c(norm_b), want_stats=False, out=out_rows)
 
 
-def head_fusion_forward(X, n_tok, P, training, drop_p, save):
+def head_fusion_forward(X, n_tok, P, training, drop_p, save, pool=None):
     """final norm -> token mean -> cat((a, v)) -> Linear -> Dropout -> Linear (Swin_AVE.py:1585-1599), fp32 logits."""
     R, C = X.shape
     Rm = R // 2
@@ -589,7 +630,8 @@ def head_fusion_forward(X, n_tok, P, training, drop_p, save):
     mask = None
     if training and drop_p > 0:
         keep = 1.0 - drop_p
-        mask = torch.empty(h0.shape, dtype=F32, device=X.device).bernoulli_(keep).div_(keep)
+        mask = pool.take(h0.numel(), keep).view(h0.shape) if pool is not None else \
+            torch.empty(h0.shape, dtype=F32, device=X.device).bernoulli_(keep).div_(keep)
     h0d = K.mul_mask(h0, mask) if mask is not None else h0
     logits = K.gemm_nt(h0d, shadow(P["mlp_head.2.weight"]), f32c(P["mlp_head.2.bias"]), out_dtype=F32)
     return logits, ((X, mean, rstd, pooled, h0d, mask, n_tok) if save else None)
@@ -712,11 +754,18 @@ class SwinModelFn(torch.autograd.Function):
             x5 = a.unsqueeze(1) if m else v
             nw = P.get(pe + ".norm.weight")
             patch_embed_into(x5, P[pe + ".proj.weight"], P[pe + ".proj.bias"], nw, P.get(pe + ".norm.bias"), X[i * Rm:(i + 1) * Rm])
+        pool = None
+        if training:
+            req = [r for st in plan.stages for spec, _ in st["blocks"] for r in block_drop_requests(spec, B)]
+            if len(mods) == 2 and plan.head_drop > 0:
+                req.append((B * T * P["mlp_head.0.weight"].shape[0], 1.0 - plan.head_drop))
+            if req:
+                pool = DropPool(req, src.device)
         tape = []
         for st in plan.stages:
             for spec, pre in st["blocks"]:
                 Pb = {n: P[pre + n] for n in st["names"][pre]}
-                X, S = block_forward(X, spec, Pb, training, save)
+                X, S = block_forward(X, spec, Pb, training, save, pool)
                 tape.append(("block", spec, pre, Pb, S))
             if st["merge"] is not None:
                 H, W, pre = st["merge"]
@@ -724,7 +773,7 @@ class SwinModelFn(torch.autograd.Function):
                 X, S = merge_forward(X, H, W, Pm, save)
                 tape.append(("merge", (H, W), pre, Pm, S))
         if len(mods) == 2:
-            logits, S = head_fusion_forward(X, plan.n_tok_last, P, training, plan.head_drop, save)
+            logits, S = head_fusion_forward(X, plan.n_tok_last, P, training, plan.head_drop, save, pool)
         else:
             logits, S = head_single_forward(X, plan.n_tok_last, P, save)
         ctx.tape, ctx.head, ctx.P, ctx.need, ctx.names, ctx.two = tape, S, P, need, names, len(mods) == 2
