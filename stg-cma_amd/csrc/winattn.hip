@@ -71,11 +71,19 @@ __device__ __forceinline__ int64_t tok_row(const WinP& a, int pg, int g, int i) 
     return (int64_t)pg * a.outer + h * a.Wimg + w;
 }
 
-// transposed fragment of a [64 x 32] LDS tile: A[i = d][k slot j] = tile[32*kt + kappa(s2, hh, j)][d]
+// transposed fragment of a row-major [64 x 32] LDS tile: A[i = d][k slot j] = tile[32*kt + kappa(s2, hh, j)][d], d = lane & 31,
+// by two ds_read_b64_tr_b16 (each 16-lane group reads a 4-row x 16-column block and receives it column-major: lane
+// 4q + p of the group supplies the address of row q, columns 4p..4p+3; 4 rows x 64 B per 32-lane half: conflict-free).
+// EXEC must be all ones here (whole waves only leave at the top of the kernels).
+typedef short s4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int kt, int s2, int hh, int d) {
+    const int gi = d & 15, c = d >> 4;
+    const bf16_t* p = s + (32 * kt + 16 * s2 + 4 * hh + (gi >> 2)) * WD + 16 * c + 4 * (gi & 3);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(p + 8 * WD));
     bf16x8_t f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)s[(32 * kt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3)) * WD + d];
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
 
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
     const float* bmq[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-        bmq[t] = a.bm + (((int64_t)(g % a.Gt) * a.H + h) * 64 + (32 * t + r)) * 64;
+        bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + r);       // tiled: see win_table_kernel
     float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -131,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
-                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 32 * kt + 8 * g4 + 4 * hh);
+                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));
 
     // St[key][q] for the 2 x 2 tiles
     f32x16_t st[2][2];               // [q tile][key tile]
@@ -243,13 +251,13 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
     // ---------------- phase A: query on the lane -> dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const float* bmq = a.bm + tb + (int64_t)(32 * qt + r) * 64;
+        const float* bmq = a.bm + tb + 4 * (32 * qt + r);
         f32x16_t dq = zero16();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             float4 add[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 32 * kt + 8 * g4 + 4 * hh);
+            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
             f32x16_t st = zero16(), dpt = zero16();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -282,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
     // ---------------- phase B: key on the lane -> dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T = sum_q Q^T[d][q] dS[q][key]
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        const float* bmk = a.bmT + tb + (int64_t)(32 * kt + r) * 64;       // [key][q]
+        const float* bmk = a.bmT + tb + 4 * (32 * kt + r);                  // tiled, lane axis = key
         f32x16_t dv = zero16(), dk = zero16();
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int q4 = 32 * qt + 8 * g4 + 4 * hh;
-                add[g4] = *reinterpret_cast<const float4*>(bmk + q4);
+                add[g4] = *reinterpret_cast<const float4*>(bmk + 256 * ((qt * 4 + g4) * 2 + hh));
                 ls[g4] = *reinterpret_cast<const float4*>(sLse + q4);
                 de[g4] = *reinterpret_cast<const float4*>(sDel + q4);
             }
@@ -336,8 +344,14 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ bias + mask table
-// bm[g][h][q][k] = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to 64 x 64;
-// bmT = transposed
+// Additive score term v(q, k) = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to
+// 64 x 64 per (window type g, head h) and stored TILED for the kernels' access pattern -- a lane owns one index x (its
+// query in `bm`, its key in `bmT`) and reads float4s along the other index y = 32 kt + 8 g4 + 4 hh + e:
+//     offset(x, y) = (((kt * 4 + g4) * 2 + hh) * 64 + x) * 4 + e
+// so one wave-instruction reads two 512-byte runs instead of 64 pieces of 64 different rows.
+//     bm : x = q, y = k          bmT: x = k, y = q
+__device__ __forceinline__ int tiled_off(int x, int y) { return ((y >> 2) * 64 + x) * 4 + (y & 3); }   // (y >> 2) == (kt*4 + g4)*2 + hh
+
 __global__ void win_table_kernel(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT, int L, int H,
                                  int n, int Gt) {
     const int total = Gt * H * 64 * 64;
@@ -351,8 +365,9 @@ __global__ void win_table_kernel(const float* table, const int64_t* index, const
             ix = ix < 0 ? 0 : (ix >= L ? L - 1 : ix);
             v = (table[ix * H + h] + (mask ? mask[((int64_t)g * n + q) * n + k] : 0.f)) * 1.4426950408889634f;
         }
-        bm[id] = v;
-        bmT[(((int64_t)g * H + h) * 64 + k) * 64 + q] = v;
+        const int64_t base = ((int64_t)g * H + h) * 4096;
+        bm[base + tiled_off(q, k)] = v;
+        bmT[base + tiled_off(k, q)] = v;
     }
 }
 

@@ -14,7 +14,14 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch: 2 900 launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

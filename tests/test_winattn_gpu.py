@@ -51,8 +51,13 @@ def _case(gpu, *, images, heads, Himg, ws, shift, seed=0, mag=1.0):
     # ---- HIP
     d = lambda t: None if t is None else t.to(gpu)
     bm, bmT = k.winattn_table(d(table), d(index.reshape(-1)), d(mask), n)
-    assert torch.equal(bm.transpose(-1, -2), bmT)
-    assert float(bm[..., :n, n:].max()) < -1e29 if n < 64 else True
+    untile = lambda t: t.view(t.shape[0], t.shape[1], 16, 64, 4).permute(0, 1, 3, 2, 4).reshape(t.shape[0], t.shape[1], 64, 64)
+    plain = untile(bm)                                      # [g][h][q][k]; stored tiled as [(k >> 2)][q][k & 3]
+    assert torch.equal(plain.transpose(-1, -2), untile(bmT))
+    assert float(plain[..., :n, n:].max()) < -1e29 if n < 64 else True
+    want = 1.4426950408889634 * (table[index.reshape(-1)].view(n, n, heads).permute(2, 0, 1)[None] +
+                                 (mask[:, None] if mask is not None else 0))
+    assert float((plain[..., :n, :n].cpu() - want).abs().max()) < 1e-5
     wg = k.WinGeom(images, heads, Himg, Himg, ws, shift, scale, bm, bmT)
     Q = d(qkv)
     O, lse = k.winattn_fwd(wg, Q[:, :C], Q[:, C:2 * C], Q[:, 2 * C:])
