@@ -301,6 +301,60 @@ def swin_forward(P, a, v, cfg, mode):
     return _lin(P, "mlp_head.1", _ln(P, "mlp_head.0", pooled))
 
 
+def swin_plain_block(P, pre, x, *, H, W, heads, window_size=7, shift_size=0, dp_scale=None):
+    """The AVQA block's third ("negative" video) stream: the frozen Swin block, no temporal attention, no adapters,
+    drop_path on both residuals (AVQA/model/Swin_AVQAModel_V1.py:780-782, :793, :808-810, :821-823, :836-838, :852-860).
+    dp_scale: optional (attn, ffn) per-sample DropPath scale tensors [BT]; None = eval."""
+    ws, shift = block_geometry(H, W, window_size, shift_size)
+    wmap = window_token_map(H, W, ws, shift)
+    mask = shift_attn_mask(H, W, ws, shift)
+    BT, N, C = x.shape
+    r = _unwindow(_spatial_attention(P, pre, x, H, W, heads, ws, shift, wmap, mask), BT, N, wmap)
+    if dp_scale is not None:
+        r = r * dp_scale[0].reshape(BT, 1, 1)
+    x = x + r
+    f = mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", x))
+    if dp_scale is not None:
+        f = f * dp_scale[1].reshape(BT, 1, 1)
+    return x + f
+
+
+def swin_backbone(P, a, v, cfg, v_nega=None):
+    """The `fusion` backbone shared by the AVS and AVQA models, eval semantics: patch embeds -> stages -> final norm.
+      AVS  (AVS/model/Swin_AVSModel.py:1790-1822):  BasicLayer returns (x, x_before_downsample) (:1190-1201); the video stream
+           before each downsample is tapped, the last tap goes through self.norm (:1813-1821).
+      AVQA (AVQA/model/Swin_AVQAModel_V1.py:1742-1766):  a third stream v_nega rides along through every block (:752-872) and
+           downsample (:1150-1154); f_v, f_a, visual_nega = norm(v), norm(a), norm(v_nega).
+    a: [B, T, H, W]; v, v_nega: [B, T, 3, H, W] (both models rearrange 'b t c h w -> b c t h w', :1793 / :1742,1748).
+    Returns dict(f_v, f_a [, f_nega], taps=[v before downsample of stages 0..n-2, norm(v) of the last stage])."""
+    depths, heads = cfg["depths"], cfg["num_heads"]
+    ws = cfg.get("window_size", 7)
+    T = cfg["num_frames"]
+    res = cfg.get("img_size", 224) // 4
+    xv = patch_embed(P, "patch_embed", v.permute(0, 2, 1, 3, 4))
+    xa = patch_embed(P, "patch_embed_audio", a.unsqueeze(1))
+    xn = patch_embed(P, "patch_embed", v_nega.permute(0, 2, 1, 3, 4)) if v_nega is not None else None
+    taps = []
+    for s, depth in enumerate(depths):
+        H = W = res // (2 ** s)
+        for i in range(depth):
+            kw = dict(H=H, W=W, heads=heads[s], window_size=ws, shift_size=0 if i % 2 == 0 else ws // 2)
+            xv, xa = swin_block(P, f"layers.{s}.blocks.{i}", (xv, xa), T=T, t_attn=(i % 2 == 0), mode="fusion_adapt", **kw)
+            if xn is not None:
+                xn = swin_plain_block(P, f"layers.{s}.blocks.{i}", xn, **kw)
+        if s < len(depths) - 1:
+            taps.append(xv)
+            xv = patch_merging(P, f"layers.{s}.downsample", xv, H, W)
+            xa = patch_merging(P, f"layers.{s}.downsample", xa, H, W)
+            if xn is not None:
+                xn = patch_merging(P, f"layers.{s}.downsample", xn, H, W)
+    out = {"f_v": _ln(P, "norm", xv), "f_a": _ln(P, "norm", xa)}
+    out["taps"] = taps + [out["f_v"]]
+    if xn is not None:
+        out["f_nega"] = _ln(P, "norm", xn)
+    return out
+
+
 def soft_target_cross_entropy(logits, target):
     """nn.CrossEntropyLoss with class-probability targets, mean reduction (traintest_adapt_ave29.py:113,159)."""
     return -(target * torch.log_softmax(logits, dim=-1)).sum(-1).mean()

@@ -244,7 +244,8 @@ def gate_bwd(dout, r, gate, dgate):
     return dr
 
 
-def add(a, b, c=None):
+def add(a, b, c=None, out=None):
+    """out = a + b (+ c), bf16; `out` may alias an input (element-wise)."""
     _chk_flat(a, "a"); _chk_flat(b, "b")
     if a.shape != b.shape:
         raise RuntimeError("add: shape mismatch")
@@ -252,7 +253,12 @@ def add(a, b, c=None):
         _chk_flat(c, "c")
         if c.shape != a.shape:
             raise RuntimeError("add: shape mismatch")
-    out = torch.empty_like(a)
+    if out is None:
+        out = torch.empty_like(a)
+    else:
+        _chk_flat(out, "out")
+        if out.shape != a.shape:
+            raise RuntimeError("add: shape mismatch")
     _lib.check(_lib.lib().stg_add(_p(a), _p(b), _p(c), _p(out), a.numel(), _stream()), "stg_add")
     return out
 

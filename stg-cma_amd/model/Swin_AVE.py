@@ -351,11 +351,35 @@ class SwinTransformer2D_Adapter_New(nn.Module):
             plan.stages.append(st)
         last = self.layers[-1].input_resolution
         plan.n_tok_last = last[0] * last[1]
-        plan.head_drop = self.mlp_head[1].p if len(plan.mods) == 2 else 0.
+        plan.head_drop = self.mlp_head[1].p if (len(plan.mods) == 2 and hasattr(self, 'mlp_head')) else 0.
         train_ok = ("Adapter", "gate_", "temporal_position_bias_table", "mlp_head.")
         plan.trainable_ok = lambda n: any(t in n for t in train_ok)
         self._plan_cache = plan
         return plan
+
+    def _flat_tensors(self):
+        names, tensors = [], []
+        for n, p in self.named_parameters():
+            names.append(n)
+            tensors.append(p)
+        for n, b in self.named_buffers():
+            if not n.endswith("attn_mask"):
+                names.append(n)
+                tensors.append(b)
+        return tuple(names), tensors
+
+    def _backbone(self, a, v, v_nega=None, taps=False):
+        """Shared by the AVS / AVQA mirrors (model/Swin_AVS.py, model/Swin_AVQA.py): ops.SwinBackboneFn on (B, T, 3, H, W)
+        clips; returns the flat fp32 feature tensors."""
+        from ..ops import SwinBackboneFn
+        if self.ftmode != 'fusion':
+            raise TypeError('ftmode is not expected !!!')
+        if not self.t_relative:
+            raise NotImplementedError("t_relative=False (absolute temporal embedding) is not on the HIP path yet")
+        if not v.is_cuda:
+            raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
+        names, tensors = self._flat_tensors()
+        return SwinBackboneFn.apply(a, v, v_nega, self._plan(), self.training, torch.is_grad_enabled(), bool(taps), names, *tensors)
 
     def forward(self, a, v, mode):
         """a: [B, T, H, W] spectrogram segments, v: [B, 3, T, H, W] frames -> fp32 logits [(B*T), label_dim]

@@ -730,6 +730,143 @@ class SwinBlockFn(torch.autograd.Function):
 SwinFusionBlockFn = SwinBlockFn
 
 
+def plain_block_forward(X, spec, P, training, pool=None):
+    """The AVQA negative-video stream: the FROZEN Swin block -- window attention and FFN with drop_path on both residuals, no
+    temporal attention, no adapters (AVQA/model/Swin_AVQAModel_V1.py:780-860).  Nothing trainable sits on or behind this
+    stream (its input is the frozen patch embedding of a negative clip), so it is forward-only.  X: fp32 [BT*N, C]."""
+    R, C = X.shape
+    N = spec.N
+    BT = R // N
+    H = spec.heads
+    g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, spec.T)
+    dp1 = drop_scale(spec.drop_path, BT, X.device, training, pool)
+    dp2 = drop_scale(spec.drop_path, BT, X.device, training, pool)
+    Y, _, _ = K.layernorm_fwd(X, f32c(P["norm1.weight"]), f32c(P["norm1.bias"]), want_stats=False)
+    QKV = K.gemm_nt(Y, shadow(P["attn.qkv.weight"]), f32c(P["attn.qkv.bias"]))
+    if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
+        bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
+        wg = K.WinGeom(BT, H, spec.H, spec.W, spec.ws, spec.shift, spec.hd ** -0.5, bm, bmT)
+        AO, _ = K.winattn_fwd(wg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=False)
+    else:
+        sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
+        AO, _ = K.attn_fwd(_window_geom(spec, BT, g, sbias, 1), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=False)
+    X1 = K.gemm_nt(AO, shadow(P["attn.proj.weight"]), f32c(P["attn.proj.bias"]), out_dtype=RESIDUAL_DTYPE, res1=X,
+                   row_scale=dp1, rs_outer=N, rs_inner=1)
+    del QKV, AO
+    Y, _, _ = K.layernorm_fwd(X1, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=False)
+    Hm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU)
+    return K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]), out_dtype=RESIDUAL_DTYPE, res1=X1,
+                     row_scale=dp2, rs_outer=N, rs_inner=1)
+
+
+class SwinBackboneFn(torch.autograd.Function):
+    """The `fusion` backbone of the AVS / AVQA models as ONE autograd node: patch embeds -> stages ->
+    final norm, returning features instead of logits.
+      outputs (all fp32): f_v [BT*N_last, C_last], f_a, then f_nega when a negative clip is given (AVQA,
+      Swin_AVQAModel_V1.py:1742-1766), then -- when `taps` -- the video stream before each downsample (AVS,
+      Swin_AVSModel.py:1190-1201, 1813-1821; views of the residual stream: do not modify in place).
+    Gradients flow from f_v, f_a and the taps; the negative stream is forward-only (nothing trainable behind it)."""
+
+    @staticmethod
+    def forward(ctx, a, v, v_nega, plan, training, grad_on, taps, names, *params):
+        P = dict(zip(names, params))
+        need = {n: bool(grad_on and f) for n, f in zip(names, ctx.needs_input_grad[8:])}
+        save = any(need.values())
+        for n in names:
+            if need[n] and not plan.trainable_ok(n):
+                _check_frozen({n: True}, [n], "Swin backbone")
+        B, T = v.shape[0], v.shape[1]
+        N0 = plan.n_patches
+        Rm = B * T * N0
+        dev = v.device
+        X = torch.empty((2 * Rm, plan.embed_dim), dtype=RESIDUAL_DTYPE, device=dev)
+        pe = ("patch_embed", "patch_embed_audio")
+        for i, x5 in enumerate((v.permute(0, 2, 1, 3, 4), a.unsqueeze(1))):     # 'b t c h w -> b c t h w' (:1793 / :1742)
+            patch_embed_into(x5, P[pe[i] + ".proj.weight"], P[pe[i] + ".proj.bias"], P.get(pe[i] + ".norm.weight"),
+                             P.get(pe[i] + ".norm.bias"), X[i * Rm:(i + 1) * Rm])
+        Xn = None
+        if v_nega is not None:
+            Xn = torch.empty((Rm, plan.embed_dim), dtype=RESIDUAL_DTYPE, device=dev)
+            patch_embed_into(v_nega.permute(0, 2, 1, 3, 4), P["patch_embed.proj.weight"], P["patch_embed.proj.bias"],
+                             P.get("patch_embed.norm.weight"), P.get("patch_embed.norm.bias"), Xn)
+        pool = None
+        if training:
+            req = []
+            for st in plan.stages:
+                for spec, _ in st["blocks"]:
+                    req += block_drop_requests(spec, B)
+                    if Xn is not None and spec.drop_path > 0.:
+                        req += [(B * T, 1.0 - spec.drop_path)] * 2
+            if req:
+                pool = DropPool(req, dev)
+        tape, tap_out = [], []
+        for st in plan.stages:
+            for spec, pre in st["blocks"]:
+                Pb = {n: P[pre + n] for n in st["names"][pre]}
+                X, S = block_forward(X, spec, Pb, training, save, pool)
+                tape.append(("block", spec, pre, Pb, S))
+                if Xn is not None:
+                    Xn = plain_block_forward(Xn, spec, Pb, training, pool)
+            if st["merge"] is not None:
+                H, W, pre = st["merge"]
+                Pm = {n: P[pre + n] for n in ("norm.weight", "norm.bias", "reduction.weight")}
+                if taps:
+                    tap_out.append(X[:X.shape[0] // 2])
+                X, S = merge_forward(X, H, W, Pm, save)
+                tape.append(("merge", (H, W), pre, Pm, S))
+                if Xn is not None:
+                    Xn, _ = merge_forward(Xn, H, W, Pm, False)
+        ng, nb = f32c(P["norm.weight"]), f32c(P["norm.bias"])
+        Fall, mean, rstd = K.layernorm_fwd(X, ng, nb, want_stats=save, out_dtype=F32)
+        half = X.shape[0] // 2
+        outs = [Fall[:half], Fall[half:]]
+        if Xn is not None:
+            Fn, _, _ = K.layernorm_fwd(Xn, ng, nb, want_stats=False, out_dtype=F32)
+            outs.append(Fn)
+            ctx.mark_non_differentiable(Fn)
+        outs += tap_out
+        ctx.tape, ctx.final, ctx.P, ctx.need, ctx.names = tape, (X, mean, rstd), P, need, names
+        ctx.n_tap, ctx.has_nega = len(tap_out), Xn is not None
+        ctx.ddp = getattr(plan, "ddp", None)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        P, need = ctx.P, ctx.need
+        X, mean, rstd = ctx.final
+        ctx.final = None
+        dev = X.device
+        arena = GradArena(ctx.names, P, need, dev)
+        grads = {}
+        half = X.shape[0] // 2
+        dY = torch.zeros(X.shape, dtype=BF16, device=dev) if (douts[0] is None or douts[1] is None) else \
+            torch.empty(X.shape, dtype=BF16, device=dev)
+        for i in range(2):
+            if douts[i] is not None:
+                dY[i * half:(i + 1) * half].copy_(douts[i])            # fp32 -> bf16 hand-over of the head's gradient
+        G = _Grads(P, need, "", arena)
+        dX = K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd, dgamma=G.buf("norm.weight"), dbeta=G.buf("norm.bias"))
+        grads.update(G.g)
+        del dY, X
+        dtaps = list(douts[2 + (1 if ctx.has_nega else 0):])
+        tape = ctx.tape
+        while tape:
+            kind, spec, pre, Pl, S = tape.pop()
+            if kind == "block":
+                dX, g = block_backward(S, spec, Pl, need, pre, dX, arena)
+                for k, val in g.items():
+                    grads[pre + k] = val
+            else:
+                dX = merge_backward(S, spec[0], spec[1], Pl, dX)
+                dt = dtaps.pop() if dtaps else None
+                if dt is not None:                                       # the tap's gradient joins the video rows
+                    dv = dX[:dX.shape[0] // 2]
+                    K.add(dv, K.cast_bf16(dt.contiguous()), out=dv)
+        if ctx.ddp is not None:
+            ctx.ddp.allreduce_(arena.flat)
+        return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
+
+
 class SwinModelFn(torch.autograd.Function):
     """The whole Swin + STG-CMA forward as ONE autograd node: patch embeddings -> stages of blocks / merges -> head.
     Between blocks the residual stream stays fp32 and the gradient stream bf16 with no autograd bookkeeping or dtype

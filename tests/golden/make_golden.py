@@ -149,6 +149,75 @@ def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True, state_f
     save(tag, **arrs)
 
 
+# --------------------------------------------------------------------------------------------------- AVS / AVQA backbones
+BACKBONE_PREFIXES = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.")
+
+
+def _seed_backbone(m, seed):
+    """Seed only the backbone tensors (the decoder / QA-head parameters of the reference classes are not on this path)."""
+    sd = m.state_dict()
+    shapes = [(k, sh) for k, sh in GP.float_shapes(sd) if k.startswith(BACKBONE_PREFIXES)]
+    sd.update(GP.seeded_state(shapes, seed))
+    m.load_state_dict(sd, strict=True)
+    names = []
+    for n, p in m.named_parameters():
+        p.requires_grad = GP.is_trainable(n) and n.startswith(BACKBONE_PREFIXES)
+        if p.requires_grad:
+            names.append(n)
+    return shapes, names
+
+
+def avs_backbone_case(A, tag, *, cfg, B, seed):
+    """Backbone part of SwinTransformer2D_Adapter_AVS.forward[fusion] (AVS/model/Swin_AVSModel.py:1793-1822), run through the
+    reference's own modules: patch embeds, BasicLayers returning (x, x_before_downsample), final norm."""
+    from einops import rearrange
+    m = A.SwinTransformer2D_Adapter_AVS(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
+                                        depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    shapes, names = _seed_backbone(m, seed)
+    T = cfg["num_frames"]
+    a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, T, 3, 224, 224), seed + 2)
+    xv, _, _ = m.patch_embed(rearrange(v, 'b t c h w -> b c t h w'))
+    xa, _, _ = m.patch_embed_audio(a.unsqueeze(1))
+    x = (m.pos_drop(xv), m.pos_drop(xa))
+    taps = []
+    for idx, layer in enumerate(m.layers):
+        x, before = layer(x)
+        taps.append(before[0] if idx != len(m.layers) - 1 else m.norm(before[0]))
+    f_a = m.norm(x[1])
+    gs = [GP.seeded_tensor(t.shape, seed + 10 + i) for i, t in enumerate(taps)]
+    ga = GP.seeded_tensor(f_a.shape, seed + 20)
+    (sum((t * g).sum() for t, g in zip(taps, gs)) + (f_a * ga).sum()).backward()
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, seed=seed)), grad_names_json=json.dumps(names),
+         grads=flat_grads(m, names), f_a=f_a, tap3=taps[3], **{f"tap{i}": taps[i][:, ::7] for i in range(3)})
+
+
+def avqa_backbone_case(Q, tag, *, cfg, B, seed):
+    """Backbone part of SwinTransformer2D_Adapter_AVQA.forward[fusion] (AVQA/model/Swin_AVQAModel_V1.py:1742-1766): the
+    (v, a, v_nega) triple through every BasicLayer, then the final norm of each stream."""
+    from einops import rearrange
+    m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
+                                         depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
+                                         adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    shapes, names = _seed_backbone(m, seed)
+    T = cfg["num_frames"]
+    a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, T, 3, 224, 224), seed + 2)
+    vn = GP.seeded_tensor((B, T, 3, 224, 224), seed + 3)
+    xv, _, _ = m.patch_embed(rearrange(v, 'b t c h w -> b c t h w'))
+    xa, _, _ = m.patch_embed_audio(a.unsqueeze(1))
+    xn, _, _ = m.patch_embed(rearrange(vn, 'b t c h w -> b c t h w'))
+    xv, xa, xn = m.pos_drop(xv), m.pos_drop(xa), m.pos_drop(xn)
+    for layer in m.layers:
+        xv, xa, xn = layer((xv, xa, xn))
+    f_v, f_a, f_n = m.norm(xv), m.norm(xa), m.norm(xn)
+    gv, ga = GP.seeded_tensor(f_v.shape, seed + 10), GP.seeded_tensor(f_a.shape, seed + 11)
+    ((f_v * gv).sum() + (f_a * ga).sum() + f_n.sum()).backward()
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, seed=seed)), grad_names_json=json.dumps(names),
+         grads=flat_grads(m, names), f_v=f_v, f_a=f_a, f_nega=f_n)
+
+
 # --------------------------------------------------------------------------------------------------- ViT (CLIP) path
 def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"):
     blk = Cm.ResidualAttentionBlock(d, heads, None, 0.5, 1, T, 0.0, mode=mode).eval()
@@ -226,6 +295,8 @@ def scheduler_case():
 
 SWIN_TINY = dict(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2,
                  adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
+AVS_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=3, adapter_mlp_ratio=[0.5, 0.5, 0.25, 0.25])
+AVQA_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
 SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
 
@@ -236,6 +307,17 @@ def main(argv):
     install_shims()
     S = load(os.path.join(REF, "AVE/model/Swin_AVE.py"), "ref_swin_ave")
     Cm = load(os.path.join(REF, "AVE/model/CLIP_AVE.py"), "ref_clip_ave")
+    lazy = {}
+
+    def ref_avs():
+        if "avs" not in lazy:
+            lazy["avs"] = load(os.path.join(REF, "AVS/model/Swin_AVSModel.py"), "ref_swin_avs")
+        return lazy["avs"]
+
+    def ref_avqa():
+        if "avqa" not in lazy:
+            lazy["avqa"] = load(os.path.join(REF, "AVQA/model/Swin_AVQAModel_V1.py"), "ref_swin_avqa")
+        return lazy["avqa"]
     cases = {
         "swin_block_even": lambda: swin_block_case(S, "swin_block_even", dim=128, res=14, T=5, B=1, heads=4, shift=0, t_attn=True,
                                                    ratio=0.125, mode="fusion_adapt", seed=100),
@@ -260,6 +342,8 @@ def main(argv):
         "vit_block_cfg1": lambda: vit_block_case(Cm, "vit_block_cfg1", d=768, heads=8, T=10, B=1, nv=196, na=196, seed=400),
         "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=256, heads=4, T=2, B=2, nv=50, na=13, seed=410),
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
+        "avs_tiny_backbone": lambda: avs_backbone_case(ref_avs(), "avs_tiny_backbone", cfg=AVS_TINY, B=1, seed=600),
+        "avqa_tiny_backbone": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone", cfg=AVQA_TINY, B=1, seed=610),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

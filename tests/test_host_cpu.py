@@ -161,3 +161,23 @@ def test_bench_cpu_baseline_leg_runs_on_host(stg):
         p.requires_grad = is_trainable(n)
     r = bench.cpu_baseline_measure(torch, m, max_passes=1)
     assert r["kind"] == "port" and r["unit"] == "clips/s" and r["value"] > 0 and r["cores"] >= 1
+
+
+@pytest.mark.parametrize("tag,mod,cls", [("avs_tiny_backbone", "Swin_AVS", "SwinTransformer2D_Adapter_AVS"),
+                                         ("avqa_tiny_backbone", "Swin_AVQA", "SwinTransformer2D_Adapter_AVQA")])
+def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls):
+    """The AVS / AVQA mirrors hold exactly the backbone tensors of the reference classes (patch embeds, layers, norm) under
+    the reference's names and shapes; the decoder / QA head (avstask_* / avqatask_*) is out of scope and raises."""
+    import importlib
+    from golden_util import load_case
+    z, cfg, shapes, names = load_case(tag)
+    M = importlib.import_module("stgcma.model." + mod)
+    m = getattr(M, cls)(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                        num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
+    sd = m.state_dict()
+    mine = [(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask")]
+    assert mine == [(k, tuple(s)) for k, s in shapes]
+    from stgcma.recipe import is_trainable
+    assert [n for n, _ in m.named_parameters() if is_trainable(n)] == names
+    with pytest.raises(NotImplementedError):
+        m(None, None)

@@ -183,3 +183,48 @@ def test_vit_tiny_model_matches_reference():
     _close(loss.reshape(1), z["loss"], tol=1e-4, what="loss")
     _close(_grads(P, names), z["grads"], what="grads")
     assert list(z["n_params"][1:]) == [sum(P[n].numel() for n in names), sum(P[n].numel() for n in names if n.startswith("mlp_head"))]
+
+
+# ----------------------------------------------------------------------------------------------- AVS / AVQA backbones
+def test_avs_backbone_matches_reference():
+    """multi-scale video taps (before each downsample, last one through norm) + norm(a), and the gradients of
+    every trainable backbone tensor for seeded upstream gradients on all five outputs."""
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avs_tiny_backbone")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, T, 3, 224, 224), cfg["seed"] + 2)
+    out = OS.swin_backbone(P, a, v, cfg)
+    taps, f_a = out["taps"], out["f_a"]
+    for i in range(3):
+        _close(taps[i][:, ::7], z[f"tap{i}"], what=f"tap{i}")
+    _close(taps[3], z["tap3"], what="tap3")
+    _close(f_a, z["f_a"], what="f_a")
+    loss = sum((t * seeded_tensor(t.shape, cfg["seed"] + 10 + i)).sum() for i, t in enumerate(taps)) + \
+        (f_a * seeded_tensor(f_a.shape, cfg["seed"] + 20)).sum()
+    loss.backward()
+    g, ref = _grads(P, names), torch.as_tensor(z["grads"])
+    assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_avqa_backbone_matches_reference():
+    """(v, a, v_nega) through every block and downsample; the negative stream is the frozen Swin block."""
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avqa_tiny_backbone")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, T, 3, 224, 224), cfg["seed"] + 2)
+    vn = seeded_tensor((B, T, 3, 224, 224), cfg["seed"] + 3)
+    out = OS.swin_backbone(P, a, v, cfg, v_nega=vn)
+    for k in ("f_v", "f_a", "f_nega"):
+        _close(out[k], z[k], what=k)
+    ((out["f_v"] * seeded_tensor(out["f_v"].shape, cfg["seed"] + 10)).sum() +
+     (out["f_a"] * seeded_tensor(out["f_a"].shape, cfg["seed"] + 11)).sum() + out["f_nega"].sum()).backward()
+    g, ref = _grads(P, names), torch.as_tensor(z["grads"])
+    assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
