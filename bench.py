@@ -156,19 +156,13 @@ def main():
     if world > 1:
         ddp.broadcast_parameters(model)
         ddp.attach(model)
-    head = [p for n, p in model.named_parameters() if n.startswith("mlp_head.")]
-    adapt = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("mlp_head.")]
-    opt = torch.optim.Adam([{"params": adapt, "lr": 1e-4}, {"params": head, "lr": 1e-5}], weight_decay=5e-7, betas=(0.95, 0.999))
+    from stgcma import recipe
+    opt = recipe.build_optimizer(model, lr=1e-4, head_lr=0.1)       # reference recipe: Adam(0.95, 0.999), wd 5e-7, two groups
     loss_fn = torch.nn.CrossEntropyLoss()
     a, v, labels = synth_batch(torch, args.batch, device, rank)
 
-    def step():
-        logits = model(a, v, "fusion")
-        loss = loss_fn(logits, labels)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
+    def step():                                                     # traintest_adapt_ave29.py:136-164
+        return recipe.train_step(model, opt, loss_fn, a, v, labels, "fusion")
 
     def fence():
         if world > 1:

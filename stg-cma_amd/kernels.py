@@ -107,7 +107,9 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
     prof = _gemm_prof
-    if prof is not None and K % 64 == 0 and M > 0:          # bench.py: launches of gemm_nt_glds_kernel (the K % 64 == 0 kernel)
+    # bench.py: launches that stg_gemm_nt routes to gemm_nt_glds_kernel<1> (K % 64 == 0, and not the long-K large-tile kernel:
+    # same rule as the host dispatch in csrc/gemm.hip)
+    if prof is not None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256):
         prof["launches"] += 1
         prof["flops"] += 2.0 * M * N * K
         if prof["launches"] % prof["stride"] == 0:         # HIP events around every stride-th launch, on the launch stream

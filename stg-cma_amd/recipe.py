@@ -20,3 +20,42 @@ def apply_freeze(model):
         if p.requires_grad:
             (head if (n[7:] if n.startswith("module.") else n) in MLP_HEAD else adapt).append(p)
     return adapt, head
+
+
+# ------------------------------------------------------------------------------------------------ the training step
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
+    """Per-iteration learning-rate table: linear warm-up, then half-cosine decay to final_value (utilities/scheduler.py:5-30;
+    traintest_adapt_ave29.py:85-101 builds one table per parameter group and indexes it by global_step, :139-144)."""
+    import numpy as np
+    warmup_iters = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.zeros(0)
+    i = np.arange(epochs * niter_per_ep - warmup_iters)
+    cos = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * i / len(i)))
+    table = np.concatenate((warm, cos))
+    assert len(table) == epochs * niter_per_ep
+    return table
+
+
+def build_optimizer(model, lr, head_lr=1.0, weight_decay=5e-7, betas=(0.95, 0.999)):
+    """The reference's optimizer (traintest_adapt_ave29.py:38-69): freeze the backbone by name, Adam over two groups --
+    adapters / gates / temporal tables at `lr`, the newly initialised mlp_head at lr * head_lr."""
+    import torch
+    adapt, head = apply_freeze(model)
+    return torch.optim.Adam([{"params": adapt, "lr": lr}, {"params": head, "lr": lr * head_lr}], weight_decay=weight_decay, betas=betas)
+
+
+def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, global_step=0):
+    """One iteration of the reference loop (traintest_adapt_ave29.py:136-164): per-group LR from the cosine tables, labels
+    'b t c -> (b t) c', forward, loss on float class-probability targets, zero_grad, backward, step.  The reference wraps the
+    forward in fp16 autocast + GradScaler; this path computes in bf16 with fp32 accumulation and fp32 logits, which needs
+    neither.  Returns the loss tensor (not synchronised)."""
+    if lr_tables is not None:
+        for idx, group in enumerate(optimizer.param_groups):
+            group["lr"] = float(lr_tables[min(idx, len(lr_tables) - 1)][global_step])
+    if labels.dim() == 3:
+        labels = labels.reshape(-1, labels.shape[-1])
+    loss = loss_fn(model(a, v, mode), labels)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss

@@ -6,6 +6,7 @@ import json
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -181,3 +182,23 @@ def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls
     assert [n for n, _ in m.named_parameters() if is_trainable(n)] == names
     with pytest.raises(NotImplementedError):
         m(None, None)
+
+
+def test_recipe_cosine_scheduler_and_optimizer_groups(stg):
+    """the product's LR tables equal the reference's (golden from utilities/scheduler.py) and the optimizer has the
+    reference's two groups."""
+    import os
+    from golden_util import GOLD
+    from stgcma import recipe
+    from stgcma.model import Swin_AVE as S
+    z = np.load(os.path.join(GOLD, "cosine_scheduler.npz"))
+    np.testing.assert_allclose(recipe.cosine_scheduler(5e-5, 2e-6, 20, 3339, warmup_epochs=2), z["t1"], rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(recipe.cosine_scheduler(1e-4, 2e-6, 3, 7, warmup_epochs=1), z["t3"], rtol=1e-12, atol=1e-18)
+    m = S.SwinTransformer2D_Adapter_New(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2,
+                                        ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
+    opt = recipe.build_optimizer(m, lr=1e-4, head_lr=10.0)
+    g0, g1 = opt.param_groups
+    assert g0["lr"] == 1e-4 and abs(g1["lr"] - 1e-3) < 1e-12 and g0["betas"] == (0.95, 0.999) and g0["weight_decay"] == 5e-7
+    assert sum(p.numel() for p in g1["params"]) == sum(p.numel() for n, p in m.named_parameters() if n.startswith("mlp_head."))
+    assert all(p.requires_grad for g in opt.param_groups for p in g["params"])
+    assert not m.layers[0].blocks[0].attn.qkv.weight.requires_grad
