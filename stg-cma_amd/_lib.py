@@ -110,6 +110,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
+ABI_VERSION = 101
 _lib = None
 
 
@@ -131,8 +132,8 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if handle.stg_version() != 101:
-        raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version 101")
+    if handle.stg_version() != ABI_VERSION:
+        raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version {ABI_VERSION}")
     _lib = handle
     return _lib
 
