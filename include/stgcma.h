@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 101
+#define STG_VERSION 102
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -166,6 +166,30 @@ int stg_winattn_table(const float* table, const int64_t* index, const float* mas
 int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Temporal attention: WindowAttention.forward's temporal branch (Swin_AVE.py:244-255; block call sites :705-716) with the
+ * '(b t) n c -> (b n) t c' rearranges as addressing.  The fused token tensor holds nm modality slabs of B clips x T frames x
+ * N tokens; frame t of token n of clip b of slab m is row ((m*B + b)*T + t)*N + n, and every (m, b, n) is one sequence of T
+ * frames.  S = scale * Q K^T + bias[m][h] (fp32 [nm, H, T, T], temporal_position_bias_table(_audio) gathered by
+ * t_relative_coords(_a), :246-253), O = softmax(S) V.  T <= 32, head dim 32.  Q, K, V share one leading dimension (the fused
+ * qkv buffer); Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*32.
+ * bm / bmT: caller-owned fp32 workspaces of nm*H*1024 floats each, FILLED by stg_tattn_fwd (block-diagonal additive tables)
+ * and read again by stg_tattn_bwd, which must be handed the same, unmodified buffers.
+ * The backward recomputes the softmax from Q and K (it needs neither O nor an LSE) and writes dQ, dK, dV in one kernel;
+ * dbias (fp32 [nm, H, T, T], atomically accumulated, optional) is the gradient of the trainable bias term.
+ */
+typedef struct {
+    const void* Q; const void* K; const void* V; int64_t ld;
+    void* O; int64_t ldo;
+    const float* bias;
+    float* bm; float* bmT;
+    int nm; int64_t B; int T; int N; int H; int D;
+    float scale;
+} stg_tattn_args;
+int stg_tattn_fwd(const stg_tattn_args* a, void* stream);
+int stg_tattn_bwd(const stg_tattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
+                  float* dbias, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels

@@ -80,6 +80,17 @@ class WinAttnArgs(C.Structure):
     ]
 
 
+class TAttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
+        ("O", c_vp), ("ldo", c_i64),
+        ("bias", c_vp),
+        ("bm", c_vp), ("bmT", c_vp),
+        ("nm", C.c_int), ("B", c_i64), ("T", C.c_int), ("N", C.c_int), ("H", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/stgcma.h declares
 SIGNATURES = {
     "stg_version": (C.c_int, []),
@@ -95,6 +106,8 @@ SIGNATURES = {
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_tattn_fwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp]),
+    "stg_tattn_bwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -110,7 +123,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 101
+ABI_VERSION = 102
 _lib = None
 
 

@@ -1,0 +1,381 @@
+// Temporal attention of the STG-CMA Swin block (WindowAttention.forward temporal branch, Swin_AVE.py:244-255, called from
+// the block at :705-716): every spatial token attends over its own T frames (T = 10 AVE / AVQA, 5 AVS), head dim 32, additive
+// temporal_position_bias_table(_audio) term, no mask.  The '(b t) n c -> (b n) t c' rearranges (:705,711) are addressing:
+// frame t of token n of clip b of modality slab m lives at row ((m*B + b)*T + t)*N + n of the fused token tensor.
+//
+// Why its own kernel family (next to attention.hip): the sequences are tiny, so the op is pure HBM streaming -- what matters
+// is that every byte of q/k/v is read once and that the backward is ONE pass.  `per = 32 / T` sequences of adjacent tokens
+// n0 .. n0+per-1 are packed into one 32-row MFMA tile (v_mfma_f32_32x32x16_bf16; off-diagonal blocks and padding rows are
+// switched off by a -1e30 additive table built from the bias), one wave owns one (token group, head), the four waves of a
+// workgroup own four adjacent heads of the SAME rows (so the workgroup consumes whole 256-byte row segments), and a wave
+// walks token groups of one (modality, head) in a grid-stride loop.  The 32 x 32 score block lives in registers: the softmax
+// is single-pass, and the backward recomputes it from q, k alone -- it needs neither the forward output nor an LSE, and
+// produces dQ, dK, dV and the bias-table gradient in the same kernel (query-on-lane pass for dQ / dbias, key-on-lane pass for
+// dK / dV from the same operand registers).  dbias is accumulated in registers over the whole loop and leaves with T*T
+// atomics per wave.
+//
+// Lane l = (r = l & 31, hh = l >> 5); accumulator row (reg, hh) = (reg & 3) + 8 * (reg >> 2) + 4 * hh.
+#include <math.h>
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+constexpr int TD = 32;             // head dim
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct TP {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; int64_t ld;
+    bf16_t* O; int64_t ldo;
+    const float* bm; const float* bmT;      // [nm*H][32][32]: query-major / key-major additive term (log2 domain)
+    int nm, B, T, N, H, per, gpb, ngroups;  // gpb = token groups per (m, b) = ceil(N / per); ngroups = B * gpb
+    float scale, scale2;
+    const bf16_t* dO; int64_t lddo;
+    bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
+    float* dbias;                           // [nm*H][T*T] or NULL
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define ACC_ROW(reg, hh) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hh))
+
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t pack8(const float* x) {
+    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// [32 rows][32 dims] bf16 tile, 64-byte rows; the 16-byte chunk c4 of row `row` sits at position c4 ^ ((row >> 1) & 3), so the
+// fragment stores below (8 consecutive rows x one chunk per 8-lane pass) spread over all banks.
+__device__ __forceinline__ int tile_off(int row, int c4) { return row * TD + ((c4 ^ ((row >> 1) & 3)) << 3); }
+
+// lane (r, hh) holds row r, dims 8hh..8hh+7 (f0) and 16+8hh..16+8hh+7 (f1) of an operand: park it in the tile
+__device__ __forceinline__ void park(bf16_t* s, int r, int hh, bf16x8_t f0, bf16x8_t f1) {
+    *reinterpret_cast<bf16x8_t*>(s + tile_off(r, hh)) = f0;
+    *reinterpret_cast<bf16x8_t*>(s + tile_off(r, 2 + hh)) = f1;
+}
+
+// transposed fragment: A[i = d][k slot j] = tile[16*s2 + 4*hh + (j & 3) + 8*(j >> 2)][d], d = lane & 31 (the row order of
+// accumulator registers 8*s2 .. 8*s2+7), by two ds_read_b64_tr_b16: each 16-lane group reads a 4-row x 16-column block and
+// receives it column-major; lane 4q + p of the group supplies the address of row q, columns 4p..4p+3.  EXEC all ones.
+typedef short s4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int s2, int hh, int d) {
+    const int gi = d & 15, c = d >> 4;
+    const int row = 16 * s2 + 4 * hh + (gi >> 2);
+    const int c4 = 2 * c + ((gi & 3) >> 1), sub = 4 * (gi & 1);
+    const bf16_t* p0 = s + tile_off(row, c4) + sub;
+    const bf16_t* p1 = s + tile_off(row + 8, c4) + sub;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ float pick(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(256, 2) tattn_fwd_kernel(TP a) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * TD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    int s = r / a.T, t = r - s * a.T;
+    if (r >= nv) { s = 0; t = 0; }
+    bf16_t* sV = smem + wave * 32 * TD;
+    const float* bmq = a.bm + ((int64_t)(m * a.H + h) * 32 + r) * 32;
+    float4 add[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 8 * g4 + 4 * hh);
+
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int b = g / a.gpb, j = g - b * a.gpb;
+        const int n0 = j * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+        const int64_t off = row * a.ld + h * TD + 8 * hh;
+        const bf16x8_t q0 = ld_frag(a.Q + off), q1 = ld_frag(a.Q + off + 16);
+        const bf16x8_t k0 = ld_frag(a.K + off), k1 = ld_frag(a.K + off + 16);
+        const bf16x8_t v0 = ld_frag(a.V + off), v1 = ld_frag(a.V + off + 16);
+        park(sV, r, hh, v0, v1);
+        f32x16_t st = zero16();                       // St[key][q]
+        st = MFMA32(k0, q0, st);
+        st = MFMA32(k1, q1, st);
+        lds_fence();
+        float x[16];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
+            mx = fmaxf(mx, x[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+            l += x[reg];
+        }
+        l += __shfl_xor(l, 32, 64);
+        f32x16_t o = zero16();                        // O^T[d][q]
+        o = MFMA32(tr_frag(sV, 0, hh, r), pack8(x), o);
+        o = MFMA32(tr_frag(sV, 1, hh, r), pack8(x + 8), o);
+        lds_fence();                                  // the tile is rewritten by the next group
+        if (r < cnt * a.T) {
+            const float inv = 1.0f / l;
+            bf16_t* op = a.O + row * a.ldo + h * TD;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(o[4 * g4 + 0] * inv, o[4 * g4 + 1] * inv);
+                w.y = pack_bf2(o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (dQ, dK, dV, dbias)
+__global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
+    constexpr int PER_WAVE = 3 * 32 * TD + 128;      // K, Q, dO tiles (bf16) + lse[32] + delta[32] (fp32 = 128 bf16 slots)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    int s = r / a.T, t = r - s * a.T;
+    if (r >= nv) { s = 0; t = 0; }
+    bf16_t* sK = smem + wave * PER_WAVE;
+    bf16_t* sQ = sK + 32 * TD;
+    bf16_t* sD = sQ + 32 * TD;
+    float* sLse = reinterpret_cast<float*>(sD + 32 * TD);
+    float* sDel = sLse + 32;
+    const int64_t tb = ((int64_t)(m * a.H + h) * 32 + r) * 32;
+    float4 add[4], addT[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        add[g4] = *reinterpret_cast<const float4*>(a.bm + tb + 8 * g4 + 4 * hh);      // lane = query, float4 along keys
+        addT[g4] = *reinterpret_cast<const float4*>(a.bmT + tb + 8 * g4 + 4 * hh);    // lane = key, float4 along queries
+    }
+    f32x16_t dbacc = zero16();                        // sum of dS^T[key][q] over this wave's groups
+
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int b = g / a.gpb, j = g - b * a.gpb;
+        const int n0 = j * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        const int nvalid = cnt * a.T;
+        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+        const int64_t off = row * a.ld + h * TD + 8 * hh;
+        const bf16x8_t q0 = ld_frag(a.Q + off), q1 = ld_frag(a.Q + off + 16);
+        const bf16x8_t k0 = ld_frag(a.K + off), k1 = ld_frag(a.K + off + 16);
+        const bf16x8_t v0 = ld_frag(a.V + off), v1 = ld_frag(a.V + off + 16);
+        const bf16_t* dp_ = a.dO + row * a.lddo + h * TD + 8 * hh;
+        const bf16x8_t d0 = ld_frag(dp_), d1 = ld_frag(dp_ + 16);
+        park(sK, r, hh, k0, k1);
+        park(sQ, r, hh, q0, q1);
+        park(sD, r, hh, d0, d1);
+
+        // ---------------- phase A: query on the lane.  St[key][q], dPt[key][q]; dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+        {
+            f32x16_t st = zero16(), dpt = zero16();
+            st = MFMA32(k0, q0, st);   st = MFMA32(k1, q1, st);
+            dpt = MFMA32(v0, d0, dpt); dpt = MFMA32(v1, d1, dpt);
+            float x[16];
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
+                mx = fmaxf(mx, x[reg]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+                l += x[reg];
+            }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = (r < nvalid) ? 1.0f / l : 0.f;      // padded / absent sequences contribute nothing
+            float delta = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[reg] *= inv;
+                delta += x[reg] * dpt[reg];
+            }
+            delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[reg] *= dpt[reg] - delta;                         // dS^T[key][q]
+                dbacc[reg] += x[reg];
+            }
+            if (hh == 0) {
+                sLse[r] = mx + __log2f(l);
+                sDel[r] = delta;
+            }
+            lds_fence();
+            f32x16_t dq = zero16();
+            dq = MFMA32(tr_frag(sK, 0, hh, r), pack8(x), dq);
+            dq = MFMA32(tr_frag(sK, 1, hh, r), pack8(x + 8), dq);
+            if (r < nvalid) {
+                bf16_t* op = a.dQ + row * a.lddqkv + h * TD;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2 w;
+                    w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
+                    w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
+                    *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
+                }
+            }
+        }
+
+        // ---------------- phase B: key on the lane.  S[q][key], dP[q][key]; dV^T[d][key] = sum_q dO^T[d][q] P[q][key],
+        //                  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
+        {
+            f32x16_t sc = zero16(), dp = zero16();
+            sc = MFMA32(q0, k0, sc); sc = MFMA32(q1, k1, sc);
+            dp = MFMA32(d0, v0, dp); dp = MFMA32(d1, v1, dp);
+            float pr[16], ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ls = *reinterpret_cast<const float4*>(sLse + 8 * g4 + 4 * hh);
+                const float4 de = *reinterpret_cast<const float4*>(sDel + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int reg = 4 * g4 + c;
+                    const bool okq = 8 * g4 + 4 * hh + c < nvalid;              // padded query rows contribute nothing
+                    const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 + pick(addT[g4], c) - pick(ls, c)) : 0.f;
+                    pr[reg] = pv;
+                    ds[reg] = pv * (dp[reg] - pick(de, c));
+                }
+            }
+            f32x16_t dv = zero16(), dk = zero16();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dv = MFMA32(tr_frag(sD, s2, hh, r), pack8(pr + 8 * s2), dv);
+                dk = MFMA32(tr_frag(sQ, s2, hh, r), pack8(ds + 8 * s2), dk);
+            }
+            if (r < nvalid) {
+                bf16_t* kp = a.dK + row * a.lddqkv + h * TD;
+                bf16_t* vp = a.dV + row * a.lddqkv + h * TD;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2 w;
+                    w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
+                    w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
+                    *reinterpret_cast<uint2*>(kp + 8 * g4 + 4 * hh) = w;
+                    w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
+                    w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
+                    *reinterpret_cast<uint2*>(vp + 8 * g4 + 4 * hh) = w;
+                }
+            }
+        }
+        lds_fence();                                  // tiles / statistics are rewritten by the next group
+    }
+
+    if (a.dbias) {
+        // fold the `per` diagonal T x T blocks of the accumulated dS^T[key][q] and add them to dbias[m][h][tq][tk]
+        float* tile = reinterpret_cast<float*>(sK);   // 32 x 32 fp32 = the K + Q tiles
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tile[ACC_ROW(reg, hh) * 32 + r] = dbacc[reg];
+        lds_fence();
+        const int TT = a.T * a.T;
+        for (int idx = lane; idx < TT; idx += 64) {
+            const int tq = idx / a.T, tk = idx - tq * a.T;
+            float acc = 0.f;
+            for (int sq = 0; sq < a.per; ++sq) acc += tile[(sq * a.T + tk) * 32 + sq * a.T + tq];
+            atomicAdd(a.dbias + (int64_t)(m * a.H + h) * TT + idx, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ additive table
+// bm[mh][q][k] = log2(e) * bias[mh][q % T][k % T] when q and k are frames of the same packed sequence, else -1e30 (other
+// sequences of the tile, padding rows);  bmT[mh][k][q] = bm[mh][q][k].
+__global__ void tattn_table_kernel(const float* bias, float* bm, float* bmT, int nmH, int T, int per) {
+    const int total = nmH * 1024;
+    const int nv = per * T;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        const int k = id & 31, q = (id >> 5) & 31, mh = id >> 10;
+        float v = NEG_BIG;
+        if (q < nv && k < nv && q / T == k / T) v = bias[((int64_t)mh * T + q % T) * T + k % T] * LOG2E;
+        bm[(int64_t)mh * 1024 + q * 32 + k] = v;
+        bmT[(int64_t)mh * 1024 + k * 32 + q] = v;
+    }
+}
+
+int fill(const stg_tattn_args* f, TP& p, const char* who) {
+    STG_CHECK(f->Q && f->K && f->V && f->bm && f->bmT, -1, "%s: null pointer", who);
+    STG_CHECK(f->D == TD, -2, "%s: head dim must be 32", who);
+    STG_CHECK(f->T >= 1 && f->T <= 32, -2, "%s: T must be in [1, 32]", who);
+    STG_CHECK(f->nm >= 1 && f->nm <= 65535 && f->B >= 0 && f->N >= 1 && f->H >= 1, -2, "%s: bad shape", who);
+    STG_CHECK(f->ld % 8 == 0 && (((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V) & 15) == 0, -2, "%s: misaligned qkv", who);
+    STG_CHECK((int64_t)f->nm * f->B * f->T * f->N < (1ll << 40), -2, "%s: too many rows", who);
+    p.Q = (const bf16_t*)f->Q; p.K = (const bf16_t*)f->K; p.V = (const bf16_t*)f->V; p.ld = f->ld;
+    p.O = (bf16_t*)f->O; p.ldo = f->ldo; p.bm = f->bm; p.bmT = f->bmT;
+    p.nm = f->nm; p.B = (int)f->B; p.T = f->T; p.N = f->N; p.H = f->H;
+    p.per = 32 / f->T;
+    p.gpb = (f->N + p.per - 1) / p.per;
+    STG_CHECK((int64_t)f->B * p.gpb < (1ll << 31), -2, "%s: too many token groups", who);
+    p.ngroups = (int)(f->B * p.gpb);
+    p.scale = f->scale; p.scale2 = f->scale * LOG2E;
+    return 0;
+}
+
+dim3 grid_for(const TP& p) {
+    const int hg = (p.H + 3) / 4;
+    int gx = 4096 / (hg * p.nm);                // ~16 workgroups per CU over the whole grid: bounds the dbias atomics
+    if (gx < 1) gx = 1;
+    if (gx > p.ngroups) gx = p.ngroups;
+    return dim3(gx, hg, p.nm);
+}
+
+}  // namespace
+
+extern "C" int stg_tattn_fwd(const stg_tattn_args* f, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_tattn_fwd: null args");
+    TP p = {};
+    int rc = fill(f, p, "stg_tattn_fwd");
+    if (rc) return rc;
+    STG_CHECK(f->bias && f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_tattn_fwd: bad bias / O");
+    if (p.ngroups == 0) return 0;
+    const int total = p.nm * p.H * 1024;
+    hipLaunchKernelGGL(tattn_table_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, f->bias, f->bm, f->bmT, p.nm * p.H, p.T, p.per);
+    STG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tattn_fwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
+                             int64_t lddqkv, float* dbias, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_tattn_bwd: null args");
+    TP p = {};
+    int rc = fill(f, p, "stg_tattn_bwd");
+    if (rc) return rc;
+    STG_CHECK(dO && dQ && dK && dV, -1, "stg_tattn_bwd: null pointer");
+    STG_CHECK(lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_tattn_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+              "stg_tattn_bwd: misaligned pointers");
+    if (p.ngroups == 0) return 0;
+    p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
+    p.dbias = dbias;
+    hipLaunchKernelGGL(tattn_bwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -117,6 +117,7 @@ def geom(device, H, W, ws, shift, T):
 
 _wintab_cache = {}   # id(bias-table parameter) -> (weakref, tag, (bm, bmT))
 USE_WINATTN = _os.environ.get("STG_WINATTN", "1") != "0"     # 0 = route W-MSA through the generic attention kernels (A/B knob)
+USE_TATTN = _os.environ.get("STG_TATTN", "1") != "0"         # 0 = route temporal attention through the generic kernels
 
 
 def win_tables(tab_p, index, mask, n):
@@ -400,8 +401,14 @@ def block_forward(X, spec, P, training, save, pool=None):
         for i, m in enumerate(spec.mods):
             tab = "attn.temporal_position_bias_table" + ("_audio" if m else "")
             K.bias_gather(f32c(P[tab]), P["attn.t_relative_coords" + ("_a" if m else "")], out=tbias[i])
-        AO, lse = K.attn_fwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
+        if USE_TATTN and K.tattn_supported(T, spec.hd):
+            tgeo = K.TGeom(nm, B, T, N, H, spec.hd ** -0.5, tbias)
+            AO, lse = K.tattn_fwd(tgeo, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]), tgeo    # backward recomputes: no O / LSE kept
+        else:
+            AO, lse = K.attn_fwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
         PO = K.gemm_nt(AO, wproj, bproj)
+        if isinstance(lse, K.TGeom):
+            AO = None
         X1 = torch.empty_like(X)
         hz = []
         for i, m in enumerate(spec.mods):
@@ -569,8 +576,12 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         tabs = [G.buf("attn.temporal_position_bias_table" + ("_audio" if m else "")) for m in spec.mods]
         dtb = torch.zeros_like(tbias) if any(t is not None for t in tabs) else None
         dQKV = torch.empty_like(QKV)
-        K.attn_bwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
-                   dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:], dbias=dtb)
+        if isinstance(lse, K.TGeom):
+            K.tattn_bwd(lse, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], dAO,
+                        dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:], dbias=dtb)
+        else:
+            K.attn_bwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
+                       dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:], dbias=dtb)
         for i, m in enumerate(spec.mods):
             if tabs[i] is not None:
                 K.bias_scatter(dtb[i], P["attn.t_relative_coords" + ("_a" if m else "")], tabs[i])

@@ -18,7 +18,7 @@ import oracle.swin as OS
 def test_library_loads_and_exports_every_declared_symbol(stg):
     from stgcma import _lib
     lib = _lib.lib()
-    assert lib.stg_version() == 101
+    assert lib.stg_version() == _lib.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "stgcma.h")).read()
     declared = set(re.findall(r"\b(stg_[a-z0-9_]+)\s*\(", header))
     declared -= {"stg_attn_bwd_prep"}          # mentioned in a comment only

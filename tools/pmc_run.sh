@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag
-timeout 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -o run -- python3 "$@" > $R/gpurun_out/pmc/${tag}.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -o run -- python3 $R/"$1" "${@:2}" > $R/gpurun_out/pmc/${tag}.log 2>&1
 f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
 python3 - "$f" $R/gpurun_out/pmc/${tag}.csv <<'PY'
 import csv, sys, collections
