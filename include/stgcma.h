@@ -70,6 +70,17 @@ int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx,
                  const float* row_scale, int64_t rs_outer, int64_t rs_inner,   /* optional DropPath scale on dY rows */
                  void* stream);
 
+/* Same contract, without memory-side atomics, for the shapes of the adapter path (one operand <= 32 columns wide, M >= 4096,
+ * 16-byte aligned operands): row splits leave partial tiles in a caller-owned fp32 workspace `ws`, and a second kernel sums
+ * them into dW / db with a plain read-modify-write (dW / db must not be written concurrently by another stream).
+ * stg_wgrad_ws_floats returns the workspace size in floats this path needs for (M, N1, N2), 0 when the shape is not eligible;
+ * with ws == NULL, a too-small workspace or an ineligible shape the call is forwarded to stg_wgrad_tn. */
+int64_t stg_wgrad_ws_floats(int64_t M, int N1, int N2);
+int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int64_t ldx,
+                    float* dW, int64_t lddw, float* db, int64_t M, int N1, int N2,
+                    const float* row_scale, int64_t rs_outer, int64_t rs_inner,
+                    float* ws, int64_t ws_floats, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm; Swin_AVE.py:341,352 norm1/norm2, :960,976 PatchMerging.norm,
  * :1099,1117-1119 PatchEmbed3D.norm, :1312 final norm; CLIP_AVE.py:33-39).
@@ -208,6 +219,13 @@ int stg_im2col_patch(const void* x, int x_dtype, void* out, int64_t B, int Cin, 
 /* fp32 -> bf16 cast for weight shadows / gradient hand-over: in [R,Cc] contiguous -> out [R, ld_out] (or, transposed,
  * out [Cc, ld_out]); columns beyond the data are zero-filled up to ld_out (GEMM needs K % 8 == 0). */
 int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpose, int64_t ld_out, void* stream);
+/* The same cast for MANY small matrices in one launch (the trainable adapter / head weights change every optimizer step,
+ * ~260 matrices for Swin-B, each needed in both orientations by the forward and the dgrad GEMMs).  `descs` is an array of n
+ * descriptors IN DEVICE MEMORY; matrix t (fp32 [R, C] contiguous at `in`) is written as bf16 [R, ld] at arena + off and, when
+ * offT >= 0, transposed as [C, ldT] at arena + offT (offsets in bf16 elements).  Padding columns are not written: zero the
+ * arena first.  max_elems = the largest R*C (sizes the grid). */
+typedef struct { const float* in; int64_t off; int64_t offT; int R, C, ld, ldT; } stg_cast_desc;
+int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_elems, void* arena, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 

@@ -80,6 +80,10 @@ class WinAttnArgs(C.Structure):
     ]
 
 
+class CastDesc(C.Structure):
+    _fields_ = [("in_", c_vp), ("off", c_i64), ("offT", c_i64), ("R", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("ldT", C.c_int)]
+
+
 class TAttnArgs(C.Structure):
     _fields_ = [
         ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
@@ -97,6 +101,9 @@ SIGNATURES = {
     "stg_last_error": (C.c_char_p, []),
     "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
     "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64, c_vp]),
+    "stg_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int]),
+    "stg_wgrad_tn_ws": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64,
+                                  c_vp, c_i64, c_vp]),
     "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, C.c_int, c_i64, c_vp, c_vp,
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
@@ -112,6 +119,7 @@ SIGNATURES = {
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_cast_bf16": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp]),
+    "stg_cast_bf16_multi": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, c_vp]),
     "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),

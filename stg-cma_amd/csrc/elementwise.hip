@@ -152,6 +152,23 @@ __global__ void im2col_kernel(const void* x, int x_f32, bf16_t* out, int64_t B, 
 }
 
 // ---- casts
+// every trainable weight matrix of a model in ONE launch: tensor t = blockIdx.y is cast to bf16 at arena + off (row-major,
+// leading dimension ld) and, transposed, at arena + offT (leading dimension ldT); the arena is pre-zeroed, so padding columns
+// are never written.  Descriptors live in device memory (the table is static for a model: offsets, not pointers, name the
+// destinations, so a fresh arena per refresh needs no new table).
+__global__ void cast_bf16_multi_kernel(const stg_cast_desc* descs, bf16_t* arena) {
+    const stg_cast_desc d = descs[blockIdx.y];
+    const int total = d.R * d.C;
+    bf16_t* out = arena + d.off;
+    bf16_t* outT = arena + d.offT;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / d.C, c = i - r * d.C;
+        const bf16_t v = f2bf(d.in[i]);
+        out[(int64_t)r * d.ld + c] = v;
+        if (d.offT >= 0) outT[(int64_t)c * d.ldT + r] = v;
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc, int64_t ld) {
     const int64_t total = R * ld;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -355,6 +372,17 @@ extern "C" int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, 
         STG_CHECK(gy < 65536, -2, "stg_cast_bf16: too many rows for transpose");
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ST, in, (bf16_t*)out, R, Cc, ld_out);
     }
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_elems, void* arena, void* stream) {
+    STG_CHECK(descs && arena, -1, "stg_cast_bf16_multi: null pointer");
+    STG_CHECK(n >= 0 && n < 65536 && max_elems >= 0, -2, "stg_cast_bf16_multi: bad count");
+    STG_CHECK((((uintptr_t)arena) & 15) == 0, -2, "stg_cast_bf16_multi: arena must be 16-byte aligned");
+    if (n == 0 || max_elems == 0) return 0;
+    int gx = (max_elems + 1023) / 1024;          // <= 4 elements per thread for the largest tensor
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(gx, n), dim3(256), 0, ST, descs, (bf16_t*)arena);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,330 @@
+// Weight gradient of the trainable adapter / head Linears (autograd of Swin_AVE.py:15-16 D_fc1 / D_fc2) for the shapes that
+// matter: a huge token dimension M (31 K .. 1 M rows), one NARROW operand (adapter hidden width, <= 32 columns) and one wide
+// operand (the channel dimension):   D[na, nb] = sum_m A[m, na] * B[m, nb].
+//
+// The op is a pure HBM stream (~1 KB of operands per 8 MFMAs).  What the atomic kernel in gemm.hip pays for is (i) 16-bit
+// LDS gathers to build k-major fragments and (ii) one memory-side fp32 atomic per output element per block -- each a
+// 64-byte fabric transaction, more bytes than the operands themselves.  Here
+//   * a WAVE owns 32-row chunks of the full narrow operand and a 128-column slab of the wide one, staged row-major into
+//     wave-private LDS (no block barrier in the loop) and read back k-major with ds_read_b64_tr_b16;
+//   * the four waves of a block take interleaved chunks of the block's row range and fold their accumulators through LDS, so
+//     a block leaves ONE partial tile, written lane-major (256-byte coalesced stores) to a caller-owned workspace;
+//   * a second kernel sums the partial tiles over the row splits and adds the result into dW / db (plain read-modify-write).
+//
+// MFMA v_mfma_f32_16x16x32_bf16, lane = (li = lane & 15, kg = lane >> 4).  k slot j of k-group kg is chunk row
+// rho(kg, j) = 4 kg + (j & 3) + 16 (j >> 2) for BOTH operands, so one ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane
+// group) serves rows 0..15 and a second rows 16..31: the eight rows touched by a 32-lane half are consecutive, and the
+// 32-byte column chunks of a row are XOR-swizzled by the row so that they fall into eight different bank groups.
+#include <math.h>
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+constexpr int WK = 32;        // rows per chunk
+constexpr int WNB = 128;      // wide-operand columns per block
+constexpr int NTB = WNB / 16;
+
+struct Wg2 {
+    const bf16_t* A; int64_t lda; int NA;      // narrow
+    const bf16_t* B; int64_t ldb; int NB;      // wide
+    float* ws;                                  // [S][ncg][nacc * 256] raw accumulators
+    int bias_on;                                // 0: none, 1: column sums of A, 2: column sums of B
+    const float* row_scale; int64_t rs_outer, rs_inner; int scale_on;   // 1: scale A rows, 2: scale B rows
+    int64_t M; int64_t rows_per_block; int ncg;
+};
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+// [32 rows][CH 32-byte chunks]: chunk i of row r sits at slot i ^ ((r >> SH) & (CH - 1)), SH = log2(8 / CH)
+template <int CH>
+__device__ __forceinline__ int chunk_slot(int r, int i) {
+    constexpr int SH = CH == 8 ? 0 : CH == 4 ? 1 : CH == 2 ? 2 : 3;
+    return r * CH + (i ^ ((r >> SH) & (CH - 1)));
+}
+template <int CH>
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int i, int li, int kg) {
+    const int r0 = 4 * kg + (li >> 2), sub = 4 * (li & 3);
+    const bf16_t* p0 = s + chunk_slot<CH>(r0, i) * 16 + sub;
+    const bf16_t* p1 = s + chunk_slot<CH>(r0 + 16, i) * 16 + sub;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ void scale8(uint4& v, float rs) {
+    v.x = pack_bf2(__uint_as_float(v.x << 16) * rs, __uint_as_float(v.x & 0xffff0000u) * rs);
+    v.y = pack_bf2(__uint_as_float(v.y << 16) * rs, __uint_as_float(v.y & 0xffff0000u) * rs);
+    v.z = pack_bf2(__uint_as_float(v.z << 16) * rs, __uint_as_float(v.z & 0xffff0000u) * rs);
+    v.w = pack_bf2(__uint_as_float(v.w << 16) * rs, __uint_as_float(v.w & 0xffff0000u) * rs);
+}
+
+// accumulators per lane: NT1 * 8 product tiles + 8 bias tiles (bias_on == 1 uses the first NT1), each f32x4
+template <int NT1>
+__global__ void __launch_bounds__(256, 2) wgrad_ws_kernel(Wg2 p) {
+    constexpr int TA = 16 * NT1;
+    constexpr int NACC = NT1 * NTB + NTB;
+    constexpr int OPER = WK * WNB + WK * TA;                       // bf16 slots of operand LDS per wave
+    constexpr int FOLD = NACC * 256 * 2;                           // bf16 slots one wave's accumulators take (fp32)
+    constexpr int SMEM = 4 * OPER > FOLD ? 4 * OPER : FOLD;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int cg = blockIdx.x, sp = blockIdx.y;
+    const int b0 = cg * WNB;
+    const int64_t mbeg = (int64_t)sp * p.rows_per_block;
+    int64_t mend = mbeg + p.rows_per_block;
+    if (mend > p.M) mend = p.M;
+    bf16_t* sB = smem + wave * OPER;
+    bf16_t* sA = sB + WK * WNB;
+
+    f32x4_t acc[NT1][NTB], accb[NTB];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        accb[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool bias_a = p.bias_on == 1 && cg == 0;
+    const bool bias_b = p.bias_on == 2;
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
+
+    const int na8 = (p.NA + 7) & ~7, nb8 = (p.NB + 7) & ~7;
+    constexpr int PA = 2 * NT1;                                    // 16-byte pieces per A row
+    uint4 va[NT1], vb[8];
+    auto gload = [&](int64_t mb) {                                 // unconditional clamped loads
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id >> 4, pc = id & 15;
+            int64_t gm = mb + row;
+            gm = gm < mend ? gm : mend - 1;
+            int gn = b0 + pc * 8;
+            gn = gn < nb8 ? gn : 0;
+            vb[i] = *reinterpret_cast<const uint4*>(p.B + gm * p.ldb + gn);
+        }
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id / PA, pc = id % PA;
+            int64_t gm = mb + row;
+            gm = gm < mend ? gm : mend - 1;
+            int gn = pc * 8;
+            gn = gn < na8 ? gn : 0;
+            va[i] = *reinterpret_cast<const uint4*>(p.A + gm * p.lda + gn);
+        }
+    };
+
+    const int64_t nchunks = (mend - mbeg + WK - 1) / WK;
+    int64_t c = wave;
+    if (c < nchunks) gload(mbeg + c * WK);
+    for (; c < nchunks; c += 4) {
+        const int64_t mb = mbeg + c * WK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id >> 4, pc = id & 15;
+            const int64_t gm = mb + row;
+            if (gm >= mend) vb[i] = make_uint4(0, 0, 0, 0);
+            else if (p.row_scale && p.scale_on == 2) scale8(vb[i], p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)]);
+            *reinterpret_cast<uint4*>(sB + chunk_slot<8>(row, pc >> 1) * 16 + (pc & 1) * 8) = vb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id / PA, pc = id % PA;
+            const int64_t gm = mb + row;
+            if (gm >= mend) va[i] = make_uint4(0, 0, 0, 0);
+            else if (p.row_scale && p.scale_on == 1) scale8(va[i], p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)]);
+            *reinterpret_cast<uint4*>(sA + chunk_slot<NT1>(row, pc >> 1) * 16 + (pc & 1) * 8) = va[i];
+        }
+        if (c + 4 < nchunks) gload(mb + 4 * WK);
+        lds_fence();
+        bf16x8_t af[NT1];
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) {
+            af[i] = tr_frag<NT1>(sA, i, li, kg);
+            if (bias_a) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+            const bf16x8_t bf = tr_frag<8>(sB, j, li, kg);
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+            if (bias_b) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf, accb[j], 0, 0, 0);
+        }
+        lds_fence();
+    }
+
+    // fold the four waves' accumulators (3 -> 2 -> 1 -> 0), then wave 0 stores the block's partial tile lane-major
+    float* fold = reinterpret_cast<float*>(smem);
+    for (int w = 3; w >= 1; --w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+#pragma unroll
+                for (int i = 0; i < NT1; ++i) *reinterpret_cast<f32x4_t*>(fold + ((i * NTB + j) * 64 + lane) * 4) = acc[i][j];
+                *reinterpret_cast<f32x4_t*>(fold + ((NT1 * NTB + j) * 64 + lane) * 4) = accb[j];
+            }
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+#pragma unroll
+                for (int i = 0; i < NT1; ++i) acc[i][j] += *reinterpret_cast<const f32x4_t*>(fold + ((i * NTB + j) * 64 + lane) * 4);
+                accb[j] += *reinterpret_cast<const f32x4_t*>(fold + ((NT1 * NTB + j) * 64 + lane) * 4);
+            }
+        }
+    }
+    if (wave == 0) {
+        float* out = p.ws + ((int64_t)sp * p.ncg + cg) * (NACC * 256);
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) *reinterpret_cast<f32x4_t*>(out + ((i * NTB + j) * 64 + lane) * 4) = acc[i][j];
+            *reinterpret_cast<f32x4_t*>(out + ((NT1 * NTB + j) * 64 + lane) * 4) = accb[j];
+        }
+    }
+}
+
+struct Wr2 {
+    const float* ws; int S, ncg, nt1;
+    float* dW; int64_t lddw; int transpose_out;
+    float* db; int bias_on;
+    int NA, NB;
+};
+
+// Sum of the S partial tiles.  A block owns 16 consecutive float4 "quads" of the raw (lane-major) tile of column group cg;
+// its 16 row-split groups stride over S with independent 16-byte loads, fold through LDS, and 16 threads scatter the 64 sums:
+// raw element e = (tile * 64 + lane) * 4 + r  <->  D[16 ia + 4 (lane >> 4) + r][16 j + (lane & 15)].
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(Wr2 p) {
+    __shared__ float4 part[16][16];
+    const int nacc = p.nt1 * NTB + NTB;
+    const int per_cg = nacc * 256;
+    const int q = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int e4 = blockIdx.x * 16 + q;                        // quad index: per_cg / 4 is a multiple of 16
+    const int cg = blockIdx.y;
+    const float4* src = reinterpret_cast<const float4*>(p.ws + (int64_t)cg * per_cg) + e4;
+    const int64_t stride4 = (int64_t)p.ncg * per_cg / 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = sg; s < p.S; s += 16) {
+        const float4 v = src[s * stride4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    part[sg][q] = a;
+    __syncthreads();
+    if (sg != 0) return;
+#pragma unroll
+    for (int g = 1; g < 16; ++g) {
+        const float4 v = part[g][q];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const int lane = e4 & 63, tile = e4 >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const float vals[4] = {a.x, a.y, a.z, a.w};
+    if (tile < p.nt1 * NTB) {
+        const int ia = tile / NTB, j = tile % NTB;
+        const int nb = cg * WNB + 16 * j + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int na = 16 * ia + 4 * lg + r;
+            if (na < p.NA && nb < p.NB) {
+                float* dst = p.transpose_out ? p.dW + (int64_t)nb * p.lddw + na : p.dW + (int64_t)na * p.lddw + nb;
+                *dst += vals[r];
+            }
+        }
+    } else if (p.db) {
+        const int j = tile - p.nt1 * NTB;
+        if (p.bias_on == 1) {                      // accb[ia] = A^T . ones: every column holds the sums; take column 0
+            if (cg == 0 && j < p.nt1 && li == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int na = 16 * j + 4 * lg + r;
+                    if (na < p.NA) p.db[na] += vals[r];
+                }
+            }
+        } else if (p.bias_on == 2) {               // accb[j] = ones^T . B: every row holds the sums; take row 0
+            const int nb = cg * WNB + 16 * j + li;
+            if (lg == 0 && nb < p.NB) p.db[nb] += vals[0];
+        }
+    }
+}
+
+struct Plan { bool ok; int nt1, ncg, S; int64_t rows_per_block, ws_floats; bool y_narrow; };
+
+Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* dY, const void* X) {
+    Plan pl = {};
+    const bool y_narrow = N1 <= N2;
+    const int NA = y_narrow ? N1 : N2, NB = y_narrow ? N2 : N1;
+    const bool aligned = (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY & 15) == 0) && (((uintptr_t)X & 15) == 0) &&
+                         lddy >= ((N1 + 7) & ~7) && ldx >= ((N2 + 7) & ~7);
+    if (!aligned || NA > 32 || M < 4096) return pl;     // 33..64 wide: the accumulators no longer fit two blocks per CU
+    pl.ok = true; pl.y_narrow = y_narrow;
+    pl.nt1 = NA <= 16 ? 1 : 2;
+    pl.ncg = (NB + WNB - 1) / WNB;
+    // ~2 blocks per CU, and at least 4 chunks per wave so that the partial tile stays a small fraction of the operand bytes
+    int64_t S = 512 / pl.ncg;
+    const int64_t smax = (M + 4 * 4 * WK - 1) / (4 * 4 * WK);
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    int64_t rpb = (M + S - 1) / S;
+    rpb = (rpb + WK - 1) / WK * WK;
+    S = (M + rpb - 1) / rpb;
+    pl.S = (int)S; pl.rows_per_block = rpb;
+    pl.ws_floats = S * pl.ncg * (int64_t)(pl.nt1 * NTB + NTB) * 256;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t stg_wgrad_ws_floats(int64_t M, int N1, int N2) {
+    if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    const Plan pl = plan_for(M, N1, N2, (N1 + 7) & ~7, (N2 + 7) & ~7, nullptr, nullptr);
+    return pl.ok ? pl.ws_floats : 0;
+}
+
+extern "C" int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                               int64_t M, int N1, int N2, const float* row_scale, int64_t rs_outer, int64_t rs_inner,
+                               float* ws, int64_t ws_floats, void* stream) {
+    STG_CHECK(dY && X && dW, -1, "stg_wgrad_tn_ws: null pointer");
+    STG_CHECK(M >= 0 && N1 > 0 && N2 > 0, -2, "stg_wgrad_tn_ws: bad shape");
+    STG_CHECK(lddy >= N1 && ldx >= N2 && lddw >= N2, -2, "stg_wgrad_tn_ws: leading dimension too small");
+    if (row_scale) STG_CHECK(rs_outer > 0 && rs_inner > 0, -2, "stg_wgrad_tn_ws: bad row_scale params");
+    if (M == 0) return 0;
+    const Plan pl = plan_for(M, N1, N2, lddy, ldx, dY, X);
+    if (!pl.ok || ws == nullptr || ws_floats < pl.ws_floats)          // shapes outside this path: the atomic kernels
+        return stg_wgrad_tn(dY, lddy, X, ldx, dW, lddw, db, M, N1, N2, row_scale, rs_outer, rs_inner, stream);
+    STG_CHECK((((uintptr_t)ws) & 15) == 0, -2, "stg_wgrad_tn_ws: workspace must be 16-byte aligned");
+    Wg2 p;
+    const bool yn = pl.y_narrow;
+    p.A = (const bf16_t*)(yn ? dY : X); p.lda = yn ? lddy : ldx; p.NA = yn ? N1 : N2;
+    p.B = (const bf16_t*)(yn ? X : dY); p.ldb = yn ? ldx : lddy; p.NB = yn ? N2 : N1;
+    p.ws = ws;
+    p.bias_on = db ? (yn ? 1 : 2) : 0;
+    p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
+    p.scale_on = yn ? 1 : 2;
+    p.M = M; p.rows_per_block = pl.rows_per_block; p.ncg = pl.ncg;
+    const dim3 grid(pl.ncg, pl.S);
+    if (pl.nt1 == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    Wr2 r;
+    r.ws = ws; r.S = pl.S; r.ncg = pl.ncg; r.nt1 = pl.nt1;
+    r.dW = dW; r.lddw = lddw; r.transpose_out = yn ? 0 : 1;
+    r.db = db; r.bias_on = p.bias_on; r.NA = p.NA; r.NB = p.NB;
+    const int per_cg = (pl.nt1 * NTB + NTB) * 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(per_cg / 64, pl.ncg), dim3(256), 0, (hipStream_t)stream, r);
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -124,6 +124,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
 
 
 _gemm_prof = None
+import os as _os
+USE_WGRAD_WS = _os.environ.get("STG_WGRAD_WS", "1") != "0"    # 0 = atomic wgrad kernels only (A/B knob)
 
 
 def gemm_profile_start(stride=7):
@@ -164,8 +166,15 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         need = ((M - 1) // rs_outer) * rs_inner + rs_inner if M > 0 else 0
         if row_scale.numel() < need:
             raise RuntimeError(f"row_scale: needs >= {need} entries, got {row_scale.numel()}")
-    _lib.check(_lib.lib().stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
-                                       _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
+    L = _lib.lib()
+    nws = L.stg_wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
+    if nws > 0:                                          # partial tiles + reduce (no memory-side atomics)
+        ws = torch.empty((nws,), dtype=F32, device=dY.device)
+        _lib.check(L.stg_wgrad_tn_ws(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
+                                     _p(row_scale), int(rs_outer), int(rs_inner), _p(ws), nws, _stream()), "stg_wgrad_tn_ws")
+        return
+    _lib.check(L.stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
+                              _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None, out_dtype=BF16):
@@ -305,6 +314,23 @@ def cast_bf16(w, transpose=False, pad_to=8):
     out = torch.empty((Cc, ld) if transpose else (R, ld), dtype=BF16, device=w.device)
     _lib.check(_lib.lib().stg_cast_bf16(_p(w2), _p(out), R, Cc, 1 if transpose else 0, ld, _stream()), "stg_cast_bf16")
     return out
+
+
+def cast_desc_table(entries, device):
+    """entries: [(src data_ptr, off, offT, R, C, ld, ldT)] -> uint8 GPU tensor holding the stg_cast_desc array."""
+    arr = (_lib.CastDesc * len(entries))()
+    for i, (ptr, off, offT, R, Cc, ld, ldT) in enumerate(entries):
+        arr[i].in_, arr[i].off, arr[i].offT, arr[i].R, arr[i].C, arr[i].ld, arr[i].ldT = ptr, off, offT, R, Cc, ld, ldT
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def cast_bf16_multi(desc, n, max_elems, arena):
+    """One launch casting n fp32 matrices (device-resident descriptor table from cast_desc_table) into the zeroed bf16 arena."""
+    if desc.dtype != torch.uint8 or not desc.is_cuda or desc.numel() != n * C.sizeof(_lib.CastDesc):
+        raise RuntimeError("cast_bf16_multi: bad descriptor table")
+    _chk_flat(arena, "arena", BF16)
+    _lib.check(_lib.lib().stg_cast_bf16_multi(_p(desc), int(n), int(max_elems), _p(arena), _stream()), "stg_cast_bf16_multi")
 
 
 def cast_f32(x):

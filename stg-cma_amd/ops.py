@@ -52,6 +52,64 @@ def shadow(p, transpose=False):
     return s
 
 
+class ShadowSet:
+    """bf16 shadows, both orientations, of ALL trainable weight matrices of a model from ONE launch.  The adapter and head
+    weights change at every optimizer step: one cast launch per matrix and orientation was ~520 launches (2.6 ms of GPU time and
+    several ms of host time) per Swin-B step.  refresh() re-casts everything into a fresh arena when any parameter's storage or
+    version changed and registers the views in the shadow cache, so shadow() hits; older arenas stay alive while referenced."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.meta, off = [], 0
+        for p in self.params:
+            R = p.shape[0]
+            Cc = p.numel() // R
+            ld, ldT = (Cc + 7) // 8 * 8, (R + 7) // 8 * 8
+            self.meta.append((R, Cc, ld, ldT, off, off + R * ld))
+            off += R * ld + Cc * ldT
+        self.total = off
+        self.max_elems = max((m[0] * m[1] for m in self.meta), default=0)
+        self.ptrs = self.tags = self.desc = None
+
+    def refresh(self):
+        if not self.params:
+            return
+        tags = tuple((p.data_ptr(), p._version) for p in self.params)
+        if tags == self.tags and all(id(p) in _shadow_cache for p in self.params):
+            return
+        for p in self.params:
+            if not p.is_cuda or p.dtype != F32 or not p.is_contiguous():
+                raise RuntimeError("stg-cma_amd: trainable weights must be contiguous fp32 GPU tensors")
+        dev = self.params[0].device
+        ptrs = tuple(t[0] for t in tags)
+        if ptrs != self.ptrs:
+            self.desc = K.cast_desc_table([(ptr, m[4], m[5], m[0], m[1], m[2], m[3]) for ptr, m in zip(ptrs, self.meta)], dev)
+            self.ptrs = ptrs
+        arena = torch.zeros(self.total, dtype=BF16, device=dev)
+        K.cast_bf16_multi(self.desc, len(self.params), self.max_elems, arena)
+        for p, tag, (R, Cc, ld, ldT, off, offT) in zip(self.params, tags, self.meta):
+            key = id(p)
+            ent = _shadow_cache.get(key)
+            if ent is None or ent[0]() is not p:
+                ent = (weakref.ref(p, lambda _r, k=key: _shadow_cache.pop(k, None)), {})
+                _shadow_cache[key] = ent
+            ent[1][False] = (tag, arena[off:off + R * ld].view(R, ld))
+            ent[1][True] = (tag, arena[offT:offT + Cc * ldT].view(Cc, ldT))
+        self.tags = tags
+
+
+def refresh_shadows(holder, names, P, need):
+    """Batch-refresh the shadows of the trainable Linear weights (adapters, head) of a model call; `holder` (the model's
+    plan) keeps the ShadowSet."""
+    sel = tuple(n for n in names if need.get(n, False) and P[n].dim() == 2 and n.endswith(".weight")
+                and ("D_fc" in n or "mlp_head" in n))
+    ss = getattr(holder, "_shadowset", None)
+    if ss is None or ss[0] != sel or any(a is not b for a, b in zip(ss[1].params, (P[n] for n in sel))):
+        ss = (sel, ShadowSet([P[n] for n in sel]))
+        holder._shadowset = ss
+    ss[1].refresh()
+
+
 def f32c(p):
     t = p.detach()
     if t.dtype != F32 or not t.is_cuda:
@@ -786,6 +844,7 @@ class SwinBackboneFn(torch.autograd.Function):
         for n in names:
             if need[n] and not plan.trainable_ok(n):
                 _check_frozen({n: True}, [n], "Swin backbone")
+        refresh_shadows(plan, names, P, need)
         B, T = v.shape[0], v.shape[1]
         N0 = plan.n_patches
         Rm = B * T * N0
@@ -891,6 +950,7 @@ class SwinModelFn(torch.autograd.Function):
         for n in names:
             if need[n] and not plan.trainable_ok(n):
                 _check_frozen({n: True}, [n], "SwinTransformer2D_Adapter_New")
+        refresh_shadows(plan, names, P, need)
         mods = plan.mods
         src = v if 0 in mods else a
         B, T = src.shape[0], (src.shape[2] if 0 in mods else src.shape[1])

@@ -13,7 +13,7 @@ import torch
 
 from . import kernels as K
 from .kernels import ACT_GELU, ACT_QUICKGELU, BF16, F32
-from .ops import (RESIDUAL_DTYPE, GradArena, _Adapter, _adapter_wgrad, _check_frozen, _cross_modal_bwd, _cross_modal_fwd, _Grads,
+from .ops import (RESIDUAL_DTYPE, refresh_shadows, GradArena, _Adapter, _adapter_wgrad, _check_frozen, _cross_modal_bwd, _cross_modal_fwd, _Grads,
                   drop_scale, f32c, shadow)
 
 _SFX = ("", "_Audio")
@@ -301,6 +301,7 @@ class VitModelFn(torch.autograd.Function):
         for n in names:
             if need[n] and not plan.trainable_ok(n):
                 _check_frozen({n: True}, [n], "MM_CLIP_AVE")
+        refresh_shadows(plan, names, P, need)
         T = plan.T
         mods = plan.mods
         src = v if 0 in mods else a

@@ -139,7 +139,11 @@ def test_gemm_strided_views(stg, gpu):
 
 
 @pytest.mark.parametrize("M,N1,N2", [(64, 16, 128), (1000, 32, 256), (333, 128, 16), (320, 29, 512), (5000, 64, 1024),
-                                     (100, 512, 2048)])
+                                     (100, 512, 2048),
+                                     # the workspace (no-atomics) path: narrow operand <= 32, M >= 4096; either operand narrow,
+                                     # ragged row / column tails, several column groups
+                                     (4096, 16, 128), (20000, 32, 512), (7777, 512, 32), (5001, 24, 200), (62720, 32, 512),
+                                     (9000, 256, 16), (4100, 29, 512)])
 def test_wgrad(stg, gpu, M, N1, N2):
     from stgcma import kernels as k
     g = torch.Generator().manual_seed(M + N1 + N2)
@@ -153,6 +157,26 @@ def test_wgrad(stg, gpu, M, N1, N2):
     # accumulates
     k.wgrad_tn(dY.to(gpu), X.to(gpu), dW, None)
     _close(dW / scale, 2 * ref / scale, tol=2e-3, what="dW accumulate")
+
+
+@pytest.mark.parametrize("M,N1,N2,outer,inner", [(6000, 512, 32, 600, 20), (8192, 16, 128, 4096, 1)])
+def test_wgrad_row_scale_workspace_path(stg, gpu, M, N1, N2, outer, inner):
+    """DropPath row scale on dY rows (T_Adapter D_fc2 wgrad, Swin_AVE.py:709,715) through the workspace kernels, column slices
+    of wider buffers as operands."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + N1)
+    dYb = _bf(torch.randn(M, N1 + 8, generator=g)); Xb = _bf(torch.randn(M, N2 + 16, generator=g))
+    dY, X = dYb[:, :N1], Xb[:, 8:8 + N2]
+    n_rs = ((M - 1) // outer) * inner + inner
+    rs = (torch.rand(n_rs, generator=g) < 0.8).float() / 0.8
+    row = torch.arange(M)
+    s = rs[(row // outer) * inner + (row % inner)]
+    dW = torch.zeros(N1, N2, device=gpu); db = torch.zeros(N1, device=gpu)
+    k.wgrad_tn(dYb.to(gpu)[:, :N1], Xb.to(gpu)[:, 8:8 + N2], dW, db, row_scale=rs.to(gpu), rs_outer=outer, rs_inner=inner)
+    ys = _bf(dY.float() * s[:, None]).float()          # the kernels scale the bf16 operand and round it back to bf16
+    scale = math.sqrt(M)
+    _close(dW / scale, ys.t() @ X.float() / scale, tol=3e-3, what="dW")
+    _close(db / scale, ys.sum(0) / scale, tol=3e-3, what="db")
 
 
 @pytest.mark.parametrize("rows,C", [(7, 128), (1000, 256), (513, 512), (100, 1024), (50, 2048), (33, 768), (20, 3072),
@@ -263,3 +287,24 @@ def test_im2col_patch_embed(stg, gpu):
         wb = _bf(w.reshape(E, -1)).to(gpu)
         out = k.gemm_nt(cols, wb, b.to(gpu))
         _close(out, ref, what=f"patch embed Cin={Cin}")
+
+
+def test_cast_bf16_multi_equals_single_casts(stg, gpu):
+    """ops.ShadowSet: one launch for every trainable weight matrix, both orientations == stg_cast_bf16 per matrix."""
+    from stgcma import kernels as k, ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 128), (128, 16), (29, 512), (512, 2048), (48, 768), (3, 5)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g).to(gpu)) for s in shapes]
+    ss = ops.ShadowSet(params)
+    ss.refresh()
+    for p in params:
+        for tr in (False, True):
+            got = ops.shadow(p, tr)
+            ref = k.cast_bf16(p.detach(), transpose=tr)
+            assert got.shape == ref.shape and torch.equal(got, ref), (tuple(p.shape), tr)
+    old = ops.shadow(params[0]).clone()
+    with torch.no_grad():
+        params[0].add_(1.0)                       # version bump -> the next refresh re-casts into a NEW arena
+    ss.refresh()
+    assert torch.equal(ops.shadow(params[0]), k.cast_bf16(params[0].detach()))
+    assert not torch.equal(ops.shadow(params[0]), old)
