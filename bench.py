@@ -127,6 +127,22 @@ def cpu_baseline(timeout_s=240):
     return dict(fail, error=(r.stderr or "no output")[-300:])
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/
+    r01_pmc_summary.json: (2 * FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
+    cannot be collected from inside the process, so the bench line quotes the last committed pass; None when absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            summ = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for name, v in summ.items():
+        if kernel in name:
+            return int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +209,7 @@ def main():
         ns = max(gp["sampled"], 1)
         avg_us = gp["sampled_ms"] * 1e3 / ns
         achieved = gp["sampled_flops"] / (gp["sampled_ms"] * 1e-3) / 1e12 if gp["sampled_ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1>")
         out = {
             "metric": "clips/sec fwd+bwd, Swin-B+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -204,7 +221,9 @@ def main():
             "mfma_frac_whole_step": round(value * GFLOP_PER_CLIP / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_glds_kernel<1>", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(gp["bytes"] / max(gp["launches"], 1)),
                          "launches_per_step": gp["launches"] // max(args.steps, 1),
                          "gflop_per_launch": round(gp["sampled_flops"] / ns / 1e9, 2),
                          "avg_launch_us": round(avg_us, 2), "sampled_launches": gp["sampled"],

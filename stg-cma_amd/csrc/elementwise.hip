@@ -315,7 +315,9 @@ extern "C" int stg_gate_bwd(const void* dout, const void* r, const float* gate, 
     STG_CHECK((((uintptr_t)dout | (uintptr_t)r | (uintptr_t)dr) & 15) == 0, -2, "stg_gate_bwd: pointers must be 16-byte aligned");
     if (numel <= 0) return 0;
     const int64_t n8 = numel >> 3;
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)dout, (const bf16_t*)r,
+    unsigned gb = grid_for(n8, 256);
+    if (gb > 256) gb = 256;      // one memory-side atomic per block on ONE address: 4096 of them serialised into ~20 us
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(gb), dim3(256), 0, ST, (const bf16_t*)dout, (const bf16_t*)r,
                        gate, (bf16_t*)dr, dgate, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;

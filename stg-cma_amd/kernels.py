@@ -112,6 +112,10 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     if prof is not None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256):
         prof["launches"] += 1
         prof["flops"] += 2.0 * M * N * K
+        nbytes = 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
+            (2.0 * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
+            (M * N * res2.element_size() if res2 is not None else 0.0)
+        prof["bytes"] += nbytes                             # algorithmic HBM bytes: every operand / output touched once
         if prof["launches"] % prof["stride"] == 0:         # HIP events around every stride-th launch, on the launch stream
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -134,7 +138,7 @@ def gemm_profile_start(stride=7):
     systematically instead: the launch sequence repeats every step with a period co-prime to 7, so over >= 7 steps every
     call site is sampled equally often."""
     global _gemm_prof
-    _gemm_prof = {"stride": int(stride), "launches": 0, "flops": 0.0, "rec": []}
+    _gemm_prof = {"stride": int(stride), "launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}
 
 
 def gemm_profile_stop():
@@ -143,7 +147,7 @@ def gemm_profile_stop():
     prof, _gemm_prof = _gemm_prof, None
     torch.cuda.synchronize()
     rec = prof["rec"]
-    return {"launches": prof["launches"], "flops": prof["flops"], "sampled": len(rec),
+    return {"launches": prof["launches"], "flops": prof["flops"], "bytes": prof["bytes"], "sampled": len(rec),
             "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _ in rec), "sampled_flops": sum(f for _, _, f in rec)}
 
 

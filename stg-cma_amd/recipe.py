@@ -59,3 +59,36 @@ def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, gl
     loss.backward()
     optimizer.step()
     return loss
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint tail
+def wa_model(exp_dir, start_epoch, end_epoch):
+    """Average the per-epoch checkpoints exp_dir/models/audio_model.{epoch}.pth, start_epoch..end_epoch inclusive, key by key
+    (AVE/run_adapt_ave29.py:203-214; "not an ensemble": one state_dict comes out).  Exactly the reference's arithmetic:
+    running sum in the dtype of the first checkpoint's tensors, then true division by float(count) -- so the integer buffers
+    (relative_position_index, t_relative_coords) come back as float tensors, which load_state_dict(strict=True) copies into the
+    int64 buffers unchanged (:226).  Keys keep their `module.` prefix (the loop saves the DataParallel-wrapped model, :226-229)."""
+    import torch
+    sdA = torch.load(exp_dir + '/models/audio_model.' + str(start_epoch) + '.pth', map_location='cpu')
+    model_cnt = 1
+    for epoch in range(start_epoch + 1, end_epoch + 1):
+        sdB = torch.load(exp_dir + '/models/audio_model.' + str(epoch) + '.pth', map_location='cpu')
+        for key in sdA:
+            sdA[key] = sdA[key] + sdB[key]
+        model_cnt += 1
+    print('wa {:d} models from {:d} to {:d}'.format(model_cnt, start_epoch, end_epoch))
+    for key in sdA:
+        sdA[key] = sdA[key] / float(model_cnt)
+    return sdA
+
+
+def save_epoch_checkpoint(model, exp_dir, epoch):
+    """What the reference loop writes every epoch (AVE/traintest_adapt_ave29.py:226-229): the state_dict of the wrapped model
+    (keys prefixed `module.`) as exp_dir/models/audio_model.{epoch}.pth."""
+    import os
+    import torch
+    os.makedirs(exp_dir + '/models', exist_ok=True)
+    sd = model.state_dict()
+    if not any(k.startswith('module.') for k in sd):
+        sd = {'module.' + k: v for k, v in sd.items()}
+    torch.save(sd, "%s/models/audio_model.%d.pth" % (exp_dir, epoch))

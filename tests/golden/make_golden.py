@@ -282,6 +282,35 @@ def structure_case(S, Cm):
     print("wrote structure.json")
 
 
+def pretrained_ingest_case(S, tag, cfg, seed, patch_size):
+    """Swin checkpoint ingestion of the REFERENCE constructor (Swin_AVE.py:1363-1415): patch-embed inflation / patch_size[0],
+    audio patch embedding = channel mean, strict=False load; D_fc2 zeroing afterwards (:1422-1468)."""
+    import contextlib
+    import io
+    import tempfile
+    torch.manual_seed(seed)
+    probe = S.SwinTransformer2D_Adapter_New(patch_size=patch_size, window_size=7, pretrained=None, ftmode="fusion", **cfg)
+    ck = GP.swin2d_checkpoint(probe.state_dict(), seed + 1)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "swin2d.pth")
+        torch.save(ck, path)
+        buf = io.StringIO()
+        torch.manual_seed(seed + 2)
+        with contextlib.redirect_stdout(buf):
+            m = S.SwinTransformer2D_Adapter_New(patch_size=patch_size, window_size=7, pretrained=path, ftmode="fusion", **cfg)
+    lines = buf.getvalue().splitlines()
+    missing = [ln for ln in lines if ln.startswith("Missing keys: ")][0][len("Missing keys: "):]
+    unexpected = [ln for ln in lines if ln.startswith("Unexpected keys: ")][0][len("Unexpected keys: "):]
+    sd = m.state_dict()
+    loaded = [k for k in sd if k in ck["model"] or k.startswith("patch_embed_audio.")]
+    keep = {k.replace(".", "__"): sd[k] for k in sd if k.startswith("patch_embed") }
+    stats = {k: [float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in loaded if sd[k].is_floating_point()}
+    zeroed = [k for k in sd if "D_fc2" in k]
+    assert all(float(sd[k].abs().max()) == 0 for k in zeroed)
+    save(tag, cfg_json=json.dumps(dict(cfg, patch_size=patch_size, seed=seed)), missing=missing, unexpected=unexpected,
+         stats_json=json.dumps(stats), **keep)
+
+
 def scheduler_case():
     sch = load(os.path.join(REF, "utilities/scheduler.py"), "ref_sched")
     import contextlib
@@ -344,6 +373,8 @@ def main(argv):
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
         "avs_tiny_backbone": lambda: avs_backbone_case(ref_avs(), "avs_tiny_backbone", cfg=AVS_TINY, B=1, seed=600),
         "avqa_tiny_backbone": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone", cfg=AVQA_TINY, B=1, seed=610),
+        "swin_pretrained_ingest": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest", SWIN_TINY, 700, [1, 4, 4]),
+        "swin_pretrained_ingest_pd2": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest_pd2", SWIN_TINY, 710, [2, 4, 4]),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

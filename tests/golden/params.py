@@ -93,3 +93,26 @@ def refinit_state(shapes, seed):
             t = torch.randn(shape, generator=g).clamp_(-2, 2) * 0.02
         out[key] = t.reshape(shape)
     return out
+
+
+def swin2d_checkpoint(state_dict, seed, patch_depth_one=True):
+    """A synthetic stand-in for swin_*_patch4_window7_224_22k.pth: {'model': sd} holding what an image Swin checkpoint holds --
+    the backbone keys of `state_dict` (a Swin+STG-CMA model's: everything except adapters, gates, temporal tables, the audio
+    patch embedding and mlp_head) with seeded values, a 2-D patch-embedding kernel [E, 3, p, p], the integer buffers as they are,
+    and the classifier 'head.*' the video model has no use for (-> unexpected keys)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in state_dict.items():
+        if is_trainable(k) or k.startswith("patch_embed_audio.") or k.startswith("mlp_head."):
+            continue
+        if not v.is_floating_point() or k.endswith("attn_mask"):
+            sd[k] = v.clone()
+        elif k == "patch_embed.proj.weight":
+            E, Cin, _, ph, pw = v.shape
+            sd[k] = torch.randn((E, Cin, ph, pw), generator=g) * 0.1
+        else:
+            sd[k] = torch.randn(tuple(v.shape), generator=g) * 0.1
+    C_last = state_dict["norm.weight"].shape[0]
+    sd["head.weight"] = torch.randn((7, C_last), generator=g) * 0.1
+    sd["head.bias"] = torch.zeros(7)
+    return {"model": sd}
