@@ -36,12 +36,28 @@ SWIN_B = dict(label_dim=29, patch_size=[1, 4, 4], num_frames=10, embed_dim=128, 
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
 
 
-def build_model(torch, device):
+VIT_B = dict(label_dim=29, layers=12, num_video_frames=10, embed_dim=768, patch_size=16, heads=8, pretrained=None, ftmode="fusion")
+# workload -> (fwd+bwd algorithmic GEMM GFLOP per clip, description).  swin_b is the headline metric (BASELINE.json configs[2]
+# at N GPUs); vit_b is configs[1] (ViT-B/16 + STG-CMA full stack, AVE shape, 197 video + 49 audio tokens, heads = 8 as the
+# reference runner builds it, AVE/run_adapt_ave29.py:130-139), selectable with --workload vit_b.
+WORKLOADS = {
+    "swin_b": (1587.5, "Swin-B + STG-CMA ftmode=fusion, AVE shape (10 frames + 10 spectrogram segments, 224^2), "
+                       "fwd+bwd+Adam on 5.6M adapter/head params"),
+    "vit_b": (1158.7, "ViT-B/16 (CLIP) + STG-CMA ftmode=fusion, AVE shape (10 frames 224^2 + 10 spectrogram segments 102x128), "
+                      "fwd+bwd+Adam on the adapter/head params"),
+}
+
+
+def build_model(torch, device, workload="swin_b"):
     import stgcma  # noqa: F401
-    from stgcma.model import Swin_AVE as S
     from stgcma.recipe import is_trainable
     torch.manual_seed(0)
-    m = S.SwinTransformer2D_Adapter_New(**SWIN_B)
+    if workload == "vit_b":
+        from stgcma.model import CLIP_AVE as Cm
+        m = Cm.MM_CLIP_AVE(**VIT_B)
+    else:
+        from stgcma.model import Swin_AVE as S
+        m = S.SwinTransformer2D_Adapter_New(**SWIN_B)
     # de-zero what the reference zero-initialises, so no kernel can shortcut zeros
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
@@ -55,10 +71,10 @@ def build_model(torch, device):
     return m.to(device).train()
 
 
-def synth_batch(torch, B, device, rank):
+def synth_batch(torch, B, device, rank, workload="swin_b"):
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     v = torch.randn((B, 3, 10, 224, 224), generator=g, device=device)
-    a = torch.randn((B, 10, 224, 224), generator=g, device=device) * 0.5
+    a = torch.randn((B, 10) + ((102, 128) if workload == "vit_b" else (224, 224)), generator=g, device=device) * 0.5
     cls = torch.randint(0, 29, (B * 10,), generator=g, device=device)
     labels = torch.nn.functional.one_hot(cls, 29).float()   # float one-hot rows, '(b t) c'
     return a, v, labels
@@ -150,6 +166,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="swin_b",
+                    help="swin_b = the headline metric (default); vit_b = BASELINE configs[1]")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -168,14 +186,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    model = build_model(torch, device)
+    model = build_model(torch, device, args.workload)
+    gflop_per_clip, workload_desc = WORKLOADS[args.workload]
     if world > 1:
         ddp.broadcast_parameters(model)
         ddp.attach(model)
     from stgcma import recipe
     opt = recipe.build_optimizer(model, lr=1e-4, head_lr=0.1)       # reference recipe: Adam(0.95, 0.999), wd 5e-7, two groups
     loss_fn = torch.nn.CrossEntropyLoss()
-    a, v, labels = synth_batch(torch, args.batch, device, rank)
+    a, v, labels = synth_batch(torch, args.batch, device, rank, args.workload)
 
     def step():                                                     # traintest_adapt_ave29.py:136-164
         return recipe.train_step(model, opt, loss_fn, a, v, labels, "fusion")
@@ -211,14 +230,13 @@ def main():
         achieved = gp["sampled_flops"] / (gp["sampled_ms"] * 1e-3) / 1e12 if gp["sampled_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1>")
         out = {
-            "metric": "clips/sec fwd+bwd, Swin-B+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
+            "metric": "clips/sec fwd+bwd, " + ("Swin-B" if args.workload == "swin_b" else "ViT-B/16") + "+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Swin-B + STG-CMA ftmode=fusion, AVE shape (10 frames + 10 spectrogram segments, 224^2), "
-                                   "fwd+bwd+Adam on 5.6M adapter/head params", "clips_per_gpu": args.batch,
+            "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": "fp32"},
-            "model_tflops": round(value * GFLOP_PER_CLIP / 1e3, 2),
-            "mfma_frac_whole_step": round(value * GFLOP_PER_CLIP / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "model_tflops": round(value * gflop_per_clip / 1e3, 2),
+            "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_glds_kernel<1>", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -229,7 +247,7 @@ def main():
                          "avg_launch_us": round(avg_us, 2), "sampled_launches": gp["sampled"],
                          "est_ms_per_step": round(avg_us * 1e-3 * gp["launches"] / max(args.steps, 1), 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
