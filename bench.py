@@ -36,6 +36,9 @@ SWIN_B = dict(label_dim=29, patch_size=[1, 4, 4], num_frames=10, embed_dim=128, 
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
 
 
+SWIN_L = dict(label_dim=29, patch_size=[1, 4, 4], num_frames=10, embed_dim=192, depths=[2, 2, 18, 2],
+              num_heads=[6, 12, 24, 48], window_size=7, pretrained=None, ftmode="fusion",
+              adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
 VIT_B = dict(label_dim=29, layers=12, num_video_frames=10, embed_dim=768, patch_size=16, heads=8, pretrained=None, ftmode="fusion")
 # workload -> (fwd+bwd algorithmic GEMM GFLOP per clip, description).  swin_b is the headline metric (BASELINE.json configs[2]
 # at N GPUs); vit_b is configs[1] (ViT-B/16 + STG-CMA full stack, AVE shape, 197 video + 49 audio tokens, heads = 8 as the
@@ -43,6 +46,8 @@ VIT_B = dict(label_dim=29, layers=12, num_video_frames=10, embed_dim=768, patch_
 WORKLOADS = {
     "swin_b": (1587.5, "Swin-B + STG-CMA ftmode=fusion, AVE shape (10 frames + 10 spectrogram segments, 224^2), "
                        "fwd+bwd+Adam on 5.6M adapter/head params"),
+    "swin_l": (3989.0, "Swin-L + STG-CMA ftmode=fusion, AVE shape, adapter ratios [.5,.25,.125,.0625] (AVE/run_swin_adapt_ave29.sh:52), "
+                       "fwd+bwd+Adam on the adapter/head params"),
     "vit_b": (1158.7, "ViT-B/16 (CLIP) + STG-CMA ftmode=fusion, AVE shape (10 frames 224^2 + 10 spectrogram segments 102x128), "
                       "fwd+bwd+Adam on the adapter/head params"),
 }
@@ -57,7 +62,7 @@ def build_model(torch, device, workload="swin_b"):
         m = Cm.MM_CLIP_AVE(**VIT_B)
     else:
         from stgcma.model import Swin_AVE as S
-        m = S.SwinTransformer2D_Adapter_New(**SWIN_B)
+        m = S.SwinTransformer2D_Adapter_New(**(SWIN_L if workload == "swin_l" else SWIN_B))
     # de-zero what the reference zero-initialises, so no kernel can shortcut zeros
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
@@ -230,7 +235,7 @@ def main():
         achieved = gp["sampled_flops"] / (gp["sampled_ms"] * 1e-3) / 1e12 if gp["sampled_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1>")
         out = {
-            "metric": "clips/sec fwd+bwd, " + ("Swin-B" if args.workload == "swin_b" else "ViT-B/16") + "+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
+            "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B", "swin_l": "Swin-L", "vit_b": "ViT-B/16"}[args.workload] + "+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
