@@ -186,7 +186,7 @@ struct RowTerms {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D, bool PK>
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_fwd_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP a) {
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 template <int D, bool PK>
-__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_bwd_dq_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
@@ -469,7 +469,9 @@ __device__ __forceinline__ void flush_dbias(const AttnP& a, f32x16_t& dbacc, int
 // The wave owns 32 keys (key on the lane): S[q][key] = Q . K^T and dP[q][key] = dO . V^T come out with the query in
 // registers; P and dS are then the B operands of dV^T[d][key] = dO^T . P and dK^T[d][key] = Q^T . dS.
 template <int D, bool PK>
-__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(AttnP a) {
+// D = 96 / 128 (ViT heads): at two waves per SIMD the accumulators spill 300+ VGPRs to scratch; one wave per SIMD (AGPRs) measured
+// 130 -> 81 ms over the ViT-B step, the other variants are faster at two
+__global__ void __launch_bounds__(256, (D > 64 && !PK ? 1 : 2)) attn_bwd_dkv_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     constexpr bool PREFETCH = D <= 64;                 // register budget: two extra tiles in flight only for small D

@@ -102,15 +102,29 @@ __global__ void __launch_bounds__(256, 2) tattn_fwd_kernel(TP a) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 8 * g4 + 4 * hh);
 
-    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    // operand fragments of the NEXT group are in flight while the current one is computed (the loop is latency-bound otherwise)
+    auto row_of = [&](int g, int& cnt) {
         const int b = g / a.gpb, j = g - b * a.gpb;
         const int n0 = j * a.per;
-        const int cnt = min(a.per, a.N - n0);
-        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
-        const int64_t off = row * a.ld + h * TD + 8 * hh;
-        const bf16x8_t q0 = ld_frag(a.Q + off), q1 = ld_frag(a.Q + off + 16);
-        const bf16x8_t k0 = ld_frag(a.K + off), k1 = ld_frag(a.K + off + 16);
-        const bf16x8_t v0 = ld_frag(a.V + off), v1 = ld_frag(a.V + off + 16);
+        cnt = min(a.per, a.N - n0);
+        return ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+    };
+    bf16x8_t nq0, nq1, nk0, nk1, nv0, nv1;
+    int ncnt = 0;
+    int64_t nrow = 0;
+    auto fetch = [&](int g) {
+        nrow = row_of(g, ncnt);
+        const int64_t off = nrow * a.ld + h * TD + 8 * hh;
+        nq0 = ld_frag(a.Q + off); nq1 = ld_frag(a.Q + off + 16);
+        nk0 = ld_frag(a.K + off); nk1 = ld_frag(a.K + off + 16);
+        nv0 = ld_frag(a.V + off); nv1 = ld_frag(a.V + off + 16);
+    };
+    if ((int)blockIdx.x < a.ngroups) fetch(blockIdx.x);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int cnt = ncnt;
+        const int64_t row = nrow;
+        const bf16x8_t q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1;
+        if (g + (int)gridDim.x < a.ngroups) fetch(g + gridDim.x);
         park(sV, r, hh, v0, v1);
         f32x16_t st = zero16();                       // St[key][q]
         st = MFMA32(k0, q0, st);
@@ -174,18 +188,31 @@ __global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
     }
     f32x16_t dbacc = zero16();                        // sum of dS^T[key][q] over this wave's groups
 
-    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+    auto row_of = [&](int g, int& cnt) {
         const int b = g / a.gpb, j = g - b * a.gpb;
         const int n0 = j * a.per;
-        const int cnt = min(a.per, a.N - n0);
+        cnt = min(a.per, a.N - n0);
+        return ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+    };
+    bf16x8_t nq0, nq1, nk0, nk1, nv0, nv1, nd0, nd1;
+    int ncnt = 0;
+    int64_t nrow = 0;
+    auto fetch = [&](int g) {                          // the NEXT group's operands are in flight during the current one
+        nrow = row_of(g, ncnt);
+        const int64_t off = nrow * a.ld + h * TD + 8 * hh;
+        nq0 = ld_frag(a.Q + off); nq1 = ld_frag(a.Q + off + 16);
+        nk0 = ld_frag(a.K + off); nk1 = ld_frag(a.K + off + 16);
+        nv0 = ld_frag(a.V + off); nv1 = ld_frag(a.V + off + 16);
+        const bf16_t* dp_ = a.dO + nrow * a.lddo + h * TD + 8 * hh;
+        nd0 = ld_frag(dp_); nd1 = ld_frag(dp_ + 16);
+    };
+    if ((int)blockIdx.x < a.ngroups) fetch(blockIdx.x);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int cnt = ncnt;
         const int nvalid = cnt * a.T;
-        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
-        const int64_t off = row * a.ld + h * TD + 8 * hh;
-        const bf16x8_t q0 = ld_frag(a.Q + off), q1 = ld_frag(a.Q + off + 16);
-        const bf16x8_t k0 = ld_frag(a.K + off), k1 = ld_frag(a.K + off + 16);
-        const bf16x8_t v0 = ld_frag(a.V + off), v1 = ld_frag(a.V + off + 16);
-        const bf16_t* dp_ = a.dO + row * a.lddo + h * TD + 8 * hh;
-        const bf16x8_t d0 = ld_frag(dp_), d1 = ld_frag(dp_ + 16);
+        const int64_t row = nrow;
+        const bf16x8_t q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1, d0 = nd0, d1 = nd1;
+        if (g + (int)gridDim.x < a.ngroups) fetch(g + gridDim.x);
         park(sK, r, hh, k0, k1);
         park(sQ, r, hh, q0, q1);
         park(sD, r, hh, d0, d1);
@@ -338,7 +365,7 @@ int fill(const stg_tattn_args* f, TP& p, const char* who) {
 
 dim3 grid_for(const TP& p) {
     const int hg = (p.H + 3) / 4;
-    int gx = 4096 / (hg * p.nm);                // ~16 workgroups per CU over the whole grid: bounds the dbias atomics
+    int gx = 2048 / (hg * p.nm);                // ~8 workgroups per CU over the whole grid: bounds the dbias atomics
     if (gx < 1) gx = 1;
     if (gx > p.ngroups) gx = p.ngroups;
     return dim3(gx, hg, p.nm);
