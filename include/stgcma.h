@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 102
+#define STG_VERSION 103
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -201,6 +201,26 @@ typedef struct {
 int stg_tattn_fwd(const stg_tattn_args* a, void* stream);
 int stg_tattn_bwd(const stg_tattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
                   float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head self-attention core of the CLIP ViT blocks: nn.MultiheadAttention inside ResidualAttentionBlock.attention
+ * (CLIP_AVE.py:106-108; spatial call sites :379-383 and the audio twin), no mask, no bias, dropout 0.  P frames x H heads,
+ * n tokens per frame at rows p*n .. p*n + n-1, head dim D in {64, 96}; Q, K, V are column slices of the fused in_proj output
+ * (one leading dimension), head h at columns h*D.  O = softmax(scale * Q K^T) V; lse (fp32 [P, H, n]) is saved in the
+ * log2 domain for the backward.  stg_mha_bwd runs two kernels (dQ, which also fills the caller's `delta` workspace
+ * fp32 [P, H, n] = rowsum(dO * O), then dK/dV) and writes dQ, dK, dV with the addressing of Q, K, V.
+ */
+typedef struct {
+    const void* Q; const void* K; const void* V; int64_t ld;
+    void* O; int64_t ldo;
+    float* lse;
+    int64_t P; int H; int n; int D;
+    float scale;
+} stg_mha_args;
+int stg_mha_supported(int n, int D);
+int stg_mha_fwd(const stg_mha_args* a, void* stream);
+int stg_mha_bwd(const stg_mha_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
+                float* delta, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels

@@ -80,6 +80,16 @@ class WinAttnArgs(C.Structure):
     ]
 
 
+class MhaArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
+        ("O", c_vp), ("ldo", c_i64),
+        ("lse", c_vp),
+        ("P", c_i64), ("H", C.c_int), ("n", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
 class CastDesc(C.Structure):
     _fields_ = [("in_", c_vp), ("off", c_i64), ("offT", c_i64), ("R", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("ldT", C.c_int)]
 
@@ -115,6 +125,9 @@ SIGNATURES = {
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_tattn_fwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp]),
     "stg_tattn_bwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "stg_mha_supported": (C.c_int, [C.c_int, C.c_int]),
+    "stg_mha_fwd": (C.c_int, [C.POINTER(MhaArgs), c_vp]),
+    "stg_mha_bwd": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -131,7 +144,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 102
+ABI_VERSION = 103
 _lib = None
 
 

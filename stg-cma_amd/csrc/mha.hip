@@ -1,0 +1,436 @@
+// Multi-head self-attention core of the CLIP ViT blocks (nn.MultiheadAttention inside ResidualAttentionBlock.attention,
+// CLIP_AVE.py:106-108, spatial calls at :379-383): P frames x H heads, n tokens per frame (197 video / 49 audio for ViT-B/16,
+// 257 for ViT-L/14), head dim 64 or 96 (the reference runner builds ViT-B with heads = 8 -> 96, AVE/run_adapt_ave29.py:137), no
+// mask, no bias.  Token i of frame p is row p*n + i of the fused qkv buffer.
+//
+// Why its own family: at head dim 96 the generic gather-mapped kernels (attention.hip) keep per-element bias / mask / map
+// bookkeeping next to 96-wide accumulators and spill hundreds of VGPRs to scratch.  These kernels are the plain flash
+// schedule with nothing else in it:
+//   * a block = one (frame, head) and four consecutive 32-row tiles, one per wave; the K / V tile (forward, dQ) or the Q / dO
+//     tile (dK/dV) of the inner loop is staged ONCE per block into LDS by all 256 threads with 16-byte loads and shared by the
+//     four waves (register prefetch of the next tile across the barrier);
+//   * scores are computed transposed (rows = keys, lane = query) so that the softmax statistics are lane-local and P / dS feed
+//     the second MFMA straight from registers as the B operand, the other operand comes k-major out of LDS through
+//     ds_read_b64_tr_b16; LDS rows are padded by 16 bytes (208 / 144-byte pitch): conflict-free for both read shapes;
+//   * the backward recomputes P from the saved log2-domain LSE; dQ also leaves delta = rowsum(dO * O) for the dK/dV kernel.
+// MFMA v_mfma_f32_32x32x16_bf16; lane l = (r = l & 31, hh = l >> 5); accumulator row (reg, hh) = (reg & 3) + 8 (reg >> 2) + 4 hh.
+#include <math.h>
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct MP {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; int64_t ld;
+    bf16_t* O; int64_t ldo;
+    float* lse;                       // [P, H, n]  log2-domain: max + log2(sum)
+    float* delta;                     // [P, H, n]
+    int P, H, n, nt;                  // nt = 32-row tiles per frame
+    float scale, scale2;
+    const bf16_t* dO; int64_t lddo;
+    bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define ACC_ROW(reg, hh) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (hh))
+
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t pack8(const float* x) {
+    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+// transposed fragment of a [32 rows][DP pitch] tile: A[i = d][k slot j] = tile[16 s2 + 4 hh + (j & 3) + 8 (j >> 2)][32 dt + d]
+template <int DP>
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int dt, int s2, int hh, int d) {
+    const int gi = d & 15, c = d >> 4;
+    const bf16_t* p = s + (16 * s2 + 4 * hh + (gi >> 2)) * DP + 32 * dt + 16 * c + 4 * (gi & 3);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(p + 8 * DP));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// natural fragment (rows on the lane): tile[r][16 s + 8 hh .. +7]
+template <int DP>
+__device__ __forceinline__ bf16x8_t nat_frag(const bf16_t* s, int r, int hh, int ks) {
+    return *reinterpret_cast<const bf16x8_t*>(s + r * DP + 16 * ks + 8 * hh);
+}
+
+// Cooperative staging of two [32][D] tiles (rows row0 .. row0+31 of frame p, clamped to the last token) by 256 threads:
+// D / 32 16-byte pieces per thread; `fetch` fills registers, `commit` writes them to LDS.
+template <int D>
+struct Stage2 {
+    static constexpr int PER = D / 32;             // pieces per thread (two tiles x 32 rows x D/8 pieces / 256)
+    static constexpr int DP = D + 8;
+    uint4 v[PER];
+    __device__ __forceinline__ void fetch(const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1, int64_t frame_row0, int n,
+                                          int row0, int h, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + 256 * i;
+            const int which = id / (4 * D), rem = id - which * 4 * D;
+            const int row = rem / (D / 8), c = rem - row * (D / 8);
+            int tok = row0 + row;
+            tok = tok < n ? tok : n - 1;
+            const bf16_t* src = which ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
+            v[i] = *reinterpret_cast<const uint4*>(src + h * D + 8 * c);
+        }
+    }
+    __device__ __forceinline__ void commit(bf16_t* s0, bf16_t* s1, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + 256 * i;
+            const int which = id / (4 * D), rem = id - which * 4 * D;
+            const int row = rem / (D / 8), c = rem - row * (D / 8);
+            *reinterpret_cast<uint4*>((which ? s1 : s0) + row * DP + 8 * c) = v[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 32 * DP];
+    bf16_t* sK = smem;
+    bf16_t* sV = smem + 32 * DP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int q0 = 32 * (qb * 4 + wave);
+    const int q = q0 + r;
+    const int qc = q < a.n ? q : a.n - 1;
+    bf16x8_t qf[KS];
+    {
+        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
+    }
+    f32x16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+    float m = NEG_BIG, l = 0.f;
+
+    Stage2<D> st;
+    st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 0, h, tid);
+    for (int kt = 0; kt < a.nt; ++kt) {
+        __syncthreads();                               // every wave is done with the previous tile
+        st.commit(sK, sV, tid);
+        if (kt + 1 < a.nt) st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1), h, tid);
+        __syncthreads();
+        f32x16_t sc = zero16();                        // St[key][q]
+#pragma unroll
+        for (int s = 0; s < KS; ++s) sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
+        float x[16];
+        float mx = m;
+        const int kbase = 32 * kt;
+        const bool tail = kbase + 32 > a.n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = sc[reg] * a.scale2;
+            if (tail && kbase + ACC_ROW(reg, hh) >= a.n) x[reg] = NEG_BIG;
+            mx = fmaxf(mx, x[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);
+        m = mx;
+        float ls = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+            ls += x[reg];
+        }
+        ls += __shfl_xor(ls, 32, 64);
+        l = l * alpha + ls;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // rescale only when some query's maximum moved
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) o[dt][reg] *= alpha;
+        }
+        const bf16x8_t p0 = pack8(x), p1 = pack8(x + 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 0, hh, r), p0, o[dt]);
+            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), p1, o[dt]);
+        }
+    }
+    if (q < a.n) {
+        const float inv = 1.0f / l;
+        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+                w.y = pack_bf2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
+            }
+        if (a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
+template <int D>
+__global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 32 * DP];
+    bf16_t* sK = smem;
+    bf16_t* sV = smem + 32 * DP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int q = 32 * (qb * 4 + wave) + r;
+    const int qc = q < a.n ? q : a.n - 1;
+    bf16x8_t qf[KS], dof[KS];
+    float delta = 0.f;
+    {
+        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* dp = a.dO + (frow + qc) * a.lddo + h * D + 8 * hh;
+        const bf16_t* op = a.O + (frow + qc) * a.ldo + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = ld_frag(qp + 16 * s);
+            dof[s] = ld_frag(dp + 16 * s);
+            const bf16x8_t of = ld_frag(op + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const int64_t si = ((int64_t)p * a.H + h) * a.n + qc;
+    const float lse = a.lse[si];
+    if (q < a.n && hh == 0) a.delta[si] = delta;
+    f32x16_t dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+
+    Stage2<D> st;
+    st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 0, h, tid);
+    for (int kt = 0; kt < a.nt; ++kt) {
+        __syncthreads();
+        st.commit(sK, sV, tid);
+        if (kt + 1 < a.nt) st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1), h, tid);
+        __syncthreads();
+        f32x16_t sc = zero16(), dp = zero16();         // St[key][q], dPt[key][q]
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
+            dp = MFMA32(nat_frag<DP>(sV, r, hh, s), dof[s], dp);
+        }
+        float ds[16];
+        const int kbase = 32 * kt;
+        const bool tail = kbase + 32 > a.n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float pr = __builtin_amdgcn_exp2f(sc[reg] * a.scale2 - lse);
+            if (tail && kbase + ACC_ROW(reg, hh) >= a.n) pr = 0.f;
+            ds[reg] = pr * (dp[reg] - delta);
+        }
+        const bf16x8_t d0 = pack8(ds), d1 = pack8(ds + 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 0, hh, r), d0, dq[dt]);
+            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), d1, dq[dt]);
+        }
+    }
+    if (q < a.n) {
+        bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(dq[dt][4 * g4 + 0] * a.scale, dq[dt][4 * g4 + 1] * a.scale);
+                w.y = pack_bf2(dq[dt][4 * g4 + 2] * a.scale, dq[dt][4 * g4 + 3] * a.scale);
+                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int D>
+__global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    // shared Q / dO tiles + lse / delta of the current query tile, then per wave its own K and V tiles
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // dkv_lds_bytes(D): 66.8 KiB at D = 96 (dynamic: > 64 KiB)
+    bf16_t* sQ = smem;
+    bf16_t* sD = smem + 32 * DP;
+    float* sLse = reinterpret_cast<float*>(smem + 2 * 32 * DP);
+    float* sDel = sLse + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    bf16_t* sK = smem + 2 * 32 * DP + 128 + wave * 2 * 32 * DP;
+    bf16_t* sV = sK + 32 * DP;
+    const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int key = 32 * (kb * 4 + wave) + r;
+    const int kc = key < a.n ? key : a.n - 1;
+    {   // own K / V tile: natural rows (keys) -> wave-private LDS; read back as B operands (columns = keys)
+        const bf16_t* kp = a.K + (frow + kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* vp = a.V + (frow + kc) * a.ld + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(sK + r * DP + 16 * s + 8 * hh) = ld_frag(kp + 16 * s);
+            *reinterpret_cast<bf16x8_t*>(sV + r * DP + 16 * s + 8 * hh) = ld_frag(vp + 16 * s);
+        }
+    }
+    f32x16_t dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+    const int64_t sbase = ((int64_t)p * a.H + h) * a.n;
+
+    Stage2<D> st;
+    float nl = 0.f, nd = 0.f;
+    auto fetch_stats = [&](int q0) {
+        if (tid < 32) {
+            int qi = q0 + tid;
+            qi = qi < a.n ? qi : a.n - 1;
+            nl = a.lse[sbase + qi];
+            nd = a.delta[sbase + qi];
+        }
+    };
+    st.fetch(a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0, h, tid);
+    fetch_stats(0);
+    for (int qt = 0; qt < a.nt; ++qt) {
+        __syncthreads();
+        st.commit(sQ, sD, tid);
+        if (tid < 32) { sLse[tid] = nl; sDel[tid] = nd; }
+        if (qt + 1 < a.nt) {
+            st.fetch(a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1), h, tid);
+            fetch_stats(32 * (qt + 1));
+        }
+        __syncthreads();
+        f32x16_t sc = zero16(), dp = zero16();         // S[q][key], dP[q][key]
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sc = MFMA32(nat_frag<DP>(sQ, r, hh, s), nat_frag<DP>(sK, r, hh, s), sc);
+            dp = MFMA32(nat_frag<DP>(sD, r, hh, s), nat_frag<DP>(sV, r, hh, s), dp);
+        }
+        float pr[16], ds[16];
+        const int qbase = 32 * qt;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 ls = *reinterpret_cast<const float4*>(sLse + 8 * g4 + 4 * hh);
+            const float4 de = *reinterpret_cast<const float4*>(sDel + 8 * g4 + 4 * hh);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int reg = 4 * g4 + c;
+                const bool okq = qbase + 8 * g4 + 4 * hh + c < a.n;              // padded query rows contribute nothing
+                const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 - lsv[c]) : 0.f;
+                pr[reg] = pv;
+                ds[reg] = pv * (dp[reg] - dev[c]);
+            }
+        }
+        const bf16x8_t p0 = pack8(pr), p1 = pack8(pr + 8), d0 = pack8(ds), d1 = pack8(ds + 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = MFMA32(tr_frag<DP>(sD, dt, 0, hh, r), p0, dv[dt]);
+            dv[dt] = MFMA32(tr_frag<DP>(sD, dt, 1, hh, r), p1, dv[dt]);
+            dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 0, hh, r), d0, dk[dt]);
+            dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 1, hh, r), d1, dk[dt]);
+        }
+    }
+    if (key < a.n) {
+        bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
+        bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf2(dk[dt][4 * g4 + 0] * a.scale, dk[dt][4 * g4 + 1] * a.scale);
+                w.y = pack_bf2(dk[dt][4 * g4 + 2] * a.scale, dk[dt][4 * g4 + 3] * a.scale);
+                *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
+                w.x = pack_bf2(dv[dt][4 * g4 + 0], dv[dt][4 * g4 + 1]);
+                w.y = pack_bf2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4 + 4 * hh) = w;
+            }
+    }
+}
+
+constexpr int dkv_lds_bytes(int D) { return (2 * 32 * (D + 8) + 128 + 4 * 2 * 32 * (D + 8)) * 2; }
+
+template <int D>
+int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
+    static const bool attr_set =
+        hipFuncSetAttribute((const void*)mha_dkv_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds_bytes(D)) == hipSuccess;
+    STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D));
+    hipLaunchKernelGGL(mha_dkv_kernel<D>, grid, dim3(256), dkv_lds_bytes(D), stream, p);
+    return 0;
+}
+
+int fill(const stg_mha_args* f, MP& p, const char* who) {
+    STG_CHECK(f->Q && f->K && f->V && f->O && f->lse, -1, "%s: null pointer", who);
+    STG_CHECK(f->D == 64 || f->D == 96, -2, "%s: head dim must be 64 or 96", who);
+    STG_CHECK(f->P >= 0 && f->P < 65536 && f->H >= 1 && f->H < 65536 && f->n >= 1 && f->n <= (1 << 20), -2, "%s: bad shape", who);
+    STG_CHECK(f->ld % 8 == 0 && f->ldo % 8 == 0, -2, "%s: leading dimensions must be multiples of 8", who);
+    STG_CHECK((((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V | (uintptr_t)f->O) & 15) == 0, -2, "%s: misaligned pointers", who);
+    p.Q = (const bf16_t*)f->Q; p.K = (const bf16_t*)f->K; p.V = (const bf16_t*)f->V; p.ld = f->ld;
+    p.O = (bf16_t*)f->O; p.ldo = f->ldo; p.lse = f->lse;
+    p.P = (int)f->P; p.H = f->H; p.n = f->n; p.nt = (f->n + 31) / 32;
+    p.scale = f->scale; p.scale2 = f->scale * LOG2E;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int stg_mha_supported(int n, int D) { return (D == 64 || D == 96) && n >= 1 ? 1 : 0; }
+
+extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_mha_fwd: null args");
+    MP p = {};
+    int rc = fill(f, p, "stg_mha_fwd");
+    if (rc) return rc;
+    if (p.P == 0) return 0;
+    const dim3 grid((p.nt + 3) / 4, p.H, p.P);
+    if (f->D == 64) hipLaunchKernelGGL(mha_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(mha_fwd_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
+                           float* delta, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_mha_bwd: null args");
+    MP p = {};
+    int rc = fill(f, p, "stg_mha_bwd");
+    if (rc) return rc;
+    STG_CHECK(dO && dQ && dK && dV && delta, -1, "stg_mha_bwd: null pointer");
+    STG_CHECK(lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_mha_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+              "stg_mha_bwd: misaligned pointers");
+    if (p.P == 0) return 0;
+    p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
+    p.delta = delta;
+    const dim3 grid((p.nt + 3) / 4, p.H, p.P);
+    if (f->D == 64) {
+        hipLaunchKernelGGL(mha_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        rc = launch_dkv<64>(grid, p, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(mha_dq_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        rc = launch_dkv<96>(grid, p, (hipStream_t)stream);
+    }
+    if (rc) return rc;
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -656,6 +656,62 @@ def tattn_bwd(g, Q, K, V, dO, *, dQ, dK, dV, dbias=None):
     return dQ, dK, dV
 
 
+class MhaGeom:
+    """ViT multi-head self-attention over the fused in_proj output: P frames x H heads, n tokens per frame at rows p*n + i,
+    head dim D in {64, 96}."""
+
+    def __init__(self, P, H, n, D, scale):
+        self.P, self.H, self.n, self.D, self.scale = int(P), int(H), int(n), int(D), float(scale)
+        if not mha_supported(self.n, self.D):
+            raise RuntimeError(f"mha: unsupported geometry n={n} D={D}")
+        self.rows = self.P * self.n
+
+
+def mha_supported(n, D):
+    return D in (64, 96) and n >= 1
+
+
+def _mha_fill(g, Q, K, V, O, lse):
+    for t, name in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
+        _chk2d(t, name, BF16)
+        if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
+            raise RuntimeError(f"mha {name}: needs >= {g.rows} rows x {g.H * g.D} columns, got {tuple(t.shape)}")
+    if not (_ld(Q) == _ld(K) == _ld(V)):
+        raise RuntimeError("mha: Q, K, V must share one leading dimension (slices of the fused in_proj output)")
+    if lse.dtype != F32 or not lse.is_cuda or not lse.is_contiguous() or lse.numel() != g.P * g.H * g.n:
+        raise RuntimeError("mha: lse must be a contiguous fp32 [P, H, n] GPU tensor")
+    a = _lib.MhaArgs()
+    a.Q, a.K, a.V, a.ld = _p(Q), _p(K), _p(V), _ld(Q)
+    a.O, a.ldo = _p(O), _ld(O)
+    a.lse = _p(lse)
+    a.P, a.H, a.n, a.D, a.scale = g.P, g.H, g.n, g.D, g.scale
+    return a
+
+
+def mha_fwd(g, Q, K, V, out=None):
+    """Returns (O bf16 [rows, H*D], lse fp32 [P, H, n] in the log2 domain)."""
+    if out is None:
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=Q.device)
+    lse = torch.empty((g.P, g.H, g.n), dtype=F32, device=Q.device)
+    a = _mha_fill(g, Q, K, V, out, lse)
+    _lib.check(_lib.lib().stg_mha_fwd(C.byref(a), _stream()), "stg_mha_fwd")
+    return out, lse
+
+
+def mha_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
+    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+        _chk2d(t, name, BF16)
+        if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
+            raise RuntimeError(f"mha_bwd {name}: needs >= {g.rows} rows x {g.H * g.D} columns")
+    if not (_ld(dQ) == _ld(dK) == _ld(dV)):
+        raise RuntimeError("mha_bwd: dQ, dK, dV must share one leading dimension")
+    a = _mha_fill(g, Q, K, V, O, lse)
+    delta = torch.empty((g.P, g.H, g.n), dtype=F32, device=Q.device)
+    _lib.check(_lib.lib().stg_mha_bwd(C.byref(a), _p(dO), _ld(dO), _p(dQ), _p(dK), _p(dV), _ld(dQ), _p(delta), _stream()),
+               "stg_mha_bwd")
+    return dQ, dK, dV
+
+
 def vit_embed(patch, cls, pos, temb, BT, T):
     """ViT token assembly -> fp32 [BT*(np+1), D]; see stg_vit_embed."""
     _chk_flat(patch, "patch"); _chk_flat(cls, "cls", F32); _chk_flat(pos, "pos", F32); _chk_flat(temb, "temb", F32)

@@ -1,0 +1,79 @@
+"""-m gpu: the ViT multi-head self-attention kernels (stg_mha_fwd / stg_mha_bwd) against an fp32 PyTorch-CPU statement of
+nn.MultiheadAttention's core, softmax(q k^T / sqrt(d)) v per (frame, head) (CLIP_AVE.py:106-108)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _close(got, ref, tol=1e-2, what=""):
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    err = (got - ref).abs(); bound = tol * torch.clamp(ref.abs(), min=1.0)
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} off; first {idx}: got {got[tuple(idx)].item()} "
+                             f"ref {ref[tuple(idx)].item()}; max err {err.max().item():.4g}")
+
+
+def _run(gpu, P, H, n, D, seed=0, mag=1.0, pad_cols=0):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(seed)
+    C = H * D
+    rows = P * n
+    QKVb = (torch.randn(rows, 3 * C + pad_cols, generator=g) * mag).to(BF16)
+    dOb = torch.randn(rows, C, generator=g).to(BF16)
+    X = QKVb[:, :3 * C].float().requires_grad_(True)
+    x = X.view(P, n, 3, H, D).permute(2, 0, 3, 1, 4)                     # [3, P, H, n, D]
+    scale = D ** -0.5
+    s = scale * (x[0] @ x[1].transpose(-1, -2))
+    o_ref = (torch.softmax(s, -1) @ x[2]).permute(0, 2, 1, 3).reshape(rows, C)
+    o_ref.backward(dOb.float())
+    QKV = QKVb.to(gpu)
+    geo = k.MhaGeom(P, H, n, D, scale)
+    O, lse = k.mha_fwd(geo, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:3 * C])
+    _close(O / mag, o_ref / mag, what="O")          # P is rounded to bf16 before P V: the error scales with |v|
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634               # the kernels keep the LSE in the log2 domain
+    _close(lse, lse_ref.detach(), tol=2e-2, what="lse")
+    dQKV = torch.full((rows, 3 * C + pad_cols), float("nan"), dtype=BF16, device=gpu)
+    k.mha_bwd(geo, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:3 * C], O, lse, dOb.to(gpu),
+              dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:3 * C])
+    gs = float(X.grad.abs().max())
+    _close(dQKV[:, :3 * C] / gs, X.grad / gs, tol=1.5e-2, what="dQKV")
+    if pad_cols:
+        assert torch.isnan(dQKV[:, 3 * C:].float()).all(), "wrote outside the qkv columns"
+
+
+def test_mha_vit_b_video_197_d96(stg, gpu):
+    _run(gpu, P=4, H=8, n=197, D=96)
+
+
+def test_mha_vit_b_audio_49_d96(stg, gpu):
+    _run(gpu, P=6, H=8, n=49, D=96, seed=1)
+
+
+def test_mha_vit_l_257_d64(stg, gpu):
+    _run(gpu, P=2, H=16, n=257, D=64, seed=2)
+
+
+@pytest.mark.parametrize("n", [1, 13, 32, 33, 128, 129])
+def test_mha_ragged_token_counts(stg, gpu, n):
+    _run(gpu, P=3, H=2, n=n, D=96, seed=10 + n)
+    _run(gpu, P=2, H=3, n=n, D=64, seed=20 + n)
+
+
+def test_mha_large_scores_and_padded_buffer(stg, gpu):
+    _run(gpu, P=2, H=4, n=50, D=96, seed=3, mag=5.0, pad_cols=8)
+
+
+def test_mha_rejects_bad_geometry(stg, gpu):
+    from stgcma import kernels as k
+    with pytest.raises(RuntimeError):
+        k.MhaGeom(1, 1, 10, 48, 1.0)
+    geo = k.MhaGeom(2, 2, 10, 64, 0.125)
+    small = torch.zeros(8, 3 * 128, dtype=BF16, device=gpu)
+    with pytest.raises(RuntimeError):
+        k.mha_fwd(geo, small[:, :128], small[:, 128:256], small[:, 256:])
