@@ -2,8 +2,8 @@
 same class names, constructor keywords, forward(a, v, mode), state_dict keys and parameter names.  Parameter containers and
 orchestration only -- the arithmetic runs in libstgcma_hip.so through ..ops_vit; no eager / CPU fallback.
 
-Not carried over: the `clip` / `loratorch` imports (CLIP_AVE.py:7-8; `loratorch` is unused, `clip.load` is only reached with
-a pretrained path -- pass a state_dict through load_state_dict instead) and the dead ablation code.
+Not carried over: the module-level `clip` / `loratorch` imports (CLIP_AVE.py:7-8; `loratorch` is unused, `clip` is imported
+lazily, only when a pretrained directory is given) and the dead ablation code.
 """
 from collections import OrderedDict
 
@@ -143,8 +143,21 @@ class MM_CLIP_AVE(nn.Module):
         if pretrained:
             self.pretrained = pretrained
         if isinstance(self.pretrained, str):
-            raise NotImplementedError("OpenAI-CLIP checkpoint ingestion (clip.load) is not part of this build; convert the "
-                                      "checkpoint once with the reference and load_state_dict() it")
+            self.apply(_init_weights)
+            print(f'load model from: {self.pretrained}')
+            try:
+                import clip                      # OpenAI CLIP package: the reference imports it at module level (CLIP_AVE.py:7)
+            except ImportError as e:
+                raise ImportError("pretrained=<dir> loads OpenAI CLIP weights through the `clip` package (CLIP_AVE.py:817-820), "
+                                  "which is not installed; install it, or convert the checkpoint once and load_state_dict() it") from e
+            name = "ViT-B/16" if self.layers == 12 else "ViT-L/14"
+            clip_model, _ = clip.load(name, device="cpu", download_root=self.pretrained)
+            pretrain_dict = self.ingest_clip_visual_state(clip_model.visual.state_dict())
+            del clip_model
+            msg = self.load_state_dict(pretrain_dict, strict=False)
+            print('Missing keys: {}'.format(msg.missing_keys))
+            print('Unexpected keys: {}'.format(msg.unexpected_keys))
+            print(f"=> loaded successfully '{self.pretrained}'")
         elif self.pretrained is None:
             self.apply(_init_weights)
         else:
@@ -153,6 +166,30 @@ class MM_CLIP_AVE(nn.Module):
             if isinstance(m, Adapter):
                 nn.init.constant_(m.D_fc2.weight, 0)
                 nn.init.constant_(m.D_fc2.bias, 0)
+
+    def ingest_clip_visual_state(self, pretrain_dict):
+        """CLIP image-encoder state_dict -> this model's keys (CLIP_AVE.py:821-850): drop the output projection, audio patch
+        conv = channel SUM of the RGB one, audio positional embedding = the class slot + the centre crop (or bilinear resize when
+        the audio grid is larger) of the 2-D grid of image positional embeddings."""
+        pretrain_dict = dict(pretrain_dict)
+        del pretrain_dict['proj']
+        pretrain_dict['conv1_audio.weight'] = torch.sum(pretrain_dict['conv1.weight'], dim=1).unsqueeze(1)
+        hw = self.oringal_hw
+        ori = pretrain_dict['positional_embedding'].unsqueeze(dim=0)
+        grid = ori[:, 1:, :].detach().reshape(1, self.ori_num_patches, self.embed_dim).transpose(1, 2).reshape(1, self.embed_dim, hw, hw)
+        if self.t_dim <= hw:
+            t0 = int(hw / 2) - int(self.t_dim / 2)
+            grid = grid[:, :, :, t0:t0 + self.t_dim]
+        else:
+            grid = torch.nn.functional.interpolate(grid, size=(hw, self.t_dim), mode='bilinear')
+        if self.f_dim <= hw:
+            f0 = int(hw / 2) - int(self.f_dim / 2)
+            grid = grid[:, :, f0:f0 + self.f_dim, :]
+        else:
+            grid = torch.nn.functional.interpolate(grid, size=(self.f_dim, self.t_dim), mode='bilinear')
+        grid = grid.reshape(1, self.embed_dim, self.num_patches_a).transpose(1, 2)
+        pretrain_dict['positional_embedding_audio'] = torch.cat([ori[:, :1, :].detach(), grid], dim=1).squeeze(dim=0)
+        return pretrain_dict
 
     @torch.jit.ignore
     def no_weight_decay(self):

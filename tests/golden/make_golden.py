@@ -311,6 +311,37 @@ def pretrained_ingest_case(S, tag, cfg, seed, patch_size):
          stats_json=json.dumps(stats), **keep)
 
 
+def clip_ingest_case(Cm, tag, *, layers, embed_dim, patch, res, audio_length, seed):
+    """OpenAI-CLIP checkpoint ingestion of the REFERENCE constructor (CLIP_AVE.py:811-853) with `clip.load` stubbed to hand
+    back a synthetic visual state_dict (the `clip` package is not installed; its only role is to produce that dict)."""
+    import contextlib
+    import io
+    sd_clip = GP.clip_visual_state(embed_dim, res // patch, layers, patch, seed)
+
+    class _Vis:
+        def state_dict(self):
+            return {k: v.clone() for k, v in sd_clip.items()}
+
+    class _Clip:
+        visual = _Vis()
+    sys.modules["clip"].load = lambda name, device="cpu", download_root=None: (_Clip(), None)
+    Cm.clip = sys.modules["clip"]
+    buf = io.StringIO()
+    torch.manual_seed(seed + 1)
+    with contextlib.redirect_stdout(buf):
+        m = Cm.MM_CLIP_AVE(label_dim=5, input_resolution=res, audio_length=audio_length, num_video_frames=2, patch_size=patch,
+                           embed_dim=embed_dim, layers=layers, heads=4, pretrained="/nonexistent/clip", ftmode="fusion")
+    lines = buf.getvalue().splitlines()
+    missing = [ln for ln in lines if ln.startswith("Missing keys: ")][0][len("Missing keys: "):]
+    unexpected = [ln for ln in lines if ln.startswith("Unexpected keys: ")][0][len("Unexpected keys: "):]
+    sd = m.state_dict()
+    loaded = [k for k in sd if k in sd_clip or k in ("conv1_audio.weight", "positional_embedding_audio")]
+    stats = {k: [float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in loaded}
+    save(tag, cfg_json=json.dumps(dict(layers=layers, embed_dim=embed_dim, patch=patch, res=res, audio_length=audio_length,
+                                       seed=seed)), missing=missing, unexpected=unexpected, stats_json=json.dumps(stats),
+         conv1_audio=sd["conv1_audio.weight"], pos_audio=sd["positional_embedding_audio"])
+
+
 def scheduler_case():
     sch = load(os.path.join(REF, "utilities/scheduler.py"), "ref_sched")
     import contextlib
@@ -375,6 +406,11 @@ def main(argv):
         "avqa_tiny_backbone": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone", cfg=AVQA_TINY, B=1, seed=610),
         "swin_pretrained_ingest": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest", SWIN_TINY, 700, [1, 4, 4]),
         "swin_pretrained_ingest_pd2": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest_pd2", SWIN_TINY, 710, [2, 4, 4]),
+        # audio grid 7 x 5 inside the 14 x 14 image grid (centre crop both ways), and 7 x 19 (time axis bilinearly stretched)
+        "clip_pretrained_ingest": lambda: clip_ingest_case(Cm, "clip_pretrained_ingest", layers=12, embed_dim=64, patch=16, res=224,
+                                                           audio_length=1024, seed=720),
+        "clip_pretrained_ingest_long": lambda: clip_ingest_case(Cm, "clip_pretrained_ingest_long", layers=12, embed_dim=64, patch=16,
+                                                                res=224, audio_length=3200, seed=730),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

@@ -116,3 +116,23 @@ def swin2d_checkpoint(state_dict, seed, patch_depth_one=True):
     sd["head.weight"] = torch.randn((7, C_last), generator=g) * 0.1
     sd["head.bias"] = torch.zeros(7)
     return {"model": sd}
+
+
+def clip_visual_state(embed_dim, grid_hw, layers, patch, seed):
+    """A synthetic stand-in for clip.load(...).visual.state_dict(): the keys the reference's ingestion touches or loads
+    (CLIP_AVE.py:821-853) with seeded values -- conv1, class / positional embeddings, ln_pre / ln_post, the transformer's
+    frozen attention / MLP / norms, and the output projection `proj` it deletes."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(s, generator=g) * 0.05
+    sd = {"class_embedding": r(embed_dim), "positional_embedding": r(grid_hw * grid_hw + 1, embed_dim), "proj": r(embed_dim, 512),
+          "conv1.weight": r(embed_dim, 3, patch, patch), "ln_pre.weight": 1 + r(embed_dim), "ln_pre.bias": r(embed_dim),
+          "ln_post.weight": 1 + r(embed_dim), "ln_post.bias": r(embed_dim)}
+    for i in range(layers):
+        pre = f"transformer.resblocks.{i}."
+        sd.update({pre + "attn.in_proj_weight": r(3 * embed_dim, embed_dim), pre + "attn.in_proj_bias": r(3 * embed_dim),
+                   pre + "attn.out_proj.weight": r(embed_dim, embed_dim), pre + "attn.out_proj.bias": r(embed_dim),
+                   pre + "ln_1.weight": 1 + r(embed_dim), pre + "ln_1.bias": r(embed_dim),
+                   pre + "ln_2.weight": 1 + r(embed_dim), pre + "ln_2.bias": r(embed_dim),
+                   pre + "mlp.c_fc.weight": r(4 * embed_dim, embed_dim), pre + "mlp.c_fc.bias": r(4 * embed_dim),
+                   pre + "mlp.c_proj.weight": r(embed_dim, 4 * embed_dim), pre + "mlp.c_proj.bias": r(embed_dim)})
+    return sd
