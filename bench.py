@@ -48,6 +48,12 @@ WORKLOADS = {
                        "fwd+bwd+Adam on 5.6M adapter/head params"),
     "swin_l": (3989.0, "Swin-L + STG-CMA ftmode=fusion, AVE shape, adapter ratios [.5,.25,.125,.0625] (AVE/run_swin_adapt_ave29.sh:52), "
                        "fwd+bwd+Adam on the adapter/head params"),
+    # backbone-only workloads (the AVS decoder / AVQA head are SURVEY 8f, not built): fwd + bwd from seeded upstream gradients on
+    # every output the reference's head consumes + Adam on the adapters; GFLOP figures are analytic approximations
+    "avs_backbone": (843.0, "Swin-B + STG-CMA AVS BACKBONE only (AVS/run_adapt_avs.py:146-160: T=5, adapter ratios [.25,.25,.125,.125]), "
+                            "multi-scale taps + audio feature, synthetic upstream gradients, no decoder"),
+    "avqa_backbone": (4920.0, "Swin-L + STG-CMA AVQA BACKBONE only (AVQA/run_adapt_avqa.py:288-301: T=10, third negative-video stream "
+                              "forward-only), synthetic upstream gradients, no QA head"),
     "vit_b": (1158.7, "ViT-B/16 (CLIP) + STG-CMA ftmode=fusion, AVE shape (10 frames 224^2 + 10 spectrogram segments 102x128), "
                       "fwd+bwd+Adam on the adapter/head params"),
 }
@@ -60,6 +66,16 @@ def build_model(torch, device, workload="swin_b"):
     if workload == "vit_b":
         from stgcma.model import CLIP_AVE as Cm
         m = Cm.MM_CLIP_AVE(**VIT_B)
+    elif workload == "avs_backbone":
+        from stgcma.model import Swin_AVS
+        m = Swin_AVS.SwinTransformer2D_Adapter_AVS(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
+                                                   num_heads=[4, 8, 16, 32], window_size=7, pretrained=None, ftmode="fusion",
+                                                   adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
+    elif workload == "avqa_backbone":
+        from stgcma.model import Swin_AVQA
+        m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(patch_size=[1, 4, 4], img_size=224, num_frames=10, embed_dim=192,
+                                                     depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7, pretrained=None,
+                                                     ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
     else:
         from stgcma.model import Swin_AVE as S
         m = S.SwinTransformer2D_Adapter_New(**(SWIN_L if workload == "swin_l" else SWIN_B))
@@ -204,6 +220,30 @@ def main():
     def step():                                                     # traintest_adapt_ave29.py:136-164
         return recipe.train_step(model, opt, loss_fn, a, v, labels, "fusion")
 
+    if args.workload in ("avs_backbone", "avqa_backbone"):
+        T = 5 if args.workload == "avs_backbone" else 10
+        g = torch.Generator(device=device).manual_seed(99 + rank)
+        vv = torch.randn((args.batch, T, 3, 224, 224), generator=g, device=device)          # 'b t c h w' (AVS :1793 / AVQA :1742)
+        aa = torch.randn((args.batch, T, 224, 224), generator=g, device=device) * 0.5
+        vn = torch.randn((args.batch, T, 3, 224, 224), generator=g, device=device) if args.workload == "avqa_backbone" else None
+        ups = {}
+
+        def step():                                                 # noqa: F811
+            if vn is None:
+                ms, a_feat = model.forward_features(aa, vv)
+                outs = list(ms) + [a_feat]
+            else:
+                outs = [o for o in model.forward_features(aa, vv, vn) if o.requires_grad]
+            loss = 0.
+            for i, o in enumerate(outs):
+                if i not in ups:
+                    ups[i] = torch.randn(o.shape, generator=g, device=device) * 1e-3
+                loss = loss + (o * ups[i]).sum()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -235,7 +275,8 @@ def main():
         achieved = gp["sampled_flops"] / (gp["sampled_ms"] * 1e-3) / 1e12 if gp["sampled_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1>")
         out = {
-            "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B", "swin_l": "Swin-L", "vit_b": "ViT-B/16"}[args.workload] + "+STG-CMA AVE-shape", "value": round(value, 3), "unit": "clips/s",
+            "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
+                                              "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone"}[args.workload], "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,

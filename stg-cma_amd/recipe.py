@@ -41,7 +41,8 @@ def build_optimizer(model, lr, head_lr=1.0, weight_decay=5e-7, betas=(0.95, 0.99
     adapters / gates / temporal tables at `lr`, the newly initialised mlp_head at lr * head_lr."""
     import torch
     adapt, head = apply_freeze(model)
-    return torch.optim.Adam([{"params": adapt, "lr": lr}, {"params": head, "lr": lr * head_lr}], weight_decay=weight_decay, betas=betas)
+    groups = [{"params": adapt, "lr": lr}] + ([{"params": head, "lr": lr * head_lr}] if head else [])   # backbones carry no mlp_head
+    return torch.optim.Adam(groups, weight_decay=weight_decay, betas=betas)
 
 
 def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, global_step=0):
