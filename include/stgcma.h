@@ -209,6 +209,9 @@ int stg_tattn_bwd(const stg_tattn_args* a, const void* dO, int64_t lddo, void* d
  * (one leading dimension), head h at columns h*D.  O = softmax(scale * Q K^T) V; lse (fp32 [P, H, n]) is saved in the
  * log2 domain for the backward.  stg_mha_bwd runs two kernels (dQ, which also fills the caller's `delta` workspace
  * fp32 [P, H, n] = rowsum(dO * O), then dK/dV) and writes dQ, dK, dV with the addressing of Q, K, V.
+ * The same kernels serve the frame-global cross-modal attention of wide adapters (Swin_AVE.py:801-805: H = 1, scale 1, K and V
+ * the SAME tensor = the other modality's hidden states; d_h = 96 in Swin-L, 64 in Swin-B stage 3): pass K == V and, in the
+ * backward, dV == NULL -- dK then receives the gradient of the shared tensor (dK + dV).
  */
 typedef struct {
     const void* Q; const void* K; const void* V; int64_t ld;

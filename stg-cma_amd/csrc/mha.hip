@@ -1,5 +1,6 @@
 // Multi-head self-attention core of the CLIP ViT blocks (nn.MultiheadAttention inside ResidualAttentionBlock.attention,
-// CLIP_AVE.py:106-108, spatial calls at :379-383): P frames x H heads, n tokens per frame (197 video / 49 audio for ViT-B/16,
+// CLIP_AVE.py:106-108, spatial calls at :379-383) -- and, with H = 1, K = V and scale 1, the frame-global cross-modal attention
+// of wide adapters (softmax(h_v h_a^T) h_a, Swin_AVE.py:801-805; d_h = 96 in every Swin-L stage, 64 in Swin-B stage 3): P frames x H heads, n tokens per frame (197 video / 49 audio for ViT-B/16,
 // 257 for ViT-L/14), head dim 64 or 96 (the reference runner builds ViT-B with heads = 8 -> 96, AVE/run_adapt_ave29.py:137), no
 // mask, no bias.  Token i of frame p is row p*n + i of the fused qkv buffer.
 //
@@ -350,6 +351,18 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
     }
     if (key < a.n) {
         bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
+        if (a.dV == nullptr) {                         // K and V are ONE tensor (cross-modal attention): its gradient is dK + dV
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2 w;
+                    w.x = pack_bf2(fmaf(dk[dt][4 * g4 + 0], a.scale, dv[dt][4 * g4 + 0]), fmaf(dk[dt][4 * g4 + 1], a.scale, dv[dt][4 * g4 + 1]));
+                    w.y = pack_bf2(fmaf(dk[dt][4 * g4 + 2], a.scale, dv[dt][4 * g4 + 2]), fmaf(dk[dt][4 * g4 + 3], a.scale, dv[dt][4 * g4 + 3]));
+                    *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
+                }
+            return;
+        }
         bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -413,7 +426,8 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     MP p = {};
     int rc = fill(f, p, "stg_mha_bwd");
     if (rc) return rc;
-    STG_CHECK(dO && dQ && dK && dV && delta, -1, "stg_mha_bwd: null pointer");
+    STG_CHECK(dO && dQ && dK && delta, -1, "stg_mha_bwd: null pointer");
+    STG_CHECK(dV != nullptr || f->K == f->V, -2, "stg_mha_bwd: dV == NULL (shared K = V gradient) needs K == V");
     STG_CHECK(lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_mha_bwd: bad leading dims");
     STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
               "stg_mha_bwd: misaligned pointers");

@@ -699,11 +699,14 @@ def mha_fwd(g, Q, K, V, out=None):
 
 
 def mha_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
-    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+    """dV=None: K and V are one tensor (cross-modal attention) and dK receives its whole gradient dK + dV."""
+    if dV is None and K.data_ptr() != V.data_ptr():
+        raise RuntimeError("mha_bwd: dV=None needs K and V to be the same tensor")
+    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK")) + (((dV, "dV"),) if dV is not None else ()):
         _chk2d(t, name, BF16)
         if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
             raise RuntimeError(f"mha_bwd {name}: needs >= {g.rows} rows x {g.H * g.D} columns")
-    if not (_ld(dQ) == _ld(dK) == _ld(dV)):
+    if not (_ld(dQ) == _ld(dK) == (_ld(dV) if dV is not None else _ld(dK))):
         raise RuntimeError("mha_bwd: dQ, dK, dV must share one leading dimension")
     a = _mha_fill(g, Q, K, V, O, lse)
     delta = torch.empty((g.P, g.H, g.n), dtype=F32, device=Q.device)

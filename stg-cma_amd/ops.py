@@ -176,6 +176,7 @@ def geom(device, H, W, ws, shift, T):
 _wintab_cache = {}   # id(bias-table parameter) -> (weakref, tag, (bm, bmT))
 USE_WINATTN = _os.environ.get("STG_WINATTN", "1") != "0"     # 0 = route W-MSA through the generic attention kernels (A/B knob)
 USE_TATTN = _os.environ.get("STG_TATTN", "1") != "0"         # 0 = route temporal attention through the generic kernels
+USE_MHA_X = _os.environ.get("STG_MHA_X", "1") != "0"         # 0 = wide frame-global cross-modal attention through the generic kernels
 
 
 def win_tables(tab_p, index, mask, n):
@@ -391,6 +392,12 @@ def _xattn_geom(spec, BT, dh, window, g):
 def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=None):
     """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808).
     geoms = (video-queries geometry, audio-queries geometry) when the two token counts differ (ViT)."""
+    if geoms is None and not window and USE_MHA_X and K.mha_supported(spec.N, hv.shape[1]):
+        # wide adapters (d_h = 64 / 96): the frame-global pair runs on the flash kernels of mha.hip (H = 1, K = V, scale 1)
+        mg = K.MhaGeom(BT, 1, spec.N, hv.shape[1], 1.0)
+        rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
+        ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
+        return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a), (rv, ra, lse_v, lse_a, mg)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
     ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
@@ -401,14 +408,21 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
 
 def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None):
     """Returns (dhv, dha) = gradients wrt the pre-fusion hidden states."""
-    rv, ra, lse_v, lse_a = saved
-    ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
+    mg = saved[4] if len(saved) == 5 else None
+    rv, ra, lse_v, lse_a = saved[:4]
+    if mg is None:
+        ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     if dgate_v is None:
         dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
     if dgate_a is None:
         dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
     drv = K.gate_bwd(dhv2, rv, gate_v, dgate_v)
     dra = K.gate_bwd(dha2, ra, gate_a, dgate_a)
+    if mg is not None:
+        dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
+        K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
+        K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
+        return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
     dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
     dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
     return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)

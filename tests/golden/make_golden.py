@@ -393,6 +393,12 @@ def main(argv):
                                                     ratio=0.25, mode="video_adapt", seed=150),
         "swin_block_audio": lambda: swin_block_case(S, "swin_block_audio", dim=64, res=14, T=2, B=2, heads=2, shift=3, t_attn=False,
                                                     ratio=0.25, mode="audio_adapt", seed=160),
+        # wide adapters (Swin-L d_h = 96 in every stage, Swin-B stage 3 / AVS ratios d_h = 64): the frame-global cross-modal pair
+        # then runs on the flash kernels of mha.hip; 196 tokens = 6 full 32-row tiles + a 4-row tail
+        "swin_block_wide64": lambda: swin_block_case(S, "swin_block_wide64", dim=128, res=14, T=2, B=1, heads=4, shift=3, t_attn=True,
+                                                     ratio=0.5, mode="fusion_adapt", seed=170),
+        "swin_block_wide96": lambda: swin_block_case(S, "swin_block_wide96", dim=192, res=14, T=2, B=2, heads=6, shift=0, t_attn=False,
+                                                     ratio=0.5, mode="fusion_adapt", seed=180),
         "swin_tiny_fusion": lambda: swin_model_case(S, "swin_tiny_fusion", cfg=SWIN_TINY, B=1, mode="fusion", seed=200),
         "swin_tiny_multimodal": lambda: swin_model_case(S, "swin_tiny_multimodal", cfg=SWIN_TINY, B=1, mode="multimodal", seed=210),
         "swin_tiny_videoonly": lambda: swin_model_case(S, "swin_tiny_videoonly", cfg=SWIN_TINY, B=1, mode="videoonly", seed=220),

@@ -77,3 +77,29 @@ def test_mha_rejects_bad_geometry(stg, gpu):
     small = torch.zeros(8, 3 * 128, dtype=BF16, device=gpu)
     with pytest.raises(RuntimeError):
         k.mha_fwd(geo, small[:, :128], small[:, 128:256], small[:, 256:])
+
+
+@pytest.mark.parametrize("D,n", [(96, 196), (64, 49), (96, 3136)])
+def test_mha_cross_modal_shared_kv(stg, gpu, D, n):
+    """Frame-global cross-modal attention of a wide adapter: r = softmax(h_q h_kv^T) h_kv, no scale, one head, K and V the SAME
+    tensor (Swin_AVE.py:801-805); dK of the kernel = the whole gradient of h_kv."""
+    from stgcma import kernels as k
+    P = 2 if n > 1000 else 3
+    g = torch.Generator().manual_seed(n + D)
+    hq_b = (torch.randn(P * n, D, generator=g) * 0.35).to(BF16)
+    hk_b = (torch.randn(P * n, D, generator=g) * 0.35).to(BF16)
+    dO_b = torch.randn(P * n, D, generator=g).to(BF16)
+    hq = hq_b.float().requires_grad_(True)
+    hk = hk_b.float().requires_grad_(True)
+    s = hq.view(P, n, D) @ hk.view(P, n, D).transpose(1, 2)
+    r_ref = (torch.softmax(s, -1) @ hk.view(P, n, D)).reshape(P * n, D)
+    r_ref.backward(dO_b.float())
+    geo = k.MhaGeom(P, 1, n, D, 1.0)
+    q, kv = hq_b.to(gpu), hk_b.to(gpu)
+    r, lse = k.mha_fwd(geo, q, kv, kv)
+    _close(r, r_ref, what="r")
+    dq = torch.full_like(q, float("nan")); dkv = torch.full_like(kv, float("nan"))
+    k.mha_bwd(geo, q, kv, kv, r, lse, dO_b.to(gpu), dQ=dq, dK=dkv, dV=None)
+    gs = float(max(hq.grad.abs().max(), hk.grad.abs().max()))
+    _close(dq / gs, hq.grad / gs, tol=1.5e-2, what="dq")
+    _close(dkv / gs, hk.grad / gs, tol=1.5e-2, what="dkv")

@@ -117,7 +117,8 @@ def test_swin_tiny_other_modes_match_reference(stg, gpu, tag, mode):
     _cmp(_flat_grads(m, names), z["grads"], f"{tag} grads", max_rel=5e-2, l2_rel=3e-2)
 
 
-@pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3", "swin_block_nofusion"])
+@pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3", "swin_block_nofusion",
+                                 "swin_block_wide64", "swin_block_wide96"])
 def test_fusion_block_matches_reference(stg, gpu, tag):
     from stgcma.model import Swin_AVE as S
     from params import seeded_tensor

@@ -25,7 +25,8 @@ def _grads(P, names):
 
 
 @pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3",
-                                 "swin_block_nofusion", "swin_block_video", "swin_block_audio"])
+                                 "swin_block_nofusion", "swin_block_video", "swin_block_audio", "swin_block_wide64",
+                                 "swin_block_wide96"])
 def test_swin_block_matches_reference(tag):
     z, cfg, shapes, names = load_case(tag)
     P = build_state(shapes, cfg["seed"], kind="swin_block", T=cfg["T"], res=cfg["res"])
