@@ -70,7 +70,7 @@ int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t ldx,
                  const float* row_scale, int64_t rs_outer, int64_t rs_inner,   /* optional DropPath scale on dY rows */
                  void* stream);
 
-/* Same contract, without memory-side atomics, for the shapes of the adapter path (one operand <= 64 columns wide, M >= 4096,
+/* Same contract, without memory-side atomics, for the shapes of the adapter path (one operand <= 96 columns wide, M >= 4096,
  * 16-byte aligned operands): row splits leave partial tiles in a caller-owned fp32 workspace `ws`, and a second kernel sums
  * them into dW / db with a plain read-modify-write (dW / db must not be written concurrently by another stream).
  * stg_wgrad_ws_floats returns the workspace size in floats this path needs for (M, N1, N2), 0 when the shape is not eligible;

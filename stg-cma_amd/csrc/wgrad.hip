@@ -1,5 +1,5 @@
 // Weight gradient of the trainable adapter / head Linears (autograd of Swin_AVE.py:15-16 D_fc1 / D_fc2) for the shapes that
-// matter: a huge token dimension M (31 K .. 1 M rows), one NARROW operand (adapter hidden width, <= 64 columns) and one wide
+// matter: a huge token dimension M (31 K .. 1 M rows), one NARROW operand (adapter hidden width, <= 96 columns) and one wide
 // operand (the channel dimension):   D[na, nb] = sum_m A[m, na] * B[m, nb].
 //
 // The op is a pure HBM stream (~1 KB of operands per 8 MFMAs).  What the atomic kernel in gemm.hip pays for is (i) 16-bit
@@ -71,7 +71,7 @@ template <int NT1>
 __global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(Wg2 p) {   // 48 / 64 wide: 160+ accumulator registers, one wave per SIMD
     constexpr int TA = 16 * NT1;
     constexpr int NACC = NT1 * NTB + NTB;
-    constexpr int CHA = NT1 == 3 ? 4 : NT1;                        // A-tile row pitch in 32-byte chunks (a power of two)
+    constexpr int CHA = NT1 > 4 ? 8 : (NT1 == 3 ? 4 : NT1);        // A-tile row pitch in 32-byte chunks (a power of two)
     constexpr int OPER = WK * WNB + WK * 16 * CHA;                 // bf16 slots of operand LDS per wave
     constexpr int FOLD = NACC * 256 * 2;                           // bf16 slots one wave's accumulators take (fp32)
     constexpr int SMEM = 4 * OPER > FOLD ? 4 * OPER : FOLD;
@@ -270,9 +270,9 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
     const int NA = y_narrow ? N1 : N2, NB = y_narrow ? N2 : N1;
     const bool aligned = (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY & 15) == 0) && (((uintptr_t)X & 15) == 0) &&
                          lddy >= ((N1 + 7) & ~7) && ldx >= ((N2 + 7) & ~7);
-    if (!aligned || NA > 64 || M < 4096) return pl;
+    if (!aligned || NA > 96 || M < 4096) return pl;
     pl.ok = true; pl.y_narrow = y_narrow;
-    pl.nt1 = NA <= 16 ? 1 : (NA <= 32 ? 2 : (NA <= 48 ? 3 : 4));
+    pl.nt1 = (NA + 15) / 16;                       // 1 .. 6 column tiles of the narrow operand
     pl.ncg = (NB + WNB - 1) / WNB;
     // ~2 blocks per CU, and at least 4 chunks per wave so that the partial tile stays a small fraction of the operand bytes
     int64_t S = 512 / pl.ncg;
@@ -320,7 +320,9 @@ extern "C" int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int6
     if (pl.nt1 == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (pl.nt1 == 2) hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (pl.nt1 == 3) hipLaunchKernelGGL(wgrad_ws_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wgrad_ws_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (pl.nt1 == 4) hipLaunchKernelGGL(wgrad_ws_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (pl.nt1 == 5) hipLaunchKernelGGL(wgrad_ws_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_ws_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     Wr2 r;
     r.ws = ws; r.S = pl.S; r.ncg = pl.ncg; r.nt1 = pl.nt1;

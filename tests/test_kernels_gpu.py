@@ -143,7 +143,7 @@ def test_gemm_strided_views(stg, gpu):
                                      # the workspace (no-atomics) path: narrow operand <= 32, M >= 4096; either operand narrow,
                                      # ragged row / column tails, several column groups
                                      (4096, 16, 128), (20000, 32, 512), (7777, 512, 32), (5001, 24, 200), (62720, 32, 512),
-                                     (9000, 256, 16), (4100, 29, 512), (8000, 48, 768), (6000, 768, 48), (15680, 64, 1024), (4500, 1024, 64)])
+                                     (9000, 256, 16), (4100, 29, 512), (8000, 48, 768), (6000, 768, 48), (15680, 64, 1024), (4500, 1024, 64), (20000, 96, 768), (9000, 192, 96), (5000, 80, 384)])
 def test_wgrad(stg, gpu, M, N1, N2):
     from stgcma import kernels as k
     g = torch.Generator().manual_seed(M + N1 + N2)
