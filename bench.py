@@ -54,6 +54,9 @@ WORKLOADS = {
                             "multi-scale taps + audio feature, synthetic upstream gradients, no decoder"),
     "avqa_backbone": (4920.0, "Swin-L + STG-CMA AVQA BACKBONE only (AVQA/run_adapt_avqa.py:288-301: T=10, third negative-video stream "
                               "forward-only), synthetic upstream gradients, no QA head"),
+    "avqa": (4920.0, "Swin-L + STG-CMA AVQA shape, FULL model (AVQA/run_adapt_avqa.py:288-301): backbone with the negative-video stream + "
+                     "QA head (question LSTM, grounding, single-query attentions), loss = CE(qa) + 0.5 CE(match) "
+                     "(traintest_adapt_avqa.py:173-179), fwd+bwd+Adam on adapters + avqatask_* (no fp8 path)"),
     "vit_b": (1158.7, "ViT-B/16 (CLIP) + STG-CMA ftmode=fusion, AVE shape (10 frames 224^2 + 10 spectrogram segments 102x128), "
                       "fwd+bwd+Adam on the adapter/head params"),
 }
@@ -71,7 +74,7 @@ def build_model(torch, device, workload="swin_b"):
         m = Swin_AVS.SwinTransformer2D_Adapter_AVS(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
                                                    num_heads=[4, 8, 16, 32], window_size=7, pretrained=None, ftmode="fusion",
                                                    adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
-    elif workload == "avqa_backbone":
+    elif workload in ("avqa_backbone", "avqa"):
         from stgcma.model import Swin_AVQA
         m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(patch_size=[1, 4, 4], img_size=224, num_frames=10, embed_dim=192,
                                                      depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7, pretrained=None,
@@ -220,6 +223,23 @@ def main():
     def step():                                                     # traintest_adapt_ave29.py:136-164
         return recipe.train_step(model, opt, loss_fn, a, v, labels, "fusion")
 
+    if args.workload == "avqa":
+        g = torch.Generator(device=device).manual_seed(77 + rank)
+        vv = torch.randn((args.batch, 10, 3, 224, 224), generator=g, device=device)
+        vn = torch.randn((args.batch, 10, 3, 224, 224), generator=g, device=device)
+        aa = torch.randn((args.batch, 10, 224, 224), generator=g, device=device) * 0.5
+        qq = torch.randint(0, 93, (args.batch, 14), generator=g, device=device)
+        ans = torch.randint(0, 42, (args.batch,), generator=g, device=device)
+        match = torch.tensor([1, 0] * (args.batch * 10), device=device)              # batch_organize: posi / nega interleaved
+
+        def step():                                                 # noqa: F811   traintest_adapt_avqa.py:168-185
+            out_qa, mp, mn = model(aa, vv, vn, qq, "fusion")
+            loss = loss_fn(out_qa, ans) + 0.5 * loss_fn(torch.stack((mp, mn), dim=1).reshape(-1, 2), match)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
     if args.workload in ("avs_backbone", "avqa_backbone"):
         T = 5 if args.workload == "avs_backbone" else 10
         g = torch.Generator(device=device).manual_seed(99 + rank)
@@ -276,7 +296,8 @@ def main():
         traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1>")
         out = {
             "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
-                                              "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone"}[args.workload], "value": round(value, 3), "unit": "clips/s",
+                                              "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
+                                              "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 103
+#define STG_VERSION 104
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -271,6 +271,39 @@ int stg_bias_scatter(const float* dbias, const int64_t* index, float* dtable, in
  * pos[1+i] + temb[t]; patch bf16 [BT*np, D] (conv-as-GEMM output), pos fp32 [np+1, D], temb fp32 [T, D], out fp32. */
 int stg_vit_embed(const void* patch, const float* cls, const float* pos, const float* temb, float* out, int64_t BT, int T,
                   int np, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AVQA question-answering head (AVQA/model/Swin_AVQAModel_V1.py:37-59 QstEncoder, :1768-1903 forward): the small kernels
+ * around its GEMMs (which run on stg_gemm_nt / stg_wgrad_tn).  bf16 storage, fp32 arithmetic.
+ */
+/* y = relu(x) (op 0) / tanh(x) (op 1)  (F.relu :1783,1821-1823; nn.Tanh :42,50,1817,1886,1891); the backward takes the INPUT x */
+int stg_unary_fwd(int op, const void* x, void* y, int64_t numel, void* stream);
+int stg_unary_bwd(int op, const void* x, const void* dy, void* dx, int64_t numel, void* stream);
+/* out = a * b (torch.mul(feat, qst_feature), :1890) */
+int stg_mul(const void* a, const void* b, void* out, int64_t numel, void* stream);
+/* nn.Embedding (:41,48): out bf16 [n, E] = table fp32 [V, E][idx];  dtable[idx] += dout (fp32 atomics) */
+int stg_embed_fwd(const float* table, const int64_t* idx, void* out, int64_t n, int V, int E, void* stream);
+int stg_embed_bwd(const void* dout, const int64_t* idx, float* dtable, int64_t n, int V, int E, void* stream);
+/* nn.LSTM cell (:44,52): gates fp32 [B, 4H] in (i, f, g, o) order = x W_ih^T + b_ih + h W_hh^T + b_hh;  c' = f c + i g,
+ * h' = o tanh(c').  c fp32, h bf16.  Backward: dh (bf16) / dc (fp32) may be NULL; dgates bf16 [B, 4H], dc_prev fp32. */
+int stg_lstm_cell_fwd(const float* gates, const float* c_prev, float* c, void* h, int64_t B, int H, void* stream);
+int stg_lstm_cell_bwd(const float* gates, const float* c_prev, const float* c, const void* dh, const float* dc,
+                      void* dgates, float* dc_prev, int64_t B, int H, void* stream);
+/* Audio-visual grounding of one frame (:1797-1815, :1829-1843): V fp32 [F, n, C] visual tokens (n <= 64), a bf16 [F, C];
+ * vmean = mean_j V_j (AdaptiveAvgPool2d), grd = sum_j softmax_j(V^_j . a^) V^_j with ^ = F.normalize(dim = C).
+ * p, rnorm fp32 [F, n] and ra fp32 [F] are saved for the backward.  dV (fp32 [F, n, C], written) may be NULL (negative clip),
+ * dvmean may be NULL. */
+int stg_grounding_fwd(const float* V, const void* a, void* vmean, void* grd, float* p, float* rnorm, float* ra,
+                      int64_t F, int n, int C, void* stream);
+int stg_grounding_bwd(const float* V, const void* a, const float* p, const float* rnorm, const float* ra,
+                      const void* dvmean, const void* dgrd, float* dV, void* da, int64_t F, int n, int C, void* stream);
+/* nn.MultiheadAttention core with ONE query per batch element (:1866-1880): q bf16 [B, H*hd], k / v bf16 [T, B, H*hd] (already
+ * projected), drop fp32 [B, H, T] = Bernoulli(keep) / keep or NULL; o = sum_t (softmax_t(scale q.k_t) * drop)_t v_t; p fp32
+ * [B, H, T] (pre-dropout) saved.  T <= 64. */
+int stg_mha1_fwd(const void* q, const void* k, const void* v, const float* drop, void* o, float* p, int B, int H, int T,
+                 int hd, float scale, void* stream);
+int stg_mha1_bwd(const void* q, const void* k, const void* v, const float* drop, const float* p, const void* dout,
+                 void* dq, void* dk, void* dv, int B, int H, int T, int hd, float scale, void* stream);
 
 #ifdef __cplusplus
 }

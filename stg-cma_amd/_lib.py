@@ -141,10 +141,21 @@ SIGNATURES = {
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_unary_fwd": (C.c_int, [C.c_int, c_vp, c_vp, c_i64, c_vp]),
+    "stg_unary_bwd": (C.c_int, [C.c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_mul": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_embed_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_embed_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_lstm_cell_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
+    "stg_lstm_cell_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
+    "stg_grounding_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_grounding_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_mha1_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_vp]),
+    "stg_mha1_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_vp]),
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 103
+ABI_VERSION = 104
 _lib = None
 
 

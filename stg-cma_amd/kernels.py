@@ -726,3 +726,132 @@ def vit_embed(patch, cls, pos, temb, BT, T):
     out = torch.empty((BT * n, D), dtype=F32, device=patch.device)
     _lib.check(_lib.lib().stg_vit_embed(_p(patch), _p(cls), _p(pos), _p(temb), _p(out), BT, T, np_, D, _stream()), "stg_vit_embed")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ AVQA head kernels (head.hip)
+RELU, TANH = 0, 1
+
+
+def unary_fwd(op, x):
+    _chk_flat(x, "x")
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().stg_unary_fwd(int(op), _p(x), _p(y), x.numel(), _stream()), "stg_unary_fwd")
+    return y
+
+
+def unary_bwd(op, y, dy):
+    _chk_flat(y, "y"); _chk_flat(dy, "dy")
+    if y.numel() != dy.numel():
+        raise RuntimeError("unary_bwd: size mismatch")
+    dx = torch.empty_like(y)
+    _lib.check(_lib.lib().stg_unary_bwd(int(op), _p(y), _p(dy), _p(dx), y.numel(), _stream()), "stg_unary_bwd")
+    return dx
+
+
+def mul(a, b):
+    _chk_flat(a, "a"); _chk_flat(b, "b")
+    if a.numel() != b.numel():
+        raise RuntimeError("mul: size mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().stg_mul(_p(a), _p(b), _p(out), a.numel(), _stream()), "stg_mul")
+    return out
+
+
+def embed_fwd(table, idx):
+    _chk_flat(table, "table", F32); _chk_flat(idx, "idx", torch.int64)
+    V, E = table.shape
+    out = torch.empty((idx.numel(), E), dtype=BF16, device=table.device)
+    _lib.check(_lib.lib().stg_embed_fwd(_p(table), _p(idx), _p(out), idx.numel(), V, E, _stream()), "stg_embed_fwd")
+    return out
+
+
+def embed_bwd(dout, idx, dtable):
+    _chk_flat(dout, "dout"); _chk_flat(idx, "idx", torch.int64); _chk_flat(dtable, "dtable", F32)
+    V, E = dtable.shape
+    if dout.numel() != idx.numel() * E:
+        raise RuntimeError("embed_bwd: size mismatch")
+    _lib.check(_lib.lib().stg_embed_bwd(_p(dout), _p(idx), _p(dtable), idx.numel(), V, E, _stream()), "stg_embed_bwd")
+
+
+def lstm_cell_fwd(gates, c_prev):
+    _chk_flat(gates, "gates", F32); _chk_flat(c_prev, "c_prev", F32)
+    B, H = c_prev.shape
+    if tuple(gates.shape) != (B, 4 * H):
+        raise RuntimeError("lstm_cell_fwd: gates must be [B, 4H]")
+    c = torch.empty_like(c_prev)
+    h = torch.empty((B, H), dtype=BF16, device=gates.device)
+    _lib.check(_lib.lib().stg_lstm_cell_fwd(_p(gates), _p(c_prev), _p(c), _p(h), B, H, _stream()), "stg_lstm_cell_fwd")
+    return h, c
+
+
+def lstm_cell_bwd(gates, c_prev, c, dh, dc):
+    B, H = c_prev.shape
+    for t, n, dt in ((gates, "gates", F32), (c_prev, "c_prev", F32), (c, "c", F32)):
+        _chk_flat(t, n, dt)
+    if dh is not None:
+        _chk_flat(dh, "dh")
+    if dc is not None:
+        _chk_flat(dc, "dc", F32)
+    dgates = torch.empty((B, 4 * H), dtype=BF16, device=gates.device)
+    dc_prev = torch.empty_like(c_prev)
+    _lib.check(_lib.lib().stg_lstm_cell_bwd(_p(gates), _p(c_prev), _p(c), _p(dh), _p(dc), _p(dgates), _p(dc_prev), B, H, _stream()),
+               "stg_lstm_cell_bwd")
+    return dgates, dc_prev
+
+
+def grounding_fwd(V, a):
+    """V fp32 [F, n, C], a bf16 [F, C] -> (vmean bf16 [F, C], grd bf16 [F, C], saved = (p, rnorm, ra))."""
+    _chk_flat(V, "V", F32); _chk_flat(a, "a")
+    Fr, n, Cc = V.shape
+    if tuple(a.shape) != (Fr, Cc) or n > 64:
+        raise RuntimeError("grounding_fwd: a must be [F, C] and n <= 64")
+    vmean = torch.empty((Fr, Cc), dtype=BF16, device=V.device)
+    grd = torch.empty_like(vmean)
+    p = torch.empty((Fr, n), dtype=F32, device=V.device)
+    rn = torch.empty_like(p)
+    ra = torch.empty((Fr,), dtype=F32, device=V.device)
+    _lib.check(_lib.lib().stg_grounding_fwd(_p(V), _p(a), _p(vmean), _p(grd), _p(p), _p(rn), _p(ra), Fr, n, Cc, _stream()),
+               "stg_grounding_fwd")
+    return vmean, grd, (p, rn, ra)
+
+
+def grounding_bwd(V, a, saved, dvmean, dgrd, want_dV=True):
+    Fr, n, Cc = V.shape
+    p, rn, ra = saved
+    _chk_flat(dgrd, "dgrd")
+    if dvmean is not None:
+        _chk_flat(dvmean, "dvmean")
+    dV = torch.empty_like(V) if want_dV else None
+    da = torch.empty_like(a)
+    _lib.check(_lib.lib().stg_grounding_bwd(_p(V), _p(a), _p(p), _p(rn), _p(ra), _p(dvmean), _p(dgrd), _p(dV), _p(da), Fr, n, Cc,
+                                            _stream()), "stg_grounding_bwd")
+    return dV, da
+
+
+def mha1_fwd(q, k, v, drop, H):
+    """q bf16 [B, E], k / v bf16 [T*B, E] (row t*B + b), drop fp32 [B, H, T] or None -> (o bf16 [B, E], p fp32 [B, H, T])."""
+    _chk_flat(q, "q"); _chk_flat(k, "k"); _chk_flat(v, "v")
+    B, E = q.shape
+    T = k.shape[0] // max(B, 1)
+    if k.shape != v.shape or k.shape[0] != T * B or k.shape[1] != E or E % H or T > 64:
+        raise RuntimeError("mha1_fwd: bad shapes")
+    if drop is not None:
+        _chk_flat(drop, "drop", F32)
+        if drop.numel() != B * H * T:
+            raise RuntimeError("mha1_fwd: drop must be [B, H, T]")
+    hd = E // H
+    o = torch.empty_like(q)
+    p = torch.empty((B, H, T), dtype=F32, device=q.device)
+    _lib.check(_lib.lib().stg_mha1_fwd(_p(q), _p(k), _p(v), _p(drop), _p(o), _p(p), B, H, T, hd, hd ** -0.5, _stream()), "stg_mha1_fwd")
+    return o, p
+
+
+def mha1_bwd(q, k, v, drop, p, dout, H):
+    _chk_flat(dout, "dout")
+    B, E = q.shape
+    T = k.shape[0] // max(B, 1)
+    hd = E // H
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _lib.check(_lib.lib().stg_mha1_bwd(_p(q), _p(k), _p(v), _p(drop), _p(p), _p(dout), _p(dq), _p(dk), _p(dv), B, H, T, hd, hd ** -0.5,
+                                       _stream()), "stg_mha1_bwd")
+    return dq, dk, dv

@@ -360,6 +360,8 @@ class SwinTransformer2D_Adapter_New(nn.Module):
     def _flat_tensors(self):
         names, tensors = [], []
         for n, p in self.named_parameters():
+            if n.startswith(("avqatask_", "avstask_")):      # task heads of the AVQA / AVS mirrors: not backbone tensors
+                continue
             names.append(n)
             tensors.append(p)
         for n, b in self.named_buffers():

@@ -6,8 +6,14 @@ The AVQA blocks carry a third stream: the frames of a NEGATIVE clip ride through
 PatchMerging (:1150-1154).  Nothing trainable sits on or behind that stream, so it runs forward-only next to the
 (video, audio) fusion stream, sharing its bf16 weight shadows and window tables.
 `forward_features(a, v, v_nega)` = lines :1742-1766 of the reference forward: (f_v, f_a, visual_nega) = norm of each stream,
-[(B T), 49, C_last] fp32 -- the inputs of the QA head (question LSTM, grounding, fusion MLPs; `avqatask_*`, :1768-1903), which
-is SURVEY section 8f rank 2 and not part of this build: `forward` raises.
+[(B T), 49, C_last] fp32 -- the inputs of the QA head.
+
+The QA head (`avqatask_*`: question LSTM encoder, audio-visual grounding on the positive and the negative clip, two
+single-query multi-head attentions, fusion MLPs; ctor :1420-1473, forward :1768-1903) is here too, under the reference's
+module names, run by ..ops_head on libstgcma_hip.so; its widths are the reference's hard-coded 1536 (= Swin-L's last stage),
+so `forward(a, v, v_nega, question, mode)` needs embed_dim = 192.  Not carried over: the grounding-pretraining checkpoint
+ingestion (`grounding_pretrained`, :1520-1541 -- load such weights with load_state_dict) and the fp8 weight path of
+BASELINE.json config 5.
 """
 import torch
 import torch.nn as nn
@@ -28,8 +34,39 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
                          norm_layer=norm_layer, ape=ape, patch_norm=patch_norm, t_relative=t_relative,
                          use_checkpoint=use_checkpoint, ftmode=ftmode, adapter_mlp_ratio=adapter_mlp_ratio)
         self.grounding_pretrained = grounding_pretrained
-        del self.mlp_head                       # the QA head replaces it in the reference; out of scope here
+        if grounding_pretrained is not None:
+            raise NotImplementedError("grounding_pretrained (:1520-1541): load the converted avqatask_fc_* weights with load_state_dict()")
+        del self.mlp_head                       # the QA head replaces it in the reference (:1420-1473)
         del self.avgpool
+        self._build_qa_head()
+
+    def _build_qa_head(self):
+        """Parameter containers of the reference's QA head under its names (Swin_AVQAModel_V1.py:1420-1473); nn.LSTM /
+        nn.MultiheadAttention / nn.Embedding only HOLD the tensors here, the arithmetic is ops_head's."""
+        Dh = 1536
+        self.avqatask_fc_a2 = nn.Linear(Dh, Dh)
+        self.avqatask_fc_fusion = nn.Linear(Dh + Dh, Dh)
+        self.avqatask_linear11 = nn.Linear(Dh, Dh)
+        self.avqatask_dropout1 = nn.Dropout(0.1)
+        self.avqatask_linear12 = nn.Linear(Dh, Dh)
+        self.avqatask_linear21 = nn.Linear(Dh, Dh)
+        self.avqatask_dropout2 = nn.Dropout(0.1)
+        self.avqatask_linear22 = nn.Linear(Dh, Dh)
+        self.avqatask_norm1 = nn.LayerNorm(Dh)
+        self.avqatask_norm2 = nn.LayerNorm(Dh)
+        self.avqatask_dropout3 = nn.Dropout(0.1)
+        self.avqatask_dropout4 = nn.Dropout(0.1)
+        self.avqatask_attn_a = nn.MultiheadAttention(Dh, 4, dropout=0.1)
+        self.avqatask_attn_v = nn.MultiheadAttention(Dh, 4, dropout=0.1)
+        self.avqatask_question_encoder = QstEncoder(93, Dh, Dh, 1, Dh)
+        self.avqatask_tanh = nn.Tanh()
+        self.avqatask_fc_ans = nn.Linear(Dh, 42)
+        self.avqatask_avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.avqatask_fc_gl = nn.Linear(Dh + Dh, Dh)
+        self.avqatask_fc1 = nn.Linear(Dh + Dh, 512)
+        self.avqatask_fc2 = nn.Linear(512, 256)
+        self.avqatask_fc3 = nn.Linear(256, 128)
+        self.avqatask_fc4 = nn.Linear(128, 2)
 
     def forward_features(self, a, v, v_nega):
         """a: [B, T, Ha, Wa]; v, v_nega: [B, T, 3, H, W].  Returns (f_v, f_a, visual_nega), each [(B T), N_last, C_last] fp32;
@@ -38,6 +75,28 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
         BT = v.shape[0] * v.shape[1]
         return tuple(t.view(BT, -1, t.shape[-1]) for t in (f_v, f_a, f_n))
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("the AVQA question-answering head (avqatask_*, Swin_AVQAModel_V1.py:1768-1903) is not part of this "
-                                  "build yet (SURVEY.md section 8f); call forward_features(a, v, v_nega) for the backbone")
+    def forward(self, a, v, v_nega, question, mode):
+        """audio [B, T, Ha, Wa], visual_posi / visual_nega [B, T, 3, H, W], question int64 [B, L], mode
+        (Swin_AVQAModel_V1.py:1654, 1740-1903) -> (out_qa [B, 42], out_match_posi [(B T), 2], out_match_nega [(B T), 2]), fp32."""
+        if mode != 'fusion' or mode != self.ftmode:
+            raise TypeError('ftmode is not expected !!!')
+        f_v, f_a, f_n = self.forward_features(a, v, v_nega)
+        if f_v.shape[-1] != 1536 or f_v.shape[1] != 49:
+            raise NotImplementedError("the QA head is hard-wired to 49 tokens x 1536 channels (Swin-L at 224 x 224, :1776-1777)")
+        from ..ops_head import avqa_head_forward
+        return avqa_head_forward(self, f_v, f_a, f_n, question, v.shape[0], v.shape[1], self.training)
+
+
+class QstEncoder(nn.Module):
+    """Parameter container of the reference's question encoder (Swin_AVQAModel_V1.py:37-59); run by ops_head.question_encoder."""
+
+    def __init__(self, qst_vocab_size, word_embed_size, embed_size, num_layers, hidden_size):
+        super().__init__()
+        self.word2vec = nn.Embedding(qst_vocab_size, word_embed_size)
+        self.tanh = nn.Tanh()
+        self.lstm = nn.LSTM(word_embed_size, hidden_size, num_layers)
+        self.fc = nn.Linear(2 * num_layers * hidden_size, embed_size)
+
+    def forward(self, question):
+        from ..ops_head import question_encoder
+        return question_encoder(self, question)

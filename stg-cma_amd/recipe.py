@@ -3,7 +3,8 @@ parameters train iff they belong to mlp_head or their NAME contains one of the a
 (the pretrained backbone, both patch embeddings, the final norm) is frozen when freeze_base=True."""
 
 TRAINABLE_SUBSTRINGS = ("adapter", "temporal_embedding", "ln_post", "Adapter", "my_tokens", "gate_", "ln_before",
-                        "temporal_position_bias_table")
+                        "temporal_position_bias_table", "avqatask_", "avstask_")   # + the AVQA / AVS loops' task-head prefixes
+                                                                                   #   (traintest_adapt_avqa.py:72, _avs.py:55)
 MLP_HEAD = tuple(f"mlp_head.{i}.{w}" for i in range(4) for w in ("weight", "bias"))
 
 

@@ -218,6 +218,32 @@ def avqa_backbone_case(Q, tag, *, cfg, B, seed):
          grads=flat_grads(m, names), f_v=f_v, f_a=f_a, f_nega=f_n)
 
 
+def avqa_full_case(Q, tag, *, cfg, B, seed):
+    """The whole SwinTransformer2D_Adapter_AVQA.forward[fusion] (AVQA/model/Swin_AVQAModel_V1.py:1740-1903): backbone + QA head
+    (question LSTM, grounding on the positive and the negative clip, two single-query attentions, fusion MLPs), eval mode,
+    every trainable tensor of the AVQA loop's name filter (traintest_adapt_avqa.py:72: adapters + `avqatask_`) with a gradient.
+    The head's widths are hard-coded to 1536, so embed_dim must be 192."""
+    m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, grounding_pretrained=None, num_frames=cfg["num_frames"],
+                                         embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
+                                         adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    shapes = seed_module(m, seed)
+    names = apply_freeze(m)
+    T = cfg["num_frames"]
+    a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, T, 3, 224, 224), seed + 2)
+    vn = GP.seeded_tensor((B, T, 3, 224, 224), seed + 3)
+    question = torch.randint(0, 93, (B, 14), generator=torch.Generator().manual_seed(seed + 4))
+    out_qa, mp, mn = m(a, v, vn, question, "fusion")
+    g1, g2, g3 = GP.seeded_tensor(out_qa.shape, seed + 5), GP.seeded_tensor(mp.shape, seed + 6), GP.seeded_tensor(mn.shape, seed + 7)
+    ((out_qa * g1).sum() + (mp * g2).sum() + (mn * g3).sum()).backward()
+    d = dict(m.named_parameters())
+    g = flat_grads(m, names)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, seed=seed)), grad_names_json=json.dumps(names),
+         out_qa=out_qa, out_match_posi=mp, out_match_nega=mn, question=question,
+         grad_norms=torch.stack([(d[n].grad if d[n].grad is not None else torch.zeros(())).norm() for n in names]),
+         grads_sample=g[::197].clone())
+
+
 # --------------------------------------------------------------------------------------------------- ViT (CLIP) path
 def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"):
     blk = Cm.ResidualAttentionBlock(d, heads, None, 0.5, 1, T, 0.0, mode=mode).eval()
@@ -357,6 +383,7 @@ SWIN_TINY = dict(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 
                  adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
 AVS_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=3, adapter_mlp_ratio=[0.5, 0.5, 0.25, 0.25])
 AVQA_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
+AVQA_FULL_TINY = dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
 SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
 
@@ -417,6 +444,7 @@ def main(argv):
                                                            audio_length=1024, seed=720),
         "clip_pretrained_ingest_long": lambda: clip_ingest_case(Cm, "clip_pretrained_ingest_long", layers=12, embed_dim=64, patch=16,
                                                                 res=224, audio_length=3200, seed=730),
+        "avqa_full_tiny": lambda: avqa_full_case(ref_avqa(), "avqa_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=620),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

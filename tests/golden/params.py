@@ -18,8 +18,12 @@ def _scale(key, shape):
         return 0.5
     if k in ("class_embedding", "positional_embedding", "positional_embedding_audio") or "temporal_embedding" in key:
         return 0.3
-    if k == "in_proj_weight":
+    if k == "in_proj_weight" or k.startswith("weight_ih") or k.startswith("weight_hh"):     # packed MHA / LSTM matrices
         return 1.0 / math.sqrt(shape[1])
+    if k.startswith("bias_ih") or k.startswith("bias_hh"):
+        return 0.05
+    if key.endswith("word2vec.weight"):                 # nn.Embedding table
+        return 0.5
     if k == "in_proj_bias":
         return 0.05
     if k == "bias":
@@ -60,7 +64,8 @@ def float_shapes(state_dict):
 
 
 TRAINABLE_SUBSTRINGS = ("adapter", "temporal_embedding", "ln_post", "Adapter", "my_tokens", "gate_", "ln_before",
-                        "temporal_position_bias_table")
+                        "temporal_position_bias_table", "avqatask_", "avstask_")   # + the AVQA / AVS loops' task-head prefixes
+                                                                                   #   (traintest_adapt_avqa.py:72, _avs.py:55)
 MLP_HEAD = tuple(f"mlp_head.{i}.{w}" for i in range(4) for w in ("weight", "bias"))
 
 

@@ -39,13 +39,14 @@ def _build(cls, cfg, shapes, gpu):
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     sd = m.state_dict()
     for k in sd:
-        if sd[k].is_floating_point() and not k.endswith("attn_mask"):
+        if sd[k].is_floating_point() and not k.endswith("attn_mask") and k in P:
             sd[k] = P[k]
     m.load_state_dict(sd, strict=True)
     m = m.to(gpu)
     names = []
+    backbone = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.")     # the goldens of this file are backbone-only
     for n, p in m.named_parameters():
-        p.requires_grad = recipe.is_trainable(n)
+        p.requires_grad = recipe.is_trainable(n) and n.startswith(backbone)
         if p.requires_grad:
             names.append(n)
     return m, names
@@ -131,7 +132,7 @@ def test_backbones_train_mode(stg, gpu):
                 p.fill_(0.3)
     m = m.to(gpu).train()
     for n, p in m.named_parameters():
-        p.requires_grad = recipe.is_trainable(n)
+        p.requires_grad = recipe.is_trainable(n) and not n.startswith("avqatask_")     # forward_features: the backbone only
     a = torch.randn(1, 2, 224, 224, device=gpu); v = torch.randn(1, 2, 3, 224, 224, device=gpu); vn = torch.randn(1, 2, 3, 224, 224, device=gpu)
     o1 = m.forward_features(a, v, vn); o2 = m.forward_features(a, v, vn)
     assert all(torch.isfinite(t).all() for t in o1)

@@ -168,7 +168,7 @@ def test_bench_cpu_baseline_leg_runs_on_host(stg):
                                          ("avqa_tiny_backbone", "Swin_AVQA", "SwinTransformer2D_Adapter_AVQA")])
 def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls):
     """The AVS / AVQA mirrors hold exactly the backbone tensors of the reference classes (patch embeds, layers, norm) under
-    the reference's names and shapes; the decoder / QA head (avstask_* / avqatask_*) is out of scope and raises."""
+    the reference's names and shapes; the AVS decoder (avstask_*) is out of scope and raises, the AVQA mirror also carries the QA head."""
     import importlib
     from golden_util import load_case
     z, cfg, shapes, names = load_case(tag)
@@ -176,12 +176,36 @@ def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls
     m = getattr(M, cls)(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                         num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
     sd = m.state_dict()
-    mine = [(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask")]
+    backbone = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.")
+    mine = [(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask") and k.startswith(backbone)]
     assert mine == [(k, tuple(s)) for k, s in shapes]
     from stgcma.recipe import is_trainable
+    assert [n for n, _ in m.named_parameters() if is_trainable(n) and n.startswith(backbone)] == names
+    rest = [k for k in sd if not k.startswith(backbone)]
+    if mod == "Swin_AVS":                                    # the dense decoder is not built: nothing else, forward raises
+        assert rest == []
+        with pytest.raises(NotImplementedError):
+            m(None, None)
+    else:                                                    # the QA head is there under the reference's avqatask_* names
+        assert rest and all(k.startswith("avqatask_") for k in rest)
+
+
+def test_avqa_full_state_dict_is_the_reference(stg):
+    """backbone + QA head: float keys, order and shapes of the mirror == the reference model's (golden avqa_full_tiny), and the
+    AVQA loop's name filter (traintest_adapt_avqa.py:72) selects the same trainable tensors."""
+    from golden_util import load_case
+    from stgcma.model import Swin_AVQA
+    from stgcma.recipe import is_trainable
+    z, cfg, shapes, names = load_case("avqa_full_tiny")
+    m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
+                                                 depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
+                                                 adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
+    sd = m.state_dict()
+    mine = [(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask")]
+    assert mine == [(k, tuple(s)) for k, s in shapes]
     assert [n for n, _ in m.named_parameters() if is_trainable(n)] == names
-    with pytest.raises(NotImplementedError):
-        m(None, None)
+    with pytest.raises(TypeError, match="ftmode is not expected"):
+        m(None, None, None, None, "videoonly")
 
 
 def test_recipe_cosine_scheduler_and_optimizer_groups(stg):

@@ -229,3 +229,31 @@ def test_avqa_backbone_matches_reference():
      (out["f_a"] * seeded_tensor(out["f_a"].shape, cfg["seed"] + 11)).sum() + out["f_nega"].sum()).backward()
     g, ref = _grads(P, names), torch.as_tensor(z["grads"])
     assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_avqa_full_model_matches_reference():
+    """backbone + QA head (question LSTM, grounding on the positive / negative clip, single-query attentions, fusion
+    MLPs) of the reference's SwinTransformer2D_Adapter_AVQA, outputs and every trainable gradient."""
+    import oracle.avqa_head as OH
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avqa_full_tiny")
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T, seed = cfg["B"], cfg["num_frames"], cfg["seed"]
+    a = seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, T, 3, 224, 224), seed + 2)
+    vn = seeded_tensor((B, T, 3, 224, 224), seed + 3)
+    question = torch.as_tensor(z["question"])
+    assert torch.equal(question, torch.randint(0, 93, (B, 14), generator=torch.Generator().manual_seed(seed + 4)))
+    out_qa, mp, mn = OH.avqa_forward(P, a, v, vn, question, cfg)
+    _close(out_qa, z["out_qa"], what="out_qa")
+    _close(mp, z["out_match_posi"], what="out_match_posi")
+    _close(mn, z["out_match_nega"], what="out_match_nega")
+    ((out_qa * seeded_tensor(out_qa.shape, seed + 5)).sum() + (mp * seeded_tensor(mp.shape, seed + 6)).sum() +
+     (mn * seeded_tensor(mn.shape, seed + 7)).sum()).backward()
+    norms = torch.stack([(P[n].grad if P[n].grad is not None else torch.zeros(())).norm() for n in names])
+    ref_norms = torch.as_tensor(z["grad_norms"])
+    assert float(((norms - ref_norms).abs() / ref_norms.clamp_min(1e-6)).max()) <= 2e-3, "per-tensor gradient norms"
+    g, ref = _grads(P, names)[::197], torch.as_tensor(z["grads_sample"])
+    assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
