@@ -54,6 +54,9 @@ WORKLOADS = {
                             "multi-scale taps + audio feature, synthetic upstream gradients, no decoder"),
     "avqa_backbone": (4920.0, "Swin-L + STG-CMA AVQA BACKBONE only (AVQA/run_adapt_avqa.py:288-301: T=10, third negative-video stream "
                               "forward-only), synthetic upstream gradients, no QA head"),
+    "avs": (843.0, "Swin-B + STG-CMA AVS shape, FULL model (AVS/run_adapt_avs.py:146-160): backbone (T=5) + dense decoder (ASPP, TPAVI, "
+                   "FeatureFusion path, output convolutions), loss = BCE on the first frame of each clip (AVS/loss.py:7-26), fwd+bwd+Adam on "
+                   "adapters + avstask_*; the GFLOP figure counts the backbone only"),
     "avqa": (4920.0, "Swin-L + STG-CMA AVQA shape, FULL model (AVQA/run_adapt_avqa.py:288-301): backbone with the negative-video stream + "
                      "QA head (question LSTM, grounding, single-query attentions), loss = CE(qa) + 0.5 CE(match) "
                      "(traintest_adapt_avqa.py:173-179), fwd+bwd+Adam on adapters + avqatask_* (no fp8 path)"),
@@ -69,9 +72,9 @@ def build_model(torch, device, workload="swin_b"):
     if workload == "vit_b":
         from stgcma.model import CLIP_AVE as Cm
         m = Cm.MM_CLIP_AVE(**VIT_B)
-    elif workload == "avs_backbone":
+    elif workload in ("avs_backbone", "avs"):
         from stgcma.model import Swin_AVS
-        m = Swin_AVS.SwinTransformer2D_Adapter_AVS(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
+        m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
                                                    num_heads=[4, 8, 16, 32], window_size=7, pretrained=None, ftmode="fusion",
                                                    adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
     elif workload in ("avqa_backbone", "avqa"):
@@ -86,7 +89,9 @@ def build_model(torch, device, workload="swin_b"):
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for n, p in m.named_parameters():
-            if "D_fc2" in n:
+            if "W_z.1.weight" in n:                              # TPAVI's BatchNorm scale (zero-initialised, TPAVI.py:62-63)
+                p.fill_(0.1)
+            elif "D_fc2" in n:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
             elif "gate_" in n:
                 p.fill_(0.1)
@@ -240,6 +245,21 @@ def main():
             opt.step()
             return loss
 
+    if args.workload == "avs":
+        g = torch.Generator(device=device).manual_seed(55 + rank)
+        vv = torch.randn((args.batch, 5, 3, 224, 224), generator=g, device=device)
+        aa = torch.randn((args.batch, 5, 224, 224), generator=g, device=device) * 0.5
+        gt = (torch.rand((args.batch, 1, 224, 224), generator=g, device=device) < 0.3).float()
+        bce = torch.nn.BCELoss()
+
+        def step():                                                 # noqa: F811   traintest_adapt_avs.py:158-170, AVS/loss.py:7-26
+            pred, _, _ = model(aa, vv, "fusion")
+            loss = bce(torch.sigmoid(pred)[::5], gt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
     if args.workload in ("avs_backbone", "avqa_backbone"):
         T = 5 if args.workload == "avs_backbone" else 10
         g = torch.Generator(device=device).manual_seed(99 + rank)
@@ -297,7 +317,7 @@ def main():
         out = {
             "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
-                                              "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
+                                              "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,

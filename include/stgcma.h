@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 104
+#define STG_VERSION 105
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -304,6 +304,28 @@ int stg_mha1_fwd(const void* q, const void* k, const void* v, const float* drop,
                  int hd, float scale, void* stream);
 int stg_mha1_bwd(const void* q, const void* k, const void* v, const float* drop, const float* p, const void* dout,
                  void* dq, void* dk, void* dv, int B, int H, int T, int hd, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AVS dense decoder (AVS/model/Swin_AVSModel_Base.py:14-130, :1474-1506, :1838-1894; AVS/model/TPAVI.py).  Feature maps are
+ * channels-last token rows [F*H*W, C] bf16.
+ */
+/* im2col of a 3x3 convolution, stride 1, padding = dilation (nn.Conv2d(k=3, padding=d, dilation=d), :18-20,56-61,:1497-1503):
+ * out bf16 [F*H*W, 9*C], column (kh*3 + kw)*C + c = x[f, h + (kh-1) d, w + (kw-1) d, c] or 0.  The convolution is then
+ * stg_gemm_nt(out, Wm) with Wm[o, (kh, kw, c)] = W[o, c, kh, kw]; its data gradient the same gather on dY with
+ * Wd[c, (kh, kw, o)] = W[o, c, 2-kh, 2-kw]; its weight gradient stg_wgrad_tn(dY, out).  C % 8 == 0. */
+int stg_im2col3x3(const void* x, int64_t ldx, void* out, int64_t F, int H, int W, int C, int dilation, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=...) (:108-110 align_corners=True, :1500 False) and its adjoint */
+int stg_bilinear_up2_fwd(const void* x, void* y, int64_t F, int H, int W, int C, int align_corners, void* stream);
+int stg_bilinear_up2_bwd(const void* dy, void* dx, int64_t F, int H, int W, int C, int align_corners, void* stream);
+/* BatchNorm over the rows of [R, C] (nn.BatchNorm3d of TPAVI's W_z, TPAVI.py:57-61).  stg_bn_colsum accumulates (atomically, into
+ * a zeroed out[2][C]) mode 0: sum x, sum x^2;  mode 2: sum (x - mean), sum (x - mean)^2 (the variance is taken in this second,
+ * centred pass: E[x^2] - mean^2 cancels catastrophically on feature maps whose mean dwarfs their spread);  mode 1: sum dy,
+ * sum dy * xhat (a = x, b = dy).  stg_bn_apply: y = (x - mean) rstd
+ * gamma + beta.  stg_bn_bwd: dx = gamma rstd (dy - sums[0]/R - xhat sums[1]/R), or gamma rstd dy when sums == NULL (eval). */
+int stg_bn_colsum(const void* a, const void* b, const float* mean, const float* rstd, float* out, int64_t R, int C, int mode, void* stream);
+int stg_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, int64_t R, int C, void* stream);
+int stg_bn_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma, const float* sums, void* dx,
+               int64_t R, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -855,3 +855,68 @@ def mha1_bwd(q, k, v, drop, p, dout, H):
     _lib.check(_lib.lib().stg_mha1_bwd(_p(q), _p(k), _p(v), _p(drop), _p(p), _p(dout), _p(dq), _p(dk), _p(dv), B, H, T, hd, hd ** -0.5,
                                        _stream()), "stg_mha1_bwd")
     return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------ AVS decoder kernels (dec.hip)
+def im2col3x3(x, F_, H, W, dilation):
+    """x bf16 [F*H*W, C] (rows may be column slices of a wider buffer) -> bf16 [F*H*W, 9*C]."""
+    _chk2d(x, "x", BF16, rows=F_ * H * W)
+    Cc = x.shape[1]
+    out = torch.empty((F_ * H * W, 9 * Cc), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_im2col3x3(_p(x), _ld(x), _p(out), F_, H, W, Cc, int(dilation), _stream()), "stg_im2col3x3")
+    return out
+
+
+def bilinear_up2_fwd(x, F_, H, W, align_corners):
+    _chk_flat(x, "x")
+    Cc = x.shape[-1]
+    if x.numel() != F_ * H * W * Cc:
+        raise RuntimeError("bilinear_up2_fwd: shape mismatch")
+    y = torch.empty((F_ * 4 * H * W, Cc), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_bilinear_up2_fwd(_p(x), _p(y), F_, H, W, Cc, int(bool(align_corners)), _stream()), "stg_bilinear_up2_fwd")
+    return y
+
+
+def bilinear_up2_bwd(dy, F_, H, W, align_corners):
+    _chk_flat(dy, "dy")
+    Cc = dy.shape[-1]
+    if dy.numel() != F_ * 4 * H * W * Cc:
+        raise RuntimeError("bilinear_up2_bwd: shape mismatch")
+    dx = torch.empty((F_ * H * W, Cc), dtype=BF16, device=dy.device)
+    _lib.check(_lib.lib().stg_bilinear_up2_bwd(_p(dy), _p(dx), F_, H, W, Cc, int(bool(align_corners)), _stream()), "stg_bilinear_up2_bwd")
+    return dx
+
+
+def bn_colsum(a, b=None, mean=None, rstd=None):
+    """[2, C] fp32: (sum a, sum a^2) when b and mean are None; (sum (a - mean), sum (a - mean)^2) when only mean is given;
+    (sum b, sum b * (a - mean) * rstd) when b is given."""
+    _chk_flat(a, "a")
+    R, Cc = a.shape
+    out = torch.zeros((2, Cc), dtype=F32, device=a.device)
+    mode = 0
+    if b is not None:
+        _chk_flat(b, "b"); _chk_flat(mean, "mean", F32); _chk_flat(rstd, "rstd", F32)
+        mode = 1
+    elif mean is not None:
+        _chk_flat(mean, "mean", F32)
+        mode = 2
+    _lib.check(_lib.lib().stg_bn_colsum(_p(a), _p(b), _p(mean), _p(rstd), _p(out), R, Cc, mode, _stream()), "stg_bn_colsum")
+    return out
+
+
+def bn_apply(x, mean, rstd, gamma, beta):
+    _chk_flat(x, "x")
+    R, Cc = x.shape
+    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (beta, "beta")):
+        _chk1d(t, n, F32, Cc)
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().stg_bn_apply(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), R, Cc, _stream()), "stg_bn_apply")
+    return y
+
+
+def bn_bwd(x, dy, mean, rstd, gamma, sums):
+    _chk_flat(x, "x"); _chk_flat(dy, "dy")
+    R, Cc = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().stg_bn_bwd(_p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(sums), _p(dx), R, Cc, _stream()), "stg_bn_bwd")
+    return dx

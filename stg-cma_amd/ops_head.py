@@ -43,6 +43,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, b, res, out_f32):
+        x = x.contiguous()
         M, Kd = x.shape
         N = W.shape[0]
         y = K.gemm_nt(x, shadow(W), f32c(b) if b is not None else None, res1=res,

@@ -244,6 +244,122 @@ def avqa_full_case(Q, tag, *, cfg, B, seed):
          grads_sample=g[::197].clone())
 
 
+# --------------------------------------------------------------------------------------------------- AVS dense decoder
+def _seed_all(mod, seed):
+    sd = mod.state_dict()
+    shapes = GP.float_shapes(sd)
+    sd.update(GP.seeded_state(shapes, seed))
+    mod.load_state_dict(sd, strict=True)
+    return shapes
+
+
+def avs_modules_case(A, tag, seed):
+    """The decoder's building blocks of the REFERENCE at small sizes (they are size-agnostic nn.Modules): Classifier_Module (ASPP,
+    Swin_AVSModel_Base.py:14-29), FeatureFusionBlock (:81-112, incl. the in-place ReLU of ResidualConvUnit :56-75), TPAVIModule
+    (TPAVI.py, mode='dot', with audio; train-mode BatchNorm and eval-mode), and the output_conv stack (:1497-1503)."""
+    import sys as _s
+    TP = _s.modules["AVS.model.TPAVI"]
+    arrs = {}
+    g = torch.Generator().manual_seed(seed)
+    # ASPP
+    aspp = A.Classifier_Module([3, 6, 12, 18], [3, 6, 12, 18], 24, 16)
+    arrs["aspp_shapes"] = json.dumps(_seed_all(aspp, seed + 1))
+    x = torch.randn(3, 16, 14, 14, generator=g).requires_grad_(True)
+    y = aspp(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    arrs.update(aspp_x=x.detach(), aspp_y=y, aspp_gy=gy, aspp_dx=x.grad, aspp_grads=torch.cat([p.grad.reshape(-1) for p in aspp.parameters()]))
+    # FeatureFusionBlock with two inputs (in-place ReLU semantics of the RCUs included)
+    ffb = A.FeatureFusionBlock(16)
+    arrs["ffb_shapes"] = json.dumps(_seed_all(ffb, seed + 2))
+    x0 = torch.randn(2, 16, 7, 7, generator=g); x1 = torch.randn(2, 16, 7, 7, generator=g)
+    a0, a1 = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+    y = ffb(a0 * 1.0, a1 * 1.0)                       # * 1.0: non-leaf copies, so the module's in-place ops are legal
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    arrs.update(ffb_x0=x0, ffb_x1=x1, ffb_y=y, ffb_gy=gy, ffb_dx0=a0.grad, ffb_dx1=a1.grad,
+                ffb_grads=torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ffb.parameters()]))
+    ffb1 = A.FeatureFusionBlock(16)
+    ffb1.load_state_dict(ffb.state_dict())
+    b0 = x0.clone().requires_grad_(True)
+    y1 = ffb1(b0 * 1.0)                               # single-input form (path4, :1887)
+    y1.backward(gy)
+    arrs.update(ffb1_y=y1, ffb1_dx0=b0.grad)
+    # TPAVI, train-mode BatchNorm then eval-mode
+    tp = TP.TPAVIModule(in_channels=32, mode='dot')
+    arrs["tpavi_shapes"] = json.dumps(_seed_all(tp, seed + 3))
+    with torch.no_grad():
+        tp.W_z[1].running_mean.copy_(torch.randn(32, generator=g) * 0.1); tp.W_z[1].running_var.copy_(torch.rand(32, generator=g) + 0.5)
+    xt = torch.randn(2, 32, 3, 5, 5, generator=g); au = torch.randn(2, 3, 128, generator=g)
+    for mode in ("train", "eval"):
+        tp.train(mode == "train")
+        rm0, rv0 = tp.W_z[1].running_mean.clone(), tp.W_z[1].running_var.clone()
+        xr, ar = xt.clone().requires_grad_(True), au.clone().requires_grad_(True)
+        for p in tp.parameters():
+            p.grad = None
+        z_, at_ = tp(xr, ar)
+        gz = torch.randn(z_.shape, generator=g); ga = torch.randn(at_.shape, generator=g)
+        ((z_ * gz).sum() + (at_ * ga).sum()).backward()
+        arrs.update({f"tpavi_{mode}_z": z_, f"tpavi_{mode}_a": at_, f"tpavi_{mode}_gz": gz, f"tpavi_{mode}_ga": ga,
+                     f"tpavi_{mode}_dx": xr.grad, f"tpavi_{mode}_da": ar.grad, f"tpavi_{mode}_rm0": rm0, f"tpavi_{mode}_rv0": rv0,
+                     f"tpavi_{mode}_rm1": tp.W_z[1].running_mean.clone(), f"tpavi_{mode}_rv1": tp.W_z[1].running_var.clone(),
+                     f"tpavi_{mode}_grads": torch.cat([p.grad.reshape(-1) for p in tp.parameters()])})
+    arrs.update(tpavi_x=xt, tpavi_audio=au)
+    # output_conv stack
+    oc = nn.Sequential(nn.Conv2d(16, 24, kernel_size=3, stride=1, padding=1), A.Interpolate(scale_factor=2, mode="bilinear"),
+                       nn.Conv2d(24, 8, kernel_size=3, stride=1, padding=1), nn.ReLU(True), nn.Conv2d(8, 1, kernel_size=1, stride=1, padding=0))
+    arrs["oc_shapes"] = json.dumps(_seed_all(oc, seed + 4))
+    xo = torch.randn(2, 16, 6, 6, generator=g).requires_grad_(True)
+    yo = oc(xo)
+    go = torch.randn(yo.shape, generator=g)
+    yo.backward(go)
+    arrs.update(oc_x=xo.detach(), oc_y=yo, oc_gy=go, oc_dx=xo.grad, oc_grads=torch.cat([p.grad.reshape(-1) for p in oc.parameters()]))
+    save(tag, seed=np.array([seed]), **arrs)
+
+
+def avs_full_case(AB, tag, *, cfg, B, seed):
+    """The whole SwinTransformer2D_Adapter_AVS_Base.forward[fusion] (AVS/model/Swin_AVSModel_Base.py:1790-1894): backbone + dense
+    decoder, train mode without DropPath (BatchNorm on batch statistics), seeded upstream gradients on pred, the returned feature
+    maps and the audio features so that every output is pinned."""
+    m = AB.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                                              num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+                                              channel=256, opt=None, config=None, vis_dim=[64, 128, 320, 512], tpavi_stages=[0, 1, 2, 3],
+                                              tpavi_vv_flag=False, tpavi_va_flag=True, drop_path_rate=0.0).train()
+    # train mode with drop_path_rate = 0: deterministic, and TPAVI's BatchNorm runs on BATCH statistics -- with seeded running
+    # statistics (eval) single channels of W_z's output reach the hundreds and the LayerNorm behind it becomes a difference of large
+    # numbers, which pins nothing at bf16
+    shapes = seed_module(m, seed)
+    with torch.no_grad():                              # BatchNorm running statistics are buffers, not covered by float seeding rules
+        gg = torch.Generator().manual_seed(seed + 50)
+        for n, b in m.named_buffers():
+            if n.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=gg) + 0.5)
+            elif n.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=gg) * 0.1)
+        # TPAVI's BatchNorm scale: the reference zero-initialises it (TPAVI.py:62-63) so the non-local branch starts as a small
+        # perturbation of the residual; with a unit-size seeded scale the branch dominates and the fp32 model's own gradients turn
+        # chaotic (sub-1 % structured changes of the taps move single gradient norms tenfold), which pins nothing
+        for n, p in m.named_parameters():
+            if "W_z.1.weight" in n:
+                p.mul_(0.1)
+    names = apply_freeze(m)
+    a = GP.seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    pred, fmaps, afeas = m(a, v, "fusion")
+    up = GP.seeded_tensor(pred.shape, seed + 3, 1e-2)
+    loss = (pred * up).sum()
+    for i, (fm, af) in enumerate(zip(fmaps, afeas)):
+        loss = loss + (fm * GP.seeded_tensor(fm.shape, seed + 10 + i, 1e-2)).sum() + (af * GP.seeded_tensor(af.shape, seed + 20 + i, 1e-1)).sum()
+    loss.backward()
+    d = dict(m.named_parameters())
+    g = flat_grads(m, names)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, seed=seed)), grad_names_json=json.dumps(names),
+         pred=pred, **{f"fmap{i}": fm[:, ::8] for i, fm in enumerate(fmaps)}, **{f"afea{i}": af for i, af in enumerate(afeas)},
+         fmap_stats=torch.stack([torch.stack([fm.sum(), fm.abs().sum()]) for fm in fmaps]),
+         grad_norms=torch.stack([(d[n].grad if d[n].grad is not None else torch.zeros(())).norm() for n in names]),
+         grads_sample=g[::97].clone())
+
+
 # --------------------------------------------------------------------------------------------------- ViT (CLIP) path
 def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"):
     blk = Cm.ResidualAttentionBlock(d, heads, None, 0.5, 1, T, 0.0, mode=mode).eval()
@@ -383,6 +499,7 @@ SWIN_TINY = dict(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 
                  adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
 AVS_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=3, adapter_mlp_ratio=[0.5, 0.5, 0.25, 0.25])
 AVQA_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
+AVS_FULL_TINY = dict(embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32], num_frames=5, adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
 AVQA_FULL_TINY = dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
 SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
@@ -400,6 +517,11 @@ def main(argv):
         if "avs" not in lazy:
             lazy["avs"] = load(os.path.join(REF, "AVS/model/Swin_AVSModel.py"), "ref_swin_avs")
         return lazy["avs"]
+
+    def ref_avs_base():
+        if "avsb" not in lazy:
+            lazy["avsb"] = load(os.path.join(REF, "AVS/model/Swin_AVSModel_Base.py"), "ref_swin_avs_base")
+        return lazy["avsb"]
 
     def ref_avqa():
         if "avqa" not in lazy:
@@ -445,6 +567,8 @@ def main(argv):
         "clip_pretrained_ingest_long": lambda: clip_ingest_case(Cm, "clip_pretrained_ingest_long", layers=12, embed_dim=64, patch=16,
                                                                 res=224, audio_length=3200, seed=730),
         "avqa_full_tiny": lambda: avqa_full_case(ref_avqa(), "avqa_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=620),
+        "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
+        "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

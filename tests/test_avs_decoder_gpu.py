@@ -1,0 +1,232 @@
+"""-m gpu: the AVS dense decoder on the HIP path.
+  * building blocks (ops_dec: ASPP, FeatureFusionBlock, TPAVI train / eval, output_conv) against the goldens produced by the
+    REFERENCE modules at small sizes (tests/golden/avs_decoder_modules.npz);
+  * the full model -- backbone + decoder -- against the golden of the reference's SwinTransformer2D_Adapter_AVS_Base
+    (avs_full_tiny.npz); a train-mode loop with the AVS loss."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLD, build_state, load_case
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _rel(got, ref):
+    got = got.detach().float().cpu().reshape(-1); ref = torch.as_tensor(np.asarray(ref)).float().reshape(-1)
+    assert got.shape == ref.shape, (tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all()
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6), float((got - ref).norm() / max(float(ref.norm()), 1e-12))
+
+
+def _chk(got, ref, what, max_rel=3e-2, l2_rel=2e-2):
+    e_max, e_l2 = _rel(got, ref)
+    assert e_max <= max_rel and e_l2 <= l2_rel, f"{what}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
+
+
+def _rows(x_nchw, gpu, grad=True):
+    """NCHW fp32 (numpy) -> channels-last bf16 rows [F*H*W, C] on the GPU."""
+    t = torch.as_tensor(np.asarray(x_nchw)).permute(0, 2, 3, 1).contiguous()
+    return t.reshape(-1, t.shape[-1]).to(BF16).to(gpu).requires_grad_(grad)
+
+
+def _nchw(rows, F_, H, W):
+    return rows.detach().float().cpu().view(F_, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _load(mod, z, key, seed_off, gpu):
+    from params import seeded_state
+    shapes = [(k, tuple(s)) for k, s in json.loads(str(z[key]))]
+    sd = mod.state_dict()
+    sd.update(seeded_state(shapes, int(z["seed"][0]) + seed_off))
+    mod.load_state_dict(sd, strict=True)
+    return mod.to(gpu), [k for k, _ in shapes if "running" not in k]
+
+
+def _pgrads(mod, keys):
+    d = dict(mod.named_parameters())
+    return torch.cat([(d[k].grad if d[k].grad is not None else torch.zeros_like(d[k])).reshape(-1).float().cpu() for k in keys])
+
+
+def test_aspp_ffb_output_conv_match_reference_modules(stg, gpu):
+    from stgcma import ops_dec as D
+    from stgcma.model import Swin_AVS as M
+    z = np.load(os.path.join(GOLD, "avs_decoder_modules.npz"))
+    # ASPP: four dilated 3x3 convolutions (dilations up to 18 on a 14 x 14 map: mostly padding)
+    aspp, keys = _load(M.Classifier_Module([3, 6, 12, 18], [3, 6, 12, 18], 24, 16), z, "aspp_shapes", 1, gpu)
+    x = _rows(z["aspp_x"], gpu)
+    y = D.aspp(x, aspp, (3, 14, 14))
+    y.backward(_rows(z["aspp_gy"], gpu, False))
+    _chk(_nchw(y, 3, 14, 14), z["aspp_y"], "aspp y"); _chk(_nchw(x.grad, 3, 14, 14), z["aspp_dx"], "aspp dx")
+    _chk(_pgrads(aspp, keys), z["aspp_grads"], "aspp grads")
+    # FeatureFusionBlock, two inputs and one
+    ffb, keys = _load(M.FeatureFusionBlock(16), z, "ffb_shapes", 2, gpu)
+    x0, x1 = _rows(z["ffb_x0"], gpu), _rows(z["ffb_x1"], gpu)
+    y, seen = D.feature_fusion(ffb, x0, x1, (2, 7, 7))
+    y.backward(_rows(z["ffb_gy"], gpu, False))
+    # gradients that pass ReLU gates: with ~0.5 % bf16 noise on the pre-activations a few of the 1568 gates of these tiny maps sit
+    # on the other side of zero than in the fp32 reference, each a full-size element error (see test_avqa_head_gpu.py)
+    GATED = dict(max_rel=1.5e-1, l2_rel=6e-2)
+    _chk(_nchw(y, 2, 14, 14), z["ffb_y"], "ffb y"); _chk(_nchw(x0.grad, 2, 7, 7), z["ffb_dx0"], "ffb dx0", **GATED)
+    _chk(_nchw(x1.grad, 2, 7, 7), z["ffb_dx1"], "ffb dx1", **GATED)
+    _chk(_pgrads(ffb, keys), z["ffb_grads"], "ffb grads", **GATED)
+    assert torch.equal(seen, torch.relu(x1.detach()))
+    ffb.zero_grad()
+    b0 = _rows(z["ffb_x0"], gpu)
+    y1, _ = D.feature_fusion(ffb, b0, None, (2, 7, 7))
+    y1.backward(_rows(z["ffb_gy"], gpu, False))
+    _chk(_nchw(y1, 2, 14, 14), z["ffb1_y"], "ffb1 y"); _chk(_nchw(b0.grad, 2, 7, 7), z["ffb1_dx0"], "ffb1 dx0", **GATED)
+    # output_conv stack: conv3x3 -> bilinear x2 (align_corners=False) -> conv3x3 -> ReLU -> conv1x1
+    oc = torch.nn.Sequential(torch.nn.Conv2d(16, 24, 3, 1, 1), M.Interpolate(2, "bilinear"), torch.nn.Conv2d(24, 8, 3, 1, 1),
+                             torch.nn.ReLU(True), torch.nn.Conv2d(8, 1, 1, 1, 0))
+    oc, keys = _load(oc, z, "oc_shapes", 4, gpu)
+    x = _rows(z["oc_x"], gpu)
+    y = D.output_conv(oc, x, (2, 6, 6))
+    assert y.dtype == F32
+    y.backward(torch.as_tensor(z["oc_gy"]).permute(0, 2, 3, 1).reshape(-1, 1).to(gpu))
+    _chk(_nchw(y, 2, 12, 12), z["oc_y"], "oc y"); _chk(_nchw(x.grad, 2, 6, 6), z["oc_dx"], "oc dx", **GATED)
+    _chk(_pgrads(oc, keys), z["oc_grads"], "oc grads", **GATED)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_tpavi_matches_reference_module(stg, gpu, mode):
+    from stgcma import ops_dec as D
+    from stgcma.model import Swin_AVS as M
+    z = np.load(os.path.join(GOLD, "avs_decoder_modules.npz"))
+    tp, keys = _load(M.TPAVIModule(in_channels=32, mode='dot'), z, "tpavi_shapes", 3, gpu)
+    with torch.no_grad():
+        tp.W_z[1].running_mean.copy_(torch.as_tensor(z[f"tpavi_{mode}_rm0"])); tp.W_z[1].running_var.copy_(torch.as_tensor(z[f"tpavi_{mode}_rv0"]))
+    B, C, T, H, W = z["tpavi_x"].shape
+    x5 = torch.as_tensor(z["tpavi_x"])                                   # [B, C, T, H, W] -> rows (b t h w)
+    x = x5.permute(0, 2, 3, 4, 1).reshape(-1, C).to(BF16).to(gpu).requires_grad_(True)
+    au = torch.as_tensor(z["tpavi_audio"]).reshape(B * T, 128).to(BF16).to(gpu).requires_grad_(True)
+    zz, at = D.tpavi(tp, x, au, B, T, H * W, mode == "train")
+    gz = torch.as_tensor(z[f"tpavi_{mode}_gz"]).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    ga = torch.as_tensor(z[f"tpavi_{mode}_ga"]).reshape(B * T, C)
+    ((zz.float() * gz.to(gpu)).sum() + (at.float() * ga.to(gpu)).sum()).backward()
+    _chk(zz.detach().float().cpu().view(B, T, H, W, C).permute(0, 4, 1, 2, 3), z[f"tpavi_{mode}_z"], "z")
+    _chk(at.detach().float().cpu().view(B, T, C), z[f"tpavi_{mode}_a"], "audio_temp")
+    _chk(x.grad.float().cpu().view(B, T, H, W, C).permute(0, 4, 1, 2, 3), z[f"tpavi_{mode}_dx"], "dx")
+    _chk(au.grad.float().cpu().view(B, T, 128), z[f"tpavi_{mode}_da"], "daudio", max_rel=5e-2, l2_rel=4e-2)
+    _chk(_pgrads(tp, keys), z[f"tpavi_{mode}_grads"], "param grads", max_rel=5e-2, l2_rel=4e-2)
+    _chk(tp.W_z[1].running_mean, z[f"tpavi_{mode}_rm1"], "running_mean"); _chk(tp.W_z[1].running_var, z[f"tpavi_{mode}_rv1"], "running_var")
+
+
+def _build_full(gpu):
+    from stgcma import recipe
+    from stgcma.model import Swin_AVS
+    z, cfg, shapes, names = load_case("avs_full_tiny")
+    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                                                    num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+                                                    drop_path_rate=0.0).train()      # the golden: train-mode BatchNorm, no DropPath
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    gg = torch.Generator().manual_seed(cfg["seed"] + 50)
+    for k, sh in shapes:                                                  # the running statistics make_golden.py drew after seeding
+        if k.endswith("running_var"):
+            P[k] = torch.rand(sh, generator=gg) + 0.5
+        elif k.endswith("running_mean"):
+            P[k] = torch.randn(sh, generator=gg) * 0.1
+        elif "W_z.1.weight" in k:
+            P[k] = P[k] * 0.1                                             # TPAVI's BatchNorm scale kept small (reference init: 0)
+    sd = m.state_dict()
+    assert [k for k in sd if sd[k].is_floating_point() and not k.endswith("attn_mask")] == [k for k, _ in shapes]
+    for k in sd:
+        if sd[k].is_floating_point() and not k.endswith("attn_mask"):
+            sd[k] = P[k]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu)
+    mine = []
+    for n, p in m.named_parameters():
+        p.requires_grad = recipe.is_trainable(n)
+        if p.requires_grad:
+            mine.append(n)
+    assert mine == names
+    return m, z, cfg, names
+
+
+def test_avs_full_model_matches_reference(stg, gpu):
+    from params import seeded_tensor
+    m, z, cfg, names = _build_full(gpu)
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2).to(gpu)
+    pred, fmaps, afeas = m(a, v, "fusion")
+    assert pred.dtype == F32 and tuple(pred.shape) == (B * 5, 1, 224, 224)
+    errs = {"pred": _rel(pred, z["pred"])}
+    for i in range(4):
+        errs[f"fmap{i}"] = _rel(fmaps[i][:, ::8], z[f"fmap{i}"])
+        errs[f"afea{i}"] = _rel(afeas[i], z[f"afea{i}"])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/model_parity_report.txt", "a") as f:
+        f.write("avs_full_tiny " + " ".join(f"{k}: max/scale={a:.3e} relL2={b:.3e}" for k, (a, b) in errs.items()) + "\n")
+    # pred sits behind 8 backbone blocks + ~25 bf16 convolutions of a seeded ("hot", unit-gain) decoder with ReLU gates in between;
+    # the feature maps (after ASPP + TPAVI) and the audio features are earlier in the chain
+    for k, (e_max, e_l2) in errs.items():
+        lim = (1.5e-1, 8e-2) if k == "pred" else (6e-2, 4e-2)
+        assert e_max <= lim[0] and e_l2 <= lim[1], f"{k}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
+    loss = (pred * seeded_tensor(pred.shape, seed + 3, 1e-2).to(gpu)).sum()
+    for i, (fm, af) in enumerate(zip(fmaps, afeas)):
+        loss = loss + (fm * seeded_tensor(fm.shape, seed + 10 + i, 1e-2).to(gpu)).sum() + (af * seeded_tensor(af.shape, seed + 20 + i, 1e-1).to(gpu)).sum()
+    loss.backward()
+    d = dict(m.named_parameters())
+    ref_norms = np.asarray(z["grad_norms"])
+    # Gradients.  Forward parity above is tight, and the backward of every building block is pinned at module level (tests above,
+    # 1-6 %).  The WHOLE-model gradient of this configuration, though, is not a well-conditioned quantity: with batch-statistics
+    # BatchNorm over a single clip, the gradients of TPAVI's inner branch (W_z.0, g, theta, phi) and of everything upstream of it
+    # swing several-fold in the fp32 oracle itself when the taps change by 0.7 % (tools/dbg_avs.py: g.weight of stage 3: 16 on the
+    # oracle's taps, 144 on the HIP taps; reference vs oracle on IDENTICAL fp32 inputs already differ by 2e-3 from summation order),
+    # and the decoder's ReLU gates add sqrt(flipped fraction) on top (test_avqa_head_gpu.py).  So direction and size are checked in
+    # aggregate: cosine of a strided sample, median norm ratio, share of tensors within 25 %.
+    ratios = []
+    for n, rn in zip(names, ref_norms):
+        if d[n].grad is None:                            # path4.resConfUnit1: unused with a single input (:1887), no gradient in the reference either
+            assert rn == 0, n
+            continue
+        assert torch.isfinite(d[n].grad).all(), n
+        if rn > 1e-3 and "gate_" not in n and "temporal_position_bias_table" not in n:
+            ratios.append((float(d[n].grad.norm()) / float(rn), n))
+    lo, hi = min(ratios), max(ratios)
+    rr = np.array([r for r, _ in ratios])
+    med, share = float(np.median(rr)), float(((rr > 0.75) & (rr < 1.25)).mean())
+    flat = torch.cat([(d[n].grad if d[n].grad is not None else torch.zeros_like(d[n])).reshape(-1).float().cpu() for n in names])[::97]
+    ref = torch.as_tensor(z["grads_sample"])
+    cos = float(torch.dot(flat, ref) / (flat.norm() * ref.norm()))
+    e_l2 = float((flat - ref).norm() / ref.norm())
+    with open("gpurun_out/model_parity_report.txt", "a") as f:
+        f.write(f"avs_full_tiny grads: cos={cos:.4f} relL2={e_l2:.3e} norm ratio median={med:.3f} share within 25%={share:.3f} min={lo} max={hi}\n")
+    assert cos >= 0.85 and 0.9 <= med <= 1.1 and share >= 0.6, f"gradient sample cosine {cos:.4f}, median norm ratio {med:.3f}, share within 25 % {share:.3f}"
+
+
+def test_avs_train_mode_loop(stg, gpu):
+    """train(): DropPath in the backbone, BatchNorm on batch statistics (running statistics move), the AVS loss on the first frame
+    of each clip (AVS/loss.py:7-26) goes down on a repeated batch."""
+    from stgcma import recipe
+    from stgcma.model import Swin_AVS
+    torch.manual_seed(0)
+    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=128, depths=[2, 2, 2, 2],
+                                                    num_heads=[4, 8, 16, 32], ftmode="fusion",
+                                                    adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125]).to(gpu).train()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "W_z.1.weight" in n:
+                p.fill_(0.5)                                              # the reference zero-initialises TPAVI's BatchNorm scale
+    opt = recipe.build_optimizer(m, lr=1e-3)
+    g = torch.Generator().manual_seed(1)
+    a = (torch.randn(1, 5, 224, 224, generator=g) * 0.5).to(gpu)
+    v = torch.randn(1, 5, 3, 224, 224, generator=g).to(gpu)
+    mask = (torch.rand(1, 1, 224, 224, generator=g) < 0.3).float().to(gpu)
+    rm0 = m.avstask_tpavi_b1.W_z[1].running_mean.clone()
+    losses = []
+    for _ in range(5):
+        pred, fmaps, afeas = m(a, v, "fusion")
+        first = torch.sigmoid(pred)[::5]                                  # index_select of every 5th prediction (:17-20)
+        loss = torch.nn.BCELoss()(first, mask)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert not torch.equal(m.avstask_tpavi_b1.W_z[1].running_mean, rm0)
+    assert int(m.avstask_tpavi_b1.W_z[1].num_batches_tracked) == 5

@@ -168,7 +168,7 @@ def test_bench_cpu_baseline_leg_runs_on_host(stg):
                                          ("avqa_tiny_backbone", "Swin_AVQA", "SwinTransformer2D_Adapter_AVQA")])
 def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls):
     """The AVS / AVQA mirrors hold exactly the backbone tensors of the reference classes (patch embeds, layers, norm) under
-    the reference's names and shapes; the AVS decoder (avstask_*) is out of scope and raises, the AVQA mirror also carries the QA head."""
+    the reference's names and shapes; the AVS mirror also carries the dense decoder (avstask_*), the AVQA mirror the QA head (avqatask_*)."""
     import importlib
     from golden_util import load_case
     z, cfg, shapes, names = load_case(tag)
@@ -182,12 +182,31 @@ def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls
     from stgcma.recipe import is_trainable
     assert [n for n, _ in m.named_parameters() if is_trainable(n) and n.startswith(backbone)] == names
     rest = [k for k in sd if not k.startswith(backbone)]
-    if mod == "Swin_AVS":                                    # the dense decoder is not built: nothing else, forward raises
-        assert rest == []
-        with pytest.raises(NotImplementedError):
-            m(None, None)
-    else:                                                    # the QA head is there under the reference's avqatask_* names
-        assert rest and all(k.startswith("avqatask_") for k in rest)
+    pre = "avstask_" if mod == "Swin_AVS" else "avqatask_"   # the dense decoder / the QA head under the reference's names
+    assert rest and all(k.startswith(pre) for k in rest)
+
+
+def test_avs_full_state_dict_is_the_reference(stg):
+    """backbone + dense decoder: float keys (BatchNorm running statistics included), order and shapes of the mirror == the
+    reference's SwinTransformer2D_Adapter_AVS_Base (golden avs_full_tiny); the AVS loop's name filter (traintest_adapt_avs.py:55)
+    selects the same trainable tensors."""
+    from golden_util import load_case
+    from stgcma.model import Swin_AVS
+    from stgcma.recipe import is_trainable
+    z, cfg, shapes, names = load_case("avs_full_tiny")
+    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                                                    num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+                                                    channel=256, opt=None, config=None, vis_dim=[64, 128, 320, 512],
+                                                    tpavi_stages=[0, 1, 2, 3], tpavi_vv_flag=False, tpavi_va_flag=True)
+    sd = m.state_dict()
+    mine = [(k, tuple(v.shape)) for k, v in sd.items() if v.is_floating_point() and not k.endswith("attn_mask")]
+    assert mine == [(k, tuple(s)) for k, s in shapes]
+    assert [n for n, _ in m.named_parameters() if is_trainable(n)] == names
+    for i in range(4):                                       # reference init: TPAVI's BatchNorm scale and shift start at zero
+        bn = getattr(m, f"avstask_tpavi_b{i + 1}").W_z[1]
+        assert float(bn.weight.abs().max()) == 0 and float(bn.bias.abs().max()) == 0
+    with pytest.raises(TypeError, match="ftmode is not expected"):
+        m(None, None, "videoonly")
 
 
 def test_avqa_full_state_dict_is_the_reference(stg):
