@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 105
+#define STG_VERSION 106
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -322,6 +322,10 @@ int stg_bilinear_up2_bwd(const void* dy, void* dx, int64_t F, int H, int W, int 
  * centred pass: E[x^2] - mean^2 cancels catastrophically on feature maps whose mean dwarfs their spread);  mode 1: sum dy,
  * sum dy * xhat (a = x, b = dy).  stg_bn_apply: y = (x - mean) rstd
  * gamma + beta.  stg_bn_bwd: dx = gamma rstd (dy - sums[0]/R - xhat sums[1]/R), or gamma rstd dy when sums == NULL (eval). */
+/* LayerNorm weight / bias gradients over many rows of bf16 [R, C] (TPAVI's trainable norm_layer, TPAVI.py:30,149: up to 500 K rows):
+ * dgamma[c] += sum_r dy (x - mean[r]) rstd[r], dbeta[c] += sum_r dy; block-folded, one atomic per (block, channel). */
+int stg_ln_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                      int64_t R, int C, void* stream);
 int stg_bn_colsum(const void* a, const void* b, const float* mean, const float* rstd, float* out, int64_t R, int C, int mode, void* stream);
 int stg_bn_apply(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, int64_t R, int C, void* stream);
 int stg_bn_bwd(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma, const float* sums, void* dx,

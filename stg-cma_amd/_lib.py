@@ -155,13 +155,14 @@ SIGNATURES = {
     "stg_im2col3x3": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_bwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_ln_param_grad": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
     "stg_bn_colsum": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_bn_apply": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
     "stg_bn_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 105
+ABI_VERSION = 106
 _lib = None
 
 

@@ -135,6 +135,28 @@ __global__ void __launch_bounds__(256) colsum2_kernel(const bf16_t* a, const bf1
         atomicAdd(out + C + c, s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
     }
 }
+// LayerNorm parameter gradients over MANY rows (TPAVI's trainable norm_layer sees up to 500 K rows; stg_layernorm_bwd's per-row
+// atomics are meant for the few rows of a classifier head): dgamma[c] += sum_r dy[r,c] (x[r,c] - mean[r]) rstd[r], dbeta[c] += sum_r dy[r,c]
+__global__ void __launch_bounds__(256) ln_param_grad_kernel(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd,
+                                                            float* dgamma, float* dbeta, int64_t R, int C) {
+    __shared__ float s0[4][64], s1[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float t0 = 0.f, t1 = 0.f;
+    if (c < C) {
+        for (int64_t r = (int64_t)blockIdx.y * 4 + rl; r < R; r += (int64_t)gridDim.y * 4) {
+            const float g = bf2f(dy[r * C + c]);
+            t0 += g;
+            t1 += g * (bf2f(x[r * C + c]) - mean[r]) * rstd[r];
+        }
+    }
+    s0[rl][cl] = t0; s1[rl][cl] = t1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        atomicAdd(dbeta + c, s0[0][cl] + s0[1][cl] + s0[2][cl] + s0[3][cl]);
+        atomicAdd(dgamma + c, s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl]);
+    }
+}
 // y = (x - mean) * rstd * gamma + beta
 __global__ void bn_apply_kernel(const bf16_t* x, const float* mean, const float* rstd, const float* gamma, const float* beta, bf16_t* y,
                                 int64_t R, int C) {
@@ -199,6 +221,18 @@ extern "C" int stg_bn_colsum(const void* a, const void* b, const float* mean, co
     int gy = (int)((R + 255) / 256);
     if (gy > 512) gy = 512;
     hipLaunchKernelGGL(colsum2_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b, mean, rstd, out, R, C, mode);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_ln_param_grad(const void* dy, const void* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                 int64_t R, int C, void* stream) {
+    STG_CHECK(dy && x && mean && rstd && dgamma && dbeta, -1, "stg_ln_param_grad: null pointer");
+    STG_CHECK(R >= 0 && C > 0, -2, "stg_ln_param_grad: bad shape");
+    if (R == 0) return 0;
+    int gy = (int)((R + 255) / 256);
+    if (gy > 512) gy = 512;
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+                       dgamma, dbeta, R, C);
     STG_LAUNCH_CHECK();
     return 0;
 }

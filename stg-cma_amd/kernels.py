@@ -920,3 +920,11 @@ def bn_bwd(x, dy, mean, rstd, gamma, sums):
     dx = torch.empty_like(x)
     _lib.check(_lib.lib().stg_bn_bwd(_p(x), _p(dy), _p(mean), _p(rstd), _p(gamma), _p(sums), _p(dx), R, Cc, _stream()), "stg_bn_bwd")
     return dx
+
+
+def ln_param_grad(dy, x, mean, rstd, dgamma, dbeta):
+    """dgamma / dbeta (fp32 [C], accumulated) of a LayerNorm over the rows of bf16 [R, C] -- block-folded column sums."""
+    _chk_flat(dy, "dy"); _chk_flat(x, "x")
+    R, Cc = x.shape
+    _chk1d(mean, "mean", F32, R); _chk1d(rstd, "rstd", F32, R); _chk1d(dgamma, "dgamma", F32, Cc); _chk1d(dbeta, "dbeta", F32, Cc)
+    _lib.check(_lib.lib().stg_ln_param_grad(_p(dy), _p(x), _p(mean), _p(rstd), _p(dgamma), _p(dbeta), R, Cc, _stream()), "stg_ln_param_grad")

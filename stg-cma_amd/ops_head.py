@@ -197,7 +197,12 @@ class LayerNormFn(torch.autograd.Function):
         x, mean, rstd = ctx.saved_tensors
         dg = torch.zeros_like(ctx.gamma, dtype=F32)
         db = torch.zeros_like(dg)
-        dx = K.layernorm_bwd(_bf(dy), x.contiguous(), f32c(ctx.gamma), mean, rstd, dgamma=dg, dbeta=db)
+        dyb, xc = _bf(dy), x.contiguous()
+        if xc.shape[0] >= 1024 and xc.dtype == BF16:          # many rows (TPAVI's norm_layer): block-folded column sums, not per-row atomics
+            dx = K.layernorm_bwd(dyb, xc, f32c(ctx.gamma), mean, rstd)
+            K.ln_param_grad(dyb, xc, mean, rstd, dg, db)
+        else:
+            dx = K.layernorm_bwd(dyb, xc, f32c(ctx.gamma), mean, rstd, dgamma=dg, dbeta=db)
         return dx, dg, db
 
 
