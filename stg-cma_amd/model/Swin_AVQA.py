@@ -11,9 +11,9 @@ PatchMerging (:1150-1154).  Nothing trainable sits on or behind that stream, so 
 The QA head (`avqatask_*`: question LSTM encoder, audio-visual grounding on the positive and the negative clip, two
 single-query multi-head attentions, fusion MLPs; ctor :1420-1473, forward :1768-1903) is here too, under the reference's
 module names, run by ..ops_head on libstgcma_hip.so; its widths are the reference's hard-coded 1536 (= Swin-L's last stage),
-so `forward(a, v, v_nega, question, mode)` needs embed_dim = 192.  Not carried over: the grounding-pretraining checkpoint
-ingestion (`grounding_pretrained`, :1520-1541 -- load such weights with load_state_dict) and the fp8 weight path of
-BASELINE.json config 5.
+so `forward(a, v, v_nega, question, mode)` needs embed_dim = 192.  The constructor ingests a Swin image checkpoint together with a
+grounding-pretraining checkpoint like the reference's (:1510-1568).  Not carried over: the fp8 weight path of BASELINE.json
+config 5.
 """
 import torch
 import torch.nn as nn
@@ -27,18 +27,78 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
                  qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm,
                  ape=False, patch_norm=True, t_relative=True, use_checkpoint=False, ftmode='videoonly',
                  adapter_mlp_ratio=[0.25, 0.25, 0.25, 0.25], **kwargs):
-        super().__init__(label_dim=1, pretrained=pretrained, img_size=img_size, patch_size=patch_size, num_frames=num_frames,
+        if pretrained is not None and not isinstance(pretrained, str):
+            raise TypeError('pretrained must be a str or None')
+        super().__init__(label_dim=1, pretrained=None, img_size=img_size, patch_size=patch_size, num_frames=num_frames,
                          in_chans=in_chans, embed_dim=embed_dim, depths=depths, num_heads=num_heads, window_size=window_size,
                          mlp_ratio=mlp_ratio, frozen_stages=frozen_stages, qkv_bias=qkv_bias, qk_scale=qk_scale,
                          drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate,
                          norm_layer=norm_layer, ape=ape, patch_norm=patch_norm, t_relative=t_relative,
                          use_checkpoint=use_checkpoint, ftmode=ftmode, adapter_mlp_ratio=adapter_mlp_ratio)
-        self.grounding_pretrained = grounding_pretrained
-        if grounding_pretrained is not None:
-            raise NotImplementedError("grounding_pretrained (:1520-1541): load the converted avqatask_fc_* weights with load_state_dict()")
         del self.mlp_head                       # the QA head replaces it in the reference (:1420-1473)
         del self.avgpool
         self._build_qa_head()
+        self.pretrained, self.grounding_pretrained = None, None
+        self.initialize_weights(pretrained=pretrained, grounding_pretrained=grounding_pretrained)
+
+    def initialize_weights(self, pretrained=None, grounding_pretrained=None):
+        """Swin_AVQAModel_V1.py:1500-1590: trunc_normal(.02) Linears / unit LayerNorms everywhere (the QA head included), then --
+        when BOTH a Swin image checkpoint and a grounding-pretraining checkpoint are given (:1510-1512) -- their ingestion: the
+        grounding model's fc_a2 / fc_gl / fc1..fc4 become avqatask_* (:1524-1541; fc_a1 and the *_pure copies have no counterpart in
+        this model and end up as unexpected keys), patch-embedding inflation and the audio patch embedding = channel mean
+        (:1547-1554), strict=False load; finally every adapter up-projection is zeroed."""
+        from ._common import trunc_normal_
+
+        def _init_weights(m):
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        if not hasattr(self, "avqatask_fc_a2"):                 # the parent constructor's call: the head does not exist yet
+            return super().initialize_weights(pretrained=None)
+        if pretrained and grounding_pretrained:
+            self.pretrained, self.grounding_pretrained = pretrained, grounding_pretrained
+        if isinstance(self.pretrained, str):
+            self.apply(_init_weights)
+            print(f'load model from: {self.pretrained}')
+            checkpoint = torch.load(self.pretrained, map_location='cpu')
+            state_dict = checkpoint['model']
+            print(f'load grounding pretraining model from: {self.grounding_pretrained}')
+            grounding_checkpoint = torch.load(self.grounding_pretrained, map_location='cpu')
+            tmp = ['module.fc_a1.weight', 'module.fc_a1.bias', 'module.fc_a2.weight', 'module.fc_a2.bias', 'module.fc_gl.weight',
+                   'module.fc_gl.bias', 'module.fc1.weight', 'module.fc1.bias', 'module.fc2.weight', 'module.fc2.bias',
+                   'module.fc3.weight', 'module.fc3.bias', 'module.fc4.weight', 'module.fc4.bias']
+            tmp2 = tmp[:4]
+            for k, v in grounding_checkpoint.items():
+                if k in tmp:
+                    state_dict[k.replace('module.', 'avqatask_')] = v
+            for k, v in grounding_checkpoint.items():
+                if k in tmp2:
+                    parts = str(k).split('.')
+                    state_dict[(parts[0] + '.' + parts[1] + '_pure.' + parts[-1]).replace('module.', 'avqatask_')] = v
+            pe = state_dict['patch_embed.proj.weight'].unsqueeze(2).repeat(1, 1, self.patch_size[0], 1, 1) / self.patch_size[0]
+            state_dict['patch_embed.proj.weight'] = pe
+            state_dict['patch_embed_audio.proj.weight'] = torch.mean(pe.unsqueeze(2), dim=1)
+            state_dict['patch_embed_audio.proj.bias'] = state_dict['patch_embed.proj.bias']
+            state_dict['patch_embed_audio.norm.weight'] = state_dict['patch_embed.norm.weight']
+            state_dict['patch_embed_audio.norm.bias'] = state_dict['patch_embed.norm.bias']
+            msg = self.load_state_dict(state_dict, strict=False)
+            print('Missing keys: {}'.format(msg.missing_keys))
+            print('Unexpected keys: {}'.format(msg.unexpected_keys))
+            print(f"=> loaded successfully '{self.pretrained}'")
+            del checkpoint
+        elif self.pretrained is None:
+            self.apply(_init_weights)
+        else:
+            raise TypeError('pretrained must be a str or None')
+        from .Swin_AVE import Adapter
+        for n, m in self.layers.named_modules():
+            if isinstance(m, Adapter):
+                nn.init.constant_(m.D_fc2.weight, 0)
+                nn.init.constant_(m.D_fc2.bias, 0)
 
     def _build_qa_head(self):
         """Parameter containers of the reference's QA head under its names (Swin_AVQAModel_V1.py:1420-1473); nn.LSTM /

@@ -484,6 +484,33 @@ def clip_ingest_case(Cm, tag, *, layers, embed_dim, patch, res, audio_length, se
          conv1_audio=sd["conv1_audio.weight"], pos_audio=sd["positional_embedding_audio"])
 
 
+def avqa_ingest_case(Q, tag, seed):
+    """SwinTransformer2D_Adapter_AVQA(pretrained=<swin ckpt>, grounding_pretrained=<grounding ckpt>) of the REFERENCE
+    (Swin_AVQAModel_V1.py:1500-1590) on synthetic checkpoints."""
+    import contextlib
+    import io
+    import tempfile
+    cfg = dict(num_frames=2, embed_dim=32, depths=[2, 2], num_heads=[1, 2], adapter_mlp_ratio=[0.5, 0.25])
+    torch.manual_seed(seed)
+    probe = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, grounding_pretrained=None, ftmode="fusion", **cfg)
+    ck = GP.swin2d_checkpoint({k: v for k, v in probe.state_dict().items() if not k.startswith("avqatask_")}, seed + 1)
+    gk = GP.grounding_checkpoint(seed + 2)
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "swin2d.pth"), os.path.join(d, "grounding.pt")
+        torch.save(ck, p1); torch.save(gk, p2)
+        buf = io.StringIO()
+        torch.manual_seed(seed + 3)
+        with contextlib.redirect_stdout(buf):
+            m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=p1, grounding_pretrained=p2, ftmode="fusion", **cfg)
+    lines = buf.getvalue().splitlines()
+    missing = [ln for ln in lines if ln.startswith("Missing keys: ")][0][len("Missing keys: "):]
+    unexpected = [ln for ln in lines if ln.startswith("Unexpected keys: ")][0][len("Unexpected keys: "):]
+    sd = m.state_dict()
+    loaded = [k for k in sd if k in ck["model"] or k.startswith("patch_embed_audio.") or k.replace("avqatask_", "module.") in gk]
+    stats = {k: [float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in loaded if sd[k].is_floating_point()}
+    save(tag, cfg_json=json.dumps(dict(cfg, seed=seed)), missing=missing, unexpected=unexpected, stats_json=json.dumps(stats))
+
+
 def scheduler_case():
     sch = load(os.path.join(REF, "utilities/scheduler.py"), "ref_sched")
     import contextlib
@@ -569,6 +596,7 @@ def main(argv):
         "avqa_full_tiny": lambda: avqa_full_case(ref_avqa(), "avqa_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=620),
         "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
+        "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }

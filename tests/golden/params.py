@@ -141,3 +141,17 @@ def clip_visual_state(embed_dim, grid_hw, layers, patch, seed):
                    pre + "mlp.c_fc.weight": r(4 * embed_dim, embed_dim), pre + "mlp.c_fc.bias": r(4 * embed_dim),
                    pre + "mlp.c_proj.weight": r(embed_dim, 4 * embed_dim), pre + "mlp.c_proj.bias": r(embed_dim)})
     return sd
+
+
+def grounding_checkpoint(seed):
+    """A synthetic stand-in for the AVQA grounding-pretraining checkpoint (AVQA/grounding_gen): the `module.`-prefixed Linear
+    weights the AVQA constructor picks up (Swin_AVQAModel_V1.py:1524-1541), in the shapes of the model's avqatask_* layers,
+    plus one key it ignores."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"fc_a1": (1536, 768), "fc_a2": (1536, 1536), "fc_gl": (1536, 3072), "fc1": (512, 3072), "fc2": (256, 512),
+              "fc3": (128, 256), "fc4": (2, 128), "fc_unrelated": (4, 4)}
+    sd = {}
+    for k, sh in shapes.items():
+        sd[f"module.{k}.weight"] = torch.randn(sh, generator=g) * 0.05
+        sd[f"module.{k}.bias"] = torch.randn(sh[0], generator=g) * 0.05
+    return sd

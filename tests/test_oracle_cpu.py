@@ -331,10 +331,7 @@ def _avs_full_state(z, cfg, shapes):
     """Parameters of the avs_full_tiny golden: seeded floats + the BatchNorm running statistics make_golden.py drew afterwards."""
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     gg = torch.Generator().manual_seed(cfg["seed"] + 50)
-    for k, _ in shapes:                                   # state_dict order == named_buffers order for the running statistics
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            pass
-    # named_buffers() yields, per BatchNorm, running_mean then running_var (then num_batches_tracked); same order as the float keys
+    # named_buffers() yields, per BatchNorm, running_mean then running_var (then num_batches_tracked): the order of the float keys
     for k, sh in shapes:
         if k.endswith("running_var"):
             P[k] = torch.rand(sh, generator=gg) + 0.5
