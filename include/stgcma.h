@@ -183,8 +183,9 @@ int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, voi
  * '(b t) n c -> (b n) t c' rearranges as addressing.  The fused token tensor holds nm modality slabs of B clips x T frames x
  * N tokens; frame t of token n of clip b of slab m is row ((m*B + b)*T + t)*N + n, and every (m, b, n) is one sequence of T
  * frames.  S = scale * Q K^T + bias[m][h] (fp32 [nm, H, T, T], temporal_position_bias_table(_audio) gathered by
- * t_relative_coords(_a), :246-253), O = softmax(S) V.  T <= 32, head dim 32.  Q, K, V share one leading dimension (the fused
- * qkv buffer); Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*32.
+ * t_relative_coords(_a), :246-253), O = softmax(S) V.  T <= 32, head dim 32 -- or, with bias == NULL (and bm / bmT unused), head dim
+ * 64 / 96: the temporal nn.MultiheadAttention of the CLIP ViT blocks (CLIP_AVE.py:369-377).  Q, K, V share one leading dimension (the fused
+ * qkv buffer); Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*D.
  * bm / bmT: caller-owned fp32 workspaces of nm*H*1024 floats each, FILLED by stg_tattn_fwd (block-diagonal additive tables)
  * and read again by stg_tattn_bwd, which must be handed the same, unmodified buffers.
  * The backward recomputes the softmax from Q and K (it needs neither O nor an LSE) and writes dQ, dK, dV in one kernel;

@@ -330,6 +330,225 @@ __global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ wide heads, no bias (ViT)
+// The CLIP ViT blocks run the same temporal attention (ResidualAttentionBlock, CLIP_AVE.py:369-377: 'n (b t) d -> t (b n) d') through
+// nn.MultiheadAttention: no additive bias, head dim 96 (ViT-B built with 8 heads) or 64 (ViT-L).  Same packing and one-pass backward;
+// the block-diagonal structure is a 16-bit mask computed once per lane (same sequence <=> key / T == query / T), operand tiles sit
+// in 16-byte-padded LDS rows, and the backward runs one wave per SIMD (its 96-wide dK / dV accumulators live in AGPRs).
+template <int DP>
+__device__ __forceinline__ bf16x8_t tr_frag_p(const bf16_t* s, int dt, int s2, int hh, int d) {
+    const int gi = d & 15, c = d >> 4;
+    const bf16_t* p = s + (16 * s2 + 4 * hh + (gi >> 2)) * DP + 32 * dt + 16 * c + 4 * (gi & 3);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(p + 8 * DP));
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+template <int D>
+__device__ __forceinline__ void park_p(bf16_t* s, int r, int hh, const bf16x8_t* f) {
+#pragma unroll
+    for (int k = 0; k < D / 16; ++k) *reinterpret_cast<bf16x8_t*>(s + r * (D + 8) + 16 * k + 8 * hh) = f[k];
+}
+// bit reg of the lane's mask: accumulator row (reg, hh) and the lane's own index r belong to the same packed sequence
+__device__ __forceinline__ unsigned same_seq_mask(int r, int hh, int T, int nv) {
+    unsigned m = 0;
+    const int sr = r / T;
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = ACC_ROW(reg, hh);
+        if (r < nv && o < nv && o / T == sr) m |= 1u << reg;
+    }
+    return m;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) tattn_nb_fwd_kernel(TP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * DP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    int s = r / a.T, t = r - s * a.T;
+    if (r >= nv) { s = 0; t = 0; }
+    bf16_t* sV = smem + wave * 32 * DP;
+    const unsigned okm = same_seq_mask(r, hh, a.T, nv);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int b = g / a.gpb, j = g - b * a.gpb;
+        const int n0 = j * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+        const int64_t off = row * a.ld + h * D + 8 * hh;
+        bf16x8_t q[KS], k[KS], v[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) { q[i] = ld_frag(a.Q + off + 16 * i); k[i] = ld_frag(a.K + off + 16 * i); v[i] = ld_frag(a.V + off + 16 * i); }
+        park_p<D>(sV, r, hh, v);
+        f32x16_t st = zero16();
+#pragma unroll
+        for (int i = 0; i < KS; ++i) st = MFMA32(k[i], q[i], st);
+        lds_fence();
+        float x[16];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = (okm >> reg) & 1u ? st[reg] * a.scale2 : NEG_BIG;
+            mx = fmaxf(mx, x[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+            l += x[reg];
+        }
+        l += __shfl_xor(l, 32, 64);
+        const bf16x8_t p0 = pack8(x), p1 = pack8(x + 8);
+        f32x16_t o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt] = MFMA32(tr_frag_p<DP>(sV, dt, 0, hh, r), p0, zero16());
+            o[dt] = MFMA32(tr_frag_p<DP>(sV, dt, 1, hh, r), p1, o[dt]);
+        }
+        lds_fence();
+        if (r < cnt * a.T) {
+            const float inv = 1.0f / l;
+            bf16_t* op = a.O + row * a.ldo + h * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    uint2 w;
+                    w.x = pack_bf2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
+                    w.y = pack_bf2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
+                }
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) tattn_nb_bwd_kernel(TP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    constexpr int PER_WAVE = 3 * 32 * DP + 128;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    int s = r / a.T, t = r - s * a.T;
+    if (r >= nv) { s = 0; t = 0; }
+    bf16_t* sK = smem + wave * PER_WAVE;
+    bf16_t* sQ = sK + 32 * DP;
+    bf16_t* sD = sQ + 32 * DP;
+    float* sLse = reinterpret_cast<float*>(sD + 32 * DP);
+    float* sDel = sLse + 32;
+    const unsigned okm = same_seq_mask(r, hh, a.T, nv);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
+        const int b = g / a.gpb, j = g - b * a.gpb;
+        const int n0 = j * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        const int nvalid = cnt * a.T;
+        const int64_t row = ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
+        const int64_t off = row * a.ld + h * D + 8 * hh;
+        const bf16_t* dp_ = a.dO + row * a.lddo + h * D + 8 * hh;
+        bf16x8_t q[KS], k[KS], v[KS], d[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            q[i] = ld_frag(a.Q + off + 16 * i); k[i] = ld_frag(a.K + off + 16 * i); v[i] = ld_frag(a.V + off + 16 * i); d[i] = ld_frag(dp_ + 16 * i);
+        }
+        park_p<D>(sK, r, hh, k);
+        park_p<D>(sQ, r, hh, q);
+        park_p<D>(sD, r, hh, d);
+        {   // phase A: query on the lane
+            f32x16_t st = zero16(), dpt = zero16();
+#pragma unroll
+            for (int i = 0; i < KS; ++i) { st = MFMA32(k[i], q[i], st); dpt = MFMA32(v[i], d[i], dpt); }
+            float x[16];
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[reg] = (okm >> reg) & 1u ? st[reg] * a.scale2 : NEG_BIG;
+                mx = fmaxf(mx, x[reg]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) { x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx); l += x[reg]; }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = (r < nvalid) ? 1.0f / l : 0.f;
+            float delta = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) { x[reg] *= inv; delta += x[reg] * dpt[reg]; }
+            delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) x[reg] *= dpt[reg] - delta;
+            if (hh == 0) { sLse[r] = mx + __log2f(l); sDel[r] = delta; }
+            lds_fence();
+            const bf16x8_t d0 = pack8(x), d1 = pack8(x + 8);
+            bf16_t* op = a.dQ + row * a.lddqkv + h * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {                       // the transposed LDS reads need EXEC all ones: only the stores are masked
+                f32x16_t dq = MFMA32(tr_frag_p<DP>(sK, dt, 0, hh, r), d0, zero16());
+                dq = MFMA32(tr_frag_p<DP>(sK, dt, 1, hh, r), d1, dq);
+                if (r < nvalid) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2 w;
+                        w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
+                        w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
+                        *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
+                    }
+                }
+            }
+        }
+        {   // phase B: key on the lane
+            f32x16_t sc = zero16(), dp = zero16();
+#pragma unroll
+            for (int i = 0; i < KS; ++i) { sc = MFMA32(q[i], k[i], sc); dp = MFMA32(d[i], v[i], dp); }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ls = *reinterpret_cast<const float4*>(sLse + 8 * g4 + 4 * hh);
+                const float4 de = *reinterpret_cast<const float4*>(sDel + 8 * g4 + 4 * hh);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int reg = 4 * g4 + c;
+                    const bool ok = ((okm >> reg) & 1u) && 8 * g4 + 4 * hh + c < nvalid;
+                    const float pv = ok ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 - pick(ls, c)) : 0.f;
+                    pr[reg] = pv;
+                    ds[reg] = pv * (dp[reg] - pick(de, c));
+                }
+            }
+            const bf16x8_t p0 = pack8(pr), p1 = pack8(pr + 8), e0 = pack8(ds), e1 = pack8(ds + 8);
+            bf16_t* kp = a.dK + row * a.lddqkv + h * D;
+            bf16_t* vp = a.dV + row * a.lddqkv + h * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x16_t dv = MFMA32(tr_frag_p<DP>(sD, dt, 0, hh, r), p0, zero16());
+                dv = MFMA32(tr_frag_p<DP>(sD, dt, 1, hh, r), p1, dv);
+                f32x16_t dk = MFMA32(tr_frag_p<DP>(sQ, dt, 0, hh, r), e0, zero16());
+                dk = MFMA32(tr_frag_p<DP>(sQ, dt, 1, hh, r), e1, dk);
+                if (r < nvalid) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint2 w;
+                        w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
+                        w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
+                        *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
+                        w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
+                        w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
+                        *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4 + 4 * hh) = w;
+                    }
+                }
+            }
+        }
+        lds_fence();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ additive table
 // bm[mh][q][k] = log2(e) * bias[mh][q % T][k % T] when q and k are frames of the same packed sequence, else -1e30 (other
 // sequences of the tile, padding rows);  bmT[mh][k][q] = bm[mh][q][k].
@@ -346,8 +565,10 @@ __global__ void tattn_table_kernel(const float* bias, float* bm, float* bmT, int
 }
 
 int fill(const stg_tattn_args* f, TP& p, const char* who) {
-    STG_CHECK(f->Q && f->K && f->V && f->bm && f->bmT, -1, "%s: null pointer", who);
-    STG_CHECK(f->D == TD, -2, "%s: head dim must be 32", who);
+    STG_CHECK(f->Q && f->K && f->V, -1, "%s: null pointer", who);
+    STG_CHECK(f->D == 32 || f->D == 64 || f->D == 96, -2, "%s: head dim must be 32, 64 or 96", who);
+    if (f->D == TD) STG_CHECK(f->bm && f->bmT, -1, "%s: head dim 32 needs the bm / bmT workspaces", who);
+    else STG_CHECK(f->bias == nullptr, -2, "%s: head dims 64 / 96 run without an additive bias (nn.MultiheadAttention, CLIP_AVE.py:106-108)", who);
     STG_CHECK(f->T >= 1 && f->T <= 32, -2, "%s: T must be in [1, 32]", who);
     STG_CHECK(f->nm >= 1 && f->nm <= 65535 && f->B >= 0 && f->N >= 1 && f->H >= 1, -2, "%s: bad shape", who);
     STG_CHECK(f->ld % 8 == 0 && (((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V) & 15) == 0, -2, "%s: misaligned qkv", who);
@@ -362,6 +583,8 @@ int fill(const stg_tattn_args* f, TP& p, const char* who) {
     p.scale = f->scale; p.scale2 = f->scale * LOG2E;
     return 0;
 }
+
+constexpr int nb_lds_bytes(int D) { return 4 * (3 * 32 * (D + 8) + 128) * 2; }
 
 dim3 grid_for(const TP& p) {
     const int hg = (p.H + 3) / 4;
@@ -378,8 +601,15 @@ extern "C" int stg_tattn_fwd(const stg_tattn_args* f, void* stream) {
     TP p = {};
     int rc = fill(f, p, "stg_tattn_fwd");
     if (rc) return rc;
-    STG_CHECK(f->bias && f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_tattn_fwd: bad bias / O");
+    STG_CHECK(f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_tattn_fwd: bad O");
     if (p.ngroups == 0) return 0;
+    if (f->D != TD) {
+        if (f->D == 64) hipLaunchKernelGGL(tattn_nb_fwd_kernel<64>, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(tattn_nb_fwd_kernel<96>, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
+    STG_CHECK(f->bias != nullptr, -1, "stg_tattn_fwd: head dim 32 needs the bias");
     const int total = p.nm * p.H * 1024;
     hipLaunchKernelGGL(tattn_table_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, f->bias, f->bm, f->bmT, p.nm * p.H, p.T, p.per);
@@ -402,6 +632,18 @@ extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t ld
     if (p.ngroups == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.dbias = dbias;
+    if (f->D != TD) {
+        STG_CHECK(dbias == nullptr, -2, "stg_tattn_bwd: no bias gradient without a bias");
+        const int lds = f->D == 64 ? nb_lds_bytes(64) : nb_lds_bytes(96);
+        static const bool attr_set =
+            hipFuncSetAttribute((const void*)tattn_nb_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, nb_lds_bytes(64)) == hipSuccess &&
+            hipFuncSetAttribute((const void*)tattn_nb_bwd_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, nb_lds_bytes(96)) == hipSuccess;
+        STG_CHECK(attr_set, -101, "stg_tattn_bwd: cannot reserve %d bytes of LDS", lds);
+        if (f->D == 64) hipLaunchKernelGGL(tattn_nb_bwd_kernel<64>, grid_for(p), dim3(256), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(tattn_nb_bwd_kernel<96>, grid_for(p), dim3(256), lds, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(tattn_bwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

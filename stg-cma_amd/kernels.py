@@ -597,27 +597,34 @@ class TGeom:
     dim 32; row(m, b, t, n) = ((m*B + b)*T + t)*N + n.  bias: fp32 [nm, H, T*T].  The additive tables the kernels read
     (bm / bmT) are workspaces filled by tattn_fwd and kept for tattn_bwd."""
 
-    def __init__(self, nm, B, T, N, H, scale, bias):
-        self.nm, self.B, self.T, self.N, self.H, self.scale = int(nm), int(B), int(T), int(N), int(H), float(scale)
+    def __init__(self, nm, B, T, N, H, scale, bias, D=32):
+        self.nm, self.B, self.T, self.N, self.H, self.scale, self.D = int(nm), int(B), int(T), int(N), int(H), float(scale), int(D)
         if not 1 <= self.T <= 32:
             raise RuntimeError("tattn: T must be in [1, 32]")
-        if bias.dtype != F32 or not bias.is_cuda or not bias.is_contiguous() or bias.numel() != self.nm * self.H * self.T * self.T:
-            raise RuntimeError("tattn: bias must be a contiguous fp32 [nm, H, T*T] GPU tensor")
-        self.bias = bias
-        self.bm = torch.empty((self.nm * self.H, 32, 32), dtype=F32, device=bias.device)
-        self.bmT = torch.empty_like(self.bm)
         self.rows = self.nm * self.B * self.T * self.N
+        self.bias = bias
+        if self.D == 32:
+            if bias is None or bias.dtype != F32 or not bias.is_cuda or not bias.is_contiguous() or bias.numel() != self.nm * self.H * self.T * self.T:
+                raise RuntimeError("tattn: bias must be a contiguous fp32 [nm, H, T*T] GPU tensor")
+            self.bm = torch.empty((self.nm * self.H, 32, 32), dtype=F32, device=bias.device)
+            self.bmT = torch.empty_like(self.bm)
+        elif self.D in (64, 96):
+            if bias is not None:
+                raise RuntimeError("tattn: head dims 64 / 96 (ViT) run without a bias")
+            self.bm = self.bmT = None
+        else:
+            raise RuntimeError("tattn: head dim must be 32, 64 or 96")
 
 
 def tattn_supported(T, hd):
-    return T <= 32 and hd == 32
+    return T <= 32 and hd in (32, 64, 96)
 
 
 def _tattn_fill(g, Q, K, V, O):
     for t, name in ((Q, "Q"), (K, "K"), (V, "V")) + (((O, "O"),) if O is not None else ()):
         _chk2d(t, name, BF16)
-        if t.shape[1] < g.H * 32 or t.shape[0] < g.rows:
-            raise RuntimeError(f"tattn {name}: needs >= {g.rows} rows x {g.H * 32} columns, got {tuple(t.shape)}")
+        if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
+            raise RuntimeError(f"tattn {name}: needs >= {g.rows} rows x {g.H * g.D} columns, got {tuple(t.shape)}")
     if not (_ld(Q) == _ld(K) == _ld(V)):
         raise RuntimeError("tattn: Q, K, V must share one leading dimension (slices of the fused qkv buffer)")
     a = _lib.TAttnArgs()
@@ -625,14 +632,14 @@ def _tattn_fill(g, Q, K, V, O):
     if O is not None:
         a.O, a.ldo = _p(O), _ld(O)
     a.bias, a.bm, a.bmT = _p(g.bias), _p(g.bm), _p(g.bmT)
-    a.nm, a.B, a.T, a.N, a.H, a.D, a.scale = g.nm, g.B, g.T, g.N, g.H, 32, g.scale
+    a.nm, a.B, a.T, a.N, a.H, a.D, a.scale = g.nm, g.B, g.T, g.N, g.H, g.D, g.scale
     return a
 
 
 def tattn_fwd(g, Q, K, V, out=None):
     """Returns O bf16 [rows, H*32]; fills g.bm / g.bmT."""
     if out is None:
-        out = torch.empty((Q.shape[0], g.H * 32), dtype=BF16, device=Q.device)
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=Q.device)
     a = _tattn_fill(g, Q, K, V, out)
     _lib.check(_lib.lib().stg_tattn_fwd(C.byref(a), _stream()), "stg_tattn_fwd")
     return out
@@ -643,8 +650,8 @@ def tattn_bwd(g, Q, K, V, dO, *, dQ, dK, dV, dbias=None):
     g must be the TGeom the forward ran with (its tables are reused)."""
     for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
         _chk2d(t, name, BF16)
-        if t.shape[1] < g.H * 32 or t.shape[0] < g.rows:
-            raise RuntimeError(f"tattn_bwd {name}: needs >= {g.rows} rows x {g.H * 32} columns")
+        if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
+            raise RuntimeError(f"tattn_bwd {name}: needs >= {g.rows} rows x {g.H * g.D} columns")
     if not (_ld(dQ) == _ld(dK) == _ld(dV)):
         raise RuntimeError("tattn_bwd: dQ, dK, dV must share one leading dimension")
     if dbias is not None and (dbias.dtype != F32 or not dbias.is_cuda or not dbias.is_contiguous()

@@ -19,6 +19,7 @@ from .ops import (RESIDUAL_DTYPE, refresh_shadows, GradArena, _Adapter, _adapter
 _SFX = ("", "_Audio")
 import os as _os
 USE_MHA = _os.environ.get("STG_MHA", "1") != "0"      # 0 = spatial ViT attention through the generic kernels (A/B knob)
+USE_TATTN_VIT = _os.environ.get("STG_TATTN_VIT", "1") != "0"   # 0 = temporal ViT attention through the generic kernels
 VIT_FROZEN = ("ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.in_proj_weight", "attn.in_proj_bias",
               "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight",
               "mlp.c_proj.bias")
@@ -63,7 +64,13 @@ def _mha(spec, BT, B, QKV, sl, temporal, save, out):
     geoms, lses = [], []
     for i, n in enumerate(spec.n_tok):
         q = QKV[sl[i]]
-        if temporal:
+        if temporal and USE_TATTN_VIT and K.tattn_supported(spec.T, spec.hd):
+            g = K.TGeom(1, B, spec.T, n, spec.heads, spec.hd ** -0.5, None, D=spec.hd)          # packed sequences, one-pass backward
+            K.tattn_fwd(g, q[:, :D], q[:, D:2 * D], q[:, 2 * D:], out=out[sl[i]])
+            geoms.append(g)
+            lses.append(None)
+            continue
+        elif temporal:
             g = K.AttnGeom(B * n, spec.heads, spec.T, spec.hd, G=n, outer=spec.T * n, temporal=n, scale=spec.hd ** -0.5)
         elif USE_MHA and K.mha_supported(n, spec.hd):
             g = K.MhaGeom(BT, spec.heads, n, spec.hd, spec.hd ** -0.5)
@@ -84,6 +91,9 @@ def _mha_bwd(spec, QKV, AO, dAO, sl, geoms, lses):
     dQKV = torch.empty_like(QKV)
     for i in range(len(spec.n_tok)):
         q, dq = QKV[sl[i]], dQKV[sl[i]]
+        if isinstance(geoms[i], K.TGeom):
+            K.tattn_bwd(geoms[i], q[:, :D], q[:, D:2 * D], q[:, 2 * D:], dAO[sl[i]], dQ=dq[:, :D], dK=dq[:, D:2 * D], dV=dq[:, 2 * D:])
+            continue
         if isinstance(geoms[i], K.MhaGeom):
             K.mha_bwd(geoms[i], q[:, :D], q[:, D:2 * D], q[:, 2 * D:], AO[sl[i]], lses[i], dAO[sl[i]],
                       dQ=dq[:, :D], dK=dq[:, D:2 * D], dV=dq[:, 2 * D:])

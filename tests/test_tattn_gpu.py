@@ -103,3 +103,36 @@ def test_tattn_rejects_bad_geometry(stg, gpu):
     small = torch.zeros(8, 3 * 128, dtype=BF16, device=gpu)
     with pytest.raises(RuntimeError):
         k.tattn_fwd(tg, small[:, :128], small[:, 128:256], small[:, 256:])
+
+
+def _ref_nb(QKV, B, T, N, H, D, scale):
+    x = QKV.view(B, T, N, 3, H, D).permute(3, 0, 2, 4, 1, 5)              # [3, B, N, H, T, D]
+    s = scale * (x[0] @ x[1].transpose(-1, -2))
+    o = torch.softmax(s, -1) @ x[2]
+    return o.permute(0, 3, 1, 2, 4).reshape(B * T * N, H * D)
+
+
+@pytest.mark.parametrize("D,H,T,N", [(96, 8, 10, 197), (96, 8, 10, 49), (64, 16, 10, 257), (64, 3, 5, 20), (96, 2, 16, 9), (96, 5, 7, 11)])
+def test_tattn_wide_heads_no_bias_vit(stg, gpu, D, H, T, N):
+    """The temporal nn.MultiheadAttention of the CLIP ViT blocks (CLIP_AVE.py:369-377): head dim 96 / 64, no bias."""
+    from stgcma import kernels as k
+    B = 2
+    g = torch.Generator().manual_seed(D + H + T + N)
+    C = H * D
+    rows = B * T * N
+    QKVb = torch.randn(rows, 3 * C, generator=g).to(BF16)
+    dOb = torch.randn(rows, C, generator=g).to(BF16)
+    Xf = QKVb.float().requires_grad_(True)
+    scale = D ** -0.5
+    o_ref = _ref_nb(Xf, B, T, N, H, D, scale)
+    o_ref.backward(dOb.float())
+    QKV = QKVb.to(gpu)
+    tg = k.TGeom(1, B, T, N, H, scale, None, D=D)
+    O = k.tattn_fwd(tg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:])
+    _close(O, o_ref, what="O")
+    dQKV = torch.full((rows, 3 * C), float("nan"), dtype=BF16, device=gpu)
+    k.tattn_bwd(tg, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], dOb.to(gpu), dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
+    gs = float(Xf.grad.abs().max())
+    _close(dQKV / gs, Xf.grad / gs, tol=1.5e-2, what="dQKV")
+    with pytest.raises(RuntimeError):
+        k.TGeom(1, B, T, N, H, scale, torch.zeros(1, H, T * T, device=gpu), D=D)      # wide heads take no bias
