@@ -207,11 +207,15 @@ def main():
     import stgcma  # noqa: F401
     from stgcma import ddp, kernels
 
-    rank, local_rank, world = ddp.init_from_env("nccl")
+    # STG_DDP_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices;
+    # RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
+    rank, local_rank, world = ddp.init_from_env(os.environ.get("STG_DDP_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    if os.environ.get("STG_DDP_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 106
+#define STG_VERSION 107
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -98,6 +98,22 @@ int stg_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int x_dtype, 
                       const float* mean, const float* rstd, const void* add_to, int64_t ldadd,
                       void* dx, int64_t lddx, float* dgamma, float* dbeta,
                       int64_t rows, int C, int gather4, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Adapter up-projection + residual join + the LayerNorm that follows it, one row-complete pass (csrc/upln.hip):
+ *   x[m,:] = res32[m,:] (+ res16[m,:]) + rs[m] * (h[m,:K] . W[:, :K]^T + bias)     fp32 residual stream, written out
+ *   y[m,:] = LayerNorm(x[m,:]) * gamma + beta                                       bf16; mean / rstd fp32 per row (may be NULL)
+ * replaces the chains `x = x + drop_path(T_Adapter(...))` -> norm1 (Swin_AVE.py:705-716,718), `x = shortcut + attn +
+ * D_fc2(h)` -> norm2 (:780-787,790) and `x = x + xn + D_fc2(h)` -> the next block's norm1 (:810-811,703/718), which as a
+ * GEMM epilogue + stg_layernorm_fwd write the fp32 row and read it straight back.
+ * rs[m] = row_scale[(m / rs_outer) * rs_inner + m % rs_inner] (DropPath; NULL = 1) is applied to the bf16 h row.
+ * stg_up_ln_supported(C, K): C in {128, 256, 512}, K % 8 == 0, K <= 64; everything else takes the two-kernel path.
+ */
+int stg_up_ln_supported(int C, int K);
+int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32, int64_t ld32,
+                  const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer, int64_t rs_inner,
+                  float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy,
+                  float* mean, float* rstd, int64_t M, int C, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic gather-mapped multi-head attention (flash-style, MFMA 32x32x16, scores never hit HBM).

@@ -118,6 +118,9 @@ SIGNATURES = {
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
                                     c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_up_ln_supported": (C.c_int, [C.c_int, C.c_int]),
+    "stg_up_ln_fwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -162,7 +165,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 106
+ABI_VERSION = 107
 _lib = None
 
 

@@ -1,0 +1,264 @@
+// Adapter up-projection + residual join + the NEXT LayerNorm in one row-complete pass (see include/stgcma.h: stg_up_ln_fwd).
+//
+//   x[m, :] = res32[m, :] (+ res16[m, :]) + rs[m] * (h[m, :K] . W[:, :K]^T + b)          fp32, written out (the residual stream)
+//   y[m, :] = LayerNorm(x[m, :]) * gamma + beta                                            bf16 (+ mean, rstd)
+//
+// In the block body (Swin_AVE.py:716, 780-787, 810-811) every residual join is an adapter's D_fc2 and is followed by a
+// LayerNorm (norm1 of the spatial pass, norm2, norm1 of the next block): as two kernels the fp32 row is written by the GEMM
+// epilogue and read straight back by the LayerNorm (2 of its 3 U of traffic).  Here a wave owns 16 COMPLETE rows: the fp32
+// residual is loaded directly into the MFMA accumulators (C operand), K <= 64 means one or two v_mfma_f32_16x16x32_bf16 per
+// 16 columns, the row statistics are a register reduction + two cross-lane adds, and x, y leave from the same registers.
+// HBM-bound by construction: per row 4C (res32) + 2C (res16) + 4C (x) + 2C (y) bytes against 2*C*K FLOP.
+//
+// Register layout.  The MFMA is issued "swapped" (first operand = W fragment, second = h fragment): lane (m = l & 15,
+// g = l >> 4) then holds D[slot 4g + r][row m], r = 0..3.  Which 16 output columns a tile's 16 slots stand for is free (it is
+// only the order in which W rows are put into the fragment), so tiles are paired: slot 4g + r of tile 2p + j <-> column
+// 32p + 8g + 4j + r.  Lane (m, g) therefore owns the 8 CONSECUTIVE columns 32p + 8g .. + 7 of every pair p: 32-byte fp32 /
+// 16-byte bf16 pieces per lane, 128 / 64 contiguous bytes per row and instruction -- and, packed to bf16, exactly the
+// A-operand layout of a k-block of 32 (used by the backward kernel below).
+#include "common.h"
+#include "../../include/stgcma.h"
+
+namespace {
+
+struct UpLnP {
+    const bf16_t* h; int64_t ldh;
+    const bf16_t* w; int64_t ldw;
+    const float* bias;
+    const float* res32; int64_t ld32;
+    const bf16_t* res16; int64_t ld16;
+    const float* row_scale; int64_t rs_outer, rs_inner;
+    float* x; int64_t ldx;
+    const float* gamma; const float* beta; float eps;
+    bf16_t* y; int64_t ldy;
+    float* mean; float* rstd;
+    int64_t M; int C; int K;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& q, float* v) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(w[j] << 16);
+        v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float* t) {
+    return make_uint4(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]), pack_bf2(t[4], t[5]), pack_bf2(t[6], t[7]));
+}
+
+// W [C, K] -> LDS in fragment order: entry (t * KS + ks) * 64 + l is lane l's 16 bytes of tile t, k-step ks
+template <int NT, int KS>
+__device__ __forceinline__ void fill_wfrag(uint4* wfrag, const bf16_t* w, int64_t ldw, int K, int tid) {
+    for (int f = tid; f < NT * KS * 64; f += 256) {
+        const int l = f & 63, tk = f >> 6;
+        const int t = tk / KS, ks = tk - t * KS;
+        const int slot = l & 15, kq = l >> 4;
+        const int col = 32 * (t >> 1) + 8 * (slot >> 2) + 4 * (t & 1) + (slot & 3);
+        const int k0 = ks * 32 + kq * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k0 < K) v = *reinterpret_cast<const uint4*>(w + (int64_t)col * ldw + k0);
+        wfrag[f] = v;
+    }
+}
+
+// NT = 16-column tiles per wave, NH = waves per row (column halves; statistics combined through LDS), C = 16 * NT * NH
+template <int NT, int NH, int KS, bool R16>
+__global__ void __launch_bounds__(256, 2) upln_fwd_kernel(UpLnP p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
+    constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int half = NH == 2 ? (wave & 1) : 0;
+    fill_wfrag<TT, KS>(wfrag, p.w, p.ldw, p.K, tid);
+    // bias / gamma / beta live in LDS and are re-read per row group through a laundered offset: as loop invariants the
+    // compiler hoists all 3 * C / 64 * 4 values per lane out of the row loop (384 VGPRs at C = 512: spills)
+    float* prm = reinterpret_cast<float*>(wfrag + TT * KS * 64);
+    float2* xch = reinterpret_cast<float2*>(prm + 3 * CC);          // [2 parities][4 waves][16 rows] (NH == 2 only)
+    for (int c = tid; c < CC; c += 256) {
+        prm[c] = p.bias[c];
+        prm[CC + c] = p.gamma[c];
+        prm[2 * CC + c] = p.beta[c];
+    }
+    __syncthreads();
+
+    constexpr int GPB = 4 / NH;                                     // row groups per block and trip
+    const float invC = 1.0f / (float)CC;
+    const int64_t ngroups = (p.M + 15) >> 4;
+    int par = 0;
+    for (int64_t base = (int64_t)blockIdx.x * GPB; base < ngroups; base += (int64_t)gridDim.x * GPB, par ^= 1) {
+        const int64_t grp = base + wave / NH;                       // may run past the end (NH == 2): clamped rows, no stores
+        const int64_t row = grp * 16 + m;
+        const bool valid = row < p.M;
+        const int64_t rc = valid ? row : p.M - 1;          // clamped: loads stay unconditional, stores are predicated
+        int go = 8 * g + half * CW;
+        int lo = lane + half * NT * KS * 64;
+        asm volatile("" : "+v"(go), "+v"(lo));
+
+        // every load of the row group is issued up front: the fp32 residual lands directly in the accumulators
+        bf16x8_t hf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int k0 = ks * 32 + g * 8;
+            const bool kok = k0 < p.K;
+            k0 = kok ? k0 : 0;
+            uint4 q = *reinterpret_cast<const uint4*>(p.h + rc * p.ldh + k0);
+            const uint32_t msk = kok ? 0xffffffffu : 0u;
+            q.x &= msk; q.y &= msk; q.z &= msk; q.w &= msk;
+            hf[ks] = __builtin_bit_cast(bf16x8_t, q);
+        }
+        f32x4_t acc[NT];
+        const float* r32 = p.res32 + rc * p.ld32 + 8 * g + half * CW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = *reinterpret_cast<const f32x4_t*>(r32 + 32 * (t >> 1) + 4 * (t & 1));
+        uint4 r16[R16 ? NT / 2 : 1];
+        if (R16) {
+            const bf16_t* q16 = p.res16 + rc * p.ld16 + 8 * g + half * CW;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) r16[pr] = *reinterpret_cast<const uint4*>(q16 + 32 * pr);
+        }
+        float rs = 1.0f;
+        if (p.row_scale) {                                  // DropPath: scales the branch (h W^T + b), not the residual
+            rs = p.row_scale[(rc / p.rs_outer) * p.rs_inner + (rc % p.rs_inner)];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                unpack8(__builtin_bit_cast(uint4, hf[ks]), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= rs;
+                hf[ks] = __builtin_bit_cast(bf16x8_t, pack8(v));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keeps the LDS fragment reads from piling up in VGPRs
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(t * KS + ks) * 64 + lo]),
+                                                                 hf[ks], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float s = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float4 b0 = *reinterpret_cast<const float4*>(prm + 32 * pr + go);
+            const float4 b1 = *reinterpret_cast<const float4*>(prm + 32 * pr + go + 4);
+            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float add[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add[j] = rs * b[j];
+            if (R16) {
+                float v[8];
+                unpack8(r16[pr], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) add[j] += v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * pr][j] += add[j];
+                acc[2 * pr + 1][j] += add[4 + j];
+                s += acc[2 * pr][j] + acc[2 * pr + 1][j];
+            }
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        float mu = s * (1.0f / (float)CW);                  // two-pass statistics of this wave's CW columns
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = acc[t][j] - mu; q += d * d; }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (NH == 2) {                                      // combine the two halves (Chan et al.: exact, no cancellation)
+            float2* xb = xch + par * 64;
+            if (g == 0) xb[wave * 16 + m] = make_float2(s, q);
+            __syncthreads();
+            const float2 o = xb[(wave ^ 1) * 16 + m];
+            const float dlt = (s - o.x) * (1.0f / (float)CW);
+            q = q + o.y + dlt * dlt * (0.5f * (float)CW);
+            mu = (s + o.x) * invC;
+        }
+        const float rstd = rsqrtf(q * invC + p.eps);
+        if (valid) {
+            float* xo = p.x + row * p.ldx + 8 * g + half * CW;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4_t*>(xo + 32 * (t >> 1) + 4 * (t & 1)) = acc[t];
+            bf16_t* yo = p.y + row * p.ldy + 8 * g + half * CW;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float4 g0 = *reinterpret_cast<const float4*>(prm + CC + 32 * pr + go);
+                const float4 g1 = *reinterpret_cast<const float4*>(prm + CC + 32 * pr + go + 4);
+                const float4 e0 = *reinterpret_cast<const float4*>(prm + 2 * CC + 32 * pr + go);
+                const float4 e1 = *reinterpret_cast<const float4*>(prm + 2 * CC + 32 * pr + go + 4);
+                const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (acc[2 * pr][j] - mu) * rstd * ga[j] + be[j];
+                    o[4 + j] = (acc[2 * pr + 1][j] - mu) * rstd * ga[4 + j] + be[4 + j];
+                }
+                *reinterpret_cast<uint4*>(yo + 32 * pr) = pack8(o);
+            }
+            if (g == 0 && half == 0) {
+                if (p.mean) p.mean[row] = mu;
+                if (p.rstd) p.rstd[row] = rstd;
+            }
+        }
+    }
+}
+
+template <int NT, int NH, int KS>
+int launch_upln(const UpLnP& p, hipStream_t st) {
+    constexpr int GPB = 4 / NH;
+    const int64_t ngroups = (p.M + 15) / 16;
+    int64_t nblk = (ngroups + GPB - 1) / GPB;
+    if (nblk > 2048) nblk = 2048;
+    const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * 64 * sizeof(float2);
+    if (p.res16) hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, true>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, false>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT, int NH>
+int dispatch_ks(const UpLnP& p, hipStream_t st) {
+    return p.K <= 32 ? launch_upln<NT, NH, 1>(p, st) : launch_upln<NT, NH, 2>(p, st);
+}
+
+}  // namespace
+
+extern "C" int stg_up_ln_supported(int C, int K) {
+    return (C == 128 || C == 256 || C == 512) && K >= 8 && K <= 64 && K % 8 == 0;
+}
+
+extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
+                             int64_t ld32, const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer,
+                             int64_t rs_inner, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                             int64_t ldy, float* mean, float* rstd, int64_t M, int C, int K, void* stream) {
+    STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "stg_up_ln_fwd: null pointer");
+    STG_CHECK(stg_up_ln_supported(C, K), -2, "stg_up_ln_fwd: unsupported C=%d K=%d (C in {128,256,512}, K <= 64, K %% 8 == 0)", C, K);
+    STG_CHECK(M >= 0, -2, "stg_up_ln_fwd: bad M");
+    STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "stg_up_ln_fwd: ldh / ldw must be multiples of 8 and >= K");
+    STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "stg_up_ln_fwd: bad ld32 / ldx / ldy");
+    STG_CHECK(res16 == nullptr || (ld16 % 8 == 0 && ld16 >= C), -2, "stg_up_ln_fwd: bad ld16");
+    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_up_ln_fwd: bad row_scale geometry");
+    STG_CHECK(((uintptr_t)h | (uintptr_t)w | (uintptr_t)res32 | (uintptr_t)res16 | (uintptr_t)x | (uintptr_t)y | (uintptr_t)bias |
+               (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, -2, "stg_up_ln_fwd: operands must be 16-byte aligned");
+    if (M == 0) return 0;
+    UpLnP p = {};
+    p.h = (const bf16_t*)h; p.ldh = ldh; p.w = (const bf16_t*)w; p.ldw = ldw; p.bias = bias;
+    p.res32 = res32; p.ld32 = ld32; p.res16 = (const bf16_t*)res16; p.ld16 = ld16;
+    p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner;
+    p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y = (bf16_t*)y; p.ldy = ldy;
+    p.mean = mean; p.rstd = rstd; p.M = M; p.C = C; p.K = K;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 16) {
+        case 8: return dispatch_ks<8, 1>(p, st);
+        case 16: return dispatch_ks<16, 1>(p, st);
+        default: return dispatch_ks<16, 2>(p, st);
+    }
+}

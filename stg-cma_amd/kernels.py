@@ -236,6 +236,52 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_to=None, gather4=None, dgamma
     return dx
 
 
+def up_ln_supported(C_, K_):
+    return bool(_lib.lib().stg_up_ln_supported(int(C_), int(K_)))
+
+
+def up_ln_fwd(h, w, bias, res32, gamma, beta, *, res16=None, row_scale=None, rs_outer=1, rs_inner=1, out=None, eps=1e-5,
+              want_stats=True, y_out=None, mean_out=None, rstd_out=None):
+    """x = res32 (+ res16) + rs * (h w^T + bias) (fp32) and y = LayerNorm(x) * gamma + beta (bf16) in one pass.
+    h [M, K] bf16, w [C, >= K] bf16 (shadow of D_fc2.weight), res32 [M, C] fp32, res16 [M, C] bf16 or None.
+    Returns (x, y, mean, rstd)."""
+    _chk2d(h, "h", BF16)
+    M, K_ = h.shape
+    Cc = w.shape[0]
+    _chk2d(w, "w", BF16, rows=Cc)
+    if w.shape[1] < K_:
+        raise RuntimeError("up_ln: w has fewer columns than h")
+    _chk1d(bias, "bias", F32, Cc)
+    _chk1d(gamma, "gamma", F32, Cc)
+    _chk1d(beta, "beta", F32, Cc)
+    _chk2d(res32, "res32", F32, cols=Cc, rows=M)
+    if res16 is not None:
+        _chk2d(res16, "res16", BF16, cols=Cc, rows=M)
+    x = torch.empty((M, Cc), dtype=F32, device=h.device) if out is None else out
+    _chk2d(x, "x", F32, cols=Cc, rows=M)
+    if x.data_ptr() == res32.data_ptr():
+        raise RuntimeError("up_ln: x must not alias res32")
+    if row_scale is not None:
+        if row_scale.dtype != F32 or not row_scale.is_cuda or not row_scale.is_contiguous():
+            raise RuntimeError("up_ln: row_scale must be a contiguous fp32 GPU vector")
+        if M > 0 and ((M - 1) // rs_outer) * rs_inner + rs_inner > row_scale.numel():
+            raise RuntimeError("up_ln: row_scale too short for (M, rs_outer, rs_inner)")
+    y = torch.empty((M, Cc), dtype=BF16, device=h.device) if y_out is None else y_out
+    _chk2d(y, "y", BF16, cols=Cc, rows=M)
+    mean, rstd = mean_out, rstd_out
+    if mean is None and want_stats:
+        mean = torch.empty((M,), dtype=F32, device=h.device)
+        rstd = torch.empty((M,), dtype=F32, device=h.device)
+    if mean is not None:
+        _chk1d(mean, "mean", F32, M)
+        _chk1d(rstd, "rstd", F32, M)
+    _lib.check(_lib.lib().stg_up_ln_fwd(_p(h), _ld(h), _p(w), _ld(w), _p(bias), _p(res32), _ld(res32), _p(res16),
+                                        _ld(res16) if res16 is not None else 0, _p(row_scale), int(rs_outer), int(rs_inner),
+                                        _p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _p(mean), _p(rstd),
+                                        M, Cc, K_, _stream()), "stg_up_ln_fwd")
+    return x, y, mean, rstd
+
+
 def _chk_flat(t, name, dtype=BF16):
     if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
         raise RuntimeError(f"{name}: expected contiguous {dtype} GPU tensor")

@@ -21,6 +21,7 @@ from . import kernels as K
 from .kernels import ACT_GELU, ACT_NONE, BF16, F32
 
 import os as _os
+USE_UPLN = _os.environ.get("STG_UPLN", "1") != "0"     # fused up-projection + residual + LayerNorm (csrc/upln.hip)
 RESIDUAL_DTYPE = BF16 if _os.environ.get("STG_RESIDUAL", "fp32").lower() == "bf16" else F32   # fp32 default; bf16 = A/B knob
 
 # ------------------------------------------------------------------------------------------------ weight shadows
@@ -445,9 +446,43 @@ def _window_geom(spec, BT, g, sbias, nm):
                       scale=spec.hd ** -0.5, bias=sbias, bias_div=P, bias_mod=1, mask=g["mask"])
 
 
-def block_forward(X, spec, P, training, save, pool=None):
+class _LnOut:
+    """Destination of a LayerNorm fused behind a residual join (K.up_ln_fwd): y / mean / rstd over ALL rows of the fused
+    tensor, filled modality slice by modality slice."""
+
+    def __init__(self, like, gamma, beta):
+        R = like.shape[0]
+        self.gamma, self.beta = gamma, beta
+        self.y = torch.empty(like.shape, dtype=BF16, device=like.device)
+        self.mean = torch.empty((R,), dtype=F32, device=like.device)
+        self.rstd = torch.empty((R,), dtype=F32, device=like.device)
+
+    def triple(self):
+        return self.y, self.mean, self.rstd
+
+
+def _join(Hh, A, out, rows, res32, res16, ln, **rs):
+    """out[rows] = res32[rows] (+ res16[rows]) + rs * (Hh A.w2^T + A.b2)  (an adapter's D_fc2 and the residual join behind it);
+    with ln (_LnOut) the LayerNorm that follows is computed in the same pass."""
+    if ln is not None:
+        K.up_ln_fwd(Hh, A.w2, A.b2, res32[rows], ln.gamma, ln.beta, res16=None if res16 is None else res16[rows], out=out[rows],
+                    y_out=ln.y[rows], mean_out=ln.mean[rows], rstd_out=ln.rstd[rows], **rs)
+    elif res16 is None:
+        K.gemm_nt(Hh, A.w2, A.b2, out=out[rows], res1=res32[rows], **rs)
+    else:
+        K.gemm_nt(Hh, A.w2, A.b2, out=out[rows], res1=res16[rows], res2=res32[rows], **rs)
+
+
+def _ln_fusable(X, ads):
+    return USE_UPLN and X.dtype == F32 and all(K.up_ln_supported(X.shape[1], A.dh) for A in ads)
+
+
+def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     """SwinTransformerBlock.forward for every mode (Swin_AVE.py:393-813) on the fused fp32 token tensor.
-    P: {name: tensor} (block_param_names + block_buffer_names).  Returns (X_out, saved-state dict or None)."""
+    P: {name: tensor} (block_param_names + block_buffer_names).  Returns (X_out, saved-state dict or None).
+    pre = (Y, mean, rstd): norm1 of X, already computed by the previous block's last residual join.
+    nxt = {"gamma", "beta"} of the NEXT block's norm1: when the join kernel supports the shape, nxt["pre"] receives that
+    block's `pre`."""
     R, C = X.shape
     assert C == spec.C and X.dtype == RESIDUAL_DTYPE
     Rm, sl = _slices(spec, R)
@@ -466,7 +501,8 @@ def block_forward(X, spec, P, training, save, pool=None):
     # ---------------- temporal attention + T_Adapter (even blocks; :705-716).  DropPath per (b, n) row.
     if spec.t_attn:
         dps = [drop_scale(spec.drop_path, B * N, X.device, training, pool) for _ in spec.mods]
-        Y, mean, rstd = K.layernorm_fwd(X, n1g, n1b, want_stats=save)
+        Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X, n1g, n1b, want_stats=save)
+        pre = None
         QKV = K.gemm_nt(Y, wqkv, bqkv)
         del Y
         tbias = torch.empty((nm, H, T * T), dtype=F32, device=X.device)
@@ -483,11 +519,13 @@ def block_forward(X, spec, P, training, save, pool=None):
             AO = None
         X1 = torch.empty_like(X)
         hz = []
-        for i, m in enumerate(spec.mods):
-            A = _Adapter(P, "T_Adapter" + _SFX[m])
+        ads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
+        pre = _LnOut(X, n1g, n1b) if _ln_fusable(X, ads) else None          # norm1 of the spatial pass
+        for i, A in enumerate(ads):
             Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True)
-            K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[i]], res1=X[sl[i]], row_scale=dps[i], rs_outer=T * N, rs_inner=N)
+            _join(Ht, A, X1, sl[i], X, None, pre, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
             hz.append((Ht, Zt))
+        pre = pre.triple() if pre is not None else None
         if save:
             S["t"] = (X, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
         del QKV, AO, PO
@@ -495,7 +533,7 @@ def block_forward(X, spec, P, training, save, pool=None):
         X1 = X
 
     # ---------------- (shifted-)window attention + S_Adapter2 (window-level cross-modal when fusing) (:718-787)
-    Y, mean, rstd = K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
+    Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
     QKV = K.gemm_nt(Y, wqkv, bqkv)
     del Y
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
@@ -515,26 +553,30 @@ def block_forward(X, spec, P, training, save, pool=None):
     else:
         H2 = [hz_[0] for hz_ in HZ]
     X2 = torch.empty_like(X)
+    ln2 = _LnOut(X, f32c(P["norm2.weight"]), f32c(P["norm2.bias"])) if _ln_fusable(X, ads) else None
     for i, A in enumerate(ads):
-        K.gemm_nt(H2[i], A.w2, A.b2, out=X2[sl[i]], res1=PO[sl[i]], res2=X1[sl[i]])
+        _join(H2[i], A, X2, sl[i], X1, PO, ln2)
     if save:
         S["s"] = (X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias)
     del QKV, AO, PO, HZ, H2
 
     # ---------------- FFN + S_Adapter (:790-811; parallel variant :438-440)
-    Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
+    Y, mean, rstd = ln2.triple() if ln2 is not None else \
+        K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
+    del ln2
     Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_dact=True)
     M = K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
     del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
     X3 = torch.empty_like(X)
+    ln3 = _LnOut(X, nxt["gamma"], nxt["beta"]) if nxt is not None and _ln_fusable(X, ads) else None
     if spec.parallel:
         # x + mlp(xn) + drop_path(0.5 * S_Adapter(xn)): DropPath per frame (dim 0 of the (BT, N, C) tensor)
         dpf = drop_scale(spec.drop_path, BT, X.device, training, pool)
         rs = (0.5 * dpf) if dpf is not None else torch.full((BT,), 0.5, dtype=F32, device=X.device)
         A = ads[0]
         Ha_, Za_ = K.gemm_nt(Y, A.w1, A.b1, act=ACT_GELU, want_dact=True)
-        K.gemm_nt(Ha_, A.w2, A.b2, out=X3, row_scale=rs, rs_outer=N, rs_inner=1, res1=M, res2=X2)
+        _join(Ha_, A, X3, slice(None), X2, M, ln3, row_scale=rs, rs_outer=N, rs_inner=1)
         if save:
             S["f"] = (X2, mean, rstd, Zm, Y, Ha_, Za_, rs)
     else:
@@ -547,9 +589,11 @@ def block_forward(X, spec, P, training, save, pool=None):
         else:
             H2 = [hz_[0] for hz_ in HZ]
         for i, A in enumerate(ads):
-            K.gemm_nt(H2[i], A.w2, A.b2, out=X3[sl[i]], res1=M[sl[i]], res2=X2[sl[i]])
+            _join(H2[i], A, X3, sl[i], X2, M, ln3)
         if save:
             S["f"] = (X2, mean, rstd, Zm, M, HZ, H2, xs)
+    if ln3 is not None:
+        nxt["pre"] = ln3.triple()
     return X3, (S if save else None)
 
 
@@ -813,6 +857,14 @@ class SwinBlockFn(torch.autograd.Function):
 SwinFusionBlockFn = SwinBlockFn
 
 
+def _next_norm1(st, j, P):
+    """norm1 of the block after block j of a stage (None behind the last one: PatchMerging / the final norm follow)."""
+    if not USE_UPLN or j + 1 >= len(st["blocks"]):
+        return None
+    nxt_pre = st["blocks"][j + 1][1]
+    return {"gamma": f32c(P[nxt_pre + "norm1.weight"]), "beta": f32c(P[nxt_pre + "norm1.bias"])}
+
+
 def plain_block_forward(X, spec, P, training, pool=None):
     """The AVQA negative-video stream: the FROZEN Swin block -- window attention and FFN with drop_path on both residuals, no
     temporal attention, no adapters (AVQA/model/Swin_AVQAModel_V1.py:780-860).  Nothing trainable sits on or behind this
@@ -885,9 +937,12 @@ class SwinBackboneFn(torch.autograd.Function):
                 pool = DropPool(req, dev)
         tape, tap_out = [], []
         for st in plan.stages:
-            for spec, pre in st["blocks"]:
+            carry = None
+            for j, (spec, pre) in enumerate(st["blocks"]):
                 Pb = {n: P[pre + n] for n in st["names"][pre]}
-                X, S = block_forward(X, spec, Pb, training, save, pool)
+                nxt = _next_norm1(st, j, P)
+                X, S = block_forward(X, spec, Pb, training, save, pool, carry, nxt)
+                carry = nxt.get("pre") if nxt is not None else None
                 tape.append(("block", spec, pre, Pb, S))
                 if Xn is not None:
                     Xn = plain_block_forward(Xn, spec, Pb, training, pool)
@@ -985,9 +1040,12 @@ class SwinModelFn(torch.autograd.Function):
                 pool = DropPool(req, src.device)
         tape = []
         for st in plan.stages:
-            for spec, pre in st["blocks"]:
+            carry = None
+            for j, (spec, pre) in enumerate(st["blocks"]):
                 Pb = {n: P[pre + n] for n in st["names"][pre]}
-                X, S = block_forward(X, spec, Pb, training, save, pool)
+                nxt = _next_norm1(st, j, P)
+                X, S = block_forward(X, spec, Pb, training, save, pool, carry, nxt)
+                carry = nxt.get("pre") if nxt is not None else None
                 tape.append(("block", spec, pre, Pb, S))
             if st["merge"] is not None:
                 H, W, pre = st["merge"]

@@ -68,7 +68,9 @@ def _check_grads(m, names, ref, tag):
                 # cancellation noise floor like the gates', not a fraction of the tensor's own (small) value
                 _cmp(dct[n].grad, r, f"{tag} grad[{n}]", max_rel=1.5e-1, l2_rel=1.2e-1)
             else:
-                _cmp(dct[n].grad, r, f"{tag} grad[{n}]", max_rel=8e-2, l2_rel=5e-2)
+                # small tensors (16 .. 512 values) behind 8 bf16 blocks: one realisation of the rounding noise moves a single
+                # tensor by +-40 % of its deviation (see NOISE in test_model_gpu.py); 6e-2 leaves ~20 % headroom
+                _cmp(dct[n].grad, r, f"{tag} grad[{n}]", max_rel=8e-2, l2_rel=6e-2)
     assert off == ref.size
 
 

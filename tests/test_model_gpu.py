@@ -18,6 +18,10 @@ BF16, F32 = torch.bfloat16, torch.float32
 _report = []
 
 
+# NOISE: every bound below holds ONE realisation of the bf16 rounding noise.  Swapping a kernel pair for an fp32-equivalent
+# fused kernel (csrc/upln.hip: x equal to 4e-6, 579 of 32 M bf16 outputs one ulp apart, tools/dbg_upln.py) moved single small
+# tensors by up to +-40 % of their deviation while the mean over the 393 compared tensors stayed put (-2 %; 184 closer, 96
+# farther).  Scalars / 16-element biases and the tiny models' logits therefore carry ~20 % headroom over the first realisation.
 def _cmp(got, ref, what, max_rel=2e-2, l2_rel=1e-2):
     got = got.detach().float().cpu().reshape(-1)
     ref = torch.as_tensor(np.asarray(ref)).float().reshape(-1)
@@ -90,7 +94,7 @@ def test_single_stream_block_matches_reference(stg, gpu, tag):
         ref = z["grads"][off:off + k]
         off += k
         if np.abs(ref).max() > 0:
-            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=6e-2, l2_rel=4e-2)
+            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=6e-2, l2_rel=5e-2 if k == 1 else 4e-2)      # NOISE (scalars: gates)
         else:
             assert d[n].grad is None or float(d[n].grad.abs().max()) == 0
 
@@ -110,7 +114,7 @@ def test_swin_tiny_other_modes_match_reference(stg, gpu, tag, mode):
     tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1).to(gpu)
     loss = torch.nn.CrossEntropyLoss()(logits, tgt)
     loss.backward()
-    _cmp(logits, z["logits"], f"{tag} logits")
+    _cmp(logits, z["logits"], f"{tag} logits", l2_rel=1.2e-2)                                              # NOISE
     err = float((logits.detach().cpu() - torch.as_tensor(z["logits"])).abs().max())
     _report.append(f"{tag} logits max abs err {err:.3e}")
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
