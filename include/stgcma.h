@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 107
+#define STG_VERSION 108
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -114,6 +114,19 @@ int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const 
                   const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer, int64_t rs_inner,
                   float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy,
                   float* mean, float* rstd, int64_t M, int C, int K, void* stream);
+
+/* LayerNorm backward + the adapter down-projection (D_fc2 dgrad) that consumes its result, one row-complete pass (csrc/upln.hip):
+ *   dx[m,:]  = rstd (gamma dy - mean(gamma dy) - xhat mean(gamma dy xhat)) (+ add_to[m,:])      bf16, written out
+ *   dh[m,:J] = rs[m] * (dx[m,:] . wt[:J,:]^T)                                                    bf16, wt = D_fc2.weight^T [J, C]
+ * replaces stg_layernorm_bwd + the stg_gemm_nt that re-reads all of dx for J <= 64 output columns (backward of
+ * Swin_AVE.py:716 / :780-787 / :810-811: the gradient of every residual join enters the adapter through D_fc2^T).
+ * x is the fp32 residual-stream row the forward normalised; frozen norms only (no dgamma / dbeta).
+ * stg_ln_bwd_down_supported(C, J): C in {128, 256, 512}, J in {16, 32, 64}. */
+int stg_ln_bwd_down_supported(int C, int J);
+int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                    const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt,
+                    const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
+                    int64_t M, int C, int J, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic gather-mapped multi-head attention (flash-style, MFMA 32x32x16, scores never hit HBM).

@@ -121,6 +121,9 @@ SIGNATURES = {
     "stg_up_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "stg_up_ln_fwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
                                 c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_ln_bwd_down_supported": (C.c_int, [C.c_int, C.c_int]),
+    "stg_ln_bwd_down": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                  c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -165,7 +168,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 107
+ABI_VERSION = 108
 _lib = None
 
 

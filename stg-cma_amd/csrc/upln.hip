@@ -229,6 +229,188 @@ int dispatch_ks(const UpLnP& p, hipStream_t st) {
     return p.K <= 32 ? launch_upln<NT, NH, 1>(p, st) : launch_upln<NT, NH, 2>(p, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward + the adapter dgrad that consumes its result (see include/stgcma.h: stg_ln_bwd_down):
+//   dx[m, :]  = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)) (+ add_to[m, :])        bf16, written out
+//   dh[m, :J] = rs[m] * (dx[m, :] . Wt[:J, :]^T)                                          bf16  (Wt = D_fc2.weight^T, [J, C])
+// Same row-complete layout as the forward kernel: the freshly packed bf16 dx pieces ARE the MFMA operand of k-block p, so the
+// down-projection costs the row no second trip through HBM (as a separate GEMM it re-read all of dx to produce J <= 64 columns).
+struct LnDownP {
+    const bf16_t* dy; int64_t lddy;
+    const float* x; int64_t ldx;
+    const float* gamma; const float* mean; const float* rstd;
+    const bf16_t* add_to; int64_t ldadd;
+    bf16_t* dx; int64_t lddx;
+    const bf16_t* wt; int64_t ldwt;
+    const float* row_scale; int64_t rs_outer, rs_inner;
+    bf16_t* dh; int64_t lddh;
+    int64_t M; int C; int J;
+};
+
+template <int NT, int NH, int NJ, bool ADD>
+__global__ void __launch_bounds__(256, 2) ln_bwd_down_kernel(LnDownP p) {
+    extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
+    constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16, NP = NT / 2, NPT = TT / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int half = NH == 2 ? (wave & 1) : 0;
+    // Wt [J, C] -> LDS in fragment order: entry (jt * NPT + pg) * 64 + l = lane l's 16 bytes of output tile jt, k-block pg.
+    // Output slots are paired like the forward kernel's columns: slot 4g + r of tile 2q + i <-> j = 32q + 8g + 4i + r.
+    for (int f = tid; f < NJ * NPT * 64; f += 256) {
+        const int l = f & 63, tk = f >> 6;
+        const int jt = tk / NPT, pg = tk - jt * NPT;
+        const int slot = l & 15, kq = l >> 4;
+        const int j = NJ == 1 ? slot : 32 * (jt >> 1) + 8 * (slot >> 2) + 4 * (jt & 1) + (slot & 3);
+        wfrag[f] = *reinterpret_cast<const uint4*>(p.wt + (int64_t)j * p.ldwt + 32 * pg + 8 * kq);
+    }
+    float* gam = reinterpret_cast<float*>(wfrag + NJ * NPT * 64);
+    float2* xch = reinterpret_cast<float2*>(gam + CC);               // [4 waves][16 rows]
+    float* hx = reinterpret_cast<float*>(xch + 64);                  // [2 groups][NJ * 4][64 lanes]  (NH == 2)
+    for (int c = tid; c < CC; c += 256) gam[c] = p.gamma[c];
+    __syncthreads();
+
+    constexpr int GPB = 4 / NH;
+    const float invC = 1.0f / (float)CC;
+    const int64_t ngroups = (p.M + 15) >> 4;
+    for (int64_t base = (int64_t)blockIdx.x * GPB; base < ngroups; base += (int64_t)gridDim.x * GPB) {
+        const int64_t grp = base + wave / NH;
+        const int64_t row = grp * 16 + m;
+        const bool valid = row < p.M;
+        const int64_t rc = valid ? row : p.M - 1;
+        int go = 8 * g + half * CW;
+        int lo = lane + half * NP * 64;
+        asm volatile("" : "+v"(go), "+v"(lo));
+
+        uint4 dyq[NP];
+        f32x4_t xh[NT];
+        uint4 adq[ADD ? NP : 1];
+        const bf16_t* dyp = p.dy + rc * p.lddy + 8 * g + half * CW;
+        const float* xp = p.x + rc * p.ldx + 8 * g + half * CW;
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) dyq[pr] = *reinterpret_cast<const uint4*>(dyp + 32 * pr);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xh[t] = *reinterpret_cast<const f32x4_t*>(xp + 32 * (t >> 1) + 4 * (t & 1));
+        if (ADD) {
+            const bf16_t* ap = p.add_to + rc * p.ldadd + 8 * g + half * CW;
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) adq[pr] = *reinterpret_cast<const uint4*>(ap + 32 * pr);
+        }
+        const float mu = p.mean[rc], rs = p.rstd[rc];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
+            const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float dv[8];
+            unpack8(dyq[pr], dv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = (xh[2 * pr][j] - mu) * rs, a1 = (xh[2 * pr + 1][j] - mu) * rs;
+                xh[2 * pr][j] = a0; xh[2 * pr + 1][j] = a1;
+                const float e0 = ga[j] * dv[j], e1 = ga[4 + j] * dv[4 + j];
+                s1 += e0 + e1;
+                s2 += e0 * a0 + e1 * a1;
+            }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (NH == 2) {
+            if (g == 0) xch[wave * 16 + m] = make_float2(s1, s2);
+            __syncthreads();
+            const float2 o = xch[(wave ^ 1) * 16 + m];
+            s1 += o.x; s2 += o.y;
+        }
+        s1 *= invC; s2 *= invC;
+        f32x4_t acc[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bf16_t* dxp = p.dx + row * p.lddx + 8 * g + half * CW;
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
+            const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
+            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float dv[8], o[8];
+            unpack8(dyq[pr], dv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rs * (ga[j] * dv[j] - s1 - xh[2 * pr][j] * s2);
+                o[4 + j] = rs * (ga[4 + j] * dv[4 + j] - s1 - xh[2 * pr + 1][j] * s2);
+            }
+            if (ADD) {
+                float av[8];
+                unpack8(adq[pr], av);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += av[j];
+            }
+            const uint4 dq = pack8(o);
+            if (valid) *reinterpret_cast<uint4*>(dxp + 32 * pr) = dq;
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, dq);
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(jt * NPT + pr) * 64 + lo]), af,
+                                                                 acc[jt], 0, 0, 0);
+        }
+        if (NH == 2) {                                      // the other half's partial products
+            float* hb = hx + (wave >> 1) * (NJ * 4 * 64);
+            if (half == 1) {
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hb[(jt * 4 + r) * 64 + lane] = acc[jt][r];
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] += hb[(jt * 4 + r) * 64 + lane];
+            }
+        }
+        if (valid && half == 0) {
+            float sc = 1.0f;
+            if (p.row_scale) sc = p.row_scale[(row / p.rs_outer) * p.rs_inner + (row % p.rs_inner)];
+            bf16_t* hp = p.dh + row * p.lddh;
+            if (NJ == 1) {
+                uint2 v;
+                v.x = pack_bf2(acc[0][0] * sc, acc[0][1] * sc); v.y = pack_bf2(acc[0][2] * sc, acc[0][3] * sc);
+                *reinterpret_cast<uint2*>(hp + 4 * g) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < NJ / 2; ++q) {
+                    float o[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o[r] = acc[2 * q][r] * sc; o[4 + r] = acc[2 * q + 1][r] * sc; }
+                    *reinterpret_cast<uint4*>(hp + 32 * q + 8 * g) = pack8(o);
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int NH, int NJ>
+int launch_lnbd(const LnDownP& p, hipStream_t st) {
+    constexpr int GPB = 4 / NH;
+    const int64_t ngroups = (p.M + 15) / 16;
+    int64_t nblk = (ngroups + GPB - 1) / GPB;
+    if (nblk > 2048) nblk = 2048;
+    const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + 64 * sizeof(float2) + (size_t)2 * NJ * 4 * 64 * 4;
+    if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, false>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT, int NH>
+int dispatch_nj(const LnDownP& p, hipStream_t st) {
+    if (p.J == 16) return launch_lnbd<NT, NH, 1>(p, st);
+    if (p.J == 32) return launch_lnbd<NT, NH, 2>(p, st);
+    return launch_lnbd<NT, NH, 4>(p, st);
+}
+
 }  // namespace
 
 extern "C" int stg_up_ln_supported(int C, int K) {
@@ -260,5 +442,36 @@ extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t 
         case 8: return dispatch_ks<8, 1>(p, st);
         case 16: return dispatch_ks<16, 1>(p, st);
         default: return dispatch_ks<16, 2>(p, st);
+    }
+}
+
+extern "C" int stg_ln_bwd_down_supported(int C, int J) {
+    return (C == 128 || C == 256 || C == 512) && (J == 16 || J == 32 || J == 64);
+}
+
+extern "C" int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                               const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt,
+                               int64_t ldwt, const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
+                               int64_t M, int C, int J, void* stream) {
+    STG_CHECK(dy && x && gamma && mean && rstd && dx && wt && dh, -1, "stg_ln_bwd_down: null pointer");
+    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "stg_ln_bwd_down: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", C, J);
+    STG_CHECK(M >= 0, -2, "stg_ln_bwd_down: bad M");
+    STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % 4 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "stg_ln_bwd_down: bad lddy / ldx / lddx");
+    STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "stg_ln_bwd_down: bad ldadd");
+    STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "stg_ln_bwd_down: bad ldwt / lddh");
+    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_ln_bwd_down: bad row_scale geometry");
+    STG_CHECK(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)add_to | (uintptr_t)dx | (uintptr_t)wt | (uintptr_t)gamma) % 16 == 0 &&
+              (uintptr_t)dh % 8 == 0 && (J == 16 || (uintptr_t)dh % 16 == 0), -2, "stg_ln_bwd_down: operands must be 16-byte aligned");
+    if (M == 0) return 0;
+    LnDownP p = {};
+    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
+    p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd; p.dx = (bf16_t*)dx; p.lddx = lddx; p.wt = (const bf16_t*)wt; p.ldwt = ldwt;
+    p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner; p.dh = (bf16_t*)dh; p.lddh = lddh;
+    p.M = M; p.C = C; p.J = J;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 16) {
+        case 8: return dispatch_nj<8, 1>(p, st);
+        case 16: return dispatch_nj<16, 1>(p, st);
+        default: return dispatch_nj<16, 2>(p, st);
     }
 }

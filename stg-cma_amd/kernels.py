@@ -282,6 +282,40 @@ def up_ln_fwd(h, w, bias, res32, gamma, beta, *, res16=None, row_scale=None, rs_
     return x, y, mean, rstd
 
 
+def ln_bwd_down_supported(C_, J_):
+    return bool(_lib.lib().stg_ln_bwd_down_supported(int(C_), int(J_)))
+
+
+def ln_bwd_down(dy, x, gamma, mean, rstd, wt, *, add_to=None, row_scale=None, rs_outer=1, rs_inner=1, dx_out=None):
+    """dx = LayerNorm backward (+ add_to), bf16, and dh = rs * (dx wt^T), bf16, in one pass.  x [M, C] fp32 (the normalised
+    residual row), dy / add_to [M, C] bf16, wt [J, C] bf16 (transposed shadow of D_fc2.weight).  Returns (dx, dh)."""
+    _chk2d(x, "x", F32)
+    M, Cc = x.shape
+    _chk2d(dy, "dy", BF16, cols=Cc, rows=M)
+    J = wt.shape[0]
+    _chk2d(wt, "wt", BF16, rows=J)
+    if wt.shape[1] < Cc:
+        raise RuntimeError("ln_bwd_down: wt has fewer columns than x")
+    _chk1d(gamma, "gamma", F32, Cc)
+    _chk1d(mean, "mean", F32, M)
+    _chk1d(rstd, "rstd", F32, M)
+    if add_to is not None:
+        _chk2d(add_to, "add_to", BF16, cols=Cc, rows=M)
+    if row_scale is not None:
+        if row_scale.dtype != F32 or not row_scale.is_cuda or not row_scale.is_contiguous():
+            raise RuntimeError("ln_bwd_down: row_scale must be a contiguous fp32 GPU vector")
+        if M > 0 and ((M - 1) // rs_outer) * rs_inner + rs_inner > row_scale.numel():
+            raise RuntimeError("ln_bwd_down: row_scale too short for (M, rs_outer, rs_inner)")
+    dx = torch.empty((M, Cc), dtype=BF16, device=x.device) if dx_out is None else dx_out
+    _chk2d(dx, "dx", BF16, cols=Cc, rows=M)
+    dh = torch.empty((M, J), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_ln_bwd_down(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(mean), _p(rstd), _p(add_to),
+                                          _ld(add_to) if add_to is not None else 0, _p(dx), _ld(dx), _p(wt), _ld(wt),
+                                          _p(row_scale), int(rs_outer), int(rs_inner), _p(dh), _ld(dh), M, Cc, J, _stream()),
+               "stg_ln_bwd_down")
+    return dx, dh
+
+
 def _chk_flat(t, name, dtype=BF16):
     if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
         raise RuntimeError(f"{name}: expected contiguous {dtype} GPU tensor")

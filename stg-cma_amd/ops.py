@@ -473,6 +473,20 @@ def _join(Hh, A, out, rows, res32, res16, ln, **rs):
         K.gemm_nt(Hh, A.w2, A.b2, out=out[rows], res1=res16[rows], res2=res32[rows], **rs)
 
 
+def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
+    """LayerNorm backward over all rows; with w2ts (one transposed D_fc2 shadow per modality) the down-projection of the
+    adapter that consumes the result is computed in the same pass.  Returns (dX, [dH per modality] or None)."""
+    if w2ts is None or not USE_UPLN or Xs.dtype != F32 or not all(K.ln_bwd_down_supported(Xs.shape[1], w.shape[0]) for w in w2ts):
+        return K.layernorm_bwd(dY, Xs, gamma, mean, rstd, add_to=add_to), None
+    dX = torch.empty(dY.shape, dtype=BF16, device=dY.device)
+    dH = []
+    for i, w in enumerate(w2ts):
+        r = sl[i]
+        kw = dict(row_scale=rss[i], **rsg) if rss is not None and rss[i] is not None else {}
+        dH.append(K.ln_bwd_down(dY[r], Xs[r], gamma, mean[r], rstd[r], w, add_to=None if add_to is None else add_to[r], dx_out=dX[r], **kw)[1])
+    return dX, dH
+
+
 def _ln_fusable(X, ads):
     return USE_UPLN and X.dtype == F32 and all(K.up_ln_supported(X.shape[1], A.dh) for A in ads)
 
@@ -597,8 +611,10 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     return X3, (S if save else None)
 
 
-def block_backward(S, spec, P, need, prefix, dX3, arena=None):
-    """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad})."""
+def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=None):
+    """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad}, dH_prev).
+    dH_in: this block's S_Adapter dgrad (dX3 . D_fc2), already computed by the LayerNorm backward that produced dX3.
+    prev: transposed D_fc2 shadows of the PREVIOUS block's S_Adapters; dH_prev is then their dgrad of dX0 (else None)."""
     R, C = dX3.shape
     Rm, sl = _slices(spec, R)
     nm = len(spec.mods)
@@ -626,7 +642,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         del Y, Ha_, Za_, dHa, dZa, dYa, dZm, Zm
     else:
         X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
-        dH2 = [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
+        dH2 = dH_in if dH_in is not None else [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
         if spec.fuse:
             dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, xs, dH2[0], dH2[1], dgv, dga)
             dHh = [dHv, dHa]
@@ -642,13 +658,14 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         del dM, Zm
         dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True))
         del dZm
-    dX2 = K.layernorm_bwd(dY, X2, f32c(P["norm2.weight"]), mean, rstd, add_to=dX3)
+    ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
+    dX2, dH2 = _ln_bwd_join(dY, X2, f32c(P["norm2.weight"]), mean, rstd, dX3, sl, [A.w2t for A in ads])
     del dY, X2, dX3
 
     # ---------------- window attention + S_Adapter2
     X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias = S.pop("s")
-    ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
-    dH2 = [K.gemm_nt(dX2[sl[i]], A.w2t) for i, A in enumerate(ads)]
+    if dH2 is None:
+        dH2 = [K.gemm_nt(dX2[sl[i]], A.w2t) for i, A in enumerate(ads)]
     if spec.fuse:
         dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, xs, dH2[0], dH2[1], dgv, dga)
         dHh = [dHv, dHa]
@@ -672,7 +689,12 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
     del QKV, AO, dAO
     dY = K.gemm_nt(dQKV, wqkv_t)
     del dQKV
-    dX1 = K.layernorm_bwd(dY, X1, n1g, mean, rstd, add_to=dX2)
+    dH_prev = None
+    if spec.t_attn:
+        tads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
+        dX1, dHts = _ln_bwd_join(dY, X1, n1g, mean, rstd, dX2, sl, [A.w2t for A in tads], S["t"][9], rs_outer=T * N, rs_inner=N)
+    else:
+        dX1, dH_prev = _ln_bwd_join(dY, X1, n1g, mean, rstd, dX2, sl, prev)
     del dY, dX2, X1
 
     # ---------------- temporal attention + T_Adapter
@@ -680,9 +702,9 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         X0, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps = S.pop("t")
         dPO = torch.empty_like(dX1)
         for i, m in enumerate(spec.mods):
-            A = _Adapter(P, "T_Adapter" + _SFX[m])
+            A = tads[i]
             Ht, Zt = hz[i]
-            dHt = K.gemm_nt(dX1[sl[i]], A.w2t, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
+            dHt = dHts[i] if dHts is not None else K.gemm_nt(dX1[sl[i]], A.w2t, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
             dZt = K.act_bwd(dHt, Zt)
             _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
             K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
@@ -704,10 +726,10 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None):
         del QKV, AO, dAO
         dY = K.gemm_nt(dQKV, wqkv_t)
         del dQKV
-        dX0 = K.layernorm_bwd(dY, X0, n1g, mean, rstd, add_to=dX1)
+        dX0, dH_prev = _ln_bwd_join(dY, X0, n1g, mean, rstd, dX1, sl, prev)
     else:
         dX0 = dX1
-    return dX0, G.g
+    return dX0, G.g, dH_prev
 
 
 # ------------------------------------------------------------------------------------------------ patch merging / embedding / heads
@@ -848,13 +870,22 @@ class SwinBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         d = dout.contiguous()
         d = K.cast_bf16(d.float().reshape(d.shape[0], -1)) if d.dtype != BF16 else d
-        dX0, g = block_backward(ctx.S, ctx.spec, ctx.P, ctx.need, "", d)
+        dX0, g, _ = block_backward(ctx.S, ctx.spec, ctx.P, ctx.need, "", d)
         ctx.S = None
         dX0 = dX0 if ctx.in_dtype == BF16 else K.cast_f32(dX0).to(ctx.in_dtype)
         return (dX0, None, None, None, None) + tuple(g.get(n) for n in ctx.names)
 
 
 SwinFusionBlockFn = SwinBlockFn
+
+
+def _prev_down(tape):
+    """Transposed D_fc2 shadows of the S_Adapters of the block below the one being differentiated (None when a PatchMerging
+    or nothing lies below, or its adapter runs parallel to the MLP with a DropPath row scale of its own)."""
+    if not USE_UPLN or not tape or tape[-1][0] != "block" or tape[-1][1].parallel:
+        return None
+    spec, Pb = tape[-1][1], tape[-1][3]
+    return [_Adapter(Pb, "S_Adapter" + _SFX[m]).w2t for m in spec.mods]
 
 
 def _next_norm1(st, j, P):
@@ -989,13 +1020,15 @@ class SwinBackboneFn(torch.autograd.Function):
         del dY, X
         dtaps = list(douts[2 + (1 if ctx.has_nega else 0):])
         tape = ctx.tape
+        dH_carry = None
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g = block_backward(S, spec, Pl, need, pre, dX, arena)
+                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape))
                 for k, val in g.items():
                     grads[pre + k] = val
             else:
+                dH_carry = None
                 dX = merge_backward(S, spec[0], spec[1], Pl, dX)
                 dt = dtaps.pop() if dtaps else None
                 if dt is not None:                                       # the tap's gradient joins the video rows
@@ -1072,13 +1105,15 @@ class SwinModelFn(torch.autograd.Function):
         grads.update(g)
         ctx.head = None
         tape = ctx.tape
+        dH_carry = None
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g = block_backward(S, spec, Pl, need, pre, dX, arena)
+                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape))
                 for k, val in g.items():
                     grads[pre + k] = val
             else:
+                dH_carry = None
                 dX = merge_backward(S, spec[0], spec[1], Pl, dX)
         if ctx.ddp is not None:
             ctx.ddp.allreduce_(arena.flat)      # one collective for every trainable gradient of the step

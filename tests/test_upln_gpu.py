@@ -70,3 +70,42 @@ def test_up_ln_unsupported_raises(stg, gpu):
     z = torch.zeros(768, device=gpu)
     with pytest.raises(RuntimeError):
         k.up_ln_fwd(h, w, z, torch.zeros(16, 768, device=gpu), z, z)
+
+
+@pytest.mark.parametrize("M,C,J,add,rs", [(64, 128, 16, True, False), (1000, 128, 16, False, True), (777, 256, 32, True, False),
+                                          (4099, 512, 32, True, False), (2048, 512, 32, False, True), (513, 512, 64, True, True),
+                                          (15, 256, 64, True, False), (1, 128, 16, False, False), (490, 256, 16, True, False)])
+def test_ln_bwd_down(stg, gpu, M, C, J, add, rs):
+    from stgcma import kernels as k
+    assert k.ln_bwd_down_supported(C, J)
+    g = torch.Generator().manual_seed(3 * M + C + J)
+    x = torch.randn(M, C, generator=g) * 2 + 0.3
+    dy = torch.randn(M, C, generator=g).to(BF16)
+    gamma = torch.randn(C, generator=g) * 0.3 + 1
+    addt = torch.randn(M, C, generator=g).to(BF16) if add else None
+    wt = (torch.randn(J, C, generator=g) * 0.1).to(BF16)
+    T, N = 5, 7
+    rst = rs_rows = None
+    if rs:
+        rst = (torch.rand(-(-M // (T * N)) * N, generator=g) < 0.8).float() / 0.8
+        rows = torch.arange(M)
+        rs_rows = rst[(rows // (T * N)) * N + rows % N]
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (C,), gamma, torch.zeros(C), 1e-5)
+    y.backward(dy.float())
+    dx_ref = xr.grad + (addt.float() if add else 0.)
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    d = lambda t: None if t is None else t.to(gpu)
+    dx, dh = k.ln_bwd_down(d(dy), d(x), d(gamma), d(mean), d(rstd), d(wt), add_to=d(addt), row_scale=d(rst), rs_outer=T * N, rs_inner=N)
+    torch.cuda.synchronize()
+    err = (dx.float().cpu() - dx_ref).abs()
+    assert float((err / dx_ref.abs().clamp(min=1.0)).max()) <= 1e-2, float(err.max())
+    # the pair it replaces: bit-identical dx is not required (reduction order), dh is checked against the bf16 dx it was made from
+    dx2 = k.layernorm_bwd(d(dy), d(x), d(gamma), d(mean), d(rstd), add_to=d(addt))
+    assert float((dx.float() - dx2.float()).abs().max()) <= 2e-2 * float(dx_ref.abs().max())
+    dh_ref = dx.float().cpu() @ wt.float().t()
+    if rs:
+        dh_ref = dh_ref * rs_rows[:, None]
+    errh = (dh.float().cpu() - dh_ref).abs()
+    assert float((errh / dh_ref.abs().clamp(min=1.0)).max()) <= 1e-2, float(errh.max())

@@ -43,3 +43,22 @@ for M, C, K in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720,
         tf, tp = timeit(fused), timeit(pair)
         byt_f = M * C * (4 + 4 + 2 + (2 if use16 else 0)) + M * K * 2
         print(f"M={M} C={C} K={K} res16={use16}: fused {tf:8.1f} us ({byt_f / tf / 1e6:6.2f} TB/s)   pair {tp:8.1f} us", flush=True)
+
+print("--- LayerNorm backward + down-projection")
+for M, C, J in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720, 512, 64)]:
+    x = torch.randn(M, C, device=dev)
+    dy = torch.randn(M, C, device=dev).to(BF16)
+    ad = torch.randn(M, C, device=dev).to(BF16)
+    ga = torch.ones(C, device=dev)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    wt = (torch.randn(J, C, device=dev) * 0.1).to(BF16)
+
+    def fused():
+        k.ln_bwd_down(dy, x, ga, mean, rstd, wt, add_to=ad)
+
+    def pair():
+        dx = k.layernorm_bwd(dy, x, ga, mean, rstd, add_to=ad)
+        k.gemm_nt(dx, wt)
+    tf, tp = timeit(fused), timeit(pair)
+    byt = M * C * (2 + 4 + 2 + 2) + M * J * 2
+    print(f"M={M} C={C} J={J}: fused {tf:8.1f} us ({byt / tf / 1e6:6.2f} TB/s)   pair {tp:8.1f} us", flush=True)
