@@ -94,6 +94,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Store of one 32-token tile of an O^T / dQ^T / dK^T / dV^T accumulator: lane (token r, half hh) holds head dims
+// 8*g4 + 4*hh + e in acc[4*g4 + e], i.e. four 8-byte pieces of the token's 64-byte row.  Two v_permlane32_swap per pair of
+// pieces (lanes r and r + 32 trade their middle pieces) leave each lane with 8 CONSECUTIVE dims: two 16-byte stores per
+// tile instead of four 8-byte ones (the store tail of these kernels is issue-bound).  Must run with every lane active;
+// only the store itself is predicated.
+__device__ __forceinline__ void store_tile32(bf16_t* rowp, const f32x16_t& acc, float sc, int hh, bool ok) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t a0 = pack_bf2(acc[8 * i + 0] * sc, acc[8 * i + 1] * sc), a1 = pack_bf2(acc[8 * i + 2] * sc, acc[8 * i + 3] * sc);
+        const uint32_t b0 = pack_bf2(acc[8 * i + 4] * sc, acc[8 * i + 5] * sc), b1 = pack_bf2(acc[8 * i + 6] * sc, acc[8 * i + 7] * sc);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);     // -> {[A.lo, B.lo], [A.hi, B.hi]} by half
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        if (ok) *reinterpret_cast<uint4*>(rowp + 16 * i + 8 * hh) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
 // host-side error plumbing (api.cpp)
 void stg_set_error(const char* fmt, ...);
 #define STG_CHECK(cond, code, ...)                \

@@ -149,17 +149,7 @@ __global__ void __launch_bounds__(256, 2) tattn_fwd_kernel(TP a) {
         o = MFMA32(tr_frag(sV, 0, hh, r), pack8(x), o);
         o = MFMA32(tr_frag(sV, 1, hh, r), pack8(x + 8), o);
         lds_fence();                                  // the tile is rewritten by the next group
-        if (r < cnt * a.T) {
-            const float inv = 1.0f / l;
-            bf16_t* op = a.O + row * a.ldo + h * TD;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(o[4 * g4 + 0] * inv, o[4 * g4 + 1] * inv);
-                w.y = pack_bf2(o[4 * g4 + 2] * inv, o[4 * g4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
-            }
-        }
+        store_tile32(a.O + row * a.ldo + h * TD, o, 1.0f / l, hh, r < cnt * a.T);
     }
 }
 
@@ -258,16 +248,7 @@ __global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
             f32x16_t dq = zero16();
             dq = MFMA32(tr_frag(sK, 0, hh, r), pack8(x), dq);
             dq = MFMA32(tr_frag(sK, 1, hh, r), pack8(x + 8), dq);
-            if (r < nvalid) {
-                bf16_t* op = a.dQ + row * a.lddqkv + h * TD;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    uint2 w;
-                    w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
-                    w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
-                    *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
-                }
-            }
+            store_tile32(a.dQ + row * a.lddqkv + h * TD, dq, a.scale, hh, r < nvalid);
         }
 
         // ---------------- phase B: key on the lane.  S[q][key], dP[q][key]; dV^T[d][key] = sum_q dO^T[d][q] P[q][key],
@@ -296,20 +277,8 @@ __global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
                 dv = MFMA32(tr_frag(sD, s2, hh, r), pack8(pr + 8 * s2), dv);
                 dk = MFMA32(tr_frag(sQ, s2, hh, r), pack8(ds + 8 * s2), dk);
             }
-            if (r < nvalid) {
-                bf16_t* kp = a.dK + row * a.lddqkv + h * TD;
-                bf16_t* vp = a.dV + row * a.lddqkv + h * TD;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    uint2 w;
-                    w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
-                    w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
-                    *reinterpret_cast<uint2*>(kp + 8 * g4 + 4 * hh) = w;
-                    w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
-                    w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
-                    *reinterpret_cast<uint2*>(vp + 8 * g4 + 4 * hh) = w;
-                }
-            }
+            store_tile32(a.dK + row * a.lddqkv + h * TD, dk, a.scale, hh, r < nvalid);
+            store_tile32(a.dV + row * a.lddqkv + h * TD, dv, 1.0f, hh, r < nvalid);
         }
         lds_fence();                                  // tiles / statistics are rewritten by the next group
     }
@@ -601,7 +570,7 @@ extern "C" int stg_tattn_fwd(const stg_tattn_args* f, void* stream) {
     TP p = {};
     int rc = fill(f, p, "stg_tattn_fwd");
     if (rc) return rc;
-    STG_CHECK(f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_tattn_fwd: bad O");
+    STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_tattn_fwd: bad O (16-byte stores)");
     if (p.ngroups == 0) return 0;
     if (f->D != TD) {
         if (f->D == 64) hipLaunchKernelGGL(tattn_nb_fwd_kernel<64>, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
@@ -626,8 +595,8 @@ extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t ld
     int rc = fill(f, p, "stg_tattn_bwd");
     if (rc) return rc;
     STG_CHECK(dO && dQ && dK && dV, -1, "stg_tattn_bwd: null pointer");
-    STG_CHECK(lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_tattn_bwd: bad leading dims");
-    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+    STG_CHECK(lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_tattn_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_tattn_bwd: misaligned pointers");
     if (p.ngroups == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;

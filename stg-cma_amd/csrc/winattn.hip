@@ -87,6 +87,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int kt, int s2, int
     return f;
 }
 
+
 // stage rows (tokens 0..63, clamped) of one of Q/K/V/dO for head h into a [64][32] LDS tile (zeros beyond n)
 __device__ __forceinline__ void stage64(const WinP& a, bf16_t* s, const bf16_t* src, int64_t ld, int pg, int g, int h, int lane) {
     uint4 v[4];
@@ -182,18 +183,8 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) o[qt] = MFMA32(tr_frag(sV, kt, s2, hh, r), pack8(x[kt] + 8 * s2), o[qt]);
         const int q = 32 * qt + r;
-        if (q < a.n) {
-            const float inv = 1.0f / l;
-            bf16_t* op = a.O + rowq[qt] * a.ldo + h * WD;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(o[qt][4 * g4 + 0] * inv, o[qt][4 * g4 + 1] * inv);
-                w.y = pack_bf2(o[qt][4 * g4 + 2] * inv, o[qt][4 * g4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
-            }
-            if (a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
-        }
+        store_tile32(a.O + rowq[qt] * a.ldo + h * WD, o[qt], 1.0f / l, hh, q < a.n);
+        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
     }
 }
 
@@ -275,16 +266,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) dq = MFMA32(tr_frag(sK, kt, s2, hh, r), pack8(ds + 8 * s2), dq);
         }
-        if (32 * qt + r < a.n) {
-            bf16_t* op = a.dQ + row[qt] * a.lddqkv + h * WD;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
-                w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
-                *reinterpret_cast<uint2*>(op + 8 * g4 + 4 * hh) = w;
-            }
-        }
+        store_tile32(a.dQ + row[qt] * a.lddqkv + h * WD, dq, a.scale, hh, 32 * qt + r < a.n);
     }
 
     // ---------------- phase B: key on the lane -> dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T = sum_q Q^T[d][q] dS[q][key]
@@ -326,20 +308,8 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
                 dk = MFMA32(tr_frag(sQ, qt, s2, hh, r), pack8(ds + 8 * s2), dk);
             }
         }
-        if (32 * kt + r < a.n) {
-            bf16_t* kp = a.dK + row[kt] * a.lddqkv + h * WD;
-            bf16_t* vp = a.dV + row[kt] * a.lddqkv + h * WD;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
-                w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
-                *reinterpret_cast<uint2*>(kp + 8 * g4 + 4 * hh) = w;
-                w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
-                w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
-                *reinterpret_cast<uint2*>(vp + 8 * g4 + 4 * hh) = w;
-            }
-        }
+        store_tile32(a.dK + row[kt] * a.lddqkv + h * WD, dk, a.scale, hh, 32 * kt + r < a.n);
+        store_tile32(a.dV + row[kt] * a.lddqkv + h * WD, dv, 1.0f, hh, 32 * kt + r < a.n);
     }
 }
 
@@ -408,7 +378,7 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     WinP p = {};
     int rc = fill(f, p, "stg_winattn_fwd");
     if (rc) return rc;
-    STG_CHECK(f->O && f->ldo % 4 == 0 && (((uintptr_t)f->O) & 7) == 0, -2, "stg_winattn_fwd: bad O");
+    STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
     hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
@@ -422,8 +392,8 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     int rc = fill(f, p, "stg_winattn_bwd");
     if (rc) return rc;
     STG_CHECK(f->O && f->lse && dO && dQ && dK && dV, -1, "stg_winattn_bwd: null pointer");
-    STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_winattn_bwd: bad leading dims");
-    STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+    STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_winattn_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
