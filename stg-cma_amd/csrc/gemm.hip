@@ -134,7 +134,7 @@ enum { EV_GENERIC = 0, EV_PLAIN, EV_GELU, EV_QGELU, EV_DSRC, EV_R16, EV_BRQ };
 
 template <int V>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
-                                                   int lane, float* stg) {
+                                                   int lane, float* stg, int ngap = 0) {
     constexpr bool G = V == EV_GENERIC;
     const bool alpha_on = G ? p.alpha != 1.0f : false;
     const int act = G ? p.act : (V == EV_GELU ? (int)STG_ACT_GELU : V == EV_QGELU ? (int)STG_ACT_QUICKGELU : (int)STG_ACT_NONE);
@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
 
     const int lrow = lane & 15, lk = lane >> 4;
     const int rr = lane >> 3, cc = lane & 7;
-    int n = n0 + wn * 64 + cc * 8;
+    int n = n0 + wn * 64 + cc * 8 + ((cc & 4) ? ngap : 0);     // ngap: the tile's right 32 columns sit ngap further right (8-phase kernel)
     const bool col_ok = n < p.N;
     if (!col_ok) n = 0;                                // clamped: loads stay unconditional, stores are predicated
     float bias[8];
@@ -238,16 +238,16 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
 
 // smem: the block's tile buffer (>= 32 KiB), free once every wave is past the main loop's final barrier
 __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm,
-                                                       int wn, int lane, float* stg) {
+                                                       int wn, int lane, float* stg, int ngap = 0) {
     if (p.dbg == 3 && accs.v[0][0][0] != 12345.678f) return;
     switch (p.epi_variant) {
-        case EV_PLAIN: gemm_epilogue_rows<EV_PLAIN>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_GELU: gemm_epilogue_rows<EV_GELU>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_QGELU: gemm_epilogue_rows<EV_QGELU>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_DSRC: gemm_epilogue_rows<EV_DSRC>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_R16: gemm_epilogue_rows<EV_R16>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_BRQ: gemm_epilogue_rows<EV_BRQ>(p, accs, m0, n0, wm, wn, lane, stg); break;
-        case EV_GENERIC: gemm_epilogue_rows<EV_GENERIC>(p, accs, m0, n0, wm, wn, lane, stg); break;
+        case EV_PLAIN: gemm_epilogue_rows<EV_PLAIN>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_GELU: gemm_epilogue_rows<EV_GELU>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_QGELU: gemm_epilogue_rows<EV_QGELU>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_DSRC: gemm_epilogue_rows<EV_DSRC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_R16: gemm_epilogue_rows<EV_R16>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_BRQ: gemm_epilogue_rows<EV_BRQ>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_GENERIC: gemm_epilogue_rows<EV_GENERIC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         default: gemm_epilogue_elems(p, accs, m0, n0, wm, wn, lane & 15, lane >> 4); break;     // unaligned / N % 8 != 0
     }
 }
@@ -556,6 +556,173 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
             for (int mi = 0; mi < 4; ++mi) t.v[ni][mi] = acc[ni][half * 4 + mi];
         if (half) lds_wave_sync();
         gemm_epilogue_dispatch(p, t, m0 + wm * 128 + half * 64, n0 + wn * 64, 0, 0, lane, stg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8-phase variant of the 256 x 256 x 64 kernel (K % 64 == 0, N % 256 == 0, row-layout epilogue only).
+// Same block tile and the same MFMA / k order as gemm_nt_big_kernel (results are bit-identical), different pipeline: the
+// simple loop above stalls every k-tile on the vmcnt(0) in front of its barrier while the next tile's DMA is in flight and
+// leaves the MFMA pipe idle while fragments are read.  Here
+//   * a k-tile is staged as FOUR 16 KiB half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255) into 2 x 4 LDS slots, one
+//     half-tile per phase, two half-tiles always in flight across the barriers (counted vmcnt, raw s_barrier);
+//   * a wave's 128 x 64 output is interleaved over the halves -- rows {wr*64.. of half 0} + {wr*64.. of half 1}, columns
+//     {wc*32.. of half 0} + {wc*32.. of half 1} -- so phase p of a k-tile computes one 64 x 32 x 64 quadrant from
+//     (A0,W0) (A0,W1) (A1,W1) (A1,W0): 16 MFMAs behind 12 / 4 / 8 / 4 fragment reads, and each slot is dead early
+//     (A0 after phase 0, W1 after phase 1, A1 after phase 2, W0 after phase 3);
+//   * waves 4-7 run one barrier behind waves 0-3: one group reads fragments / issues DMA while the other runs its MFMA cluster.
+// Schedule of k-tile t (slot parity t & 1), phase p: reads as above; DMA issue p0: A1(t+1)  p1: W0(t+1)  p2: A0(t+2)  p3: W1(t+2);
+// in p3, before its first barrier, s_waitcnt vmcnt(4): everything but the two half-tiles just issued has landed.
+// RAW: A1(t+1), W0(t+1) are retired by that wait >= 1 barrier before any wave reads them (phase 0 / 2 of t+1, the late group
+// included); A0(t+2), W1(t+2) by the wait of tile t+1.  WAR: a slot is re-staged >= 3 barrier intervals after its last ds_read
+// (late group included): A0 p0 -> p2, W1 p1 -> p3, A1 p2 -> p0', W0 p3 -> p1'.
+__global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 128 rows x 64 bf16 = 128 KiB
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int64_t m0 = (int64_t)bm * GBM;
+    const int n0 = bn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lrow = lane & 15, lk = lane >> 4;
+    constexpr int SLOT = 128 * BK;                       // bf16 elements per half-tile slot
+    enum { HA0 = 0, HA1 = 1, HW0 = 2, HW1 = 3 };
+
+    // DMA pieces of a half-tile: chunk q = j * 512 + tid (j = 0, 1) -> row q >> 3 (0..127), position q & 7 <- source chunk (q & 7) ^ (row & 7)
+    uint32_t oa[2][2], ow[2][2];                         // [half][j] byte offsets from the block's A / W base rows
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = j * 512 + tid;
+            const int row = hf * 128 + (q >> 3), c = (q & 7) ^ ((q >> 3) & 7);
+            const int64_t rm = p.M - 1 - m0;
+            const int ra = row < rm ? row : (int)rm;     // rows beyond M are clamped (their products are never stored)
+            oa[hf][j] = (uint32_t)(((int64_t)ra * p.lda + c * 8) * 2);
+            ow[hf][j] = (uint32_t)(((int64_t)row * p.ldw + c * 8) * 2);          // N % 256 == 0: always in range
+        }
+    const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda);
+    const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    const int nk = p.K / BK;
+    auto issue = [&](int which, int kt) {                // which: HA0 / HA1 / HW0 / HW1 of k-tile kt (clamped: a dummy re-load past the end)
+        kt = kt < nk ? kt : nk - 1;
+        bf16_t* dst = smem8 + ((kt & 1) * 4 + which) * SLOT + wave * 512;
+        const bool isw = which >= HW0;
+        const int hf = which & 1;
+        const char* g = (isw ? baseW : baseA) + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (isw ? ow[hf][j] : oa[hf][j])),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+    };
+
+    f32x4_t acc[2][2][2][4];                             // [mh][nh][ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[a][b][c][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // fragment offsets inside a slot (bf16 elements): A rows wr*64 + mi*16 + lrow, W rows wc*32 + ni*16 + lrow; chunk 4*s + lk
+    int offA[4][2], offW[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { const int r = wr * 64 + mi * 16 + lrow; offA[mi][s2] = r * BK + swz(r, 4 * s2 + lk) * 8; }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { const int r = wc * 32 + ni * 16 + lrow; offW[ni][s2] = r * BK + swz(r, 4 * s2 + lk) * 8; }
+    }
+
+    // prologue: all of tile 0 + the two early half-tiles of tile 1; the last two stay in flight
+    issue(HA0, 0); issue(HW0, 0); issue(HW1, 0); issue(HA1, 0); issue(HA0, 1); issue(HW1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Fragment reads per phase are balanced against the 16-MFMA cluster of the other wave group (8 ds_read_b128 of a group's
+    // four waves = 256 LDS clocks = one cluster):  p0: W0 + the k-step-1 half of A0 (8)   p1: W1 (4)   p2: A1 (8)
+    // p3: W0 again + the k-step-0 half of the NEXT tile's A0 (8; second A register set, that half-tile landed a k-tile ago).
+    bf16x8_t af[2][4][2], wf[2][2];                      // A sub-tile sets [tile parity][mi][s]; W sub-tile [ni][s]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) af[0][mi][0] = *reinterpret_cast<const bf16x8_t*>(smem8 + HA0 * SLOT + offA[mi][0]);
+    if (wr == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run one barrier behind
+
+    for (int kt2 = 0; kt2 < nk; kt2 += 2) {
+#pragma unroll
+        for (int cur = 0; cur < 2; ++cur) {
+            const int kt = kt2 + cur;
+            const bf16_t* sl = smem8 + cur * 4 * SLOT;           // nk is even: parity of kt == cur
+            const bf16_t* sn = smem8 + (cur ^ 1) * 4 * SLOT;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int mh = ph >> 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
+                if (ph != 2) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            wf[ni][s2] = *reinterpret_cast<const bf16x8_t*>(sl + (HW0 + nh) * SLOT + offW[ni][s2]);
+                }
+                if (ph == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) af[cur][mi][1] = *reinterpret_cast<const bf16x8_t*>(sl + HA0 * SLOT + offA[mi][1]);
+                } else if (ph == 2) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) af[cur][mi][s2] = *reinterpret_cast<const bf16x8_t*>(sl + HA1 * SLOT + offA[mi][s2]);
+                } else if (ph == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) af[cur ^ 1][mi][0] = *reinterpret_cast<const bf16x8_t*>(sn + HA0 * SLOT + offA[mi][0]);
+                }
+                if (ph == 0) issue(HA1, kt + 1);
+                if (ph == 1) issue(HW0, kt + 1);
+                if (ph == 2) issue(HA0, kt + 2);
+                if (ph == 3) { issue(HW1, kt + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_setprio(1);
+                if (p.dbg != 2)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+                            acc[mh][nh][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][s2], af[cur][mi][s2], acc[mh][nh][ni][mi], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();           // pairs with the late group's last barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy tail DMAs land before the staging regions reuse the slots
+    __builtin_amdgcn_s_barrier();
+
+    // epilogue: per row half one 64 x 64 piece whose right 32 columns sit 96 further right, through the wave's private 8 KiB region
+    float* stg = reinterpret_cast<float*>(smem8) + wave * 2048;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        AccTile t;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) t.v[nh * 2 + ni][mi] = acc[mh][nh][ni][mi];
+        if (mh) lds_wave_sync();
+        gemm_epilogue_dispatch(p, t, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
     }
 }
 
@@ -890,6 +1057,19 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     const bool big_ok = a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
+    static const int ph8_mode = [] { const char* e = getenv("STG_GEMM_8PH"); return e ? atoi(e) : 1; }();   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
+    const bool ph8_ok = a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
+    if (ph8_ok && ((ph8_mode == 1 && big) || ph8_mode == 2)) {
+        static const bool attr8 = [] {
+            return hipFuncSetAttribute((const void*)gemm_nt_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2) == hipSuccess;
+        }();
+        STG_CHECK(attr8, -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
+        const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
+        p.nbm = (int)gbm; p.nbn = (int)gbn;
+        hipLaunchKernelGGL(gemm_nt_8ph_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
     if (big) {
         static const bool attr_set = [] {
             return hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
