@@ -308,3 +308,38 @@ def test_cast_bf16_multi_equals_single_casts(stg, gpu):
     ss.refresh()
     assert torch.equal(ops.shadow(params[0]), k.cast_bf16(params[0].detach()))
     assert not torch.equal(ops.shadow(params[0]), old)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4097, 768, 3072, "b"), (300, 256, 1024, ""), (1000, 512, 2048, "bap"), (777, 1024, 1152, "d"),
+                                       (256, 256, 128, "b"), (5000, 256, 1536, "r"), (2049, 512, 1024, "bR")])
+def test_gemm_long_k_shapes(stg, gpu, M, N, K, epi):
+    """Shapes the host dispatch routes to the 8-phase 256 x 256 kernel (K >= 1024, K % 128 == 0, N % 256 == 0) and its
+    neighbours (K % 128 != 0 -> large-tile kernel; K = 128 -> 128 x 128 kernel), with row tails and every epilogue family."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.05)
+    b = torch.randn(N, generator=g) if "b" in epi else None
+    z = A.float() @ W.float().t() + (b if b is not None else 0.)
+    kw = {}
+    ref = z
+    if "a" in epi:
+        kw.update(act=k.ACT_GELU, want_dact=True)
+        ref = torch.nn.functional.gelu(z)
+    if "d" in epi:
+        src = _bf(torch.randn(M, N, generator=g))
+        kw["dact_src"] = src.to(gpu)
+        ref = z * src.float()
+    if "r" in epi:
+        r1 = _bf(torch.randn(M, N, generator=g))
+        kw["res1"] = r1.to(gpu)
+        ref = ref + r1.float()
+    if "R" in epi:
+        r2 = torch.randn(M, N, generator=g)
+        kw.update(res1=_bf(torch.zeros(M, N)).to(gpu), res2=r2.to(gpu), out_dtype=F32)
+        ref = ref + r2
+    out = k.gemm_nt(A.to(gpu), W.to(gpu), None if b is None else b.to(gpu), **kw)
+    if "a" in epi:
+        out, dact = out
+        _close(dact, _gelu_grad(z), what=f"dact {M}x{N}x{K}")
+    _close(out, ref, tol=2e-2 if K >= 2048 else 1e-2, what=f"gemm {epi} {M}x{N}x{K}")
