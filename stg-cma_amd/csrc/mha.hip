@@ -170,19 +170,12 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
             o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), p1, o[dt]);
         }
     }
-    if (q < a.n) {
+    {
         const float inv = 1.0f / l;
-        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;
+        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;                  // 16-byte stores (store_tile32: every lane takes part)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
-                w.y = pack_bf2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
-            }
-        if (a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
+        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, q < a.n);
+        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
     }
 }
 
@@ -251,17 +244,10 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
             dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), d1, dq[dt]);
         }
     }
-    if (q < a.n) {
+    {
         bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(dq[dt][4 * g4 + 0] * a.scale, dq[dt][4 * g4 + 1] * a.scale);
-                w.y = pack_bf2(dq[dt][4 * g4 + 2] * a.scale, dq[dt][4 * g4 + 3] * a.scale);
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
-            }
+        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, dq[dt], a.scale, hh, q < a.n);
     }
 }
 
@@ -349,33 +335,25 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
             dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 1, hh, r), d1, dk[dt]);
         }
     }
-    if (key < a.n) {
+    {
+        const bool okk = key < a.n;
         bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
         if (a.dV == nullptr) {                         // K and V are ONE tensor (cross-modal attention): its gradient is dK + dV
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x16_t c;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    uint2 w;
-                    w.x = pack_bf2(fmaf(dk[dt][4 * g4 + 0], a.scale, dv[dt][4 * g4 + 0]), fmaf(dk[dt][4 * g4 + 1], a.scale, dv[dt][4 * g4 + 1]));
-                    w.y = pack_bf2(fmaf(dk[dt][4 * g4 + 2], a.scale, dv[dt][4 * g4 + 2]), fmaf(dk[dt][4 * g4 + 3], a.scale, dv[dt][4 * g4 + 3]));
-                    *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
-                }
+                for (int i = 0; i < 16; ++i) c[i] = fmaf(dk[dt][i], a.scale, dv[dt][i]);
+                store_tile32(kp + 32 * dt, c, 1.0f, hh, okk);
+            }
             return;
         }
         bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf2(dk[dt][4 * g4 + 0] * a.scale, dk[dt][4 * g4 + 1] * a.scale);
-                w.y = pack_bf2(dk[dt][4 * g4 + 2] * a.scale, dk[dt][4 * g4 + 3] * a.scale);
-                *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
-                w.x = pack_bf2(dv[dt][4 * g4 + 0], dv[dt][4 * g4 + 1]);
-                w.y = pack_bf2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
-                *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4 + 4 * hh) = w;
-            }
+        for (int dt = 0; dt < DT; ++dt) {
+            store_tile32(kp + 32 * dt, dk[dt], a.scale, hh, okk);
+            store_tile32(vp + 32 * dt, dv[dt], 1.0f, hh, okk);
+        }
     }
 }
 
@@ -428,8 +406,8 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (rc) return rc;
     STG_CHECK(dO && dQ && dK && delta, -1, "stg_mha_bwd: null pointer");
     STG_CHECK(dV != nullptr || f->K == f->V, -2, "stg_mha_bwd: dV == NULL (shared K = V gradient) needs K == V");
-    STG_CHECK(lddo % 8 == 0 && lddqkv % 4 == 0, -2, "stg_mha_bwd: bad leading dims");
-    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 7) == 0, -2,
+    STG_CHECK(lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_mha_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_mha_bwd: misaligned pointers");
     if (p.P == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;

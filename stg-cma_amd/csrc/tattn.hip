@@ -381,18 +381,11 @@ __global__ void __launch_bounds__(256, 2) tattn_nb_fwd_kernel(TP a) {
             o[dt] = MFMA32(tr_frag_p<DP>(sV, dt, 1, hh, r), p1, o[dt]);
         }
         lds_fence();
-        if (r < cnt * a.T) {
+        {
             const float inv = 1.0f / l;
             bf16_t* op = a.O + row * a.ldo + h * D;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    uint2 w;
-                    w.x = pack_bf2(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv);
-                    w.y = pack_bf2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
-                }
+            for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, r < cnt * a.T);
         }
     }
 }
@@ -462,15 +455,7 @@ __global__ void __launch_bounds__(256, 2) tattn_nb_bwd_kernel(TP a) {
             for (int dt = 0; dt < DT; ++dt) {                       // the transposed LDS reads need EXEC all ones: only the stores are masked
                 f32x16_t dq = MFMA32(tr_frag_p<DP>(sK, dt, 0, hh, r), d0, zero16());
                 dq = MFMA32(tr_frag_p<DP>(sK, dt, 1, hh, r), d1, dq);
-                if (r < nvalid) {
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        uint2 w;
-                        w.x = pack_bf2(dq[4 * g4 + 0] * a.scale, dq[4 * g4 + 1] * a.scale);
-                        w.y = pack_bf2(dq[4 * g4 + 2] * a.scale, dq[4 * g4 + 3] * a.scale);
-                        *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g4 + 4 * hh) = w;
-                    }
-                }
+                store_tile32(op + 32 * dt, dq, a.scale, hh, r < nvalid);
             }
         }
         {   // phase B: key on the lane
@@ -500,18 +485,8 @@ __global__ void __launch_bounds__(256, 2) tattn_nb_bwd_kernel(TP a) {
                 dv = MFMA32(tr_frag_p<DP>(sD, dt, 1, hh, r), p1, dv);
                 f32x16_t dk = MFMA32(tr_frag_p<DP>(sQ, dt, 0, hh, r), e0, zero16());
                 dk = MFMA32(tr_frag_p<DP>(sQ, dt, 1, hh, r), e1, dk);
-                if (r < nvalid) {
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        uint2 w;
-                        w.x = pack_bf2(dk[4 * g4 + 0] * a.scale, dk[4 * g4 + 1] * a.scale);
-                        w.y = pack_bf2(dk[4 * g4 + 2] * a.scale, dk[4 * g4 + 3] * a.scale);
-                        *reinterpret_cast<uint2*>(kp + 32 * dt + 8 * g4 + 4 * hh) = w;
-                        w.x = pack_bf2(dv[4 * g4 + 0], dv[4 * g4 + 1]);
-                        w.y = pack_bf2(dv[4 * g4 + 2], dv[4 * g4 + 3]);
-                        *reinterpret_cast<uint2*>(vp + 32 * dt + 8 * g4 + 4 * hh) = w;
-                    }
-                }
+                store_tile32(kp + 32 * dt, dk, a.scale, hh, r < nvalid);
+                store_tile32(vp + 32 * dt, dv, 1.0f, hh, r < nvalid);
             }
         }
         lds_fence();
