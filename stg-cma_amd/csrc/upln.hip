@@ -49,8 +49,8 @@ __device__ __forceinline__ uint4 pack8(const float* t) {
 
 // W [C, K] -> LDS in fragment order: entry (t * KS + ks) * 64 + l is lane l's 16 bytes of tile t, k-step ks
 template <int NT, int KS>
-__device__ __forceinline__ void fill_wfrag(uint4* wfrag, const bf16_t* w, int64_t ldw, int K, int tid) {
-    for (int f = tid; f < NT * KS * 64; f += 256) {
+__device__ __forceinline__ void fill_wfrag(uint4* wfrag, const bf16_t* w, int64_t ldw, int K, int tid, int nthreads) {
+    for (int f = tid; f < NT * KS * 64; f += nthreads) {
         const int l = f & 63, tk = f >> 6;
         const int t = tk / KS, ks = tk - t * KS;
         const int slot = l & 15, kq = l >> 4;
@@ -62,27 +62,28 @@ __device__ __forceinline__ void fill_wfrag(uint4* wfrag, const bf16_t* w, int64_
     }
 }
 
-// NT = 16-column tiles per wave, NH = waves per row (column halves; statistics combined through LDS), C = 16 * NT * NH
-template <int NT, int NH, int KS, bool R16>
-__global__ void __launch_bounds__(256, 2) upln_fwd_kernel(UpLnP p) {
+// NT = 16-column tiles per wave, NH = waves per row (column halves; statistics combined through LDS), C = 16 * NT * NH;
+// NW = waves per block (8 where the W fragments of one block take most of the LDS: C = 768 shares one copy among 8 waves)
+template <int NT, int NH, int KS, bool R16, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLnP p) {
     extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
     constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int half = NH == 2 ? (wave & 1) : 0;
-    fill_wfrag<TT, KS>(wfrag, p.w, p.ldw, p.K, tid);
+    fill_wfrag<TT, KS>(wfrag, p.w, p.ldw, p.K, tid, NW * 64);
     // bias / gamma / beta live in LDS and are re-read per row group through a laundered offset: as loop invariants the
     // compiler hoists all 3 * C / 64 * 4 values per lane out of the row loop (384 VGPRs at C = 512: spills)
     float* prm = reinterpret_cast<float*>(wfrag + TT * KS * 64);
-    float2* xch = reinterpret_cast<float2*>(prm + 3 * CC);          // [2 parities][4 waves][16 rows] (NH == 2 only)
-    for (int c = tid; c < CC; c += 256) {
+    float2* xch = reinterpret_cast<float2*>(prm + 3 * CC);          // [2 parities][NW waves][16 rows] (NH == 2 only)
+    for (int c = tid; c < CC; c += NW * 64) {
         prm[c] = p.bias[c];
         prm[CC + c] = p.gamma[c];
         prm[2 * CC + c] = p.beta[c];
     }
     __syncthreads();
 
-    constexpr int GPB = 4 / NH;                                     // row groups per block and trip
+    constexpr int GPB = NW / NH;                                    // row groups per block and trip
     const float invC = 1.0f / (float)CC;
     const int64_t ngroups = (p.M + 15) >> 4;
     int par = 0;
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) upln_fwd_kernel(UpLnP p) {
         q += __shfl_xor(q, 16, 64);
         q += __shfl_xor(q, 32, 64);
         if (NH == 2) {                                      // combine the two halves (Chan et al.: exact, no cancellation)
-            float2* xb = xch + par * 64;
+            float2* xb = xch + par * (NW * 16);
             if (g == 0) xb[wave * 16 + m] = make_float2(s, q);
             __syncthreads();
             const float2 o = xb[(wave ^ 1) * 16 + m];
@@ -211,15 +212,20 @@ __global__ void __launch_bounds__(256, 2) upln_fwd_kernel(UpLnP p) {
     }
 }
 
-template <int NT, int NH, int KS>
+template <int NT, int NH, int KS, int NW = 4>
 int launch_upln(const UpLnP& p, hipStream_t st) {
-    constexpr int GPB = 4 / NH;
+    constexpr int GPB = NW / NH;
     const int64_t ngroups = (p.M + 15) / 16;
     int64_t nblk = (ngroups + GPB - 1) / GPB;
     if (nblk > 2048) nblk = 2048;
-    const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * 64 * sizeof(float2);
-    if (p.res16) hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, true>), dim3((unsigned)nblk), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, false>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * NW * 16 * sizeof(float2);
+    if (lds > 64 * 1024) {
+        static const bool ok = hipFuncSetAttribute((const void*)upln_fwd_kernel<NT, NH, KS, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                               hipFuncSetAttribute((const void*)upln_fwd_kernel<NT, NH, KS, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        STG_CHECK(ok, -101, "stg_up_ln_fwd: cannot reserve %d bytes of LDS", (int)lds);
+    }
+    if (p.res16) hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, true, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
+    else hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, false, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -247,8 +253,8 @@ struct LnDownP {
     int64_t M; int C; int J;
 };
 
-template <int NT, int NH, int NJ, bool ADD>
-__global__ void __launch_bounds__(256, 2) ln_bwd_down_kernel(LnDownP p) {
+template <int NT, int NH, int NJ, bool ADD, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(LnDownP p) {
     extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
     constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16, NP = NT / 2, NPT = TT / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,20 +262,21 @@ __global__ void __launch_bounds__(256, 2) ln_bwd_down_kernel(LnDownP p) {
     const int half = NH == 2 ? (wave & 1) : 0;
     // Wt [J, C] -> LDS in fragment order: entry (jt * NPT + pg) * 64 + l = lane l's 16 bytes of output tile jt, k-block pg.
     // Output slots are paired like the forward kernel's columns: slot 4g + r of tile 2q + i <-> j = 32q + 8g + 4i + r.
-    for (int f = tid; f < NJ * NPT * 64; f += 256) {
+    for (int f = tid; f < NJ * NPT * 64; f += NW * 64) {
         const int l = f & 63, tk = f >> 6;
         const int jt = tk / NPT, pg = tk - jt * NPT;
         const int slot = l & 15, kq = l >> 4;
-        const int j = NJ == 1 ? slot : 32 * (jt >> 1) + 8 * (slot >> 2) + 4 * (jt & 1) + (slot & 3);
+        const int j = (NJ == 1 || ((NJ & 1) && jt == NJ - 1)) ? 16 * jt + slot                     // an unpaired (last) tile
+                                                                : 32 * (jt >> 1) + 8 * (slot >> 2) + 4 * (jt & 1) + (slot & 3);
         wfrag[f] = *reinterpret_cast<const uint4*>(p.wt + (int64_t)j * p.ldwt + 32 * pg + 8 * kq);
     }
     float* gam = reinterpret_cast<float*>(wfrag + NJ * NPT * 64);
-    float2* xch = reinterpret_cast<float2*>(gam + CC);               // [4 waves][16 rows]
-    float* hx = reinterpret_cast<float*>(xch + 64);                  // [2 groups][NJ * 4][64 lanes]  (NH == 2)
-    for (int c = tid; c < CC; c += 256) gam[c] = p.gamma[c];
+    float2* xch = reinterpret_cast<float2*>(gam + CC);               // [NW waves][16 rows]
+    float* hx = reinterpret_cast<float*>(xch + NW * 16);             // [NW / 2 groups][NJ * 4][64 lanes]  (NH == 2)
+    for (int c = tid; c < CC; c += NW * 64) gam[c] = p.gamma[c];
     __syncthreads();
 
-    constexpr int GPB = 4 / NH;
+    constexpr int GPB = NW / NH;
     const float invC = 1.0f / (float)CC;
     const int64_t ngroups = (p.M + 15) >> 4;
     for (int64_t base = (int64_t)blockIdx.x * GPB; base < ngroups; base += (int64_t)gridDim.x * GPB) {
@@ -374,32 +381,36 @@ __global__ void __launch_bounds__(256, 2) ln_bwd_down_kernel(LnDownP p) {
             float sc = 1.0f;
             if (p.row_scale) sc = p.row_scale[(row / p.rs_outer) * p.rs_inner + (row % p.rs_inner)];
             bf16_t* hp = p.dh + row * p.lddh;
-            if (NJ == 1) {
+#pragma unroll
+            for (int q = 0; q < NJ / 2; ++q) {
+                float o[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[r] = acc[2 * q][r] * sc; o[4 + r] = acc[2 * q + 1][r] * sc; }
+                *reinterpret_cast<uint4*>(hp + 32 * q + 8 * g) = pack8(o);
+            }
+            if (NJ & 1) {                                   // the unpaired last tile: columns 16 (NJ - 1) + 4 g .. + 3
                 uint2 v;
-                v.x = pack_bf2(acc[0][0] * sc, acc[0][1] * sc); v.y = pack_bf2(acc[0][2] * sc, acc[0][3] * sc);
-                *reinterpret_cast<uint2*>(hp + 4 * g) = v;
-            } else {
-#pragma unroll
-                for (int q = 0; q < NJ / 2; ++q) {
-                    float o[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { o[r] = acc[2 * q][r] * sc; o[4 + r] = acc[2 * q + 1][r] * sc; }
-                    *reinterpret_cast<uint4*>(hp + 32 * q + 8 * g) = pack8(o);
-                }
+                v.x = pack_bf2(acc[NJ - 1][0] * sc, acc[NJ - 1][1] * sc); v.y = pack_bf2(acc[NJ - 1][2] * sc, acc[NJ - 1][3] * sc);
+                *reinterpret_cast<uint2*>(hp + 16 * (NJ - 1) + 4 * g) = v;
             }
         }
     }
 }
 
-template <int NT, int NH, int NJ>
+template <int NT, int NH, int NJ, int NW = 4>
 int launch_lnbd(const LnDownP& p, hipStream_t st) {
-    constexpr int GPB = 4 / NH;
+    constexpr int GPB = NW / NH;
     const int64_t ngroups = (p.M + 15) / 16;
     int64_t nblk = (ngroups + GPB - 1) / GPB;
     if (nblk > 2048) nblk = 2048;
-    const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + 64 * sizeof(float2) + (size_t)2 * NJ * 4 * 64 * 4;
-    if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true>), dim3((unsigned)nblk), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, false>), dim3((unsigned)nblk), dim3(256), lds, st, p);
+    const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + NW * 16 * sizeof(float2) + (size_t)(NW / 2) * NJ * 4 * 64 * 4;
+    if (lds > 64 * 1024) {
+        static const bool ok = hipFuncSetAttribute((const void*)ln_bwd_down_kernel<NT, NH, NJ, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                               hipFuncSetAttribute((const void*)ln_bwd_down_kernel<NT, NH, NJ, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        STG_CHECK(ok, -101, "stg_ln_bwd_down: cannot reserve %d bytes of LDS", (int)lds);
+    }
+    if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, false, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -414,7 +425,7 @@ int dispatch_nj(const LnDownP& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int stg_up_ln_supported(int C, int K) {
-    return (C == 128 || C == 256 || C == 512) && K >= 8 && K <= 64 && K % 8 == 0;
+    return (C == 128 || C == 256 || C == 512 || C == 768) && K >= 8 && K <= 64 && K % 8 == 0;
 }
 
 extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
@@ -422,7 +433,7 @@ extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t 
                              int64_t rs_inner, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
                              int64_t ldy, float* mean, float* rstd, int64_t M, int C, int K, void* stream) {
     STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "stg_up_ln_fwd: null pointer");
-    STG_CHECK(stg_up_ln_supported(C, K), -2, "stg_up_ln_fwd: unsupported C=%d K=%d (C in {128,256,512}, K <= 64, K %% 8 == 0)", C, K);
+    STG_CHECK(stg_up_ln_supported(C, K), -2, "stg_up_ln_fwd: unsupported C=%d K=%d (C in {128,256,512,768}, K <= 64, K %% 8 == 0)", C, K);
     STG_CHECK(M >= 0, -2, "stg_up_ln_fwd: bad M");
     STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "stg_up_ln_fwd: ldh / ldw must be multiples of 8 and >= K");
     STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "stg_up_ln_fwd: bad ld32 / ldx / ldy");
@@ -441,11 +452,14 @@ extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t 
     switch (C / 16) {
         case 8: return dispatch_ks<8, 1>(p, st);
         case 16: return dispatch_ks<16, 1>(p, st);
-        default: return dispatch_ks<16, 2>(p, st);
+        case 32: return dispatch_ks<16, 2>(p, st);
+        default: return p.K <= 32 ? launch_upln<24, 2, 1, 8>(p, st) : launch_upln<24, 2, 2, 8>(p, st);      // C = 768 (CLIP ViT-B)
     }
 }
 
 extern "C" int stg_ln_bwd_down_supported(int C, int J) {
+    // C = 768 (CLIP ViT-B) is left to stg_layernorm_bwd + stg_gemm_nt: with 24 tiles per wave the kernel sits at the 256-VGPR cap
+    // with spills and one 8-wave block per CU, and measured 177 us against 125 us for the pair
     return (C == 128 || C == 256 || C == 512) && (J == 16 || J == 32 || J == 64);
 }
 

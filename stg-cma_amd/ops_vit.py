@@ -14,7 +14,8 @@ import torch
 from . import kernels as K
 from .kernels import ACT_GELU, ACT_QUICKGELU, BF16, F32
 from .ops import (RESIDUAL_DTYPE, refresh_shadows, GradArena, _Adapter, _adapter_wgrad, _check_frozen, _cross_modal_bwd, _cross_modal_fwd, _Grads,
-                  drop_scale, f32c, shadow)
+                  _join, _LnOut, _ln_fusable, drop_scale, f32c, shadow)
+from . import ops as _ops
 
 _SFX = ("", "_Audio")
 import os as _os
@@ -109,7 +110,9 @@ def _xgeoms(spec, BT, dh):
             K.AttnGeom(BT, 1, na, dh, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=1.0))
 
 
-def vit_block_forward(X, spec, P, training, save):
+def vit_block_forward(X, spec, P, training, save, pre=None, nxt=None):
+    """ResidualAttentionBlock.forward (CLIP_AVE.py:361-429).  pre / nxt: as in ops.block_forward -- the LayerNorm behind each of
+    the three residual joins (ln_1 of the spatial pass, ln_2, ln_1 of the next block) rides on the join kernel."""
     R, D = X.shape
     assert D == spec.D and X.dtype == RESIDUAL_DTYPE
     BT, sl = _ranges(spec, R)
@@ -122,7 +125,7 @@ def vit_block_forward(X, spec, P, training, save):
 
     # ---- temporal adaptation (CLIP_AVE.py:369-377)
     dps = [drop_scale(spec.drop_path, n, X.device, training) for n in spec.n_tok]
-    Y, mean, rstd = K.layernorm_fwd(X, n1g, n1b, want_stats=save)
+    Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X, n1g, n1b, want_stats=save)
     QKV = K.gemm_nt(Y, wqkv, bqkv)
     del Y
     AO = torch.empty((R, D), dtype=BF16, device=X.device)
@@ -130,17 +133,19 @@ def vit_block_forward(X, spec, P, training, save):
     PO = K.gemm_nt(AO, wout, bout)
     X1 = torch.empty_like(X)
     hz = []
-    for i, m in enumerate(spec.mods):
-        A = _Adapter(P, "T_Adapter" + _SFX[m])
+    tads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
+    ln1 = _LnOut(X, n1g, n1b) if _ln_fusable(X, tads) else None
+    for i, A in enumerate(tads):
         Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True)
-        K.gemm_nt(Ht, A.w2, A.b2, out=X1[sl[i]], res1=X[sl[i]], row_scale=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
+        _join(Ht, A, X1, sl[i], X, None, ln1, row_scale=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
         hz.append((Ht, Zt))
     if save:
         S["t"] = (X, mean, rstd, QKV, AO, tg, tlse, PO, hz, dps)
     del QKV, AO, PO
 
     # ---- spatial adaptation (+ cross-modal fusion of the adapter hidden states) (:379-401)
-    Y, mean, rstd = K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
+    Y, mean, rstd = ln1.triple() if ln1 is not None else K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
+    del ln1
     QKV = K.gemm_nt(Y, wqkv, bqkv)
     del Y
     AO = torch.empty((R, D), dtype=BF16, device=X.device)
@@ -156,14 +161,17 @@ def vit_block_forward(X, spec, P, training, save):
     else:
         H2 = [h[0] for h in HZ]
     X2 = torch.empty_like(X)
+    ln2 = _LnOut(X, f32c(P["ln_2.weight"]), f32c(P["ln_2.bias"])) if _ln_fusable(X, ads) else None
     for i, A in enumerate(ads):
-        K.gemm_nt(H2[i], A.w2, A.b2, out=X2[sl[i]], res1=PO[sl[i]], res2=X1[sl[i]])
+        _join(H2[i], A, X2, sl[i], X1, PO, ln2)
     if save:
         S["s"] = (X1, mean, rstd, QKV, AO, sg, slse, PO, HZ, H2, xs)
     del QKV, AO, PO, HZ, H2
 
     # ---- joint adaptation: QuickGELU MLP, then MLP_Adapter on its output (:403-429)
-    Y, mean, rstd = K.layernorm_fwd(X2, f32c(P["ln_2.weight"]), f32c(P["ln_2.bias"]), want_stats=save)
+    Y, mean, rstd = ln2.triple() if ln2 is not None else \
+        K.layernorm_fwd(X2, f32c(P["ln_2.weight"]), f32c(P["ln_2.bias"]), want_stats=save)
+    del ln2
     Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.c_fc.weight"]), f32c(P["mlp.c_fc.bias"]), act=ACT_QUICKGELU, want_dact=True)
     del Y
     M = K.gemm_nt(Hm, shadow(P["mlp.c_proj.weight"]), f32c(P["mlp.c_proj.bias"]))
@@ -178,10 +186,13 @@ def vit_block_forward(X, spec, P, training, save):
     else:
         H2 = [h[0] for h in HZ]
     X3 = torch.empty_like(X)
+    ln3 = _LnOut(X, nxt["gamma"], nxt["beta"]) if nxt is not None and _ln_fusable(X, ads) else None
     for i, A in enumerate(ads):
-        K.gemm_nt(H2[i], A.w2, A.b2, out=X3[sl[i]], res1=M[sl[i]], res2=X2[sl[i]])
+        _join(H2[i], A, X3, sl[i], X2, M, ln3)
     if save:
         S["f"] = (X2, mean, rstd, Zm, M, HZ, H2, xs)
+    if ln3 is not None:
+        nxt["pre"] = ln3.triple()
     return X3, (S if save else None)
 
 
@@ -341,9 +352,16 @@ class VitModelFn(torch.autograd.Function):
                 emb.append(_embed(P, a.unsqueeze(1), "conv1_audio.weight", "positional_embedding_audio",
                                   "temporal_embedding_audio", T, save, rows))
         tape = []
-        for spec, pre, bnames in plan.blocks(n_tok):
+        blocks = list(plan.blocks(n_tok))
+        carry = None
+        for j, (spec, pre, bnames) in enumerate(blocks):
             Pb = {n: P[pre + n] for n in bnames}
-            X, S = vit_block_forward(X, spec, Pb, training, save)
+            nxt = None
+            if _ops.USE_UPLN and j + 1 < len(blocks):                    # ln_1 of the next block rides on this block's last join
+                npre = blocks[j + 1][1]
+                nxt = {"gamma": f32c(P[npre + "ln_1.weight"]), "beta": f32c(P[npre + "ln_1.bias"])}
+            X, S = vit_block_forward(X, spec, Pb, training, save, carry, nxt)
+            carry = nxt.get("pre") if nxt is not None else None
             tape.append((spec, pre, Pb, S))
         # ---- head: ln_post on the class tokens, cat((a, v)), mlp_head (CLIP_AVE.py:1128-1140)
         BT = B * T

@@ -21,7 +21,8 @@ def _ref_fwd(h, w, b, r32, r16, rs, gamma, beta, eps=1e-5):
 
 @pytest.mark.parametrize("M,C,K,r16,rs", [(64, 128, 16, True, False), (1000, 128, 16, False, True), (777, 256, 32, True, False),
                                           (4099, 512, 32, True, False), (2048, 512, 32, False, True), (513, 512, 64, True, True),
-                                          (15, 256, 24, True, False), (1, 128, 8, False, False), (320, 512, 48, True, False)])
+                                          (15, 256, 24, True, False), (1, 128, 8, False, False), (320, 512, 48, True, False),
+                                          (1970, 768, 48, True, False), (490, 768, 48, False, True), (33, 768, 64, True, True)])
 def test_up_ln_fwd(stg, gpu, M, C, K, r16, rs):
     from stgcma import kernels as k
     assert k.up_ln_supported(C, K)
@@ -64,12 +65,12 @@ def test_up_ln_fwd(stg, gpu, M, C, K, r16, rs):
 def test_up_ln_unsupported_raises(stg, gpu):
     from stgcma import kernels as k
     assert not k.up_ln_supported(1024, 128)
-    assert not k.up_ln_supported(768, 48)
-    h = torch.zeros(16, 48, dtype=BF16, device=gpu)
-    w = torch.zeros(768, 48, dtype=BF16, device=gpu)
-    z = torch.zeros(768, device=gpu)
+    assert not k.up_ln_supported(1536, 96)
+    h = torch.zeros(16, 96, dtype=BF16, device=gpu)
+    w = torch.zeros(1536, 96, dtype=BF16, device=gpu)
+    z = torch.zeros(1536, device=gpu)
     with pytest.raises(RuntimeError):
-        k.up_ln_fwd(h, w, z, torch.zeros(16, 768, device=gpu), z, z)
+        k.up_ln_fwd(h, w, z, torch.zeros(16, 1536, device=gpu), z, z)
 
 
 @pytest.mark.parametrize("M,C,J,add,rs", [(64, 128, 16, True, False), (1000, 128, 16, False, True), (777, 256, 32, True, False),

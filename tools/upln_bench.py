@@ -22,7 +22,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for M, C, K in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720, 512, 64)]:
+for M, C, K in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720, 512, 64), (63040, 768, 48), (15680, 768, 48)]:
     h = torch.randn(M, K, device=dev).to(BF16)
     w = (torch.randn(C, K, device=dev) * 0.1).to(BF16)
     b = torch.randn(C, device=dev)
@@ -45,7 +45,7 @@ for M, C, K in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720,
         print(f"M={M} C={C} K={K} res16={use16}: fused {tf:8.1f} us ({byt_f / tf / 1e6:6.2f} TB/s)   pair {tp:8.1f} us", flush=True)
 
 print("--- LayerNorm backward + down-projection")
-for M, C, J in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720, 512, 64)]:
+for M, C, J in [(1003520, 128, 16), (250880, 256, 32), (62720, 512, 32), (62720, 512, 64), (63040, 768, 48), (15680, 768, 48)]:
     x = torch.randn(M, C, device=dev)
     dy = torch.randn(M, C, device=dev).to(BF16)
     ad = torch.randn(M, C, device=dev).to(BF16)
