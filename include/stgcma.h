@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 108
+#define STG_VERSION 109
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -58,6 +58,13 @@ typedef struct {
     const void* res1; int64_t ldr1; int res1_dtype;   /* STG_BF16 (branch tensors) or STG_F32 (the residual stream) */
     const void* res2; int64_t ldr2; int res2_dtype;
     int64_t M; int N; int K;
+    /* Implicit 3x3 convolution (conv_H > 0; AVS decoder, Swin_AVSModel_Base.py:14-130): A is the channels-last feature map
+     * [F*conv_H*conv_W, conv_C] (lda >= conv_C) and the GEMM runs over its im2col image without ever forming it: logical
+     * A'[m, tap*conv_C + c] = A[pixel(m) shifted by ((tap/3 - 1)*conv_d, (tap%3 - 1)*conv_d), c], zero outside the frame
+     * (padding == dilation), K = 9*conv_C, W = [N, (kh, kw, c)].  conv_C % 64 == 0, M % (conv_H*conv_W) == 0;
+     * conv_zero: >= 16 zero bytes, 16-byte aligned (the source of padded taps). */
+    int conv_H; int conv_W; int conv_d; int conv_C;
+    const void* conv_zero;
 } stg_gemm_args;
 int stg_gemm_nt(const stg_gemm_args* args, void* stream);
 

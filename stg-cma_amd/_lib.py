@@ -32,6 +32,8 @@ class GemmArgs(C.Structure):
         ("res1", c_vp), ("ldr1", c_i64), ("res1_dtype", C.c_int),
         ("res2", c_vp), ("ldr2", c_i64), ("res2_dtype", C.c_int),
         ("M", c_i64), ("N", C.c_int), ("K", C.c_int),
+        ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_d", C.c_int), ("conv_C", C.c_int),
+        ("conv_zero", c_vp),
     ]
 
 
@@ -168,7 +170,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 108
+ABI_VERSION = 109
 _lib = None
 
 

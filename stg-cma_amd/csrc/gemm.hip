@@ -38,6 +38,7 @@ struct GemmParams {
     int nbm, nbn;
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
+    int conv_H, conv_W, conv_d, conv_C; const bf16_t* conv_zero;     // implicit 3x3 convolution (conv_H > 0), see stgcma.h
     int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work, 3 = no epilogue
 };
 
@@ -371,7 +372,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
 // swizzle lives on the per-lane SOURCE address: LDS position `pos` of row r receives global chunk pos ^ (r & 7), and the
 // fragment reads apply the same involution.  Rows beyond M / N are clamped (their products are never stored).
 // 2-stage pipeline: issue tile t+1's DMA, run tile t's MFMAs, then vmcnt(0) + barrier.
-template <int NST>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
+// CONV: implicit 3x3 convolution (its own instantiation: the plain kernel sits exactly at its 128-VGPR budget)
+template <int NST, bool CONV = false>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
 __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
     const int nblk = p.nbm * p.nbn;
@@ -391,6 +393,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
     // this lane's 4 + 4 DMA pieces per k-tile: LDS chunk q = (wave*4 + j)*64 + lane  ->  row q>>3, position q&7
     const bf16_t* pa[4];
     const bf16_t* pw[4];
+    int py[CONV ? 4 : 1], px[CONV ? 4 : 1];          // implicit convolution: the pixel (y, x) of this lane's four A rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane;
@@ -401,10 +404,34 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
         gn = gn < p.N ? gn : p.N - 1;
         pa[j] = p.A + gm * p.lda + c * 8;
         pw[j] = p.W + (int64_t)gn * p.ldw + c * 8;
+        if (CONV) {
+            const int rem = (int)(gm % ((int64_t)p.conv_H * p.conv_W));
+            py[j] = rem / p.conv_W;
+            px[j] = rem - py[j] * p.conv_W;
+        }
     }
     auto stage = [&](int buf, int kt) {
         bf16_t* sA = smem + buf * (BM + BN) * BK;
         bf16_t* sW = sA + BM * BK;
+        if (CONV) {
+            // k-tile kt of the im2col image = channels c0 .. c0 + 63 of tap (kh, kw): the DMA source of a row is the same
+            // channel run of the neighbouring pixel (a constant element offset from the row's own pointer) or the zero line
+            const int k0 = kt * BK;
+            const int tap = k0 / p.conv_C, c0 = k0 - tap * p.conv_C;
+            const int dy = (tap / 3 - 1) * p.conv_d, dx = (tap % 3 - 1) * p.conv_d;
+            const int64_t shift = ((int64_t)dy * p.conv_W + dx) * p.lda + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = py[j] + dy, xx = px[j] + dx;
+                const bool in = yy >= 0 && yy < p.conv_H && xx >= 0 && xx < p.conv_W;
+                const bf16_t* src = in ? pa[j] + shift : p.conv_zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[j] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 512), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kt * BK),
@@ -1008,7 +1035,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     STG_CHECK(a->K % 8 == 0, -2, "stg_gemm_nt: K=%d must be a multiple of 8", a->K);
     STG_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, -2, "stg_gemm_nt: lda/ldw must be multiples of 8");
     STG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, -2, "stg_gemm_nt: A/W must be 16-byte aligned");
-    STG_CHECK(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
+    STG_CHECK((a->conv_H > 0 || a->lda >= a->K) && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
     STG_CHECK(a->c_dtype == STG_BF16 || a->c_dtype == STG_F32, -3, "stg_gemm_nt: unsupported c_dtype %d", a->c_dtype);
     STG_CHECK(a->act >= 0 && a->act <= 2, -3, "stg_gemm_nt: bad act");
     STG_CHECK(!a->dact || a->act != 0, -3, "stg_gemm_nt: dact output needs an activation");
@@ -1027,6 +1054,14 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     p.res1 = a->res1; p.ldr1 = a->ldr1; p.res1_f32 = (a->res1_dtype == STG_F32);
     p.res2 = a->res2; p.ldr2 = a->ldr2; p.res2_f32 = (a->res2_dtype == STG_F32);
     p.M = a->M; p.N = a->N; p.K = a->K;
+    p.conv_H = a->conv_H; p.conv_W = a->conv_W; p.conv_d = a->conv_d; p.conv_C = a->conv_C; p.conv_zero = (const bf16_t*)a->conv_zero;
+    const bool conv = a->conv_H > 0;
+    if (conv) {
+        STG_CHECK(a->conv_W > 0 && a->conv_d >= 1 && a->conv_C > 0 && a->conv_C % BK == 0 && a->K == 9 * a->conv_C, -2,
+                  "stg_gemm_nt: implicit convolution needs conv_C %% 64 == 0 and K == 9 * conv_C");
+        STG_CHECK(a->lda >= a->conv_C && a->M % ((int64_t)a->conv_H * a->conv_W) == 0, -2, "stg_gemm_nt: implicit convolution: bad lda / M");
+        STG_CHECK(a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0, -2, "stg_gemm_nt: implicit convolution needs a 16-byte aligned zero line");
+    }
     { const char* e = getenv("STG_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int64_t nbm = (a->M + BM - 1) / BM;
     const int64_t nbn = (a->N + BN - 1) / BN;
@@ -1054,11 +1089,11 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         if (force_generic) p.epi_variant = EV_GENERIC;            // A/B knob: every option a run-time test
     }
     static const int big_mode = [] { const char* e = getenv("STG_GEMM_BIG"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 whenever legal
-    const bool big_ok = a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
+    const bool big_ok = !conv && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
     static const int ph8_mode = [] { const char* e = getenv("STG_GEMM_8PH"); return e ? atoi(e) : 1; }();   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
-    const bool ph8_ok = a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
+    const bool ph8_ok = !conv && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
     if (ph8_ok && ((ph8_mode == 1 && big) || ph8_mode == 2)) {
         static const bool attr8 = [] {
             return hipFuncSetAttribute((const void*)gemm_nt_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2) == hipSuccess;
@@ -1079,7 +1114,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 2 * (GBM + GBN) * BK * 2, (hipStream_t)stream, p);
-    } else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (conv) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

@@ -61,13 +61,33 @@ def _chk1d(t, name, dtype, n):
         raise RuntimeError(f"{name}: expected contiguous {dtype} GPU vector of length {n}")
 
 
+_zero_lines = {}
+
+
+def _zero_line(device):
+    z = _zero_lines.get(device)
+    if z is None:
+        z = _zero_lines[device] = torch.zeros(64, dtype=BF16, device=device)
+    return z
+
+
+def conv3x3_gemm_supported(Cin):
+    return Cin % 64 == 0
+
+
 def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
-            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None):
+            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None):
     """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, dact) with dact = bf16(act'(pre-activation)),
     the tensor a later call takes as dact_src (or act_bwd as its second argument)."""
     M, K = A.shape
     N = W.shape[0]
     _chk2d(A, "A", BF16)
+    if conv is not None:                                  # implicit 3x3 convolution: A is the [F*H*W, Cin] feature map, K = 9 * Cin
+        Hc, Wc, dc = conv
+        Cin = K
+        K = 9 * Cin
+        if Cin % 64 != 0 or M % (Hc * Wc) != 0 or dc < 1:
+            raise RuntimeError("gemm_nt(conv=...): needs Cin % 64 == 0 and rows = F * H * W")
     _chk2d(W, "W", BF16, cols=K)
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
@@ -106,10 +126,13 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
+    if conv is not None:
+        zl = _zero_line(A.device)
+        a.conv_H, a.conv_W, a.conv_d, a.conv_C, a.conv_zero = int(Hc), int(Wc), int(dc), int(Cin), _p(zl)
     prof = _gemm_prof
     # bench.py: launches that stg_gemm_nt routes to gemm_nt_glds_kernel<1> (K % 64 == 0, and not the long-K large-tile kernel:
     # same rule as the host dispatch in csrc/gemm.hip)
-    if prof is not None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256):
+    if prof is not None and conv is None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256):
         prof["launches"] += 1
         prof["flops"] += 2.0 * M * N * K
         nbytes = 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \

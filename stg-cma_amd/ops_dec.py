@@ -25,9 +25,11 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, F_, H, Wd, d):
         O, I = W.shape[0], W.shape[1]
-        cols = K.im2col3x3(x.contiguous(), F_, H, Wd, d)
         Wm = K.cast_bf16(W.detach().permute(0, 2, 3, 1).reshape(O, 9 * I).contiguous())          # [O, (kh, kw, i)]
-        y = K.gemm_nt(cols, Wm, f32c(b) if b is not None else None)
+        if K.conv3x3_gemm_supported(I):            # implicit GEMM: the 9x im2col image is never written
+            y = K.gemm_nt(x.contiguous(), Wm, f32c(b) if b is not None else None, conv=(H, Wd, d))
+        else:
+            y = K.gemm_nt(K.im2col3x3(x.contiguous(), F_, H, Wd, d), Wm, f32c(b) if b is not None else None)
         ctx.save_for_backward(x)
         ctx.W, ctx.has_b, ctx.geom = W, b is not None, (F_, H, Wd, d)
         return y
@@ -42,7 +44,7 @@ class Conv3x3Fn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             Wf = K.cast_bf16(W.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(I, 9 * O).contiguous())   # [I, (kh, kw, o)], flipped taps
-            dx = K.gemm_nt(K.im2col3x3(dyb, F_, H, Wd, d), Wf)
+            dx = K.gemm_nt(dyb, Wf, conv=(H, Wd, d)) if K.conv3x3_gemm_supported(O) else K.gemm_nt(K.im2col3x3(dyb, F_, H, Wd, d), Wf)
         if ctx.needs_input_grad[1]:
             dWm = torch.zeros((O, 9 * I), dtype=F32, device=x.device)
             db = torch.zeros((O,), dtype=F32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None

@@ -343,3 +343,22 @@ def test_gemm_long_k_shapes(stg, gpu, M, N, K, epi):
         out, dact = out
         _close(dact, _gelu_grad(z), what=f"dact {M}x{N}x{K}")
     _close(out, ref, tol=2e-2 if K >= 2048 else 1e-2, what=f"gemm {epi} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("F_,H,W,Cin,Cout,d", [(3, 14, 14, 64, 64, 1), (2, 28, 28, 256, 256, 3), (1, 7, 7, 128, 32, 1), (2, 14, 14, 256, 256, 18),
+                                               (5, 56, 56, 64, 128, 6)])
+def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
+    """stg_gemm_nt in implicit-convolution mode (DMA sources gathered per tap, zero line for the padding) against the im2col
+    image + the same GEMM: same k order, so bit-identical; and against F.conv2d in fp32."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(F_ + H + Cin + d)
+    x = _bf(torch.randn(F_ * H * W, Cin, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    wm = _bf(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin))
+    y_imp = k.gemm_nt(x.to(gpu), wm.to(gpu), b.to(gpu), conv=(H, W, d))
+    y_col = k.gemm_nt(k.im2col3x3(x.to(gpu), F_, H, W, d), wm.to(gpu), b.to(gpu))
+    assert torch.equal(y_imp, y_col)
+    xn = x.float().view(F_, H, W, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xn, _bf(w).float(), b, padding=d, dilation=d).permute(0, 2, 3, 1).reshape(-1, Cout)
+    _close(y_imp, ref, tol=2e-2, what="implicit conv")
