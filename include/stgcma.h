@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 109
+#define STG_VERSION 110
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -351,6 +351,13 @@ int stg_mha1_bwd(const void* q, const void* k, const void* v, const float* drop,
  * stg_gemm_nt(out, Wm) with Wm[o, (kh, kw, c)] = W[o, c, kh, kw]; its data gradient the same gather on dY with
  * Wd[c, (kh, kw, o)] = W[o, c, 2-kh, 2-kw]; its weight gradient stg_wgrad_tn(dY, out).  C % 8 == 0. */
 int stg_im2col3x3(const void* x, int64_t ldx, void* out, int64_t F, int H, int W, int C, int dilation, void* stream);
+/* Weight gradient of the same convolution without the im2col image (autograd of nn.Conv2d(I, O, 3, padding = dilation) at
+ * Swin_AVSModel_Base.py:27,37-38,117): ws[s, o, (kh, kw, i)] = sum over the s-th slice of the rows m of dy[m, o] * x[pixel(m) shifted
+ * by tap (kh, kw), i]; dW = sum_s ws[s] (fp32; the caller reduces and owns the workspace).  O % 128 == 0, I % 128 == 0.
+ * stg_conv3x3_wgrad_ws_floats returns the workspace size in floats (and the number of slices), -1 when the shape is unsupported. */
+int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out);
+int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
+                      int64_t F, int H, int W, int O, int I, int dilation, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=...) (:108-110 align_corners=True, :1500 False) and its adjoint */
 int stg_bilinear_up2_fwd(const void* x, void* y, int64_t F, int H, int W, int C, int align_corners, void* stream);
 int stg_bilinear_up2_bwd(const void* dy, void* dx, int64_t F, int H, int W, int C, int align_corners, void* stream);

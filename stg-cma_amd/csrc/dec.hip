@@ -36,6 +36,126 @@ __global__ void im2col3x3_kernel(const bf16_t* x, int64_t ldx, bf16_t* out, int6
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 convolution weight gradient
+// dW[o, (kh, kw, i)] = sum_m dY[m, o] * X[pixel(m) shifted by tap (kh, kw), i]   (zero outside the frame)
+// A "tn" GEMM whose reduction index is the token row m (both operands are m-major in memory) and whose X operand is the
+// im2col image that is never formed: one block owns a 128 (o) x 128 (columns of ONE tap) tile of dW for a slice of the rows,
+// streams 64-row tiles of dY and of the tap-shifted X through LDS by global_load_lds (zero line for padded taps and for rows
+// outside the slice), reads both as k-major MFMA fragments with ds_read_b64_tr_b16, and leaves its fp32 partial tile in a
+// workspace [splits, O, 9 I]; the caller sums over the splits.  (The path it replaces wrote the 9x im2col image and then ran
+// the generic atomic wgrad: 38 + 13 ms per AVS step.)
+struct CwP {
+    const bf16_t* dy; int64_t lddy;
+    const bf16_t* x; int64_t ldx;
+    const bf16_t* zero;
+    float* ws;                       // [splits][O][9 * I]
+    int64_t M; int H, W, d, O, I;
+    int splits; int64_t rows_per_split;   // multiple of 64
+    int nto, ntc;                    // tiles over O and over 9 * I
+};
+
+typedef short cw_s4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int cw_swz(int row) { return (row & 7) << 1; }          // 16-byte chunk XOR (16 chunks per 256-byte row)
+
+// k-major fragment for v_mfma_f32_16x16x32_bf16 from a row-major [64 m][128 c] LDS tile: lane (i = l & 15, kq = l >> 4) gets
+// tile[32 s + 8 kq + j][16 t + i], j = 0..7, by two transposing reads (4 rows x 16 columns per 16-lane group each).
+__device__ __forceinline__ bf16x8_t cw_frag(const bf16_t* tile, int t, int s, int lane) {
+    const int gi = lane & 15, kq = lane >> 4;
+    const int r0 = 32 * s + 8 * kq + (gi >> 2), r1 = r0 + 4;
+    const int ch = 2 * t + ((gi & 3) >> 1), sub = (gi & 1) * 4;
+    const bf16_t* p0 = tile + r0 * 128 + ((ch ^ cw_swz(r0)) << 3) + sub;
+    const bf16_t* p1 = tile + r1 * 128 + ((ch ^ cw_swz(r1)) << 3) + sub;
+    const cw_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cw_s4_t*)p0);
+    const cw_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cw_s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 64 * 128];
+    bf16_t* sY = smem;
+    bf16_t* sX = smem + 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave >> 1, wc = wave & 1;
+    const int tile = blockIdx.x % (p.nto * p.ntc), split = blockIdx.x / (p.nto * p.ntc);
+    const int to = tile / p.ntc, tc = tile - to * p.ntc;
+    const int o0 = to * 128, col0 = tc * 128;
+    const int tap = col0 / p.I, i0 = col0 - tap * p.I;
+    const int dy = (tap / 3 - 1) * p.d, dx = (tap % 3 - 1) * p.d;
+    const int64_t shift = (int64_t)dy * p.W + dx;
+    const int64_t r0 = (int64_t)split * p.rows_per_split;
+    int64_t r1 = r0 + p.rows_per_split;
+    r1 = r1 < p.M ? r1 : p.M;
+
+    // DMA pieces: chunk q = j * 256 + tid (j = 0..3) -> tile row q >> 4 (0..63), position q & 15 <- source chunk (q & 15) ^ swz(row)
+    int prow[4], pch[4], py[4], px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = j * 256 + tid;
+        prow[j] = q >> 4;
+        pch[j] = (q & 15) ^ cw_swz(prow[j]);
+        const int64_t m = r0 + prow[j];
+        const int rem = (int)(m % ((int64_t)p.H * p.W));
+        py[j] = rem / p.W;
+        px[j] = rem - py[j] * p.W;
+    }
+    const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
+
+    f32x4_t acc[4][4];               // [col tile][o tile]: D[col][o], lane o = l & 15, registers = 4 consecutive columns
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t mb = r0; mb < r1; mb += 64) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t m = mb + prow[j];
+            const bool live = m < r1;
+            const int yy = py[j] + dy, xx = px[j] + dx;
+            const bool in = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const bf16_t* sy = live ? p.dy + m * p.lddy + o0 + pch[j] * 8 : p.zero;
+            const bf16_t* sx = in ? p.x + (m + shift) * p.ldx + i0 + pch[j] * 8 : p.zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
+                                             (__attribute__((address_space(3))) void*)(sY + (j * 256 + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                             (__attribute__((address_space(3))) void*)(sX + (j * 256 + wave * 64) * 8), 16, 0, 0);
+            // this row's pixel 64 rows further on
+            px[j] += adv_x; py[j] += adv_y;
+            if (px[j] >= p.W) { px[j] -= p.W; py[j] += 1; }
+            if (py[j] >= p.H) { py[j] -= p.H; if (py[j] >= p.H) py[j] -= p.H; }
+        }
+        __syncthreads();                                    // (drains vmcnt) the tile has landed
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8_t fy[4], fx[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fy[t] = cw_frag(sY, wo * 4 + t, s2, lane);
+                fx[t] = cw_frag(sX, wc * 4 + t, s2, lane);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+                    acc[ct][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ct], fy[ot], acc[ct][ot], 0, 0, 0);
+        }
+        __syncthreads();                                    // every wave is done reading before the next tile's DMA
+    }
+    // partial tile -> workspace: lane (o = l & 15, g = l >> 4) holds columns 4 g .. 4 g + 3 of each 16-column tile
+    const int o_l = lane & 15, g = lane >> 4;
+    const int64_t ldws = 9 * (int64_t)p.I;
+    float* wsp = p.ws + ((int64_t)split * p.O + o0 + wo * 64) * ldws + col0 + wc * 64;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            *reinterpret_cast<f32x4_t*>(wsp + (int64_t)(ot * 16 + o_l) * ldws + ct * 16 + 4 * g) = acc[ct][ot];
+}
+
 // ------------------------------------------------------------------------------------------------ bilinear x2 (F.interpolate)
 __device__ __forceinline__ void src_index(int o, int in_size, int out_size, int align, int& i0, int& i1, float& w1) {
     float s;
@@ -252,6 +372,39 @@ extern "C" int stg_bn_bwd(const void* x, const void* dy, const float* mean, cons
     if (R == 0) return 0;
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(grid_for(R * C, 256)), dim3(256), 0, ST, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, gamma, sums,
                        (bf16_t*)dx, R, C);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out) {
+    if (M <= 0 || O <= 0 || I <= 0 || O % 128 != 0 || I % 128 != 0) return -1;
+    const int tiles = (O / 128) * (9 * I / 128);
+    int64_t splits = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU
+    const int64_t max_splits = (M + 2047) / 2048;                      // >= 2048 rows per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits_out) *splits_out = (int)splits;
+    return splits * O * 9 * (int64_t)I;
+}
+
+extern "C" int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
+                                 int64_t ws_floats, int64_t F, int H, int W, int O, int I, int dilation, void* stream) {
+    STG_CHECK(dy && x && zero_line && ws, -1, "stg_conv3x3_wgrad: null pointer");
+    STG_CHECK(F > 0 && H > 0 && W > 0 && dilation >= 1 && O % 128 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
+              "stg_conv3x3_wgrad: needs O %% 128 == 0 and I %% 128 == 0");
+    STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "stg_conv3x3_wgrad: bad leading dimensions");
+    STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "stg_conv3x3_wgrad: pointers must be 16-byte aligned");
+    const int64_t M = F * H * W;
+    int splits = 0;
+    const int64_t need = stg_conv3x3_wgrad_ws_floats(M, O, I, &splits);
+    STG_CHECK(need > 0 && ws_floats >= need, -2, "stg_conv3x3_wgrad: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)need);
+    CwP p = {};
+    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const bf16_t*)x; p.ldx = ldx; p.zero = (const bf16_t*)zero_line; p.ws = ws;
+    p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I;
+    p.splits = splits;
+    p.rows_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
+    p.nto = O / 128; p.ntc = 9 * I / 128;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits)), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -977,6 +977,27 @@ def im2col3x3(x, F_, H, W, dilation):
     return out
 
 
+def conv3x3_wgrad_supported(O, I):
+    return O % 128 == 0 and I % 128 == 0
+
+
+def conv3x3_wgrad(dy, x, F_, H, W, dilation):
+    """dW [O, 9 * I] fp32 (columns ordered (kh, kw, i)) of a 3x3 convolution with padding = dilation, from dy [F*H*W, O] and
+    x [F*H*W, I] (bf16, channels-last rows), without the im2col image."""
+    M = F_ * H * W
+    _chk2d(dy, "dy", BF16, rows=M)
+    _chk2d(x, "x", BF16, rows=M)
+    O, I = dy.shape[1], x.shape[1]
+    splits = C.c_int(0)
+    n = _lib.lib().stg_conv3x3_wgrad_ws_floats(M, O, I, C.byref(splits))
+    if n <= 0:
+        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 128 == 0 and I % 128 == 0)")
+    ws = torch.empty((splits.value, O, 9 * I), dtype=F32, device=x.device)
+    _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), F_, H, W, O, I,
+                                            int(dilation), _stream()), "stg_conv3x3_wgrad")
+    return ws.sum(0) if splits.value > 1 else ws[0]
+
+
 def bilinear_up2_fwd(x, F_, H, W, align_corners):
     _chk_flat(x, "x")
     Cc = x.shape[-1]

@@ -46,9 +46,14 @@ class Conv3x3Fn(torch.autograd.Function):
             Wf = K.cast_bf16(W.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(I, 9 * O).contiguous())   # [I, (kh, kw, o)], flipped taps
             dx = K.gemm_nt(dyb, Wf, conv=(H, Wd, d)) if K.conv3x3_gemm_supported(O) else K.gemm_nt(K.im2col3x3(dyb, F_, H, Wd, d), Wf)
         if ctx.needs_input_grad[1]:
-            dWm = torch.zeros((O, 9 * I), dtype=F32, device=x.device)
-            db = torch.zeros((O,), dtype=F32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
-            K.wgrad_tn(dyb, K.im2col3x3(x.contiguous(), F_, H, Wd, d), dWm, db)
+            want_db = ctx.has_b and ctx.needs_input_grad[2]
+            if K.conv3x3_wgrad_supported(O, I):        # tn-GEMM with the tap gather inside: no im2col image, no atomics
+                dWm = K.conv3x3_wgrad(dyb.contiguous(), x.contiguous(), F_, H, Wd, d)
+                db = K.bn_colsum(dyb.contiguous())[0].clone() if want_db else None
+            else:
+                dWm = torch.zeros((O, 9 * I), dtype=F32, device=x.device)
+                db = torch.zeros((O,), dtype=F32, device=x.device) if want_db else None
+                K.wgrad_tn(dyb, K.im2col3x3(x.contiguous(), F_, H, Wd, d), dWm, db)
             dW = dWm.view(O, 3, 3, I).permute(0, 3, 1, 2).contiguous()
         return dx, dW, db, None, None, None, None
 

@@ -362,3 +362,24 @@ def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
     xn = x.float().view(F_, H, W, Cin).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xn, _bf(w).float(), b, padding=d, dilation=d).permute(0, 2, 3, 1).reshape(-1, Cout)
     _close(y_imp, ref, tol=2e-2, what="implicit conv")
+
+
+@pytest.mark.parametrize("F_,H,W,I,O,d", [(3, 14, 14, 128, 128, 1), (2, 28, 28, 256, 256, 3), (7, 7, 7, 256, 128, 1), (2, 14, 14, 256, 256, 18),
+                                          (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1)])
+def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
+    """The conv weight gradient without the im2col image against autograd of F.conv2d in fp32 (same bf16-rounded operands)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(F_ + H + I + d)
+    x = _bf(torch.randn(F_ * H * W, I, generator=g))
+    dy = _bf(torch.randn(F_ * H * W, O, generator=g))
+    w = torch.zeros(O, I, 3, 3, requires_grad=True)
+    xn = x.float().view(F_, H, W, I).permute(0, 3, 1, 2)
+    y = torch.nn.functional.conv2d(xn, w, None, padding=d, dilation=d)
+    y.backward(dy.float().view(F_, H, W, O).permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(O, 9 * I)
+    got = k.conv3x3_wgrad(dy.to(gpu), x.to(gpu), F_, H, W, d)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    err = float((got.cpu() - ref).abs().max())
+    assert err <= 2e-3 * scale, (err, scale)
+    assert k.bn_colsum(dy.to(gpu))[0].cpu().allclose(dy.float().sum(0), rtol=1e-4, atol=1e-2)
