@@ -132,7 +132,9 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     prof = _gemm_prof
     # bench.py: launches that stg_gemm_nt routes to gemm_nt_glds_kernel<1> (K % 64 == 0, and not the long-K large-tile kernel:
     # same rule as the host dispatch in csrc/gemm.hip)
-    if prof is not None and conv is None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256):
+    wide8 = K >= 512 and K % 128 == 0 and N >= 1536 and N % 256 == 0 and M >= 256 and dact_src is None and res1 is None and res2 is None and \
+        row_scale is None and alpha == 1.0 and out.dtype == BF16
+    if prof is not None and conv is None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256) and not wide8:
         prof["launches"] += 1
         prof["flops"] += 2.0 * M * N * K
         nbytes = 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
