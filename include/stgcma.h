@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 110
+#define STG_VERSION 111
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -358,6 +358,12 @@ int stg_im2col3x3(const void* x, int64_t ldx, void* out, int64_t F, int H, int W
 int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out);
 int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
                       int64_t F, int H, int W, int O, int I, int dilation, void* stream);
+/* The same tn-GEMM without taps: ws[s] = partial dY^T X of the s-th row slice for a trainable Linear / 1x1 convolution whose
+ * two widths are both multiples of 128 (the AVS decoder's tap Linears and TPAVI 1x1 convolutions, Swin_AVSModel_Base.py,
+ * TPAVI.py:40-75), in place of the atomic fallback of stg_wgrad_tn; dW = sum_s ws[s] (caller), db = column sums of dY. */
+int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* splits_out);
+int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
+                   int64_t M, int N1, int N2, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=...) (:108-110 align_corners=True, :1500 False) and its adjoint */
 int stg_bilinear_up2_fwd(const void* x, void* y, int64_t F, int H, int W, int C, int align_corners, void* stream);
 int stg_bilinear_up2_bwd(const void* dy, void* dx, int64_t F, int H, int W, int C, int align_corners, void* stream);

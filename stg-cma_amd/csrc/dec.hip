@@ -49,7 +49,7 @@ struct CwP {
     const bf16_t* x; int64_t ldx;
     const bf16_t* zero;
     float* ws;                       // [splits][O][9 * I]
-    int64_t M; int H, W, d, O, I;
+    int64_t M; int H, W, d, O, I; int taps;   // taps = 9 (3x3 convolution) or 1 (plain dW = dY^T X: no shift, H = W = 1)
     int splits; int64_t rows_per_split;   // multiple of 64
     int nto, ntc;                    // tiles over O and over 9 * I
 };
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
     const int to = tile / p.ntc, tc = tile - to * p.ntc;
     const int o0 = to * 128, col0 = tc * 128;
     const int tap = col0 / p.I, i0 = col0 - tap * p.I;
-    const int dy = (tap / 3 - 1) * p.d, dx = (tap % 3 - 1) * p.d;
+    const int dy = p.taps == 9 ? (tap / 3 - 1) * p.d : 0, dx = p.taps == 9 ? (tap % 3 - 1) * p.d : 0;
     const int64_t shift = (int64_t)dy * p.W + dx;
     const int64_t r0 = (int64_t)split * p.rows_per_split;
     int64_t r1 = r0 + p.rows_per_split;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
             const int64_t m = mb + prow[j];
             const bool live = m < r1;
             const int yy = py[j] + dy, xx = px[j] + dx;
-            const bool in = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const bool in = live && (p.taps == 1 || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W));
             const bf16_t* sy = live ? p.dy + m * p.lddy + o0 + pch[j] * 8 : p.zero;
             const bf16_t* sx = in ? p.x + (m + shift) * p.ldx + i0 + pch[j] * 8 : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
     }
     // partial tile -> workspace: lane (o = l & 15, g = l >> 4) holds columns 4 g .. 4 g + 3 of each 16-column tile
     const int o_l = lane & 15, g = lane >> 4;
-    const int64_t ldws = 9 * (int64_t)p.I;
+    const int64_t ldws = p.taps * (int64_t)p.I;
     float* wsp = p.ws + ((int64_t)split * p.O + o0 + wo * 64) * ldws + col0 + wc * 64;
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
@@ -376,35 +376,49 @@ extern "C" int stg_bn_bwd(const void* x, const void* dy, const float* mean, cons
     return 0;
 }
 
-extern "C" int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out) {
+static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) {
     if (M <= 0 || O <= 0 || I <= 0 || O % 128 != 0 || I % 128 != 0) return -1;
-    const int tiles = (O / 128) * (9 * I / 128);
+    const int tiles = (O / 128) * (taps * I / 128);
     int64_t splits = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU
     const int64_t max_splits = (M + 2047) / 2048;                      // >= 2048 rows per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits_out) *splits_out = (int)splits;
-    return splits * O * 9 * (int64_t)I;
+    return splits * O * taps * (int64_t)I;
 }
 
-extern "C" int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
-                                 int64_t ws_floats, int64_t F, int H, int W, int O, int I, int dilation, void* stream) {
-    STG_CHECK(dy && x && zero_line && ws, -1, "stg_conv3x3_wgrad: null pointer");
-    STG_CHECK(F > 0 && H > 0 && W > 0 && dilation >= 1 && O % 128 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
-              "stg_conv3x3_wgrad: needs O %% 128 == 0 and I %% 128 == 0");
-    STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "stg_conv3x3_wgrad: bad leading dimensions");
-    STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "stg_conv3x3_wgrad: pointers must be 16-byte aligned");
-    const int64_t M = F * H * W;
+static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
+                     int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream) {
+    STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
+    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 128 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
+              "%s: needs O %% 128 == 0 and I %% 128 == 0", who);
+    STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "%s: bad leading dimensions", who);
+    STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;
-    const int64_t need = stg_conv3x3_wgrad_ws_floats(M, O, I, &splits);
-    STG_CHECK(need > 0 && ws_floats >= need, -2, "stg_conv3x3_wgrad: workspace too small (%lld < %lld floats)", (long long)ws_floats, (long long)need);
+    const int64_t need = cw_ws_floats(M, O, I, taps, &splits);
+    STG_CHECK(need > 0 && ws_floats >= need, -2, "%s: workspace too small (%lld < %lld floats)", who, (long long)ws_floats, (long long)need);
     CwP p = {};
     p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const bf16_t*)x; p.ldx = ldx; p.zero = (const bf16_t*)zero_line; p.ws = ws;
-    p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I;
+    p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I; p.taps = taps;
     p.splits = splits;
     p.rows_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
-    p.nto = O / 128; p.ntc = 9 * I / 128;
+    p.nto = O / 128; p.ntc = taps * I / 128;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits)), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out) { return cw_ws_floats(M, O, I, 9, splits_out); }
+
+extern "C" int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
+                                 int64_t ws_floats, int64_t F, int H, int W, int O, int I, int dilation, void* stream) {
+    STG_CHECK(F > 0, -2, "stg_conv3x3_wgrad: bad F");
+    return cw_launch("stg_conv3x3_wgrad", dy, lddy, x, ldx, zero_line, ws, ws_floats, F * H * W, H, W, O, I, dilation, 9, stream);
+}
+
+extern "C" int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* splits_out) { return cw_ws_floats(M, N1, N2, 1, splits_out); }
+
+extern "C" int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
+                              int64_t M, int N1, int N2, void* stream) {
+    return cw_launch("stg_wgrad_wide", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream);
 }

@@ -196,6 +196,16 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         if row_scale.numel() < need:
             raise RuntimeError(f"row_scale: needs >= {need} entries, got {row_scale.numel()}")
     L = _lib.lib()
+    if USE_WGRAD_WS and row_scale is None and N1 % 128 == 0 and N2 % 128 == 0 and N1 == dY.shape[1] and M >= 4096:
+        # both operands wide (the AVS decoder's Linears / 1x1 convolutions): tn-GEMM with partial tiles instead of the atomic fallback
+        splits = C.c_int(0)
+        n = L.stg_wgrad_wide_ws_floats(M, N1, N2, C.byref(splits))
+        ws = torch.empty((splits.value, N1, N2), dtype=F32, device=dY.device)
+        _lib.check(L.stg_wgrad_wide(_p(dY), _ld(dY), _p(X), _ld(X), _p(_zero_line(dY.device)), _p(ws), n, M, N1, N2, _stream()), "stg_wgrad_wide")
+        dW.add_(ws.sum(0) if splits.value > 1 else ws[0])
+        if db is not None:
+            db.add_(bn_colsum(dY if dY.is_contiguous() else dY.contiguous())[0])
+        return
     nws = L.stg_wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
     if nws > 0:                                          # partial tiles + reduce (no memory-side atomics)
         ws = torch.empty((nws,), dtype=F32, device=dY.device)

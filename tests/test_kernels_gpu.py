@@ -383,3 +383,19 @@ def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
     err = float((got.cpu() - ref).abs().max())
     assert err <= 2e-3 * scale, (err, scale)
     assert k.bn_colsum(dy.to(gpu))[0].cpu().allclose(dy.float().sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(5000, 128, 128), (20000, 256, 1024), (4096, 256, 128), (31360, 128, 256)])
+def test_wgrad_wide(stg, gpu, M, N1, N2):
+    """wgrad_tn with both widths multiples of 128 takes the tn-GEMM with partial tiles (no atomics): against fp32 torch."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + N1 + N2)
+    dy = _bf(torch.randn(M, N1, generator=g))
+    x = _bf(torch.randn(M, N2, generator=g))
+    dW = torch.full((N1, N2), 0.5, device=gpu)
+    db = torch.full((N1,), -1.0, device=gpu)
+    k.wgrad_tn(dy.to(gpu), x.to(gpu), dW, db)
+    ref = dy.float().t() @ x.float() + 0.5
+    scale = float(ref.abs().max())
+    assert float((dW.cpu() - ref).abs().max()) <= 2e-3 * scale
+    assert torch.allclose(db.cpu(), dy.float().sum(0) - 1.0, rtol=1e-4, atol=2e-2)
