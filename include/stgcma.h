@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 111
+#define STG_VERSION 112
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -65,6 +65,10 @@ typedef struct {
      * conv_zero: >= 16 zero bytes, 16-byte aligned (the source of padded taps). */
     int conv_H; int conv_W; int conv_d; int conv_C;
     const void* conv_zero;
+    /* Batched mode (batch > 1; TPAVI's per-clip 128 x 128 mixing matrices, TPAVI.py:113-139): problem b = 0..batch-1 uses
+     * A + b*a_bstride, W + b*w_bstride, C + b*c_bstride (elements) with the same M, N, K; bias is shared; no dact / dact_src /
+     * residuals / row_scale / convolution in this mode. */
+    int batch; int64_t a_bstride; int64_t w_bstride; int64_t c_bstride;
 } stg_gemm_args;
 int stg_gemm_nt(const stg_gemm_args* args, void* stream);
 
@@ -364,6 +368,10 @@ int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
 int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* splits_out);
 int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
                    int64_t M, int N1, int N2, void* stream);
+/* batch of independent dY_b^T X_b over consecutive groups of M rows (problem b: rows b*M .. b*M + M - 1 of both operands):
+ * ws[b, s, N1, N2] partial tiles; stg_wgrad_wide_ws_floats(M, N1, N2, &splits) floats per problem. */
+int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
+                           int64_t M, int N1, int N2, int batch, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=...) (:108-110 align_corners=True, :1500 False) and its adjoint */
 int stg_bilinear_up2_fwd(const void* x, void* y, int64_t F, int H, int W, int C, int align_corners, void* stream);
 int stg_bilinear_up2_bwd(const void* dy, void* dx, int64_t F, int H, int W, int C, int align_corners, void* stream);

@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("M", c_i64), ("N", C.c_int), ("K", C.c_int),
         ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_d", C.c_int), ("conv_C", C.c_int),
         ("conv_zero", c_vp),
+        ("batch", C.c_int), ("a_bstride", c_i64), ("w_bstride", c_i64), ("c_bstride", c_i64),
     ]
 
 
@@ -164,6 +165,7 @@ SIGNATURES = {
     "stg_conv3x3_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_wgrad_wide_batched": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_conv3x3_wgrad": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_bwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -174,7 +176,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 111
+ABI_VERSION = 112
 _lib = None
 
 

@@ -52,6 +52,7 @@ struct CwP {
     int64_t M; int H, W, d, O, I; int taps;   // taps = 9 (3x3 convolution) or 1 (plain dW = dY^T X: no shift, H = W = 1)
     int splits; int64_t rows_per_split;   // multiple of 64
     int nto, ntc;                    // tiles over O and over 9 * I
+    int64_t ws_bstride;              // batched (blockIdx.y = problem): rows b*M .. b*M + M - 1 of both operands, ws + b*ws_bstride
 };
 
 typedef short cw_s4_t __attribute__((ext_vector_type(4)));
@@ -80,6 +81,9 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave >> 1, wc = wave & 1;
+    p.dy += (int64_t)blockIdx.y * p.M * p.lddy;
+    p.x += (int64_t)blockIdx.y * p.M * p.ldx;
+    p.ws += (int64_t)blockIdx.y * p.ws_bstride;
     const int tile = blockIdx.x % (p.nto * p.ntc), split = blockIdx.x / (p.nto * p.ntc);
     const int to = tile / p.ntc, tc = tile - to * p.ntc;
     const int o0 = to * 128, col0 = tc * 128;
@@ -388,7 +392,7 @@ static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) 
 }
 
 static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
-                     int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream) {
+                     int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1) {
     STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
     STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 128 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
               "%s: needs O %% 128 == 0 and I %% 128 == 0", who);
@@ -396,14 +400,16 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
     STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;
     const int64_t need = cw_ws_floats(M, O, I, taps, &splits);
-    STG_CHECK(need > 0 && ws_floats >= need, -2, "%s: workspace too small (%lld < %lld floats)", who, (long long)ws_floats, (long long)need);
+    STG_CHECK(need > 0 && ws_floats >= need * batch, -2, "%s: workspace too small (%lld < %lld floats)", who, (long long)ws_floats, (long long)need * batch);
+    STG_CHECK(batch >= 1 && batch <= 65535, -2, "%s: bad batch", who);
     CwP p = {};
+    p.ws_bstride = need;
     p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const bf16_t*)x; p.ldx = ldx; p.zero = (const bf16_t*)zero_line; p.ws = ws;
     p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I; p.taps = taps;
     p.splits = splits;
     p.rows_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
     p.nto = O / 128; p.ntc = taps * I / 128;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits)), dim3(256), 0, ST, p);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits), (unsigned)batch), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -421,4 +427,9 @@ extern "C" int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* spli
 extern "C" int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
                               int64_t M, int N1, int N2, void* stream) {
     return cw_launch("stg_wgrad_wide", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream);
+}
+
+extern "C" int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
+                                      int64_t ws_floats, int64_t M, int N1, int N2, int batch, void* stream) {
+    return cw_launch("stg_wgrad_wide_batched", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream, batch);
 }

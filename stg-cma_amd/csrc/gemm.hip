@@ -39,6 +39,7 @@ struct GemmParams {
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
     int conv_H, conv_W, conv_d, conv_C; const bf16_t* conv_zero;     // implicit 3x3 convolution (conv_H > 0), see stgcma.h
+    int batch; int64_t a_bstride, w_bstride, c_bstride;              // batched mode (blockIdx.y = problem), see stgcma.h
     int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work, 3 = no epilogue
 };
 
@@ -373,9 +374,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
 // fragment reads apply the same involution.  Rows beyond M / N are clamped (their products are never stored).
 // 2-stage pipeline: issue tile t+1's DMA, run tile t's MFMAs, then vmcnt(0) + barrier.
 // CONV: implicit 3x3 convolution (its own instantiation: the plain kernel sits exactly at its 128-VGPR budget)
-template <int NST, bool CONV = false>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
+template <int NST, bool CONV = false, bool BATCH = false>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
 __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
+    if (BATCH) {                                             // blockIdx.y = problem: same shape, strided operands
+        p.A += (int64_t)blockIdx.y * p.a_bstride;
+        p.W += (int64_t)blockIdx.y * p.w_bstride;
+        p.C = p.c_f32 ? (void*)(reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.c_bstride)
+                      : (void*)(reinterpret_cast<bf16_t*>(p.C) + (int64_t)blockIdx.y * p.c_bstride);
+    }
     const int nblk = p.nbm * p.nbn;
     int bid = blockIdx.x;
     {
@@ -1056,6 +1063,12 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.conv_H = a->conv_H; p.conv_W = a->conv_W; p.conv_d = a->conv_d; p.conv_C = a->conv_C; p.conv_zero = (const bf16_t*)a->conv_zero;
     const bool conv = a->conv_H > 0;
+    p.batch = a->batch > 1 ? a->batch : 1; p.a_bstride = a->a_bstride; p.w_bstride = a->w_bstride; p.c_bstride = a->c_bstride;
+    if (p.batch > 1) {
+        STG_CHECK(!conv && !a->dact && !a->dact_src && !a->res1 && !a->res2 && !a->row_scale, -3, "stg_gemm_nt: batched mode takes bias / alpha / activation only");
+        STG_CHECK(a->K % BK == 0 && a->a_bstride % 8 == 0 && a->w_bstride % 8 == 0 && a->c_bstride % 8 == 0 && p.batch <= 65535, -2,
+                  "stg_gemm_nt: batched mode needs K %% 64 == 0 and strides that keep 16-byte alignment");
+    }
     if (conv) {
         STG_CHECK(a->conv_W > 0 && a->conv_d >= 1 && a->conv_C > 0 && a->conv_C % BK == 0 && a->K == 9 * a->conv_C, -2,
                   "stg_gemm_nt: implicit convolution needs conv_C %% 64 == 0 and K == 9 * conv_C");
@@ -1089,11 +1102,11 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         if (force_generic) p.epi_variant = EV_GENERIC;            // A/B knob: every option a run-time test
     }
     static const int big_mode = [] { const char* e = getenv("STG_GEMM_BIG"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 whenever legal
-    const bool big_ok = !conv && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
+    const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
     static const int ph8_mode = [] { const char* e = getenv("STG_GEMM_8PH"); return e ? atoi(e) : 1; }();   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
-    const bool ph8_ok = !conv && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
+    const bool ph8_ok = !conv && p.batch == 1 && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
@@ -1118,7 +1131,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 2 * (GBM + GBN) * BK * 2, (hipStream_t)stream, p);
-    } else if (conv) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (p.batch > 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch), dim3(256), 0, (hipStream_t)stream, p);
+    else if (conv) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();

@@ -76,9 +76,11 @@ def conv3x3_gemm_supported(Cin):
 
 
 def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
-            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None):
+            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None, batch=None):
     """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, dact) with dact = bf16(act'(pre-activation)),
     the tensor a later call takes as dact_src (or act_bwd as its second argument)."""
+    if batch is not None:
+        return _gemm_nt_batched(A, W, bias, out, out_dtype, alpha, act, int(batch))
     M, K = A.shape
     N = W.shape[0]
     _chk2d(A, "A", BF16)
@@ -150,6 +152,48 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             return (out, pre) if want_dact else out
     _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_dact else out
+
+
+def _gemm_nt_batched(A, W, bias, out, out_dtype, alpha, act, nb):
+    """nb independent problems of one shape: A [nb * M, K] (consecutive row groups), W [nb, N, K] -> C [nb * M, N]."""
+    _chk2d(A, "A", BF16)
+    R, Kd = A.shape
+    if W.dim() != 3 or W.shape[0] != nb or W.shape[2] != Kd or W.dtype != BF16 or not W.is_contiguous() or R % nb != 0 or Kd % 64 != 0:
+        raise RuntimeError("gemm_nt(batch=nb): needs A [nb*M, K], contiguous bf16 W [nb, N, K], K % 64 == 0")
+    M, N = R // nb, W.shape[1]
+    if out is None:
+        out = torch.empty((R, N), dtype=out_dtype, device=A.device)
+    _chk2d(out, "out", out.dtype, cols=N, rows=R)
+    a = _lib.GemmArgs()
+    a.A, a.lda = _p(A), _ld(A)
+    a.W, a.ldw = _p(W), Kd
+    a.C, a.ldc, a.c_dtype = _p(out), _ld(out), (STG_BF16 if out.dtype == BF16 else STG_F32)
+    if bias is not None:
+        _chk1d(bias, "bias", F32, N)
+    a.bias, a.alpha, a.act = _p(bias), float(alpha), int(act)
+    a.M, a.N, a.K = M, N, Kd
+    a.batch, a.a_bstride, a.w_bstride, a.c_bstride = nb, M * _ld(A), N * Kd, M * _ld(out)
+    _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt (batched)")
+    return out
+
+
+def bmm_tn(A, B, rows):
+    """[nb, N1, N2] fp32 = A_b^T B_b over consecutive groups of `rows` rows of A [nb*rows, N1] and B [nb*rows, N2] (bf16);
+    N1, N2 multiples of 128."""
+    _chk2d(A, "A", BF16)
+    _chk2d(B, "B", BF16, rows=A.shape[0])
+    R = A.shape[0]
+    if rows <= 0 or R % rows != 0:
+        raise RuntimeError("bmm_tn: rows must divide the row count")
+    nb, N1, N2 = R // rows, A.shape[1], B.shape[1]
+    splits = C.c_int(0)
+    n = _lib.lib().stg_wgrad_wide_ws_floats(rows, N1, N2, C.byref(splits))
+    if n <= 0:
+        raise RuntimeError("bmm_tn: widths must be multiples of 128")
+    ws = torch.empty((nb, splits.value, N1, N2), dtype=F32, device=A.device)
+    _lib.check(_lib.lib().stg_wgrad_wide_batched(_p(A), _ld(A), _p(B), _ld(B), _p(_zero_line(A.device)), _p(ws), ws.numel(), rows, N1, N2,
+                                                 nb, _stream()), "stg_wgrad_wide_batched")
+    return ws.sum(1) if splits.value > 1 else ws[:, 0]
 
 
 _gemm_prof = None

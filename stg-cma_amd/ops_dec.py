@@ -127,23 +127,35 @@ class TpaviMixFn(torch.autograd.Function):
     def forward(ctx, theta, phi, gbar, B, T, HW):
         theta, phi, gbar = theta.contiguous(), phi.contiguous(), gbar.contiguous()
         Ci = theta.shape[1]
-        y = torch.empty_like(theta)
-        Ms = torch.zeros((B, Ci, Ci), dtype=F32, device=theta.device)
         n = T * HW
-        for b in range(B):
-            K.wgrad_tn(phi[b * T:(b + 1) * T], gbar[b * T:(b + 1) * T], Ms[b])                 # M_b * T = phi_b^T gbar_b
-            K.gemm_nt(theta[b * n:(b + 1) * n], K.cast_bf16(Ms[b], transpose=True), out=y[b * n:(b + 1) * n], alpha=1.0 / T)
+        batched = Ci % 128 == 0
+        if batched:                                   # all clips at once: one tn launch for the M_b, one batched GEMM for y
+            Ms = K.bmm_tn(phi, gbar, T).contiguous()                                            # M_b * T = phi_b^T gbar_b
+            y = K.gemm_nt(theta, Ms.transpose(1, 2).contiguous().to(BF16), alpha=1.0 / T, batch=B)
+        else:
+            y = torch.empty_like(theta)
+            Ms = torch.zeros((B, Ci, Ci), dtype=F32, device=theta.device)
+            for b in range(B):
+                K.wgrad_tn(phi[b * T:(b + 1) * T], gbar[b * T:(b + 1) * T], Ms[b])
+                K.gemm_nt(theta[b * n:(b + 1) * n], K.cast_bf16(Ms[b], transpose=True), out=y[b * n:(b + 1) * n], alpha=1.0 / T)
         ctx.save_for_backward(theta, phi, gbar, Ms)
-        ctx.geom = (B, T, HW)
+        ctx.geom = (B, T, HW, batched)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         theta, phi, gbar, Ms = ctx.saved_tensors
-        B, T, HW = ctx.geom
+        B, T, HW, batched = ctx.geom
         Ci = theta.shape[1]
         n = T * HW
-        dyb = _bf(dy)
+        dyb = _bf(dy).contiguous()
+        if batched and T * Ci % 8 == 0:
+            dtheta = K.gemm_nt(dyb, Ms.to(BF16).contiguous(), alpha=1.0 / T, batch=B)          # dy_b . M_b^T
+            dM = K.bmm_tn(theta, dyb, n)                                                         # dM_b * T = theta_b^T dy_b
+            # the [T, Ci] per-clip products: rows padded to the GEMM's 16-byte granularity are not needed (T rows per problem)
+            dphi = K.gemm_nt(gbar, dM.to(BF16).contiguous(), alpha=1.0 / T, batch=B)             # gbar_b . dM_b^T
+            dgbar = K.gemm_nt(phi, dM.transpose(1, 2).contiguous().to(BF16), alpha=1.0 / T, batch=B)
+            return dtheta, dphi, dgbar, None, None, None
         dtheta = torch.empty_like(theta)
         dphi, dgbar = torch.empty_like(phi), torch.empty_like(gbar)
         for b in range(B):

@@ -399,3 +399,25 @@ def test_wgrad_wide(stg, gpu, M, N1, N2):
     scale = float(ref.abs().max())
     assert float((dW.cpu() - ref).abs().max()) <= 2e-3 * scale
     assert torch.allclose(db.cpu(), dy.float().sum(0) - 1.0, rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("nb,rows,N1,N2", [(3, 5, 128, 128), (4, 245, 128, 128), (2, 15680, 128, 256)])
+def test_bmm_tn(stg, gpu, nb, rows, N1, N2):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(nb + rows)
+    A = _bf(torch.randn(nb * rows, N1, generator=g))
+    B = _bf(torch.randn(nb * rows, N2, generator=g))
+    got = k.bmm_tn(A.to(gpu), B.to(gpu), rows).cpu()
+    ref = torch.einsum("brn,brm->bnm", A.float().view(nb, rows, N1), B.float().view(nb, rows, N2))
+    assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nb,M,N,K", [(3, 5, 128, 128), (4, 245, 128, 128), (2, 1000, 256, 64)])
+def test_gemm_batched(stg, gpu, nb, M, N, K):
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(nb + M + N)
+    A = _bf(torch.randn(nb * M, K, generator=g))
+    W = _bf(torch.randn(nb, N, K, generator=g) * 0.1)
+    got = k.gemm_nt(A.to(gpu), W.to(gpu), alpha=0.2, batch=nb)
+    ref = 0.2 * torch.einsum("bmk,bnk->bmn", A.float().view(nb, M, K), W.float()).reshape(nb * M, N)
+    _close(got, ref, what="batched gemm")
