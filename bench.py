@@ -313,12 +313,22 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
-        # dominant kernel = gemm_nt_glds_kernel: algorithmic FLOPs per launch / average launch duration, both over the sampled
-        # launches of the timed region (see kernels.gemm_profile_start)
-        ns = max(gp["sampled"], 1)
-        avg_us = gp["sampled_ms"] * 1e3 / ns
-        achieved = gp["sampled_flops"] / (gp["sampled_ms"] * 1e-3) / 1e12 if gp["sampled_ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("gemm_nt_glds_kernel<1")
+        # roofline of the dominant kernel: algorithmic FLOPs per launch / average launch duration, both over the sampled launches of the
+        # timed region (see kernels.gemm_profile_start).  Two GEMM kernels carry the step about equally (the 128 x 128 kernel and the
+        # 8-phase 256 x 256 kernel): the one with the larger share of the step is `roofline`, the other `roofline_second`.
+        def roof(pk, kname):
+            ns = max(pk["sampled"], 1)
+            avg_us = pk["sampled_ms"] * 1e3 / ns
+            ach = pk["sampled_flops"] / (pk["sampled_ms"] * 1e-3) / 1e12 if pk["sampled_ms"] > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(kname.split("<")[0] + ("<1" if "glds" in kname else ""))
+            return {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(pk["bytes"] / max(pk["launches"], 1)),
+                    "launches_per_step": pk["launches"] // max(args.steps, 1), "gflop_per_launch": round(pk["sampled_flops"] / ns / 1e9, 2),
+                    "avg_launch_us": round(avg_us, 2), "sampled_launches": pk["sampled"],
+                    "est_ms_per_step": round(avg_us * 1e-3 * pk["launches"] / max(args.steps, 1), 2)}
+        roofs = sorted((roof(gp["glds"], "gemm_nt_glds_kernel<1, false, false>"), roof(gp["k8"], "gemm_nt_8ph_kernel")),
+                       key=lambda r: -r["est_ms_per_step"])
         out = {
             "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
@@ -330,14 +340,7 @@ def main():
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),
             "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_glds_kernel<1, false, false>", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": round(gp["bytes"] / max(gp["launches"], 1)),
-                         "launches_per_step": gp["launches"] // max(args.steps, 1),
-                         "gflop_per_launch": round(gp["sampled_flops"] / ns / 1e9, 2),
-                         "avg_launch_us": round(avg_us, 2), "sampled_launches": gp["sampled"],
-                         "est_ms_per_step": round(avg_us * 1e-3 * gp["launches"] / max(args.steps, 1), 2)},
+            "roofline": roofs[0], "roofline_second": roofs[1],
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
             out["cpu_baseline"] = cpu_baseline()

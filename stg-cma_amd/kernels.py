@@ -132,24 +132,28 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         zl = _zero_line(A.device)
         a.conv_H, a.conv_W, a.conv_d, a.conv_C, a.conv_zero = int(Hc), int(Wc), int(dc), int(Cin), _p(zl)
     prof = _gemm_prof
-    # bench.py: launches that stg_gemm_nt routes to gemm_nt_glds_kernel<1> (K % 64 == 0, and not the long-K large-tile kernel:
-    # same rule as the host dispatch in csrc/gemm.hip)
-    wide8 = K >= 512 and K % 128 == 0 and N >= 1536 and N % 256 == 0 and M >= 256 and dact_src is None and res1 is None and res2 is None and \
-        row_scale is None and alpha == 1.0 and out.dtype == BF16
-    if prof is not None and conv is None and K % 64 == 0 and M > 0 and not (K >= 1024 and N % 256 == 0 and M >= 256) and not wide8:
-        prof["launches"] += 1
-        prof["flops"] += 2.0 * M * N * K
-        nbytes = 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
-            (2.0 * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
-            (M * N * res2.element_size() if res2 is not None else 0.0)
-        prof["bytes"] += nbytes                             # algorithmic HBM bytes: every operand / output touched once
-        if prof["launches"] % prof["stride"] == 0:         # HIP events around every stride-th launch, on the launch stream
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
-            e1.record()
-            prof["rec"].append((e0, e1, 2.0 * M * N * K))
-            return (out, pre) if want_dact else out
+    # bench.py samples the two kernels that carry the step: which one stg_gemm_nt picks follows the host dispatch in csrc/gemm.hip
+    # (8-phase: K % 128 == 0, N % 256 == 0, M >= 256 and either K >= 1024 or a wide plain / activation output; else, for
+    # K % 64 == 0, gemm_nt_glds_kernel<1>)
+    if prof is not None and conv is None and K % 64 == 0 and M > 0:
+        wide8 = K >= 512 and N >= 1536 and dact_src is None and res1 is None and res2 is None and row_scale is None and alpha == 1.0 and \
+            out.dtype == BF16
+        is8 = K % 128 == 0 and N % 256 == 0 and M >= 256 and (K >= 1024 or wide8)
+        big_other = (not is8) and K >= 1024 and N % 256 == 0 and M >= 256          # K % 128 != 0: the one-barrier large-tile kernel
+        if not big_other:
+            pk = prof["k8"] if is8 else prof["glds"]
+            pk["launches"] += 1
+            pk["flops"] += 2.0 * M * N * K
+            pk["bytes"] += 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
+                (2.0 * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
+                (M * N * res2.element_size() if res2 is not None else 0.0)          # algorithmic HBM bytes: every operand / output once
+            if pk["launches"] % prof["stride"] == 0:       # HIP events around every stride-th launch, on the launch stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+                e1.record()
+                pk["rec"].append((e0, e1, 2.0 * M * N * K))
+                return (out, pre) if want_dact else out
     _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_dact else out
 
@@ -202,22 +206,25 @@ USE_WGRAD_WS = _os.environ.get("STG_WGRAD_WS", "1") != "0"    # 0 = atomic wgrad
 
 
 def gemm_profile_start(stride=7):
-    """Start sampling launches of the dominant kernel (gemm_nt_glds_kernel): every `stride`-th launch is bracketed by HIP
-    events on its stream.  Events around EVERY launch (1464 per step) cost ~10 % of the step, so the timed region is sampled
-    systematically instead: the launch sequence repeats every step with a period co-prime to 7, so over >= 7 steps every
-    call site is sampled equally often."""
+    """Start sampling launches of the two GEMM kernels that carry the step (gemm_nt_glds_kernel<1>, gemm_nt_8ph_kernel): every
+    `stride`-th launch of each is bracketed by HIP events on the launch stream (events around every launch cost ~10 % of the step)."""
     global _gemm_prof
-    _gemm_prof = {"stride": int(stride), "launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}
+    _gemm_prof = {"stride": int(stride), "glds": {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []},
+                  "k8": {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}}
 
 
 def gemm_profile_stop():
-    """Stop sampling; returns {launches, flops (all launches), sampled, sampled_ms, sampled_flops} after synchronising."""
+    """{kernel: {launches, flops, bytes, sampled, sampled_ms, sampled_flops}} for 'glds' and 'k8' since gemm_profile_start."""
     global _gemm_prof
     prof, _gemm_prof = _gemm_prof, None
     torch.cuda.synchronize()
-    rec = prof["rec"]
-    return {"launches": prof["launches"], "flops": prof["flops"], "bytes": prof["bytes"], "sampled": len(rec),
-            "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _ in rec), "sampled_flops": sum(f for _, _, f in rec)}
+    out = {}
+    for key in ("glds", "k8"):
+        pk = prof[key]
+        rec = pk["rec"]
+        out[key] = {"launches": pk["launches"], "flops": pk["flops"], "bytes": pk["bytes"], "sampled": len(rec),
+                    "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _ in rec), "sampled_flops": sum(f for _, _, f in rec)}
+    return out
 
 
 def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inner=1):
