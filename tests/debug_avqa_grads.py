@@ -1,4 +1,4 @@
-"""Debug: HIP AVQA head vs the fp32 oracle head on the SAME backbone features (isolates head error from backbone error)."""
+"""Debug (checker script, lives under tests/ because it imports the oracle): HIP AVQA head vs the fp32 oracle head on the SAME backbone features (isolates head error from backbone error)."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tests/golden')
 import stgcma

@@ -1,4 +1,4 @@
-"""Debug: TPAVI gradient norms -- HIP decoder, oracle on HIP taps, oracle on oracle taps -- same script, same upstream."""
+"""Debug (checker script, lives under tests/ because it imports the oracle): TPAVI gradient norms -- HIP decoder, oracle on HIP taps, oracle on oracle taps -- same script, same upstream."""
 import sys, torch, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/tests/golden')
 import stgcma

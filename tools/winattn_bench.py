@@ -3,7 +3,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, stgcma
 from stgcma import kernels as K, ops
-import oracle.swin as OS
 dev = "cuda"
 def t(fn, iters=None):
     iters = iters or int(os.environ.get('ITERS', 10))
@@ -23,7 +22,9 @@ for res, heads in [rh for rh in ((56, 4), (28, 8), (14, 16), (7, 32)) if rh[0] i
         qkv = torch.randn(rows, 3 * C, device=dev).bfloat16()
         dO = torch.randn(rows, C, device=dev).bfloat16()
         table = torch.randn(169, heads, device=dev)
-        index = OS.relative_position_index(7).reshape(-1).to(dev)
+        co = torch.stack(torch.meshgrid(torch.arange(7), torch.arange(7), indexing="ij")).flatten(1)     # Swin_AVE.py:199-207
+        rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0) + 6
+        index = (rel[:, :, 0] * 13 + rel[:, :, 1]).reshape(-1).to(dev)
         mask = ops.shift_mask(res, res, 7, shift).to(dev) if shift else None
         bm, bmT = K.winattn_table(table, index, mask, 49)
         wg = K.WinGeom(images, heads, res, res, 7, shift, 32 ** -0.5, bm, bmT)
