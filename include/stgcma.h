@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 112
+#define STG_VERSION 113
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -302,6 +302,9 @@ int stg_add(const void* a, const void* b, const void* c, void* out, int64_t nume
 /* dz = dh * dact  (bf16), backward of the adapter activation (Swin_AVE.py:21 GELU; CLIP QuickGELU) given the derivative
  * act'(pre-activation) that stg_gemm_nt saved in its `dact` output */
 int stg_act_bwd(const void* dh, const void* dact, void* dz, int64_t numel, void* stream);
+/* out = (a + b + c) * z (bf16): the three gradient paths into an adapter hidden state (own path + the two cross-modal
+ * directions, backward of Swin_AVE.py:750-760 / :799-808) joined and taken through the activation derivative in one pass. */
+int stg_add3_mul(const void* a, const void* b, const void* c, const void* z, void* out, int64_t numel, void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

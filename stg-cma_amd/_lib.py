@@ -147,6 +147,7 @@ SIGNATURES = {
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_act_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_add3_mul": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -176,7 +177,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 112
+ABI_VERSION = 113
 _lib = None
 
 

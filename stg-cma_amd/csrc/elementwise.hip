@@ -94,6 +94,29 @@ __global__ void add_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* c, bf
     }
 }
 
+// ---- out = (a + b + c) * z: the join of the three gradient paths into an adapter's hidden state and the activation backward
+// behind it (one rounding instead of two, one launch instead of two)
+__global__ void add3_mul_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* c, const bf16_t* z, bf16_t* out, int64_t n8, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        unpack8(reinterpret_cast<const uint4*>(a)[i], x);
+        unpack8(reinterpret_cast<const uint4*>(b)[i], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        unpack8(reinterpret_cast<const uint4*>(c)[i], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        unpack8(reinterpret_cast<const uint4*>(z)[i], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= y[j];
+        reinterpret_cast<uint4*>(out)[i] = pack8(x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        out[i] = f2bf((bf2f(a[i]) + bf2f(b[i]) + bf2f(c[i])) * bf2f(z[i]));
+    }
+}
+
 // ---- dz = dh * act'(z)
 __global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int64_t n8, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -329,6 +352,16 @@ extern "C" int stg_add(const void* a, const void* b, const void* c, void* out, i
     const int64_t n8 = numel >> 3;
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b,
                        (const bf16_t*)c, (bf16_t*)out, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_add3_mul(const void* a, const void* b, const void* c, const void* z, void* out, int64_t numel, void* stream) {
+    STG_CHECK(a && b && c && z && out, -1, "stg_add3_mul: null pointer");
+    STG_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)z | (uintptr_t)out) & 15) == 0, -2, "stg_add3_mul: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(add3_mul_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c,
+                       (const bf16_t*)z, (bf16_t*)out, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;
 }

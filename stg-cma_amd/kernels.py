@@ -444,6 +444,17 @@ def add(a, b, c=None, out=None):
     return out
 
 
+def add3_mul(a, b, c, z):
+    """(a + b + c) * z, bf16, one pass."""
+    for t, n in ((a, "a"), (b, "b"), (c, "c"), (z, "z")):
+        _chk_flat(t, n)
+        if t.shape != a.shape:
+            raise RuntimeError("add3_mul: shape mismatch")
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().stg_add3_mul(_p(a), _p(b), _p(c), _p(z), _p(out), a.numel(), _stream()), "stg_add3_mul")
+    return out
+
+
 def act_bwd(dh, z):
     """dz = dh * z, z = the activation derivative saved by gemm_nt(want_dact=True)."""
     _chk_flat(dh, "dh"); _chk_flat(z, "z")

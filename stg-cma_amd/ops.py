@@ -407,8 +407,9 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
     return hv2, ha2, (rv, ra, lse_v, lse_a)
 
 
-def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None):
-    """Returns (dhv, dha) = gradients wrt the pre-fusion hidden states."""
+def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None, zs=None):
+    """Returns (dhv, dha) = gradients wrt the pre-fusion hidden states; with zs = (Z_v, Z_a), the saved activation derivatives of
+    the adapters' D_fc1, the gradients wrt the D_fc1 pre-activations instead (the join and the activation backward in one pass)."""
     mg = saved[4] if len(saved) == 5 else None
     rv, ra, lse_v, lse_a = saved[:4]
     if mg is None:
@@ -423,9 +424,13 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
         K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
+        if zs is not None:
+            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
         return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
     dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
     dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
+    if zs is not None:
+        return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
     return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
 
 
@@ -644,16 +649,16 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
         dH2 = dH_in if dH_in is not None else [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
         if spec.fuse:
-            dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, xs, dH2[0], dH2[1], dgv, dga)
-            dHh = [dHv, dHa]
+            dZs = list(_cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, xs, dH2[0], dH2[1], dgv, dga,
+                                        zs=(HZ[0][1], HZ[1][1])))
         else:
-            dHh = dH2
+            dZs = [K.act_bwd(dH2[i], HZ[i][1]) for i in range(len(ads))]
         dM = torch.empty_like(dX3)
         for i, A in enumerate(ads):
-            dZ = K.act_bwd(dHh[i], HZ[i][1])
+            dZ = dZs[i]
             _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
-        del HZ, H2, xs, dH2, dHh, M
+        del HZ, H2, xs, dH2, dZs, M
         dZm = K.gemm_nt(dM, shadow(P["mlp.fc2.weight"], True), dact_src=Zm)
         del dM, Zm
         dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True))
@@ -667,16 +672,16 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     if dH2 is None:
         dH2 = [K.gemm_nt(dX2[sl[i]], A.w2t) for i, A in enumerate(ads)]
     if spec.fuse:
-        dHv, dHa = _cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, xs, dH2[0], dH2[1], dgv, dga)
-        dHh = [dHv, dHa]
+        dZs = list(_cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, xs, dH2[0], dH2[1], dgv, dga,
+                                    zs=(HZ[0][1], HZ[1][1])))
     else:
-        dHh = dH2
+        dZs = [K.act_bwd(dH2[i], HZ[i][1]) for i in range(len(ads))]
     dPO = torch.empty_like(dX2)
     for i, A in enumerate(ads):
-        dZ = K.act_bwd(dHh[i], HZ[i][1])
+        dZ = dZs[i]
         _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
         K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
-    del HZ, H2, xs, dH2, dHh, PO
+    del HZ, H2, xs, dH2, dZs, PO
     dAO = K.gemm_nt(dPO, wproj_t)
     del dPO
     dQKV = torch.empty_like(QKV)

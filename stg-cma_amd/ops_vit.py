@@ -210,14 +210,13 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
         ads = [_Adapter(P, base + _SFX[m]) for m in spec.mods]
         dH2 = [K.gemm_nt(dOut[sl[i]], A.w2t) for i, A in enumerate(ads)]
         if spec.fuse:
-            dHv, dHa = _cross_modal_bwd(None, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, None, xs, dH2[0], dH2[1], dgv, dga,
-                                        geoms=_xgeoms(spec, BT, ads[0].dh))
-            dHh = [dHv, dHa]
+            dZs = list(_cross_modal_bwd(None, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, None, xs, dH2[0], dH2[1], dgv, dga,
+                                        geoms=_xgeoms(spec, BT, ads[0].dh), zs=(HZ[0][1], HZ[1][1])))
         else:
-            dHh = dH2
+            dZs = [K.act_bwd(dH2[i], HZ[i][1]) for i in range(len(ads))]
         dIn = torch.empty_like(dOut)
         for i, A in enumerate(ads):
-            dZ = K.act_bwd(dHh[i], HZ[i][1])
+            dZ = dZs[i]
             _adapter_wgrad(G, A.name, dZ, Xin[sl[i]], dOut[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dIn[sl[i]], res1=dOut[sl[i]])
         return dIn
