@@ -327,7 +327,7 @@ def main():
                     "launches_per_step": pk["launches"] // max(args.steps, 1), "gflop_per_launch": round(pk["sampled_flops"] / ns / 1e9, 2),
                     "avg_launch_us": round(avg_us, 2), "sampled_launches": pk["sampled"],
                     "est_ms_per_step": round(avg_us * 1e-3 * pk["launches"] / max(args.steps, 1), 2)}
-        roofs = sorted((roof(gp["glds"], "gemm_nt_glds_kernel<1, false, false>"), roof(gp["k8"], "gemm_nt_8ph_kernel")),
+        roofs = sorted((roof(gp["glds"], "gemm_nt_glds_kernel<1, false, false, false>"), roof(gp["k8"], "gemm_nt_8ph_kernel")),
                        key=lambda r: -r["est_ms_per_step"])
         out = {
             "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",

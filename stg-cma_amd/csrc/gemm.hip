@@ -374,7 +374,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
 // fragment reads apply the same involution.  Rows beyond M / N are clamped (their products are never stored).
 // 2-stage pipeline: issue tile t+1's DMA, run tile t's MFMAs, then vmcnt(0) + barrier.
 // CONV: implicit 3x3 convolution (its own instantiation: the plain kernel sits exactly at its 128-VGPR budget)
-template <int NST, bool CONV = false, bool BATCH = false>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
+// KTAIL: K % 64 != 0 (K % 8 == 0): the chunks of the last k-tile beyond K come from the zero line (Swin-L adapters, K = 96)
+template <int NST, bool CONV = false, bool BATCH = false, bool KTAIL = false>   // NST = 2: double-buffered LDS (64 KiB, 2 blocks / CU);  NST = 1: single buffer (32 KiB, up to 4 blocks / CU)
 __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
     if (BATCH) {                                             // blockIdx.y = problem: same shape, strided operands
@@ -401,6 +402,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
     const bf16_t* pa[4];
     const bf16_t* pw[4];
     int py[CONV ? 4 : 1], px[CONV ? 4 : 1];          // implicit convolution: the pixel (y, x) of this lane's four A rows
+    int pc[KTAIL ? 4 : 1];                           // k-tail: this lane's source chunk (0..7) of each piece
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane;
@@ -411,6 +413,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
         gn = gn < p.N ? gn : p.N - 1;
         pa[j] = p.A + gm * p.lda + c * 8;
         pw[j] = p.W + (int64_t)gn * p.ldw + c * 8;
+        if (KTAIL) pc[j] = c;
         if (CONV) {
             const int rem = (int)(gm % ((int64_t)p.conv_H * p.conv_W));
             py[j] = rem / p.conv_W;
@@ -441,9 +444,12 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kt * BK),
+            const bool kin = !KTAIL || kt * BK + pc[KTAIL ? j : 0] * 8 < p.K;
+            const bf16_t* sa = kin ? pa[j] + kt * BK : p.conv_zero;
+            const bf16_t* sw = kin ? pw[j] + kt * BK : p.conv_zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                              (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[j] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sw,
                                              (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 512), 16, 0, 0);
         }
     };
@@ -455,7 +461,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = KTAIL ? (p.K + BK - 1) / BK : p.K / BK;
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -1101,6 +1107,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         static const int force_generic = [] { const char* e = getenv("STG_GEMM_EPI"); return e && atoi(e) == 0; }();
         if (force_generic) p.epi_variant = EV_GENERIC;            // A/B knob: every option a run-time test
     }
+    static const bool ktail_on = [] { const char* e = getenv("STG_GEMM_KTAIL"); return !e || atoi(e) != 0; }();      // A/B knob
     static const int big_mode = [] { const char* e = getenv("STG_GEMM_BIG"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 whenever legal
     const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
@@ -1134,6 +1141,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     } else if (p.batch > 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch), dim3(256), 0, (hipStream_t)stream, p);
     else if (conv) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (ktail_on && a->K > BK && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0)      // K = 96 ...: LDS-DMA kernel with a zero-filled k tail
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

@@ -128,6 +128,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
+    if K % 64 != 0 and K > 64:                            # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
+        a.conv_zero = _p(_zero_line(A.device))
     if conv is not None:
         zl = _zero_line(A.device)
         a.conv_H, a.conv_W, a.conv_d, a.conv_C, a.conv_zero = int(Hc), int(Wc), int(dc), int(Cin), _p(zl)

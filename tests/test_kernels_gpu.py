@@ -311,7 +311,8 @@ def test_cast_bf16_multi_equals_single_casts(stg, gpu):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4097, 768, 3072, "b"), (300, 256, 1024, ""), (1000, 512, 2048, "bap"), (777, 1024, 1152, "d"),
-                                       (256, 256, 128, "b"), (5000, 256, 1536, "r"), (2049, 512, 1024, "bR")])
+                                       (256, 256, 128, "b"), (5000, 256, 1536, "r"), (2049, 512, 1024, "bR"),
+                                       (3000, 768, 96, "b"), (1000, 192, 96, "r"), (700, 96, 72, ""), (515, 1536, 96, "bR"), (900, 384, 80, "bap")])
 def test_gemm_long_k_shapes(stg, gpu, M, N, K, epi):
     """Shapes the host dispatch routes to the 8-phase 256 x 256 kernel (K >= 1024, K % 128 == 0, N % 256 == 0) and its
     neighbours (K % 128 != 0 -> large-tile kernel; K = 128 -> 128 x 128 kernel), with row tails and every epilogue family."""
