@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
             const bool live = m < r1;
             const int yy = py[j] + dy, xx = px[j] + dx;
             const bool in = live && (p.taps == 1 || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W));
-            const bf16_t* sy = live ? p.dy + m * p.lddy + o0 + pch[j] * 8 : p.zero;
+            const bf16_t* sy = (live && o0 + pch[j] * 8 < p.O) ? p.dy + m * p.lddy + o0 + pch[j] * 8 : p.zero;      // O % 128 != 0: zero columns
             const bf16_t* sx = in ? p.x + (m + shift) * p.ldx + i0 + pch[j] * 8 : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
                                              (__attribute__((address_space(3))) void*)(sY + (j * 256 + wave * 64) * 8), 16, 0, 0);
@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-            *reinterpret_cast<f32x4_t*>(wsp + (int64_t)(ot * 16 + o_l) * ldws + ct * 16 + 4 * g) = acc[ct][ot];
+            if (o0 + wo * 64 + ot * 16 + o_l < p.O)
+                *reinterpret_cast<f32x4_t*>(wsp + (int64_t)(ot * 16 + o_l) * ldws + ct * 16 + 4 * g) = acc[ct][ot];
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear x2 (F.interpolate)
@@ -381,8 +382,8 @@ extern "C" int stg_bn_bwd(const void* x, const void* dy, const float* mean, cons
 }
 
 static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) {
-    if (M <= 0 || O <= 0 || I <= 0 || O % 128 != 0 || I % 128 != 0) return -1;
-    const int tiles = (O / 128) * (taps * I / 128);
+    if (M <= 0 || O <= 0 || I <= 0 || O % 8 != 0 || I % 128 != 0) return -1;      // O is padded to 128 with zero columns inside the kernel
+    const int tiles = ((O + 127) / 128) * (taps * I / 128);
     int64_t splits = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU
     const int64_t max_splits = (M + 2047) / 2048;                      // >= 2048 rows per block
     if (splits > max_splits) splits = max_splits;
@@ -394,8 +395,8 @@ static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) 
 static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
                      int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1) {
     STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
-    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 128 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
-              "%s: needs O %% 128 == 0 and I %% 128 == 0", who);
+    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
+              "%s: needs O %% 8 == 0 and I %% 128 == 0", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "%s: bad leading dimensions", who);
     STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;
@@ -408,7 +409,7 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
     p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I; p.taps = taps;
     p.splits = splits;
     p.rows_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
-    p.nto = O / 128; p.ntc = taps * I / 128;
+    p.nto = (O + 127) / 128; p.ntc = taps * I / 128;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits), (unsigned)batch), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;

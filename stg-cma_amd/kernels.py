@@ -1054,7 +1054,7 @@ def im2col3x3(x, F_, H, W, dilation):
 
 
 def conv3x3_wgrad_supported(O, I):
-    return O % 128 == 0 and I % 128 == 0
+    return O % 8 == 0 and I % 128 == 0
 
 
 def conv3x3_wgrad(dy, x, F_, H, W, dilation):
@@ -1067,7 +1067,7 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation):
     splits = C.c_int(0)
     n = _lib.lib().stg_conv3x3_wgrad_ws_floats(M, O, I, C.byref(splits))
     if n <= 0:
-        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 128 == 0 and I % 128 == 0)")
+        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 128 == 0)")
     ws = torch.empty((splits.value, O, 9 * I), dtype=F32, device=x.device)
     _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), F_, H, W, O, I,
                                             int(dilation), _stream()), "stg_conv3x3_wgrad")

@@ -366,7 +366,7 @@ def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
 
 
 @pytest.mark.parametrize("F_,H,W,I,O,d", [(3, 14, 14, 128, 128, 1), (2, 28, 28, 256, 256, 3), (7, 7, 7, 256, 128, 1), (2, 14, 14, 256, 256, 18),
-                                          (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1)])
+                                          (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1), (2, 28, 28, 128, 32, 1), (1, 14, 14, 128, 200, 2)])
 def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
     """The conv weight gradient without the im2col image against autograd of F.conv2d in fp32 (same bf16-rounded operands)."""
     from stgcma import kernels as k
