@@ -61,7 +61,7 @@ typedef struct {
     /* Implicit 3x3 convolution (conv_H > 0; AVS decoder, Swin_AVSModel_Base.py:14-130): A is the channels-last feature map
      * [F*conv_H*conv_W, conv_C] (lda >= conv_C) and the GEMM runs over its im2col image without ever forming it: logical
      * A'[m, tap*conv_C + c] = A[pixel(m) shifted by ((tap/3 - 1)*conv_d, (tap%3 - 1)*conv_d), c], zero outside the frame
-     * (padding == dilation), K = 9*conv_C, W = [N, (kh, kw, c)].  conv_C % 64 == 0, M % (conv_H*conv_W) == 0;
+     * (padding == dilation), K = 9*conv_C, W = [N, (kh, kw, c)].  conv_C % 64 == 0 or conv_C in {8, 16, 32}, M % (conv_H*conv_W) == 0;
      * conv_zero: >= 16 zero bytes, 16-byte aligned (the source of padded taps; also, when given with K % 64 != 0 and K > 64, of the
      * k tail of the LDS-DMA kernel, which then replaces the register-staged one). */
     int conv_H; int conv_W; int conv_d; int conv_C;

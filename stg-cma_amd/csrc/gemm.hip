@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
     const bf16_t* pa[4];
     const bf16_t* pw[4];
     int py[CONV ? 4 : 1], px[CONV ? 4 : 1];          // implicit convolution: the pixel (y, x) of this lane's four A rows
-    int pc[KTAIL ? 4 : 1];                           // k-tail: this lane's source chunk (0..7) of each piece
+    int pc[(KTAIL || CONV) ? 4 : 1];                 // k-tail / few-channel convolution: this lane's source chunk (0..7) of each piece
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = (wave * 4 + j) * 64 + lane;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
         gn = gn < p.N ? gn : p.N - 1;
         pa[j] = p.A + gm * p.lda + c * 8;
         pw[j] = p.W + (int64_t)gn * p.ldw + c * 8;
-        if (KTAIL) pc[j] = c;
+        if (KTAIL || CONV) pc[j] = c;
         if (CONV) {
             const int rem = (int)(gm % ((int64_t)p.conv_H * p.conv_W));
             py[j] = rem / p.conv_W;
@@ -430,6 +430,26 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
             const int tap = k0 / p.conv_C, c0 = k0 - tap * p.conv_C;
             const int dy = (tap / 3 - 1) * p.conv_d, dx = (tap % 3 - 1) * p.conv_d;
             const int64_t shift = ((int64_t)dy * p.conv_W + dx) * p.lda + c0;
+            if (p.conv_C < BK) {
+                // few channels (conv_C = 8 / 16 / 32: a k-tile spans several taps, and K = 9 conv_C ends inside the last one): the
+                // tap is a property of the lane's 16-byte piece; pieces at or beyond K read the zero line on both operands
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ke = k0 + pc[j] * 8;
+                    const int tj = ke / p.conv_C, cj = ke - tj * p.conv_C;
+                    const int dyj = (tj / 3 - 1) * p.conv_d, dxj = (tj % 3 - 1) * p.conv_d;
+                    const int yy = py[j] + dyj, xx = px[j] + dxj;
+                    const bool kin = ke < p.K;
+                    const bool in = kin && yy >= 0 && yy < p.conv_H && xx >= 0 && xx < p.conv_W;
+                    const bf16_t* src = in ? pa[j] - pc[j] * 8 + ((int64_t)dyj * p.conv_W + dxj) * p.lda + cj : p.conv_zero;
+                    const bf16_t* sw = kin ? pw[j] + kt * BK : p.conv_zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 512), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sw,
+                                                     (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 512), 16, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int yy = py[j] + dy, xx = px[j] + dx;
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = KTAIL ? (p.K + BK - 1) / BK : p.K / BK;
+    const int nk = (KTAIL || CONV) ? (p.K + BK - 1) / BK : p.K / BK;
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -1076,8 +1096,8 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
                   "stg_gemm_nt: batched mode needs K %% 64 == 0 and strides that keep 16-byte alignment");
     }
     if (conv) {
-        STG_CHECK(a->conv_W > 0 && a->conv_d >= 1 && a->conv_C > 0 && a->conv_C % BK == 0 && a->K == 9 * a->conv_C, -2,
-                  "stg_gemm_nt: implicit convolution needs conv_C %% 64 == 0 and K == 9 * conv_C");
+        STG_CHECK(a->conv_W > 0 && a->conv_d >= 1 && a->conv_C > 0 && (a->conv_C % BK == 0 || a->conv_C == 8 || a->conv_C == 16 || a->conv_C == 32) &&
+                  a->K == 9 * a->conv_C, -2, "stg_gemm_nt: implicit convolution needs conv_C %% 64 == 0 (or 8 / 16 / 32) and K == 9 * conv_C");
         STG_CHECK(a->lda >= a->conv_C && a->M % ((int64_t)a->conv_H * a->conv_W) == 0, -2, "stg_gemm_nt: implicit convolution: bad lda / M");
         STG_CHECK(a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0, -2, "stg_gemm_nt: implicit convolution needs a 16-byte aligned zero line");
     }

@@ -72,7 +72,7 @@ def _zero_line(device):
 
 
 def conv3x3_gemm_supported(Cin):
-    return Cin % 64 == 0
+    return Cin % 64 == 0 or Cin in (8, 16, 32)
 
 
 def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
@@ -88,8 +88,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         Hc, Wc, dc = conv
         Cin = K
         K = 9 * Cin
-        if Cin % 64 != 0 or M % (Hc * Wc) != 0 or dc < 1:
-            raise RuntimeError("gemm_nt(conv=...): needs Cin % 64 == 0 and rows = F * H * W")
+        if not conv3x3_gemm_supported(Cin) or M % (Hc * Wc) != 0 or dc < 1:
+            raise RuntimeError("gemm_nt(conv=...): needs Cin % 64 == 0 (or 8 / 16 / 32) and rows = F * H * W")
     _chk2d(W, "W", BF16, cols=K)
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)

@@ -347,7 +347,7 @@ def test_gemm_long_k_shapes(stg, gpu, M, N, K, epi):
 
 
 @pytest.mark.parametrize("F_,H,W,Cin,Cout,d", [(3, 14, 14, 64, 64, 1), (2, 28, 28, 256, 256, 3), (1, 7, 7, 128, 32, 1), (2, 14, 14, 256, 256, 18),
-                                               (5, 56, 56, 64, 128, 6)])
+                                               (5, 56, 56, 64, 128, 6), (2, 28, 28, 32, 128, 1), (3, 14, 14, 16, 64, 2), (1, 14, 14, 8, 32, 1)])
 def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
     """stg_gemm_nt in implicit-convolution mode (DMA sources gathered per tap, zero line for the padding) against the im2col
     image + the same GEMM: same k order, so bit-identical; and against F.conv2d in fp32."""
@@ -359,7 +359,10 @@ def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
     wm = _bf(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin))
     y_imp = k.gemm_nt(x.to(gpu), wm.to(gpu), b.to(gpu), conv=(H, W, d))
     y_col = k.gemm_nt(k.im2col3x3(x.to(gpu), F_, H, W, d), wm.to(gpu), b.to(gpu))
-    assert torch.equal(y_imp, y_col)
+    if Cin % 64 == 0:
+        assert torch.equal(y_imp, y_col)
+    else:                               # K = 9 Cin is not a multiple of 64: the im2col path runs on another kernel (other k order)
+        _close(y_imp, y_col.float(), tol=1e-2, what="implicit vs im2col")
     xn = x.float().view(F_, H, W, Cin).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xn, _bf(w).float(), b, padding=d, dilation=d).permute(0, 2, 3, 1).reshape(-1, Cout)
     _close(y_imp, ref, tol=2e-2, what="implicit conv")
