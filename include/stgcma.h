@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 113
+#define STG_VERSION 114
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -366,13 +366,14 @@ int stg_im2col3x3(const void* x, int64_t ldx, void* out, int64_t F, int H, int W
  * stg_conv3x3_wgrad_ws_floats returns the workspace size in floats (and the number of slices), -1 when the shape is unsupported. */
 int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out);
 int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
+                      float* db_ws /* [splits, O] partial column sums of dy (bias gradient), or NULL */,
                       int64_t F, int H, int W, int O, int I, int dilation, void* stream);
 /* The same tn-GEMM without taps: ws[s] = partial dY^T X of the s-th row slice for a trainable Linear / 1x1 convolution whose
  * two widths are both multiples of 128 (the AVS decoder's tap Linears and TPAVI 1x1 convolutions, Swin_AVSModel_Base.py,
  * TPAVI.py:40-75), in place of the atomic fallback of stg_wgrad_tn; dW = sum_s ws[s] (caller), db = column sums of dY. */
 int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* splits_out);
 int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
-                   int64_t M, int N1, int N2, void* stream);
+                   float* db_ws /* [splits, N1] or NULL */, int64_t M, int N1, int N2, void* stream);
 /* batch of independent dY_b^T X_b over consecutive groups of M rows (problem b: rows b*M .. b*M + M - 1 of both operands):
  * ws[b, s, N1, N2] partial tiles; stg_wgrad_wide_ws_floats(M, N1, N2, &splits) floats per problem. */
 int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,

@@ -165,9 +165,9 @@ SIGNATURES = {
     "stg_im2col3x3": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_conv3x3_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
-    "stg_wgrad_wide": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_wgrad_wide": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide_batched": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
-    "stg_conv3x3_wgrad": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
+    "stg_conv3x3_wgrad": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_bwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_ln_param_grad": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, c_vp]),
@@ -177,7 +177,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 113
+ABI_VERSION = 114
 _lib = None
 
 

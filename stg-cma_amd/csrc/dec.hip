@@ -49,6 +49,7 @@ struct CwP {
     const bf16_t* x; int64_t ldx;
     const bf16_t* zero;
     float* ws;                       // [splits][O][9 * I]
+    float* dbws;                     // [splits][O] column sums of dY (the bias gradient), or NULL
     int64_t M; int H, W, d, O, I; int taps;   // taps = 9 (3x3 convolution) or 1 (plain dW = dY^T X: no shift, H = W = 1)
     int splits; int64_t rows_per_split;   // multiple of 64
     int nto, ntc;                    // tiles over O and over 9 * I
@@ -114,6 +115,14 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient: column sums of dY ride on the MFMA pipe (ones as the other operand) in the waves that see each dY tile first
+    const bool do_db = p.dbws != nullptr && tc == 0 && wc == 0;
+    f32x4_t accb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) accb[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
     for (int64_t mb = r0; mb < r1; mb += 64) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -146,11 +155,21 @@ __global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot)
                     acc[ct][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ct], fy[ot], acc[ct][ot], 0, 0, 0);
+            if (do_db) {
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) accb[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[ot], accb[ot], 0, 0, 0);
+            }
         }
         __syncthreads();                                    // every wave is done reading before the next tile's DMA
     }
     // partial tile -> workspace: lane (o = l & 15, g = l >> 4) holds columns 4 g .. 4 g + 3 of each 16-column tile
     const int o_l = lane & 15, g = lane >> 4;
+    if (do_db && g == 0) {                               // every "column" of accb is the same sum: lane (o, 0) register 0
+        float* dbp = p.dbws + (int64_t)split * p.O + o0 + wo * 64;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+            if (o0 + wo * 64 + ot * 16 + o_l < p.O) dbp[ot * 16 + o_l] = accb[ot][0];
+    }
     const int64_t ldws = p.taps * (int64_t)p.I;
     float* wsp = p.ws + ((int64_t)split * p.O + o0 + wo * 64) * ldws + col0 + wc * 64;
 #pragma unroll
@@ -393,7 +412,8 @@ static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) 
 }
 
 static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
-                     int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1) {
+                     int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1,
+                     float* dbws = nullptr) {
     STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
     STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
               "%s: needs O %% 8 == 0 and I %% 128 == 0", who);
@@ -405,6 +425,7 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
     STG_CHECK(batch >= 1 && batch <= 65535, -2, "%s: bad batch", who);
     CwP p = {};
     p.ws_bstride = need;
+    p.dbws = batch == 1 ? dbws : nullptr;
     p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const bf16_t*)x; p.ldx = ldx; p.zero = (const bf16_t*)zero_line; p.ws = ws;
     p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I; p.taps = taps;
     p.splits = splits;
@@ -418,16 +439,16 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
 extern "C" int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out) { return cw_ws_floats(M, O, I, 9, splits_out); }
 
 extern "C" int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
-                                 int64_t ws_floats, int64_t F, int H, int W, int O, int I, int dilation, void* stream) {
+                                 int64_t ws_floats, float* db_ws, int64_t F, int H, int W, int O, int I, int dilation, void* stream) {
     STG_CHECK(F > 0, -2, "stg_conv3x3_wgrad: bad F");
-    return cw_launch("stg_conv3x3_wgrad", dy, lddy, x, ldx, zero_line, ws, ws_floats, F * H * W, H, W, O, I, dilation, 9, stream);
+    return cw_launch("stg_conv3x3_wgrad", dy, lddy, x, ldx, zero_line, ws, ws_floats, F * H * W, H, W, O, I, dilation, 9, stream, 1, db_ws);
 }
 
 extern "C" int64_t stg_wgrad_wide_ws_floats(int64_t M, int N1, int N2, int* splits_out) { return cw_ws_floats(M, N1, N2, 1, splits_out); }
 
 extern "C" int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
-                              int64_t M, int N1, int N2, void* stream) {
-    return cw_launch("stg_wgrad_wide", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream);
+                              float* db_ws, int64_t M, int N1, int N2, void* stream) {
+    return cw_launch("stg_wgrad_wide", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream, 1, db_ws);
 }
 
 extern "C" int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,

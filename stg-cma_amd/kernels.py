@@ -254,10 +254,12 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         splits = C.c_int(0)
         n = L.stg_wgrad_wide_ws_floats(M, N1, N2, C.byref(splits))
         ws = torch.empty((splits.value, N1, N2), dtype=F32, device=dY.device)
-        _lib.check(L.stg_wgrad_wide(_p(dY), _ld(dY), _p(X), _ld(X), _p(_zero_line(dY.device)), _p(ws), n, M, N1, N2, _stream()), "stg_wgrad_wide")
+        dbw = torch.empty((splits.value, N1), dtype=F32, device=dY.device) if db is not None else None
+        _lib.check(L.stg_wgrad_wide(_p(dY), _ld(dY), _p(X), _ld(X), _p(_zero_line(dY.device)), _p(ws), n, _p(dbw), M, N1, N2, _stream()),
+                   "stg_wgrad_wide")
         dW.add_(ws.sum(0) if splits.value > 1 else ws[0])
         if db is not None:
-            db.add_(bn_colsum(dY if dY.is_contiguous() else dY.contiguous())[0])
+            db.add_(dbw.sum(0))
         return
     nws = L.stg_wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
     if nws > 0:                                          # partial tiles + reduce (no memory-side atomics)
@@ -1057,9 +1059,9 @@ def conv3x3_wgrad_supported(O, I):
     return O % 8 == 0 and I % 128 == 0
 
 
-def conv3x3_wgrad(dy, x, F_, H, W, dilation):
+def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     """dW [O, 9 * I] fp32 (columns ordered (kh, kw, i)) of a 3x3 convolution with padding = dilation, from dy [F*H*W, O] and
-    x [F*H*W, I] (bf16, channels-last rows), without the im2col image."""
+    x [F*H*W, I] (bf16, channels-last rows), without the im2col image; with want_db also db [O] = column sums of dy."""
     M = F_ * H * W
     _chk2d(dy, "dy", BF16, rows=M)
     _chk2d(x, "x", BF16, rows=M)
@@ -1069,9 +1071,13 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation):
     if n <= 0:
         raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 128 == 0)")
     ws = torch.empty((splits.value, O, 9 * I), dtype=F32, device=x.device)
-    _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), F_, H, W, O, I,
+    dbw = torch.empty((splits.value, O), dtype=F32, device=x.device) if want_db else None
+    _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), _p(dbw), F_, H, W, O, I,
                                             int(dilation), _stream()), "stg_conv3x3_wgrad")
-    return ws.sum(0) if splits.value > 1 else ws[0]
+    dW = ws.sum(0) if splits.value > 1 else ws[0]
+    if want_db:
+        return dW, dbw.sum(0)
+    return dW
 
 
 def bilinear_up2_fwd(x, F_, H, W, align_corners):

@@ -48,8 +48,8 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             want_db = ctx.has_b and ctx.needs_input_grad[2]
             if K.conv3x3_wgrad_supported(O, I):        # tn-GEMM with the tap gather inside: no im2col image, no atomics
-                dWm = K.conv3x3_wgrad(dyb.contiguous(), x.contiguous(), F_, H, Wd, d)
-                db = K.bn_colsum(dyb.contiguous())[0].clone() if want_db else None
+                res = K.conv3x3_wgrad(dyb.contiguous(), x.contiguous(), F_, H, Wd, d, want_db=want_db)
+                dWm, db = res if want_db else (res, None)
             else:
                 dWm = torch.zeros((O, 9 * I), dtype=F32, device=x.device)
                 db = torch.zeros((O,), dtype=F32, device=x.device) if want_db else None
