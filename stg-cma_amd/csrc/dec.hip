@@ -75,7 +75,7 @@ __device__ __forceinline__ bf16x8_t cw_frag(const bf16_t* tile, int t, int s, in
     return f;
 }
 
-__global__ void __launch_bounds__(256, 3) conv_wgrad_kernel(CwP p) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 64 * 128];
     bf16_t* sY = smem;
     bf16_t* sX = smem + 64 * 128;
