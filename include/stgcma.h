@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 114
+#define STG_VERSION 115
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
@@ -376,6 +376,8 @@ int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64_t ldx, con
                    float* db_ws /* [splits, N1] or NULL */, int64_t M, int N1, int N2, void* stream);
 /* batch of independent dY_b^T X_b over consecutive groups of M rows (problem b: rows b*M .. b*M + M - 1 of both operands):
  * ws[b, s, N1, N2] partial tiles; stg_wgrad_wide_ws_floats(M, N1, N2, &splits) floats per problem. */
+/* out[b, :] (+)= sum_s ws[b, s, :] (fp32; n floats per slice, n % 4 == 0): folds the partial tiles of the three entries above. */
+int stg_sum_splits(const float* ws, float* out, int splits, int64_t n, int64_t batch, int accumulate, void* stream);
 int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,
                            int64_t M, int N1, int N2, int batch, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=...) (:108-110 align_corners=True, :1500 False) and its adjoint */

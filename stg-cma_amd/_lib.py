@@ -166,6 +166,7 @@ SIGNATURES = {
     "stg_conv3x3_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int, c_vp]),
     "stg_wgrad_wide": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_sum_splits": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, c_vp]),
     "stg_wgrad_wide_batched": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_conv3x3_wgrad": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bilinear_up2_fwd": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -177,7 +178,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 114
+ABI_VERSION = 115
 _lib = None
 
 

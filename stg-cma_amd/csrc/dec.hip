@@ -180,6 +180,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
                 *reinterpret_cast<f32x4_t*>(wsp + (int64_t)(ot * 16 + o_l) * ldws + ct * 16 + 4 * g) = acc[ct][ot];
 }
 
+// out[b, i] (+)= sum_s ws[b, s, i]: the row-slice partial tiles of conv_wgrad_kernel folded (fp32, 16-byte accesses)
+__global__ void sum_splits_kernel(const float* ws, float* out, int S, int64_t n4, int64_t batch, int accumulate) {
+    const int64_t total = batch * n4;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = id / n4, i = id - b * n4;
+        const float4* src = reinterpret_cast<const float4*>(ws) + b * S * n4 + i;
+        float4 a = accumulate ? reinterpret_cast<const float4*>(out)[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sidx = 0; sidx < S; ++sidx) {
+            const float4 v = src[(int64_t)sidx * n4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[id] = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bilinear x2 (F.interpolate)
 __device__ __forceinline__ void src_index(int o, int in_size, int out_size, int align, int& i0, int& i1, float& w1) {
     float s;
@@ -454,4 +469,14 @@ extern "C" int stg_wgrad_wide(const void* dy, int64_t lddy, const void* x, int64
 extern "C" int stg_wgrad_wide_batched(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws,
                                       int64_t ws_floats, int64_t M, int N1, int N2, int batch, void* stream) {
     return cw_launch("stg_wgrad_wide_batched", dy, lddy, x, ldx, zero_line, ws, ws_floats, M, 1, 1, N1, N2, 1, 1, stream, batch);
+}
+
+extern "C" int stg_sum_splits(const float* ws, float* out, int splits, int64_t n, int64_t batch, int accumulate, void* stream) {
+    STG_CHECK(ws && out, -1, "stg_sum_splits: null pointer");
+    STG_CHECK(splits >= 1 && n >= 0 && n % 4 == 0 && batch >= 1 && (((uintptr_t)ws | (uintptr_t)out) & 15) == 0, -2,
+              "stg_sum_splits: needs n %% 4 == 0 and 16-byte aligned pointers");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(grid_for(batch * (n / 4), 256)), dim3(256), 0, ST, ws, out, splits, n / 4, batch, accumulate ? 1 : 0);
+    STG_LAUNCH_CHECK();
+    return 0;
 }

@@ -183,6 +183,22 @@ def _gemm_nt_batched(A, W, bias, out, out_dtype, alpha, act, nb):
     return out
 
 
+def _sum_splits(ws, out=None, accumulate=False):
+    """ws [S, ...] or [nb, S, ...] (batched when out is 1 dim smaller than ws by the split axis): fold the split axis in fp32."""
+    batched = out is not None and ws.dim() == out.dim() + 1 and ws.dim() >= 3 and ws.shape[0] == out.shape[0] and ws.shape[2:] == out.shape[1:]
+    if batched:
+        nb, S = ws.shape[0], ws.shape[1]
+    else:
+        nb, S = 1, ws.shape[0]
+    n = ws.numel() // (nb * S)
+    if out is None:
+        out = torch.empty(ws.shape[1:], dtype=F32, device=ws.device)
+    if not out.is_contiguous() or out.dtype != F32 or out.numel() != nb * n:
+        raise RuntimeError("_sum_splits: out must be a contiguous fp32 tensor of one slice")
+    _lib.check(_lib.lib().stg_sum_splits(_p(ws), _p(out), int(S), n, nb, 1 if accumulate else 0, _stream()), "stg_sum_splits")
+    return out
+
+
 def bmm_tn(A, B, rows):
     """[nb, N1, N2] fp32 = A_b^T B_b over consecutive groups of `rows` rows of A [nb*rows, N1] and B [nb*rows, N2] (bf16);
     N1, N2 multiples of 128."""
@@ -199,7 +215,8 @@ def bmm_tn(A, B, rows):
     ws = torch.empty((nb, splits.value, N1, N2), dtype=F32, device=A.device)
     _lib.check(_lib.lib().stg_wgrad_wide_batched(_p(A), _ld(A), _p(B), _ld(B), _p(_zero_line(A.device)), _p(ws), ws.numel(), rows, N1, N2,
                                                  nb, _stream()), "stg_wgrad_wide_batched")
-    return ws.sum(1) if splits.value > 1 else ws[:, 0]
+    out = torch.empty((nb, N1, N2), dtype=F32, device=A.device)
+    return _sum_splits(ws, out)
 
 
 _gemm_prof = None
@@ -257,9 +274,12 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         dbw = torch.empty((splits.value, N1), dtype=F32, device=dY.device) if db is not None else None
         _lib.check(L.stg_wgrad_wide(_p(dY), _ld(dY), _p(X), _ld(X), _p(_zero_line(dY.device)), _p(ws), n, _p(dbw), M, N1, N2, _stream()),
                    "stg_wgrad_wide")
-        dW.add_(ws.sum(0) if splits.value > 1 else ws[0])
+        if dW.is_contiguous():
+            _sum_splits(ws, dW, accumulate=True)
+        else:
+            dW.add_(_sum_splits(ws))
         if db is not None:
-            db.add_(dbw.sum(0))
+            db.add_(dbw.sum(0))                           # [splits, N1] -> [N1]: a few hundred floats
         return
     nws = L.stg_wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
     if nws > 0:                                          # partial tiles + reduce (no memory-side atomics)
@@ -1074,9 +1094,9 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     dbw = torch.empty((splits.value, O), dtype=F32, device=x.device) if want_db else None
     _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), _p(dbw), F_, H, W, O, I,
                                             int(dilation), _stream()), "stg_conv3x3_wgrad")
-    dW = ws.sum(0) if splits.value > 1 else ws[0]
+    dW = _sum_splits(ws)
     if want_db:
-        return dW, dbw.sum(0)
+        return dW, dbw.sum(0)                             # [splits, O] -> [O]: a few hundred floats
     return dW
 
 
