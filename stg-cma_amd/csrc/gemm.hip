@@ -1137,7 +1137,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
-    const bool ph8_wide = a->K >= 512 && a->N >= 1536 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU);
+    const bool ph8_wide = a->K >= 512 && a->N >= 1536 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         static const bool attr8 = [] {
             return hipFuncSetAttribute((const void*)gemm_nt_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2) == hipSuccess;

@@ -138,7 +138,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     # (8-phase: K % 128 == 0, N % 256 == 0, M >= 256 and either K >= 1024 or a wide plain / activation output; else, for
     # K % 64 == 0, gemm_nt_glds_kernel<1>)
     if prof is not None and conv is None and K % 64 == 0 and M > 0:
-        wide8 = K >= 512 and N >= 1536 and dact_src is None and res1 is None and res2 is None and row_scale is None and alpha == 1.0 and \
+        wide8 = K >= 512 and N >= 1536 and M >= 8192 and dact_src is None and res1 is None and res2 is None and row_scale is None and alpha == 1.0 and \
             out.dtype == BF16
         is8 = K % 128 == 0 and N % 256 == 0 and M >= 256 and (K >= 1024 or wide8)
         big_other = (not is8) and K >= 1024 and N % 256 == 0 and M >= 256          # K % 128 != 0: the one-barrier large-tile kernel

@@ -9,7 +9,9 @@ dev = "cuda"
 reps = int(os.environ.get("REPS", 12))
 shapes = [(125440, 512, 2048, "b"), (125440, 512, 1536, ""), (125440, 2048, 512, "bap"), (125440, 2048, 512, "d"), (125440, 1536, 512, "b"),
           (125440, 512, 512, "b"), (31360, 1024, 4096, "b"), (31360, 4096, 1024, "bap"), (1000, 256, 64, "b"), (256, 256, 128, ""),
-          (300, 512, 192, "b"), (501760, 256, 1024, "b"), (4097, 768, 3072, "")]
+          (300, 512, 192, "b"), (501760, 256, 1024, "b"), (4097, 768, 3072, ""),
+          (78720, 2304, 768, "b"), (78720, 3072, 768, "bap"), (78720, 768, 3072, "b"), (31360, 6144, 1536, "bap"), (125440, 3072, 768, "b"),
+          (1000, 1536, 512, "b"), (257, 2048, 1024, "bap"), (15680, 4608, 1536, "b")]
 def csum(t):
     return int(t.view(torch.int16).to(torch.int64).sum().item()) if t.dtype == torch.bfloat16 else int(t.view(torch.int32).to(torch.int64).sum().item())
 for (M, N, Kd, tag) in shapes:
