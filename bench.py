@@ -73,13 +73,13 @@ def build_model(torch, device, workload="swin_b"):
         from stgcma.model import CLIP_AVE as Cm
         m = Cm.MM_CLIP_AVE(**VIT_B)
     elif workload in ("avs_backbone", "avs"):
-        from stgcma.model import Swin_AVS
-        m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
+        from stgcma.model import Swin_AVSModel
+        m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(patch_size=[1, 4, 4], img_size=224, num_frames=5, embed_dim=128, depths=[2, 2, 18, 2],
                                                    num_heads=[4, 8, 16, 32], window_size=7, pretrained=None, ftmode="fusion",
                                                    adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
     elif workload in ("avqa_backbone", "avqa"):
-        from stgcma.model import Swin_AVQA
-        m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(patch_size=[1, 4, 4], img_size=224, num_frames=10, embed_dim=192,
+        from stgcma.model import Swin_AVQAModel_V1
+        m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(patch_size=[1, 4, 4], img_size=224, num_frames=10, embed_dim=192,
                                                      depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], window_size=7, pretrained=None,
                                                      ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
     else:

@@ -9,8 +9,10 @@
  *
  * Conventions
  *   - every function returns 0 on success, <0 on error (stg_last_error() holds the message, thread-local);
- *   - the caller owns all memory (device pointers from the PyTorch allocator), the library never allocates,
- *     frees or keeps global mutable state => re-entrant across threads / devices / streams;
+ *   - the caller owns all memory (device pointers from the PyTorch allocator), the library never allocates or
+ *     frees => re-entrant across threads / devices / streams.  Process state is limited to (a) the per-device
+ *     "dynamic LDS size reserved" bits of the large-LDS kernels and (b) the dispatch options of stg_set_option,
+ *     which default to the product configuration and are never read from the environment;
  *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, never synchronised;
  *   - activations are bf16 (uint16 storage) row-major with explicit leading dimensions (in elements);
  *     statistics, biases, trainable-parameter gradients and logits are fp32;
@@ -23,13 +25,18 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 115
+#define STG_VERSION 200
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
 
 int stg_version(void);
 const char* stg_last_error(void);
+/* Dispatch options for A/B measurements (tools/, tests): "gemm_epi" (0: generic epilogue), "gemm_ktail" (0: register-staged
+ * kernel for K % 64 != 0), "gemm_big" (0 off / 1 auto / 2 whenever legal), "gemm_8ph" (0 off / 1 auto / 2 every legal shape /
+ * 3 long-K only), "xattn" (0: frame-global cross-modal attention on the generic kernels), "gemm_dbg" (diagnostics build only).
+ * Returns -2 for an unknown name.  The product never calls it. */
+int stg_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = epi( A[M,K] . W[N,K]^T )      (bf16 MFMA 16x16x32, fp32 accumulate)

@@ -4,7 +4,8 @@ plain functions over a flat {state_dict key: tensor} dict, eval semantics (every
 
 Only tests/ may import this; the product path (stg-cma_amd/ops_head.py) never does.  The LSTM and the single-query multi-head
 attention are written out from their definitions (torch.nn.LSTM gate order i, f, g, o; nn.MultiheadAttention's packed
-in-projection), not through the nn modules.  Pinned by tests/golden/avqa_full_tiny.npz (the reference model itself run in the
+in-projection), not through the nn modules.  The 512-d head variant of AVQA/model/Swin_AVQAModel.py (AVQA/test.py:8) is the same code
+behind three extra Linears.  Pinned by tests/golden/avqa_full_tiny.npz and avqa512_full_tiny.npz (the reference models run in the
 build container, tests/golden/make_golden.py::avqa_full_case) through tests/test_oracle_cpu.py.
 """
 import math
@@ -71,10 +72,15 @@ def _ground_and_match(P, fv, audio_feat):
 
 def avqa_head(P, f_v, f_a, f_nega, question, B, T):
     """(:1768-1903) f_*: [(B T), 49, 1536] -> (out_qa [B, 42], out_match_posi [(B T), 2], out_match_nega [(B T), 2])."""
+    if "avqatask_yb_fc_v.weight" in P:
+        # the 512-d variant, AVQA/model/Swin_AVQAModel.py:1772-1783 (projections of the three streams) and :1798 (fc_a1 + ReLU)
+        f_v, f_nega = _lin(P, "avqatask_yb_fc_v", f_v), _lin(P, "avqatask_yb_fc_v", f_nega)
+        audio = F.relu(_lin(P, "avqatask_fc_a1", _lin(P, "avqatask_yb_fc_a", f_a).mean(dim=1)))
+    else:
+        audio = F.relu(f_a.mean(dim=1))                                # Swin_AVQAModel_V1.py:1791, :1800
     C = f_v.shape[-1]
-    audio = f_a.mean(dim=1)
     qst = question_encoder(P, "avqatask_question_encoder", question)
-    audio_feat = _lin(P, "avqatask_fc_a2", F.relu(audio))
+    audio_feat = _lin(P, "avqatask_fc_a2", audio)
     vgrd_posi, out_match_posi = _ground_and_match(P, f_v, audio_feat)
     _, out_match_nega = _ground_and_match(P, f_nega, audio_feat)
     vis = vgrd_posi.view(B, T, C)

@@ -112,6 +112,7 @@ class TAttnArgs(C.Structure):
 SIGNATURES = {
     "stg_version": (C.c_int, []),
     "stg_last_error": (C.c_char_p, []),
+    "stg_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
     "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64, c_vp]),
     "stg_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int]),
@@ -178,7 +179,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 115
+ABI_VERSION = 200
 _lib = None
 
 
@@ -203,6 +204,11 @@ def lib():
     if handle.stg_version() != ABI_VERSION:
         raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version {ABI_VERSION}")
     _lib = handle
+    # A/B knobs of tools/ (never set in production): forwarded ONCE from the environment to the library's explicit options
+    for env, opt in (("STG_GEMM_EPI", "gemm_epi"), ("STG_GEMM_KTAIL", "gemm_ktail"), ("STG_GEMM_BIG", "gemm_big"),
+                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn")):
+        if env in os.environ:
+            check(handle.stg_set_option(opt.encode(), int(os.environ[env])), f"stg_set_option({opt})")
     return _lib
 
 

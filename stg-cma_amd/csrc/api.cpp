@@ -1,6 +1,8 @@
 // Host-side glue of libstgcma_hip.so: version + thread-local error string (see include/stgcma.h).
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include "../../include/stgcma.h"
 
 static thread_local char g_err[512] = "";
@@ -14,3 +16,18 @@ void stg_set_error(const char* fmt, ...) {
 
 extern "C" int stg_version(void) { return STG_VERSION; }
 extern "C" const char* stg_last_error(void) { return g_err; }
+
+// ---- dispatch options (declared in common.h)
+std::atomic<int> stg_opt_gemm_epi{1}, stg_opt_gemm_ktail{1}, stg_opt_gemm_big{1}, stg_opt_gemm_8ph{1}, stg_opt_gemm_dbg{0}, stg_opt_xattn{1};
+
+extern "C" int stg_set_option(const char* name, int value) {
+    if (name == nullptr) { stg_set_error("stg_set_option: null name"); return -1; }
+    if (!strcmp(name, "gemm_epi")) stg_opt_gemm_epi = value;
+    else if (!strcmp(name, "gemm_ktail")) stg_opt_gemm_ktail = value;
+    else if (!strcmp(name, "gemm_big")) stg_opt_gemm_big = value;
+    else if (!strcmp(name, "gemm_8ph")) stg_opt_gemm_8ph = value;
+    else if (!strcmp(name, "gemm_dbg")) stg_opt_gemm_dbg = value;     // read by the diagnostics build only
+    else if (!strcmp(name, "xattn")) stg_opt_xattn = value;
+    else { stg_set_error("stg_set_option: unknown option '%s'", name); return -2; }
+    return 0;
+}

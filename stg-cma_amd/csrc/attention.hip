@@ -705,9 +705,8 @@ inline int64_t groups(const AttnP& p) { return ((int64_t)p.P + p.pack - 1) / p.p
 
 }  // namespace
 
-static bool xattn_on() {          // STG_XATTN=0: keep the frame-global cross-modal attention on the generic kernels (A/B knob)
-    static const bool on = [] { const char* e = getenv("STG_XATTN"); return !(e && atoi(e) == 0); }();
-    return on;
+static bool xattn_on() {          // option "xattn" = 0: keep the frame-global cross-modal attention on the generic kernels (A/B knob)
+    return stg_opt_xattn.load(std::memory_order_relaxed) != 0;
 }
 
 extern "C" int stg_attn_fwd(const stg_attn_args* f, void* stream) {

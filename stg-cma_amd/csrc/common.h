@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere; bf16 is carried as raw uint16_t in memory.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #define STG_WAVE 64
@@ -112,6 +113,28 @@ __device__ __forceinline__ void store_tile32(bf16_t* rowp, const f32x16_t& acc, 
 
 // host-side error plumbing (api.cpp)
 void stg_set_error(const char* fmt, ...);
+
+// Dispatch options (A/B knobs of tools/ and of the tests): process-wide integers defined in api.cpp and written only by
+// stg_set_option -- nothing on a launch path reads the environment.
+extern std::atomic<int> stg_opt_gemm_epi;     // 0: every GEMM epilogue option a run-time test (EV_GENERIC)
+extern std::atomic<int> stg_opt_gemm_ktail;   // 0: K % 64 != 0 shapes on the register-staged kernel
+extern std::atomic<int> stg_opt_gemm_big;     // 256 x 256 simple-loop kernel: 0 off, 1 auto, 2 whenever legal
+extern std::atomic<int> stg_opt_gemm_8ph;     // 8-phase kernel: 0 off, 1 auto (default), 2 every legal shape, 3 long-K shapes only
+extern std::atomic<int> stg_opt_gemm_dbg;     // diagnostics build only (-DSTG_GEMM_DIAG)
+extern std::atomic<int> stg_opt_xattn;        // 0: frame-global cross-modal attention on the generic attention kernels
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: `done` (one static per kernel instantiation) remembers the
+// devices that have it, so a model on cuda:1 (nn.DataParallel replicas, one process driving several GPUs) gets it too.
+template <typename Kern>
+inline bool stg_reserve_lds(Kern kern, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 #define STG_CHECK(cond, code, ...)                \
     do {                                          \
         if (!(cond)) {                            \

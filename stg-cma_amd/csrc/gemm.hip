@@ -12,10 +12,17 @@
 // Block tile 128x128x64, 256 threads = 2x2 waves of 64x64, LDS double buffered (64 KiB => 2 blocks / CU),
 // global prefetch of tile k+1 into registers while tile k is in the MFMA loop (one barrier per k-tile).
 // Block ids are remapped so that the N-tiles sharing one A row-panel run on the same XCD (its L2 holds the panel).
-#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "../../include/stgcma.h"
+
+// Timing-only ablations exist in the diagnostics build alone (make diag -> libstgcma_hip_diag.so, -DSTG_GEMM_DIAG): the product
+// kernels carry no run-time debug branches.
+#ifdef STG_GEMM_DIAG
+#define DIAG_ON(p, v) ((p).dbg == (v))
+#else
+#define DIAG_ON(p, v) false
+#endif
 
 namespace {
 
@@ -40,7 +47,9 @@ struct GemmParams {
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
     int conv_H, conv_W, conv_d, conv_C; const bf16_t* conv_zero;     // implicit 3x3 convolution (conv_H > 0), see stgcma.h
     int batch; int64_t a_bstride, w_bstride, c_bstride;              // batched mode (blockIdx.y = problem), see stgcma.h
-    int dbg;   // timing-only ablations (STG_GEMM_DBG): 1 = no in-loop tile loads, 2 = no MFMA work, 3 = no epilogue
+#ifdef STG_GEMM_DIAG
+    int dbg;   // diagnostics build only (libstgcma_hip_diag.so, tools/): 1 = no in-loop tile loads, 2 = no MFMA work, 3 = no epilogue
+#endif
 };
 
 __device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) {
@@ -241,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
 // smem: the block's tile buffer (>= 32 KiB), free once every wave is past the main loop's final barrier
 __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm,
                                                        int wn, int lane, float* stg, int ngap = 0) {
-    if (p.dbg == 3 && accs.v[0][0][0] != 12345.678f) return;
+    if (DIAG_ON(p, 3) && accs.v[0][0][0] != 12345.678f) return;
     switch (p.epi_variant) {
         case EV_PLAIN: gemm_epilogue_rows<EV_PLAIN>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         case EV_GELU: gemm_epilogue_rows<EV_GELU>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
@@ -486,10 +495,10 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = NST == 2 ? (kt & 1) : 0;
-        if (NST == 2 && kt + 1 < nk && p.dbg != 1) stage(cur ^ 1, kt + 1);
+        if (NST == 2 && kt + 1 < nk && !DIAG_ON(p, 1)) stage(cur ^ 1, kt + 1);
         const bf16_t* sA = smem + cur * (BM + BN) * BK;
         const bf16_t* sW = sA + BM * BK;
-        if (p.dbg != 2)
+        if (!DIAG_ON(p, 2))
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t af[4], wf[4];
@@ -582,7 +591,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const bf16_t* sA = smem + cur * (GBM + GBN) * BK;
         const bf16_t* sW = sA + GBM * BK;
-        if (p.dbg != 2)
+        if (!DIAG_ON(p, 2))
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8_t af[8], wf[4];
@@ -753,7 +762,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_setprio(1);
-                if (p.dbg != 2)
+                if (!DIAG_ON(p, 2))
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -1059,6 +1068,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
     }
 }
 
+std::atomic<uint64_t> lds_8ph_done{0}, lds_big_done{0};
+
 }  // namespace
 
 extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
@@ -1101,7 +1112,9 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         STG_CHECK(a->lda >= a->conv_C && a->M % ((int64_t)a->conv_H * a->conv_W) == 0, -2, "stg_gemm_nt: implicit convolution: bad lda / M");
         STG_CHECK(a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0, -2, "stg_gemm_nt: implicit convolution needs a 16-byte aligned zero line");
     }
-    { const char* e = getenv("STG_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+#ifdef STG_GEMM_DIAG
+    p.dbg = stg_opt_gemm_dbg.load(std::memory_order_relaxed);
+#endif
     const int64_t nbm = (a->M + BM - 1) / BM;
     const int64_t nbn = (a->N + BN - 1) / BN;
     STG_CHECK(nbm * nbn < (1ll << 31), -2, "stg_gemm_nt: grid too large");
@@ -1124,25 +1137,21 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
             else if (!p.c_f32 && !a->act && !a->dact_src && r1b && !a->res2) p.epi_variant = EV_R16;
             else if (p.c_f32 && !a->act && !a->dact_src && r1b && r2q) p.epi_variant = EV_BRQ;
         }
-        static const int force_generic = [] { const char* e = getenv("STG_GEMM_EPI"); return e && atoi(e) == 0; }();
-        if (force_generic) p.epi_variant = EV_GENERIC;            // A/B knob: every option a run-time test
+        if (stg_opt_gemm_epi.load(std::memory_order_relaxed) == 0) p.epi_variant = EV_GENERIC;   // A/B knob: every option a run-time test
     }
-    static const bool ktail_on = [] { const char* e = getenv("STG_GEMM_KTAIL"); return !e || atoi(e) != 0; }();      // A/B knob
-    static const int big_mode = [] { const char* e = getenv("STG_GEMM_BIG"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 whenever legal
+    const bool ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed) != 0;
+    const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
     const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
-    static const int ph8_mode = [] { const char* e = getenv("STG_GEMM_8PH"); return e ? atoi(e) : 1; }();   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
+    const int ph8_mode = stg_opt_gemm_8ph.load(std::memory_order_relaxed);   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
     const bool ph8_ok = !conv && p.batch == 1 && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
     const bool ph8_wide = a->K >= 512 && a->N >= 1536 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
-        static const bool attr8 = [] {
-            return hipFuncSetAttribute((const void*)gemm_nt_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2) == hipSuccess;
-        }();
-        STG_CHECK(attr8, -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
+        STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
         hipLaunchKernelGGL(gemm_nt_8ph_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
@@ -1150,11 +1159,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         return 0;
     }
     if (big) {
-        static const bool attr_set = [] {
-            return hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * (GBM + GBN) * BK * 2) == hipSuccess;
-        }();
-        STG_CHECK(attr_set, -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
+        STG_CHECK(stg_reserve_lds(gemm_nt_big_kernel, 2 * (GBM + GBN) * BK * 2, lds_big_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 2 * (GBM + GBN) * BK * 2, (hipStream_t)stream, p);

@@ -361,8 +361,8 @@ constexpr int dkv_lds_bytes(int D) { return (2 * 32 * (D + 8) + 128 + 4 * 2 * 32
 
 template <int D>
 int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
-    static const bool attr_set =
-        hipFuncSetAttribute((const void*)mha_dkv_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds_bytes(D)) == hipSuccess;
+    static std::atomic<uint64_t> done{0};
+    const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D>, dkv_lds_bytes(D), done);
     STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D));
     hipLaunchKernelGGL(mha_dkv_kernel<D>, grid, dim3(256), dkv_lds_bytes(D), stream, p);
     return 0;

@@ -579,9 +579,8 @@ extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t ld
     if (f->D != TD) {
         STG_CHECK(dbias == nullptr, -2, "stg_tattn_bwd: no bias gradient without a bias");
         const int lds = f->D == 64 ? nb_lds_bytes(64) : nb_lds_bytes(96);
-        static const bool attr_set =
-            hipFuncSetAttribute((const void*)tattn_nb_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, nb_lds_bytes(64)) == hipSuccess &&
-            hipFuncSetAttribute((const void*)tattn_nb_bwd_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, nb_lds_bytes(96)) == hipSuccess;
+        static std::atomic<uint64_t> d64{0}, d96{0};
+        const bool attr_set = stg_reserve_lds(tattn_nb_bwd_kernel<64>, nb_lds_bytes(64), d64) && stg_reserve_lds(tattn_nb_bwd_kernel<96>, nb_lds_bytes(96), d96);
         STG_CHECK(attr_set, -101, "stg_tattn_bwd: cannot reserve %d bytes of LDS", lds);
         if (f->D == 64) hipLaunchKernelGGL(tattn_nb_bwd_kernel<64>, grid_for(p), dim3(256), lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(tattn_nb_bwd_kernel<96>, grid_for(p), dim3(256), lds, (hipStream_t)stream, p);

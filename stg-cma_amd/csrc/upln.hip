@@ -220,8 +220,8 @@ int launch_upln(const UpLnP& p, hipStream_t st) {
     if (nblk > 2048) nblk = 2048;
     const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * NW * 16 * sizeof(float2);
     if (lds > 64 * 1024) {
-        static const bool ok = hipFuncSetAttribute((const void*)upln_fwd_kernel<NT, NH, KS, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                               hipFuncSetAttribute((const void*)upln_fwd_kernel<NT, NH, KS, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        static std::atomic<uint64_t> d1{0}, d0{0};
+        const bool ok = stg_reserve_lds(upln_fwd_kernel<NT, NH, KS, true, NW>, (int)lds, d1) && stg_reserve_lds(upln_fwd_kernel<NT, NH, KS, false, NW>, (int)lds, d0);
         STG_CHECK(ok, -101, "stg_up_ln_fwd: cannot reserve %d bytes of LDS", (int)lds);
     }
     if (p.res16) hipLaunchKernelGGL((upln_fwd_kernel<NT, NH, KS, true, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
@@ -405,8 +405,8 @@ int launch_lnbd(const LnDownP& p, hipStream_t st) {
     if (nblk > 2048) nblk = 2048;
     const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + NW * 16 * sizeof(float2) + (size_t)(NW / 2) * NJ * 4 * 64 * 4;
     if (lds > 64 * 1024) {
-        static const bool ok = hipFuncSetAttribute((const void*)ln_bwd_down_kernel<NT, NH, NJ, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                               hipFuncSetAttribute((const void*)ln_bwd_down_kernel<NT, NH, NJ, false, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        static std::atomic<uint64_t> d1{0}, d0{0};
+        const bool ok = stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, true, NW>, (int)lds, d1) && stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, false, NW>, (int)lds, d0);
         STG_CHECK(ok, -101, "stg_ln_bwd_down: cannot reserve %d bytes of LDS", (int)lds);
     }
     if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);

@@ -22,7 +22,17 @@ import torch.distributed as dist
 
 
 class GradSync:
-    """Averages a flat gradient buffer across the ranks of `group` in place."""
+    """Averages the trainable gradients of one backward pass across the ranks of `group`.
+
+    Two carriers, one accounting:
+      * the backbone's flat fp32 arena (ops.GradArena), all-reduced in place from inside the autograd node (allreduce_), and
+      * `extra`: trainable parameters whose gradients autograd accumulates outside that node -- the AVS dense decoder
+        (`avstask_*`, ops_dec Functions) and the AVQA question-answering head (`avqatask_*`, ops_head Functions).  Their
+        post-accumulate hooks arm ONE end-of-backward callback that packs every such gradient into a single flat bucket,
+        all-reduces it and writes the averages back (a parameter that received no gradient on this rank contributes zeros, so
+        every rank sends the same bucket).
+    `last_numel` = gradient elements exchanged by the most recent backward pass (arena + bucket, without alignment padding);
+    a model is fully covered when it equals the number of trainable elements."""
 
     def __init__(self, group=None):
         if not dist.is_available() or not dist.is_initialized():
@@ -32,10 +42,12 @@ class GradSync:
         self.backend = dist.get_backend(group)
         self.calls = 0
         self.last_numel = 0
+        self.extra = []
+        self._acc = 0
+        self._armed = -1                       # id of the backward pass whose end-of-pass callback is queued
 
-    def allreduce_(self, flat):
-        self.calls += 1
-        self.last_numel = flat.numel()
+    # ---------------------------------------------------------------- the collective
+    def _average(self, flat):
         if self.world == 1 or flat.numel() == 0:
             return flat
         if self.backend == "nccl":            # RCCL on ROCm: average inside the collective, no extra kernel
@@ -45,12 +57,63 @@ class GradSync:
             flat.div_(self.world)
         return flat
 
+    def allreduce_(self, flat, n_real=None):
+        """Average `flat` in place.  n_real: gradient elements in it when it carries alignment padding."""
+        self.calls += 1
+        self._acc += flat.numel() if n_real is None else n_real
+        self._average(flat)
+        self._arm()
+        return flat
+
+    # ---------------------------------------------------------------- end-of-backward bookkeeping + the extra bucket
+    def _arm(self, *_):
+        gid = torch._C._current_graph_task_id()
+        if gid == -1:                          # not inside a backward pass (a direct allreduce_ call): account for it now
+            self.last_numel, self._acc = self._acc, 0
+        elif gid != self._armed:               # first event of this backward pass (a pass that raised leaves a stale id behind)
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+            self._armed = gid
+
+    def _finish(self):
+        self._armed = -1
+        ps = [p for p in self.extra if p.requires_grad]
+        if ps:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps])
+            self._average(flat)
+            off = 0
+            for p in ps:
+                seg = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+                if p.grad is None:
+                    p.grad = seg.to(p.dtype).clone()
+                else:
+                    p.grad.copy_(seg)
+            self._acc += flat.numel()
+        self.last_numel, self._acc = self._acc, 0
+
+    def watch(self, params):
+        """Route parameters whose gradients do not pass through the backbone arena into the end-of-backward bucket."""
+        for p in params:
+            if not any(p is q for q in self.extra):
+                self.extra.append(p)
+                p.register_post_accumulate_grad_hook(self._arm)
+
 
 def attach(model, group=None):
-    """Enable in-node gradient averaging for a stg-cma_amd model (Swin_AVE.SwinTransformer2D_Adapter_New, ...)."""
+    """Enable gradient averaging for a stg-cma_amd model: the backbone arena inside its autograd node plus -- for the AVS / AVQA
+    mirrors -- every task-head parameter (`avstask_*` / `avqatask_*`, AVS/traintest_adapt_avs.py:55, AVQA/traintest_adapt_avqa.py:72)
+    through the end-of-backward bucket.  Call once after construction (before or after the loop's freeze).
+
+    BatchNorm of the AVS decoder (TPAVI `W_z`, AVS/model/TPAVI.py:57-61): batch statistics stay PER RANK, which is what the
+    reference's nn.DataParallel does (each replica normalises its own chunk, AVS/traintest_adapt_avs.py:35-38); its affine
+    parameters are `avstask_*` tensors and are averaged like every other gradient.  Running statistics: the reference keeps
+    replica 0's; `broadcast_buffers` copies rank 0's to every rank (call it before validation / checkpointing)."""
     sync = GradSync(group)
     plan = model._plan()
     plan.ddp = sync
+    if hasattr(model, "_flat_tensors"):
+        inside = set(model._flat_tensors()[0])
+        sync.watch(p for n, p in model.named_parameters() if n not in inside)
     return sync
 
 
@@ -74,6 +137,17 @@ def broadcast_parameters(model, src=0, group=None):
     """Make every rank start from rank `src`'s trainable values (frozen weights come from the same checkpoint / seed)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    for p in model.parameters():
-        if p.requires_grad:
-            dist.broadcast(p.data, src=src, group=group)
+    with torch.no_grad():                       # an in-place write on the parameter itself: bumps its version, so the bf16
+        for p in model.parameters():            # weight shadows (ops.shadow, keyed on the version) are re-cast
+            if p.requires_grad:
+                dist.broadcast(p, src=src, group=group)
+
+
+def broadcast_buffers(model, src=0, group=None):
+    """Copy rank `src`'s floating-point buffers (the AVS decoder's BatchNorm running statistics) to every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for b in model.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b, src=src, group=group)

@@ -240,4 +240,5 @@ class MM_CLIP_AVE(nn.Module):
         for n, p in self.named_parameters():
             names.append(n)
             tensors.append(p)
-        return VitModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)
+        with torch.cuda.device(ref.device):     # launches go to the current device's stream: make that the tensors' device
+            return VitModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)

@@ -371,7 +371,7 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         return tuple(names), tensors
 
     def _backbone(self, a, v, v_nega=None, taps=False):
-        """Shared by the AVS / AVQA mirrors (model/Swin_AVS.py, model/Swin_AVQA.py): ops.SwinBackboneFn on (B, T, 3, H, W)
+        """Shared by the AVS / AVQA mirrors (model/Swin_AVSModel.py, model/Swin_AVQAModel_V1.py): ops.SwinBackboneFn on (B, T, 3, H, W)
         clips; returns the flat fp32 feature tensors."""
         from ..ops import SwinBackboneFn
         if self.ftmode != 'fusion':
@@ -381,7 +381,8 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         if not v.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
         names, tensors = self._flat_tensors()
-        return SwinBackboneFn.apply(a, v, v_nega, self._plan(), self.training, torch.is_grad_enabled(), bool(taps), names, *tensors)
+        with torch.cuda.device(v.device):       # launches go to the current device's stream: make that the tensors' device
+            return SwinBackboneFn.apply(a, v, v_nega, self._plan(), self.training, torch.is_grad_enabled(), bool(taps), names, *tensors)
 
     def forward(self, a, v, mode):
         """a: [B, T, H, W] spectrogram segments, v: [B, 3, T, H, W] frames -> fp32 logits [(B*T), label_dim]
@@ -403,4 +404,5 @@ class SwinTransformer2D_Adapter_New(nn.Module):
             if not n.endswith("attn_mask"):
                 names.append(n)
                 tensors.append(b)
-        return SwinModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)
+        with torch.cuda.device(ref.device):     # launches go to the current device's stream: make that the tensors' device
+            return SwinModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)

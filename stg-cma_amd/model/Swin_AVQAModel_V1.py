@@ -100,10 +100,15 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
                 nn.init.constant_(m.D_fc2.weight, 0)
                 nn.init.constant_(m.D_fc2.bias, 0)
 
+    HEAD_DIM = 1536          # Swin_AVQAModel_V1.py: the head runs at the backbone's last-stage width
+    PROJECT_FEATURES = False  # Swin_AVQAModel.py (512-d variant): avqatask_yb_fc_v / _a project the backbone features first
+
     def _build_qa_head(self):
         """Parameter containers of the reference's QA head under its names (Swin_AVQAModel_V1.py:1420-1473); nn.LSTM /
         nn.MultiheadAttention / nn.Embedding only HOLD the tensors here, the arithmetic is ops_head's."""
-        Dh = 1536
+        Dh = self.HEAD_DIM
+        if self.PROJECT_FEATURES:                         # Swin_AVQAModel.py:1421 (the 512-d variant only)
+            self.avqatask_fc_a1 = nn.Linear(128, Dh)
         self.avqatask_fc_a2 = nn.Linear(Dh, Dh)
         self.avqatask_fc_fusion = nn.Linear(Dh + Dh, Dh)
         self.avqatask_linear11 = nn.Linear(Dh, Dh)
@@ -127,6 +132,9 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
         self.avqatask_fc2 = nn.Linear(512, 256)
         self.avqatask_fc3 = nn.Linear(256, 128)
         self.avqatask_fc4 = nn.Linear(128, 2)
+        if self.PROJECT_FEATURES:                         # Swin_AVQAModel.py:1472-1473
+            self.avqatask_yb_fc_v = nn.Linear(1536, Dh)
+            self.avqatask_yb_fc_a = nn.Linear(1536, 128)
 
     def forward_features(self, a, v, v_nega):
         """a: [B, T, Ha, Wa]; v, v_nega: [B, T, 3, H, W].  Returns (f_v, f_a, visual_nega), each [(B T), N_last, C_last] fp32;

@@ -357,10 +357,12 @@ class GradArena:
     def __init__(self, names, P, need, device):
         self.off = {}
         total = 0
+        self.n_real = 0
         for n in names:
             if need.get(n, False):
                 self.off[n] = total
                 total += (P[n].numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+                self.n_real += P[n].numel()
         self.flat = torch.zeros(total, dtype=F32, device=device)
 
     def view(self, name, like):
@@ -1040,7 +1042,7 @@ class SwinBackboneFn(torch.autograd.Function):
                     dv = dX[:dX.shape[0] // 2]
                     K.add(dv, K.cast_bf16(dt.contiguous()), out=dv)
         if ctx.ddp is not None:
-            ctx.ddp.allreduce_(arena.flat)
+            ctx.ddp.allreduce_(arena.flat, arena.n_real)
         return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)
 
 
@@ -1121,5 +1123,5 @@ class SwinModelFn(torch.autograd.Function):
                 dH_carry = None
                 dX = merge_backward(S, spec[0], spec[1], Pl, dX)
         if ctx.ddp is not None:
-            ctx.ddp.allreduce_(arena.flat)      # one collective for every trainable gradient of the step
+            ctx.ddp.allreduce_(arena.flat, arena.n_real)      # one collective for every trainable gradient of the step
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)

@@ -283,9 +283,19 @@ def avqa_head_forward(m, f_v, f_a, f_nega, question, B, T, training):
     """Lines :1768-1903 of the reference forward.  f_v, f_a, f_nega: fp32 [(B T), 49, C] (norm of each backbone stream);
     returns (out_qa [B, 42], out_match_posi [(B T), 2], out_match_nega [(B T), 2]), fp32."""
     BT, n, C = f_v.shape
-    audio = MeanFn.apply(CastFn.apply(f_a.reshape(BT * n, C)), BT, n)          # f_a.mean(dim=1)  (:1791)
+    if getattr(m, "PROJECT_FEATURES", False):
+        # the 512-d variant (AVQA/model/Swin_AVQAModel.py:1772-1783, 1798-1801): project the three streams down first
+        def proj(f, lin, f32):
+            return linear(CastFn.apply(f.reshape(BT * n, C)), lin.weight, lin.bias, out_f32=f32)
+        f_v = proj(f_v, m.avqatask_yb_fc_v, True).view(BT, n, -1)
+        f_nega = proj(f_nega, m.avqatask_yb_fc_v, True).view(BT, n, -1)
+        audio = MeanFn.apply(proj(f_a, m.avqatask_yb_fc_a, False), BT, n)
+        audio = relu(linear(audio, m.avqatask_fc_a1.weight, m.avqatask_fc_a1.bias))
+        C = f_v.shape[-1]
+    else:
+        audio = relu(MeanFn.apply(CastFn.apply(f_a.reshape(BT * n, C)), BT, n))   # f_a.mean(dim=1), F.relu  (:1791, :1800)
     qst = question_encoder(m.avqatask_question_encoder, question)              # [B, C]
-    audio_feat = linear(relu(audio), m.avqatask_fc_a2.weight, m.avqatask_fc_a2.bias)        # [(B T), C]  (:1783-1784)
+    audio_feat = linear(audio, m.avqatask_fc_a2.weight, m.avqatask_fc_a2.bias)              # [(B T), C]  (:1801)
 
     def ground_and_match(fv):
         vmean, grd = GroundingFn.apply(fv, audio_feat)                          # :1797-1815

@@ -450,5 +450,5 @@ class VitModelFn(torch.autograd.Function):
             K.wgrad_tn(_t_onehot(BT, n_tok[i], T, dU.device), dU, gt.view(T, D), None, n1=T)
             grads[tname] = gt
         if ctx.ddp is not None:
-            ctx.ddp.allreduce_(arena.flat)
+            ctx.ddp.allreduce_(arena.flat, arena.n_real)
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in names)

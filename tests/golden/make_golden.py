@@ -530,6 +530,9 @@ AVS_FULL_TINY = dict(embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32
 AVQA_FULL_TINY = dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
 SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
+# AVE/run_adapt_ave29.py:167-181 (MM-Swin-AVE-Large) = the backbone geometry of AVQA/run_adapt_avqa.py:288-301 (BASELINE config 5)
+SWIN_L = dict(label_dim=29, embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48], num_frames=10,
+              adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
 
 
 def main(argv):
@@ -554,6 +557,11 @@ def main(argv):
         if "avqa" not in lazy:
             lazy["avqa"] = load(os.path.join(REF, "AVQA/model/Swin_AVQAModel_V1.py"), "ref_swin_avqa")
         return lazy["avqa"]
+
+    def ref_avqa512():
+        if "avqa512" not in lazy:
+            lazy["avqa512"] = load(os.path.join(REF, "AVQA/model/Swin_AVQAModel.py"), "ref_swin_avqa512")
+        return lazy["avqa512"]
     cases = {
         "swin_block_even": lambda: swin_block_case(S, "swin_block_even", dim=128, res=14, T=5, B=1, heads=4, shift=0, t_attn=True,
                                                    ratio=0.125, mode="fusion_adapt", seed=100),
@@ -594,6 +602,11 @@ def main(argv):
         "clip_pretrained_ingest_long": lambda: clip_ingest_case(Cm, "clip_pretrained_ingest_long", layers=12, embed_dim=64, patch=16,
                                                                 res=224, audio_length=3200, seed=730),
         "avqa_full_tiny": lambda: avqa_full_case(ref_avqa(), "avqa_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=620),
+        # the 512-d head variant that AVQA/test.py:8 imports (yb_fc_v / yb_fc_a projections, fc_a1)
+        "avqa512_full_tiny": lambda: avqa_full_case(ref_avqa512(), "avqa512_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=630),
+        # full-depth Swin-L at the reference's initialisation scale: the fixture the fp8 frozen-weight path is measured on
+        "swin_l_fusion_refinit": lambda: swin_model_case(S, "swin_l_fusion_refinit", cfg=SWIN_L, B=1, mode="fusion", seed=320,
+                                                         store_all_grads=False, state_fn=GP.refinit_state),
         "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),

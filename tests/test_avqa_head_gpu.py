@@ -166,13 +166,16 @@ def _rel(got, ref):
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6), float((got - ref).norm() / max(float(ref.norm()), 1e-12))
 
 
-def test_avqa_full_model_matches_reference(stg, gpu):
-    """backbone + QA head against the reference model's outputs and gradients (eval mode: every dropout off)."""
+@pytest.mark.parametrize("case,modname", [("avqa_full_tiny", "Swin_AVQAModel_V1"), ("avqa512_full_tiny", "Swin_AVQAModel")])
+def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
+    """backbone + QA head against the reference model's outputs and gradients (eval mode: every dropout off): the runner's V1
+    model (AVQA/run_adapt_avqa.py:20) and the 512-d variant of AVQA/test.py:8."""
+    import importlib
     from stgcma import recipe
-    from stgcma.model import Swin_AVQA
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avqa_full_tiny")
-    m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
+    z, cfg, shapes, names = load_case(case)
+    Swin_AVQAModel_V1 = importlib.import_module("stgcma.model." + modname)
+    m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
                                                  depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
                                                  adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
@@ -226,9 +229,9 @@ def test_avqa_train_mode_dropouts_and_step(stg, gpu):
     """train(): attention / feed-forward dropouts active, DropPath on all three streams, the AVQA loop's loss
     (CE(qa) + 0.5 * CE(match), traintest_adapt_avqa.py:173-179) goes down on a repeated batch."""
     from stgcma import recipe
-    from stgcma.model import Swin_AVQA
+    from stgcma.model import Swin_AVQAModel_V1
     torch.manual_seed(0)
-    m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=2, embed_dim=192, depths=[2, 2, 2, 2],
+    m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=2, embed_dim=192, depths=[2, 2, 2, 2],
                                                  num_heads=[6, 12, 24, 48], ftmode="fusion",
                                                  adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625]).to(gpu).train()
     opt = recipe.build_optimizer(m, lr=3e-4)

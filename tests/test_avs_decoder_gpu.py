@@ -54,7 +54,7 @@ def _pgrads(mod, keys):
 
 def test_aspp_ffb_output_conv_match_reference_modules(stg, gpu):
     from stgcma import ops_dec as D
-    from stgcma.model import Swin_AVS as M
+    from stgcma.model import Swin_AVSModel as M
     z = np.load(os.path.join(GOLD, "avs_decoder_modules.npz"))
     # ASPP: four dilated 3x3 convolutions (dilations up to 18 on a 14 x 14 map: mostly padding)
     aspp, keys = _load(M.Classifier_Module([3, 6, 12, 18], [3, 6, 12, 18], 24, 16), z, "aspp_shapes", 1, gpu)
@@ -95,7 +95,7 @@ def test_aspp_ffb_output_conv_match_reference_modules(stg, gpu):
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_tpavi_matches_reference_module(stg, gpu, mode):
     from stgcma import ops_dec as D
-    from stgcma.model import Swin_AVS as M
+    from stgcma.model import Swin_AVSModel as M
     z = np.load(os.path.join(GOLD, "avs_decoder_modules.npz"))
     tp, keys = _load(M.TPAVIModule(in_channels=32, mode='dot'), z, "tpavi_shapes", 3, gpu)
     with torch.no_grad():
@@ -118,9 +118,9 @@ def test_tpavi_matches_reference_module(stg, gpu, mode):
 
 def _build_full(gpu):
     from stgcma import recipe
-    from stgcma.model import Swin_AVS
+    from stgcma.model import Swin_AVSModel
     z, cfg, shapes, names = load_case("avs_full_tiny")
-    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+    m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                                                     num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
                                                     drop_path_rate=0.0).train()      # the golden: train-mode BatchNorm, no DropPath
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
@@ -205,9 +205,9 @@ def test_avs_train_mode_loop(stg, gpu):
     """train(): DropPath in the backbone, BatchNorm on batch statistics (running statistics move), the AVS loss on the first frame
     of each clip (AVS/loss.py:7-26) goes down on a repeated batch."""
     from stgcma import recipe
-    from stgcma.model import Swin_AVS
+    from stgcma.model import Swin_AVSModel
     torch.manual_seed(0)
-    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=128, depths=[2, 2, 2, 2],
+    m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=128, depths=[2, 2, 2, 2],
                                                     num_heads=[4, 8, 16, 32], ftmode="fusion",
                                                     adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125]).to(gpu).train()
     with torch.no_grad():

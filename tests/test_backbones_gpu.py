@@ -1,4 +1,4 @@
-"""-m gpu: the AVS / AVQA backbone mirrors (stg-cma_amd/model/Swin_AVS.py, Swin_AVQA.py) against golden
+"""-m gpu: the AVS / AVQA backbone mirrors (stg-cma_amd/model/Swin_AVSModel.py, Swin_AVQAModel_V1.py) against golden
 vectors generated from the reference's own AVS / AVQA model classes.  Same metrics / tolerances as test_model_gpu.py."""
 import os
 
@@ -76,10 +76,10 @@ def _check_grads(m, names, ref, tag):
 
 def test_avs_backbone_matches_reference(stg, gpu):
     """a19: taps before every downsample + norm'd last stage + norm(a); gradients arrive through all five outputs."""
-    from stgcma.model import Swin_AVS
+    from stgcma.model import Swin_AVSModel
     from params import seeded_tensor
     z, cfg, shapes, names = load_case("avs_tiny_backbone")
-    m, mine = _build(Swin_AVS.SwinTransformer2D_Adapter_AVS, cfg, shapes, gpu)
+    m, mine = _build(Swin_AVSModel.SwinTransformer2D_Adapter_AVS, cfg, shapes, gpu)
     assert mine == names
     B, T = cfg["B"], cfg["num_frames"]
     a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5).to(gpu)
@@ -100,10 +100,10 @@ def test_avs_backbone_matches_reference(stg, gpu):
 
 def test_avqa_backbone_matches_reference(stg, gpu):
     """a18: the negative clip rides through every block as the plain frozen Swin block (forward-only)."""
-    from stgcma.model import Swin_AVQA
+    from stgcma.model import Swin_AVQAModel_V1
     from params import seeded_tensor
     z, cfg, shapes, names = load_case("avqa_tiny_backbone")
-    m, mine = _build(Swin_AVQA.SwinTransformer2D_Adapter_AVQA, cfg, shapes, gpu)
+    m, mine = _build(Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA, cfg, shapes, gpu)
     assert mine == names
     B, T = cfg["B"], cfg["num_frames"]
     a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5).to(gpu)
@@ -121,9 +121,9 @@ def test_avqa_backbone_matches_reference(stg, gpu):
 
 def test_backbones_train_mode(stg, gpu):
     """DropPath active on all three streams: finite, stochastic, gradients for every trainable tensor."""
-    from stgcma.model import Swin_AVQA
+    from stgcma.model import Swin_AVQAModel_V1
     from stgcma import recipe
-    m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=2, embed_dim=32, depths=[2, 2, 2, 2],
+    m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=2, embed_dim=32, depths=[2, 2, 2, 2],
                                                  num_heads=[1, 2, 4, 8], ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():

@@ -164,8 +164,8 @@ def test_bench_cpu_baseline_leg_runs_on_host(stg):
     assert r["kind"] == "port" and r["unit"] == "clips/s" and r["value"] > 0 and r["cores"] >= 1
 
 
-@pytest.mark.parametrize("tag,mod,cls", [("avs_tiny_backbone", "Swin_AVS", "SwinTransformer2D_Adapter_AVS"),
-                                         ("avqa_tiny_backbone", "Swin_AVQA", "SwinTransformer2D_Adapter_AVQA")])
+@pytest.mark.parametrize("tag,mod,cls", [("avs_tiny_backbone", "Swin_AVSModel", "SwinTransformer2D_Adapter_AVS"),
+                                         ("avqa_tiny_backbone", "Swin_AVQAModel_V1", "SwinTransformer2D_Adapter_AVQA")])
 def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls):
     """The AVS / AVQA mirrors hold exactly the backbone tensors of the reference classes (patch embeds, layers, norm) under
     the reference's names and shapes; the AVS mirror also carries the dense decoder (avstask_*), the AVQA mirror the QA head (avqatask_*)."""
@@ -182,7 +182,7 @@ def test_avs_avqa_backbone_state_dict_is_the_reference_subset(stg, tag, mod, cls
     from stgcma.recipe import is_trainable
     assert [n for n, _ in m.named_parameters() if is_trainable(n) and n.startswith(backbone)] == names
     rest = [k for k in sd if not k.startswith(backbone)]
-    pre = "avstask_" if mod == "Swin_AVS" else "avqatask_"   # the dense decoder / the QA head under the reference's names
+    pre = "avstask_" if mod == "Swin_AVSModel" else "avqatask_"   # the dense decoder / the QA head under the reference's names
     assert rest and all(k.startswith(pre) for k in rest)
 
 
@@ -191,10 +191,10 @@ def test_avs_full_state_dict_is_the_reference(stg):
     reference's SwinTransformer2D_Adapter_AVS_Base (golden avs_full_tiny); the AVS loop's name filter (traintest_adapt_avs.py:55)
     selects the same trainable tensors."""
     from golden_util import load_case
-    from stgcma.model import Swin_AVS
+    from stgcma.model import Swin_AVSModel
     from stgcma.recipe import is_trainable
     z, cfg, shapes, names = load_case("avs_full_tiny")
-    m = Swin_AVS.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+    m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                                                     num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
                                                     channel=256, opt=None, config=None, vis_dim=[64, 128, 320, 512],
                                                     tpavi_stages=[0, 1, 2, 3], tpavi_vv_flag=False, tpavi_va_flag=True)
@@ -213,10 +213,10 @@ def test_avqa_full_state_dict_is_the_reference(stg):
     """backbone + QA head: float keys, order and shapes of the mirror == the reference model's (golden avqa_full_tiny), and the
     AVQA loop's name filter (traintest_adapt_avqa.py:72) selects the same trainable tensors."""
     from golden_util import load_case
-    from stgcma.model import Swin_AVQA
+    from stgcma.model import Swin_AVQAModel_V1
     from stgcma.recipe import is_trainable
     z, cfg, shapes, names = load_case("avqa_full_tiny")
-    m = Swin_AVQA.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
+    m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
                                                  depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
                                                  adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
     sd = m.state_dict()

@@ -231,12 +231,14 @@ def test_avqa_backbone_matches_reference():
     assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
 
 
-def test_avqa_full_model_matches_reference():
+@pytest.mark.parametrize("case", ["avqa_full_tiny", "avqa512_full_tiny"])
+def test_avqa_full_model_matches_reference(case):
     """backbone + QA head (question LSTM, grounding on the positive / negative clip, single-query attentions, fusion
-    MLPs) of the reference's SwinTransformer2D_Adapter_AVQA, outputs and every trainable gradient."""
+    MLPs) of the reference's SwinTransformer2D_Adapter_AVQA, outputs and every trainable gradient; the V1 (1536-d) model of the
+    runner and the 512-d variant of AVQA/test.py."""
     import oracle.avqa_head as OH
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avqa_full_tiny")
+    z, cfg, shapes, names = load_case(case)
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     for n in names:
         P[n].requires_grad_(True)
