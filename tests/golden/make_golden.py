@@ -360,6 +360,40 @@ def avs_full_case(AB, tag, *, cfg, B, seed):
          grads_sample=g[::97].clone())
 
 
+def avs_full_evalbn_case(AB, tag, *, cfg, B, seed):
+    """The same model in EVAL mode with CALIBRATED BatchNorm statistics: one train-mode forward with momentum 1 sets every running
+    mean / variance to the batch statistics of these very inputs, then eval() -- BatchNorm is a fixed per-channel affine map with
+    O(1) outputs, so the whole-model gradients are well conditioned (the train-mode fixture above is not: batch statistics over a
+    single clip).  The calibrated statistics travel in the fixture.  Upstream gradient on `pred` only."""
+    m = AB.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                                              num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+                                              channel=256, opt=None, config=None, vis_dim=[64, 128, 320, 512], tpavi_stages=[0, 1, 2, 3],
+                                              tpavi_vv_flag=False, tpavi_va_flag=True, drop_path_rate=0.0).train()
+    shapes = seed_module(m, seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "W_z.1.weight" in n:
+                p.mul_(0.5)
+    a = GP.seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = GP.seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    bns = [mod for mod in m.modules() if isinstance(mod, nn.modules.batchnorm._BatchNorm)]
+    for bn in bns:
+        bn.momentum = 1.0
+    with torch.no_grad():
+        m(a, v, "fusion")
+    m.eval()
+    stats = {n: b.clone() for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var"))}
+    names = apply_freeze(m)
+    pred, fmaps, afeas = m(a, v, "fusion")
+    (pred * GP.seeded_tensor(pred.shape, seed + 3, 1e-2)).sum().backward()
+    d = dict(m.named_parameters())
+    g = flat_grads(m, names)
+    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(cfg, B=B, seed=seed)), grad_names_json=json.dumps(names),
+         pred=pred, stat_names_json=json.dumps(list(stats)), **{f"stat{i}": t for i, t in enumerate(stats.values())},
+         grad_norms=torch.stack([(d[n].grad if d[n].grad is not None else torch.zeros(())).norm() for n in names]),
+         grads_sample=g[::97].clone())
+
+
 # --------------------------------------------------------------------------------------------------- ViT (CLIP) path
 def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"):
     blk = Cm.ResidualAttentionBlock(d, heads, None, 0.5, 1, T, 0.0, mode=mode).eval()
@@ -609,6 +643,7 @@ def main(argv):
                                                          store_all_grads=False, state_fn=GP.refinit_state),
         "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
+        "avs_full_tiny_evalbn": lambda: avs_full_evalbn_case(ref_avs_base(), "avs_full_tiny_evalbn", cfg=AVS_FULL_TINY, B=1, seed=840),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,

@@ -380,3 +380,38 @@ def test_avs_full_model_matches_reference():
     g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
     assert float((g - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
     assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) >= 0.9999
+
+
+def _avs_evalbn_state(z, cfg, shapes):
+    """Parameters of avs_full_tiny_evalbn: seeded floats, TPAVI's BatchNorm scale halved, the CALIBRATED running statistics from the
+    fixture (make_golden.py::avs_full_evalbn_case)."""
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    for k, _ in shapes:
+        if "W_z.1.weight" in k:
+            P[k] = P[k] * 0.5
+    for i, k in enumerate(json.loads(str(z["stat_names_json"]))):
+        P[k] = torch.as_tensor(np.asarray(z[f"stat{i}"]))
+    return P
+
+
+def test_avs_full_model_eval_batchnorm_matches_reference():
+    """The well-conditioned whole-model gradient fixture of the AVS model: eval-mode BatchNorm on calibrated running statistics."""
+    import oracle.avs_decoder as OD
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avs_full_tiny_evalbn")
+    P = _avs_evalbn_state(z, cfg, shapes)
+    for n in names:
+        P[n].requires_grad_(True)
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    pred, _, _ = OD.avs_forward(P, a, v, cfg, bn_training=False)
+    _close(pred, z["pred"], what="pred")
+    (pred * seeded_tensor(pred.shape, seed + 3, 1e-2)).sum().backward()
+    norms = torch.stack([(P[n].grad if P[n].grad is not None else torch.zeros(())).norm() for n in names])
+    ref_norms = torch.as_tensor(z["grad_norms"])
+    live = ref_norms > 1e-3 * ref_norms.max()
+    rel = ((norms - ref_norms).abs() / ref_norms.clamp_min(1e-9))[live]
+    assert float(rel.max()) <= 1e-2, f"per-tensor gradient norms: worst {float(rel.max()):.3e}"
+    g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
+    assert float((g - ref).norm() / ref.norm()) <= 2e-3
