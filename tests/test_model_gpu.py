@@ -277,6 +277,69 @@ def test_train_mode_droppath_and_dropout_run(stg, gpu):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
 
 
+@pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_video"])
+def test_droppath_mask_semantics(stg, gpu, tag, monkeypatch):
+    """DropPath of the reference blocks: on the temporal residual the mask is drawn on dim 0 of the '(b n) t c' layout -- ONE
+    Bernoulli(keep) / keep value per (clip, token) row, constant over the T frames and the channels (Swin_AVE.py:705-716); on the
+    parallel FFN adapter of 'video_adapt' one value per frame of the '(b t) n c' layout (:438-440).  The block is run in train mode
+    with KNOWN masks (ops.drop_scale patched) and compared, forward and backward, with the oracle given the same masks."""
+    import oracle.swin as OS
+    from stgcma import ops
+    from stgcma.model import Swin_AVE as S
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case(tag)
+    P = build_state(shapes, cfg["seed"], kind="swin_block", T=cfg["T"], res=cfg["res"])
+    p_drop = 0.3
+    blk = S.SwinTransformerBlock(dim=cfg["dim"], input_resolution=(cfg["res"], cfg["res"]), num_frames=cfg["T"],
+                                 num_heads=cfg["heads"], window_size=7, shift_size=cfg["shift"], t_attn=cfg["t_attn"],
+                                 adapter_mlp_ratio=cfg["ratio"], mode=cfg["mode"], drop_path=p_drop).train()
+    _load_into(blk, P, "blk.")
+    blk = blk.to(gpu)
+    _apply_freeze(blk)
+    B, T, N, C = cfg["B"], cfg["T"], cfg["res"] ** 2, cfg["dim"]
+    BT = B * T
+    two = cfg["mode"] == "fusion_adapt"
+    drawn = []
+
+    def fake_drop_scale(p, n_rows, device, training, pool=None):
+        assert training and abs(p - p_drop) < 1e-12
+        g = torch.Generator().manual_seed(900 + len(drawn))
+        m = (torch.rand(n_rows, generator=g) < (1 - p)).float() / (1 - p)
+        drawn.append(m)
+        return m.to(device)
+    monkeypatch.setattr(ops, "drop_scale", fake_drop_scale)
+    xs = [seeded_tensor((BT, N, C), cfg["seed"] + 1 + i) for i in range(2 if two else 1)]
+    gs = [seeded_tensor((BT, N, C), cfg["seed"] + 3 + i) for i in range(2 if two else 1)]
+    X = torch.cat([x.reshape(-1, C) for x in xs]).to(gpu).requires_grad_(True)
+    out = blk(X)
+    out.backward(torch.cat([g.reshape(-1, C) for g in gs]).to(gpu))
+    # the masks the block asked for: one per modality with B * N entries (temporal residual), then -- parallel mode -- B * T entries
+    want = [B * N] * (2 if two else 1) + ([BT] if not two else [])
+    assert [m.numel() for m in drawn] == want, [m.numel() for m in drawn]
+    assert all(set(m.unique().tolist()) <= {0.0, 1.0 / (1 - p_drop)} for m in drawn)
+    assert all(0 < float((m == 0).float().mean()) < 1 for m in drawn), "the seeded masks must drop some rows and keep others"
+    dps = {"t_v": drawn[0], "t_a": drawn[1]} if two else {"t_v": drawn[0], "ffn": drawn[1]}
+    for n in P:
+        if P[n].is_floating_point():
+            P[n] = P[n].clone().requires_grad_(True)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    ref = OS.swin_block(P, "blk", tuple(xr) if two else xr[0], H=cfg["res"], W=cfg["res"], T=T, heads=cfg["heads"],
+                        shift_size=cfg["shift"], t_attn=cfg["t_attn"], mode=cfg["mode"], dp_scale=dps)
+    ref = ref if two else (ref,)
+    sum((r * g).sum() for r, g in zip(ref, gs)).backward()
+    R = BT * N
+    for i, r in enumerate(ref):
+        _cmp(out[i * R:(i + 1) * R], r.detach().reshape(-1, C), f"{tag} droppath out[{i}]")
+        _cmp(X.grad[i * R:(i + 1) * R], xr[i].grad.reshape(-1, C), f"{tag} droppath din[{i}]", max_rel=3e-2, l2_rel=2e-2)
+    d = dict(blk.named_parameters())
+    for n in ("T_Adapter.D_fc2.weight", "T_Adapter.D_fc1.weight", "S_Adapter.D_fc2.weight"):
+        _cmp(d[n].grad, P["blk." + n].grad, f"{tag} droppath grad[{n}]", max_rel=6e-2, l2_rel=4e-2)
+    # a dropped (clip, token) row passes the temporal branch unchanged for EVERY frame: with everything dropped the block equals
+    # its own eval-mode spatial + FFN part applied to the input -- checked through the oracle above; here the direct invariant:
+    kept = drawn[0].view(B, N) != 0
+    assert kept.any() and (~kept).any()
+
+
 def test_product_path_has_no_cpu_fallback(stg):
     from stgcma.model import Swin_AVE as S
     m = S.SwinTransformer2D_Adapter_New(label_dim=29, embed_dim=32, depths=[2, 2], num_heads=[1, 2], num_frames=2,
