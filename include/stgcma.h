@@ -25,10 +25,10 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 200
+#define STG_VERSION 201
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
-enum stg_dtype { STG_F32 = 0, STG_BF16 = 1 };
+enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2 };
 
 int stg_version(void);
 const char* stg_last_error(void);
@@ -77,8 +77,30 @@ typedef struct {
      * A + b*a_bstride, W + b*w_bstride, C + b*c_bstride (elements) with the same M, N, K; bias is shared; no dact / dact_src /
      * residuals / row_scale / convolution in this mode. */
     int batch; int64_t a_bstride; int64_t w_bstride; int64_t c_bstride;
+    /* Operand dtype (BASELINE config 5: the fp8 frozen-weight path of the Swin-L AVQA model; no reference counterpart --
+     * AVQA/model/Swin_AVQAModel_V1.py qkv / proj / fc1 / fc2 / reduction Linears run in fp32 / fp16 autocast there).
+     * ab_dtype == STG_BF16 (or 0): A and W are bf16 as above.  ab_dtype == STG_FP8_MX: A and W are OCP e4m3 bytes, row-major with
+     * leading dimensions lda / ldw in BYTES (multiples of 128, rows zero-padded to K rounded up to 128), each 32-wide k-block of a
+     * row scaled by an E8M0 exponent (value = 2^(e - 127) * e4m3): a_scale / w_scale are the packed scale tables stg_quant_fp8_mx
+     * writes.  The MFMA is v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulate); every epilogue option above applies unchanged.
+     * Not combinable with conv_H > 0 or batch > 1. */
+    int ab_dtype;
+    const void* a_scale; const void* w_scale;
+    /* out: which kernel the dispatch chose (STG_GEMM_KERNEL_*), for profilers that attribute time per kernel */
+    int kernel_chosen;
 } stg_gemm_args;
-int stg_gemm_nt(const stg_gemm_args* args, void* stream);
+enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
+       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7 };
+int stg_gemm_nt(stg_gemm_args* args, void* stream);
+
+/* Block-scaled e4m3 quantisation of a bf16 matrix (the producer side of ab_dtype == STG_FP8_MX): for every row r and 32-wide
+ * k-block b,  e = ceil(log2(max|x| / 448)) + 127 (127 for an all-zero block),  q = e4m3_rne(x * 2^(127 - e)).
+ *   Q   [rows, ldq] bytes, ldq = K rounded up to a multiple of 128, the pad bytes zero;
+ *   S   packed E8M0 table, rows rounded up to 64: byte ((r / 64) * KB + b) * 64 + (r % 16) * 4 + (r % 64) / 16 with KB = ldq / 32
+ *       -- the dword a lane of the scaled MFMA needs (one byte per 16-row tile of a 64-row wave tile, picked by OPSEL);
+ *       pad rows / blocks hold 127.  stg_quant_fp8_scale_bytes(rows, K) returns its size. */
+int64_t stg_quant_fp8_scale_bytes(int64_t rows, int K);
+int stg_quant_fp8_mx(const void* X, int64_t ldx, int64_t rows, int K, void* Q, int64_t ldq, void* S, void* stream);
 
 /* Weight gradient of a trainable nn.Linear y = x W^T + b   (autograd of Swin_AVE.py:15-16 D_fc1/D_fc2, :1319-1322 head)
  *   dW[N1,N2] (+)= sum_m dY[m,N1] * X[m,N2]      fp32, atomically accumulated (dW must be zeroed or hold a prior grad)

@@ -10,7 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so")   # env: an alternative build (kernel A/B runs)
 
-STG_F32, STG_BF16 = 0, 1
+STG_F32, STG_BF16, STG_FP8_MX = 0, 1, 2
+(GEMM_KERNEL_REG, GEMM_KERNEL_GLDS, GEMM_KERNEL_BIG, GEMM_KERNEL_8PH, GEMM_KERNEL_GLDS_CONV, GEMM_KERNEL_GLDS_BATCH, GEMM_KERNEL_GLDS_KTAIL,
+ GEMM_KERNEL_FP8) = range(8)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 
 c_i64 = C.c_int64
@@ -35,6 +37,8 @@ class GemmArgs(C.Structure):
         ("conv_H", C.c_int), ("conv_W", C.c_int), ("conv_d", C.c_int), ("conv_C", C.c_int),
         ("conv_zero", c_vp),
         ("batch", C.c_int), ("a_bstride", c_i64), ("w_bstride", c_i64), ("c_bstride", c_i64),
+        ("ab_dtype", C.c_int), ("a_scale", c_vp), ("w_scale", c_vp),
+        ("kernel_chosen", C.c_int),
     ]
 
 
@@ -114,6 +118,8 @@ SIGNATURES = {
     "stg_last_error": (C.c_char_p, []),
     "stg_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "stg_gemm_nt": (C.c_int, [C.POINTER(GemmArgs), c_vp]),
+    "stg_quant_fp8_scale_bytes": (c_i64, [c_i64, C.c_int]),
+    "stg_quant_fp8_mx": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, c_i64, c_vp, c_vp]),
     "stg_wgrad_tn": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64, c_vp]),
     "stg_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int]),
     "stg_wgrad_tn_ws": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64,
@@ -179,7 +185,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 200
+ABI_VERSION = 201
 _lib = None
 
 

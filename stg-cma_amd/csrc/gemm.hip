@@ -796,6 +796,113 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp8 variant (ab_dtype == STG_FP8_MX): A and W are OCP e4m3 bytes with one E8M0 scale per 32-wide k-block of a row (stg_quant_fp8_mx).
+// Same 128 x 128 block tile, 2 x 2 waves of 64 x 64 and the same LDS geometry as gemm_nt_glds_kernel -- a k-tile is 128 BYTES per row,
+// now 128 k-elements -- but ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 output tile and k-tile instead of two bf16 16x16x32:
+// per MFMA clock twice the math of the bf16 form at the same LDS and DMA bytes per k-tile.  Operand map (probed on the device,
+// tools/probe/mx_probe.hip): lane 16 g + i carries row i, bytes k = 16 g .. +15 and 64 + 16 g .. +15 -- the 16-byte chunks g and
+// 4 + g of the row's 128-byte k-tile, i.e. the very chunks the bf16 kernel reads for its two k-steps -- and the scale of k-block g.
+// Fragments are 8 VGPRs each (64 for the wave tile), so the kernel runs 2 workgroups per CU with double-buffered LDS.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+template <int OW, int OA>
+__device__ __forceinline__ f32x4_t mfma_mx(const i32x8_t& w, const i32x8_t& a, const f32x4_t c, int sw, int sa) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 0, OW, sw, OA, sa);     // cbsz = blgp = 0: e4m3 x e4m3
+}
+
+struct Fp8Scales { const uint32_t* SA; const uint32_t* SW; int KB; int nrbA; int nrbW; };
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_fp8_kernel(GemmParams p, Fp8Scales e) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (BM + BN) * 128];
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / p.nbn, bn = bid % p.nbn;
+    const int64_t m0 = (int64_t)bm * BM;
+    const int n0 = bn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const uint8_t* A8 = reinterpret_cast<const uint8_t*>(p.A);
+    const uint8_t* W8 = reinterpret_cast<const uint8_t*>(p.W);
+
+    const uint8_t* pa[4];
+    const uint8_t* pw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = (wave * 4 + j) * 64 + lane;
+        const int row = q >> 3, c = (q & 7) ^ (row & 7);
+        int64_t gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        pa[j] = A8 + gm * p.lda + c * 16;
+        pw[j] = W8 + (int64_t)gn * p.ldw + c * 16;
+    }
+    auto stage = [&](int buf, int kt) {
+        uint8_t* sA = smem + buf * (BM + BN) * 128;
+        uint8_t* sW = sA + BM * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kt * 128),
+                                             (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[j] + kt * 128),
+                                             (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+    };
+    // scale dwords of this lane: (64-row group, k-block 4 kt + lk, row lrow of each 16-row tile)
+    int64_t rbA = m0 / 64 + wm;
+    rbA = rbA < e.nrbA ? rbA : e.nrbA - 1;
+    int rbW = n0 / 64 + wn;
+    rbW = rbW < e.nrbW ? rbW : e.nrbW - 1;
+    const uint32_t* psa = e.SA + (rbA * e.KB + lk) * 16 + lrow;
+    const uint32_t* psw = e.SW + ((int64_t)rbW * e.KB + lk) * 16 + lrow;
+
+    AccTile accs;
+    auto& acc = accs.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = e.KB / 4;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const int sa = (int)psa[kt * 64], sw = (int)psw[kt * 64];
+        const uint8_t* sA = smem + cur * (BM + BN) * 128;
+        const uint8_t* sW = sA + BM * 128;
+        i32x8_t af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ar = wm * 64 + i * 16 + lrow;
+            const int wr = wn * 64 + i * 16 + lrow;
+            const uint4 alo = *reinterpret_cast<const uint4*>(sA + ar * 128 + swz(ar, lk) * 16);
+            const uint4 ahi = *reinterpret_cast<const uint4*>(sA + ar * 128 + swz(ar, 4 + lk) * 16);
+            const uint4 wlo = *reinterpret_cast<const uint4*>(sW + wr * 128 + swz(wr, lk) * 16);
+            const uint4 whi = *reinterpret_cast<const uint4*>(sW + wr * 128 + swz(wr, 4 + lk) * 16);
+            af[i] = (i32x8_t){(int)alo.x, (int)alo.y, (int)alo.z, (int)alo.w, (int)ahi.x, (int)ahi.y, (int)ahi.z, (int)ahi.w};
+            wf[i] = (i32x8_t){(int)wlo.x, (int)wlo.y, (int)wlo.z, (int)wlo.w, (int)whi.x, (int)whi.y, (int)whi.z, (int)whi.w};
+        }
+#define STG_MX_ROW(NI)                                                      \
+        acc[NI][0] = mfma_mx<NI, 0>(wf[NI], af[0], acc[NI][0], sw, sa);     \
+        acc[NI][1] = mfma_mx<NI, 1>(wf[NI], af[1], acc[NI][1], sw, sa);     \
+        acc[NI][2] = mfma_mx<NI, 2>(wf[NI], af[2], acc[NI][2], sw, sa);     \
+        acc[NI][3] = mfma_mx<NI, 3>(wf[NI], af[3], acc[NI][3], sw, sa);
+        STG_MX_ROW(0) STG_MX_ROW(1) STG_MX_ROW(2) STG_MX_ROW(3)
+#undef STG_MX_ROW
+        __syncthreads();      // drains vmcnt (tile kt + 1 has landed) and every wave is done reading tile kt
+    }
+    gemm_epilogue_dispatch(p, accs, m0, n0, wm, wn, lane, reinterpret_cast<float*>(smem) + (wm * 2 + wn) * 2048);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: dW[N1,N2] += sum_m dY[m,N1] X[m,N2]   (reduction over the huge token dimension, tiny output)
 // MFMA k index = token row, so both operands are needed k-major per lane; tiles are staged row-major in LDS
 // (coalesced 16-byte global loads) and fragments are gathered with 16-bit LDS reads (the op is HBM-bound:
@@ -1072,14 +1179,24 @@ std::atomic<uint64_t> lds_8ph_done{0}, lds_big_done{0};
 
 }  // namespace
 
-extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
+extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     STG_CHECK(a != nullptr, -1, "stg_gemm_nt: null args");
     STG_CHECK(a->A && a->W && a->C, -1, "stg_gemm_nt: null A/W/C");
     STG_CHECK(a->M >= 0 && a->N > 0 && a->K > 0, -2, "stg_gemm_nt: bad shape M=%lld N=%d K=%d", (long long)a->M, a->N, a->K);
     STG_CHECK(a->K % 8 == 0, -2, "stg_gemm_nt: K=%d must be a multiple of 8", a->K);
-    STG_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, -2, "stg_gemm_nt: lda/ldw must be multiples of 8");
     STG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, -2, "stg_gemm_nt: A/W must be 16-byte aligned");
-    STG_CHECK((a->conv_H > 0 || a->lda >= a->K) && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
+    const bool fp8 = a->ab_dtype == STG_FP8_MX;
+    STG_CHECK(fp8 || a->ab_dtype == 0 || a->ab_dtype == STG_BF16, -3, "stg_gemm_nt: unsupported ab_dtype %d", a->ab_dtype);
+    if (fp8) {
+        const int64_t kp = ((int64_t)a->K + 127) / 128 * 128;
+        STG_CHECK(a->a_scale && a->w_scale && (((uintptr_t)a->a_scale | (uintptr_t)a->w_scale) & 3) == 0, -1, "stg_gemm_nt: fp8 operands need their scale tables");
+        STG_CHECK(a->lda % 16 == 0 && a->ldw % 16 == 0 && a->lda >= kp && a->ldw >= kp && a->ldc >= a->N, -2,
+                  "stg_gemm_nt: fp8 leading dimensions are bytes, multiples of 16 and >= K rounded up to 128");
+        STG_CHECK(a->conv_H <= 0 && a->batch <= 1, -3, "stg_gemm_nt: fp8 operands do not combine with the implicit convolution / batched mode");
+    } else {
+        STG_CHECK(a->lda % 8 == 0 && a->ldw % 8 == 0, -2, "stg_gemm_nt: lda/ldw must be multiples of 8");
+        STG_CHECK((a->conv_H > 0 || a->lda >= a->K) && a->ldw >= a->K && a->ldc >= a->N, -2, "stg_gemm_nt: leading dimension too small");
+    }
     STG_CHECK(a->c_dtype == STG_BF16 || a->c_dtype == STG_F32, -3, "stg_gemm_nt: unsupported c_dtype %d", a->c_dtype);
     STG_CHECK(a->act >= 0 && a->act <= 2, -3, "stg_gemm_nt: bad act");
     STG_CHECK(!a->dact || a->act != 0, -3, "stg_gemm_nt: dact output needs an activation");
@@ -1139,6 +1256,17 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         }
         if (stg_opt_gemm_epi.load(std::memory_order_relaxed) == 0) p.epi_variant = EV_GENERIC;   // A/B knob: every option a run-time test
     }
+    if (fp8) {
+        STG_CHECK(p.epi_variant >= 0, -2, "stg_gemm_nt: fp8 operands need the row-layout epilogue (N %% 8 == 0, 16-byte aligned outputs)");
+        Fp8Scales e;
+        e.SA = (const uint32_t*)a->a_scale; e.SW = (const uint32_t*)a->w_scale;
+        e.KB = (int)(((int64_t)a->K + 127) / 128 * 4);
+        e.nrbA = (int)((a->M + 63) / 64); e.nrbW = (a->N + 63) / 64;
+        a->kernel_chosen = STG_GEMM_KERNEL_FP8;
+        hipLaunchKernelGGL(gemm_nt_fp8_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p, e);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
     const bool ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed) != 0;
     const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
     const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
@@ -1154,6 +1282,7 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
+        a->kernel_chosen = STG_GEMM_KERNEL_8PH;
         hipLaunchKernelGGL(gemm_nt_8ph_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
         STG_LAUNCH_CHECK();
         return 0;
@@ -1162,13 +1291,24 @@ extern "C" int stg_gemm_nt(const stg_gemm_args* a, void* stream) {
         STG_CHECK(stg_reserve_lds(gemm_nt_big_kernel, 2 * (GBM + GBN) * BK * 2, lds_big_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
+        a->kernel_chosen = STG_GEMM_KERNEL_BIG;
         hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 2 * (GBM + GBN) * BK * 2, (hipStream_t)stream, p);
-    } else if (p.batch > 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch), dim3(256), 0, (hipStream_t)stream, p);
-    else if (conv) hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    else if (a->K % BK == 0) hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    else if (ktail_on && a->K > BK && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0)      // K = 96 ...: LDS-DMA kernel with a zero-filled k tail
+    } else if (p.batch > 1) {
+        a->kernel_chosen = STG_GEMM_KERNEL_GLDS_BATCH;
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (conv) {
+        a->kernel_chosen = STG_GEMM_KERNEL_GLDS_CONV;
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<1, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (a->K % BK == 0) {
+        a->kernel_chosen = STG_GEMM_KERNEL_GLDS;
+        hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (ktail_on && a->K > BK && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail
+        a->kernel_chosen = STG_GEMM_KERNEL_GLDS_KTAIL;
         hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        a->kernel_chosen = STG_GEMM_KERNEL_REG;
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
+    }
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -75,30 +75,77 @@ def conv3x3_gemm_supported(Cin):
     return Cin % 64 == 0 or Cin in (8, 16, 32)
 
 
+class Fp8:
+    """A block-scaled e4m3 matrix (stg_quant_fp8_mx): q uint8 [rows, Kp] (Kp = K rounded up to 128, pad bytes zero), s uint8 packed
+    E8M0 scale table, logical shape (rows, K)."""
+    __slots__ = ("q", "s", "rows", "K")
+
+    def __init__(self, q, s, rows, K):
+        self.q, self.s, self.rows, self.K = q, s, rows, K
+
+    @property
+    def shape(self):
+        return (self.rows, self.K)
+
+    @property
+    def device(self):
+        return self.q.device
+
+
+def quant_fp8(x):
+    """bf16 [rows, K] (K % 8 == 0, row-major, 16-byte aligned rows) -> Fp8: per 32-wide k-block of a row one E8M0 exponent
+    e = ceil(log2(max|x| / 448)) + 127 and e4m3 round-to-nearest-even of x * 2^(127 - e)."""
+    _chk2d(x, "x", BF16)
+    rows, Kd = x.shape
+    if Kd % 8 != 0 or _ld(x) % 8 != 0:
+        raise RuntimeError("quant_fp8: K and the leading dimension must be multiples of 8")
+    Kp = (Kd + 127) // 128 * 128
+    q = torch.empty((rows, Kp), dtype=torch.uint8, device=x.device)
+    nb = int(_lib.lib().stg_quant_fp8_scale_bytes(rows, Kd))
+    sc = torch.empty((max(nb, 4),), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.lib().stg_quant_fp8_mx(_p(x), _ld(x), rows, Kd, _p(q), Kp, _p(sc), _stream()), "stg_quant_fp8_mx")
+    return Fp8(q, sc, rows, Kd)
+
+
 def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
             row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None, batch=None):
     """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, dact) with dact = bf16(act'(pre-activation)),
-    the tensor a later call takes as dact_src (or act_bwd as its second argument)."""
+    the tensor a later call takes as dact_src (or act_bwd as its second argument).  A and W are bf16 tensors, or both Fp8
+    (quant_fp8): the block-scaled e4m3 MFMA path."""
     if batch is not None:
         return _gemm_nt_batched(A, W, bias, out, out_dtype, alpha, act, int(batch))
+    fp8 = isinstance(A, Fp8)
+    if fp8 != isinstance(W, Fp8):
+        raise RuntimeError("gemm_nt: A and W must both be bf16 tensors or both Fp8")
     M, K = A.shape
     N = W.shape[0]
-    _chk2d(A, "A", BF16)
+    dev = A.device
+    if fp8:
+        if W.K != K or conv is not None:
+            raise RuntimeError("gemm_nt(fp8): K mismatch / no implicit convolution on fp8 operands")
+    else:
+        _chk2d(A, "A", BF16)
     if conv is not None:                                  # implicit 3x3 convolution: A is the [F*H*W, Cin] feature map, K = 9 * Cin
         Hc, Wc, dc = conv
         Cin = K
         K = 9 * Cin
         if not conv3x3_gemm_supported(Cin) or M % (Hc * Wc) != 0 or dc < 1:
             raise RuntimeError("gemm_nt(conv=...): needs Cin % 64 == 0 (or 8 / 16 / 32) and rows = F * H * W")
-    _chk2d(W, "W", BF16, cols=K)
+    if not fp8:
+        _chk2d(W, "W", BF16, cols=K)
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+        out = torch.empty((M, N), dtype=out_dtype, device=dev)
     _chk2d(out, "out", out.dtype, cols=N, rows=M)
     if out.dtype not in (BF16, F32):
         raise RuntimeError("out dtype must be bf16 or fp32")
     a = _lib.GemmArgs()
-    a.A, a.lda = _p(A), _ld(A)
-    a.W, a.ldw = _p(W), _ld(W)
+    if fp8:
+        a.A, a.lda, a.a_scale = _p(A.q), A.q.shape[1], _p(A.s)
+        a.W, a.ldw, a.w_scale = _p(W.q), W.q.shape[1], _p(W.s)
+        a.ab_dtype = _lib.STG_FP8_MX
+    else:
+        a.A, a.lda = _p(A), _ld(A)
+        a.W, a.ldw = _p(W), _ld(W)
     a.C, a.ldc, a.c_dtype = _p(out), _ld(out), (STG_BF16 if out.dtype == BF16 else STG_F32)
     if bias is not None:
         _chk1d(bias, "bias", F32, N)
@@ -109,7 +156,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     if want_dact:
         if act == ACT_NONE:
             raise RuntimeError("gemm_nt: want_dact needs an activation")
-        pre = torch.empty((M, N), dtype=BF16, device=A.device)
+        pre = torch.empty((M, N), dtype=BF16, device=dev)
         a.dact, a.ldp = _p(pre), _ld(pre)
     if dact_src is not None:
         _chk2d(dact_src, "dact_src", BF16, cols=N, rows=M)
@@ -128,34 +175,43 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
-    if K % 64 != 0 and K > 64:                            # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
-        a.conv_zero = _p(_zero_line(A.device))
+    if not fp8 and K % 64 != 0 and K > 64:                # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
+        a.conv_zero = _p(_zero_line(dev))
     if conv is not None:
-        zl = _zero_line(A.device)
+        zl = _zero_line(dev)
         a.conv_H, a.conv_W, a.conv_d, a.conv_C, a.conv_zero = int(Hc), int(Wc), int(dc), int(Cin), _p(zl)
     prof = _gemm_prof
-    # bench.py samples the two kernels that carry the step: which one stg_gemm_nt picks follows the host dispatch in csrc/gemm.hip
-    # (8-phase: K % 128 == 0, N % 256 == 0, M >= 256 and either K >= 1024 or a wide plain / activation output; else, for
-    # K % 64 == 0, gemm_nt_glds_kernel<1>)
-    if prof is not None and conv is None and K % 64 == 0 and M > 0:
-        wide8 = K >= 512 and N >= 1536 and M >= 8192 and dact_src is None and res1 is None and res2 is None and row_scale is None and alpha == 1.0 and \
-            out.dtype == BF16
-        is8 = K % 128 == 0 and N % 256 == 0 and M >= 256 and (K >= 1024 or wide8)
-        big_other = (not is8) and K >= 1024 and N % 256 == 0 and M >= 256          # K % 128 != 0: the one-barrier large-tile kernel
-        if not big_other:
-            pk = prof["k8"] if is8 else prof["glds"]
-            pk["launches"] += 1
-            pk["flops"] += 2.0 * M * N * K
-            pk["bytes"] += 2.0 * M * K + 2.0 * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
+    if prof is not None and conv is None and M > 0:
+        # per-class accounting for bench.py: class = (kernel the C dispatch chose, N, K, epilogue signature).  The kernel of a call
+        # signature is learnt from stg_gemm_nt's `kernel_chosen` on its first launch (no host-side copy of the dispatch rules).
+        epi = ("b" if bias is not None else "") + ("a" if act else "") + ("p" if want_dact else "") + ("d" if dact_src is not None else "") + \
+              ("" if res1 is None else ("r" if res1.dtype == BF16 else "q")) + ("" if res2 is None else ("R" if res2.dtype == BF16 else "Q")) + \
+              ("s" if row_scale is not None else "") + ("A" if alpha != 1.0 else "") + ("" if out.dtype == BF16 else "F")
+        sig = (M, N, K, epi, fp8)
+        kid = prof["kid"].get(sig)
+        if kid is not None:
+            ck = (kid, N, K, epi)
+            pc = prof["classes"].get(ck)
+            if pc is None:
+                pc = prof["classes"][ck] = {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}
+            esz = 1.0 if fp8 else 2.0
+            nbytes = esz * M * K + esz * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
                 (2.0 * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
                 (M * N * res2.element_size() if res2 is not None else 0.0)          # algorithmic HBM bytes: every operand / output once
-            if pk["launches"] % prof["stride"] == 0:       # HIP events around every stride-th launch, on the launch stream
+            pc["launches"] += 1
+            pc["flops"] += 2.0 * M * N * K
+            pc["bytes"] += nbytes
+            if pc["launches"] % prof["stride"] == 0:       # HIP events around every stride-th launch of the class, on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
                 e1.record()
-                pk["rec"].append((e0, e1, 2.0 * M * N * K))
+                pc["rec"].append((e0, e1, 2.0 * M * N * K, nbytes))
                 return (out, pre) if want_dact else out
+        _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+        if kid is None:
+            prof["kid"][sig] = int(a.kernel_chosen)
+        return (out, pre) if want_dact else out
     _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
     return (out, pre) if want_dact else out
 
@@ -224,25 +280,39 @@ import os as _os
 USE_WGRAD_WS = _os.environ.get("STG_WGRAD_WS", "1") != "0"    # 0 = atomic wgrad kernels only (A/B knob)
 
 
+GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GLDS: "gemm_nt_glds_kernel<1, false, false, false>",
+                     _lib.GEMM_KERNEL_BIG: "gemm_nt_big_kernel", _lib.GEMM_KERNEL_8PH: "gemm_nt_8ph_kernel",
+                     _lib.GEMM_KERNEL_GLDS_CONV: "gemm_nt_glds_kernel<1, true, false, false>",
+                     _lib.GEMM_KERNEL_GLDS_BATCH: "gemm_nt_glds_kernel<1, false, true, false>",
+                     _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel"}
+
+
 def gemm_profile_start(stride=7):
-    """Start sampling launches of the two GEMM kernels that carry the step (gemm_nt_glds_kernel<1>, gemm_nt_8ph_kernel): every
-    `stride`-th launch of each is bracketed by HIP events on the launch stream (events around every launch cost ~10 % of the step)."""
+    """Start per-class accounting of stg_gemm_nt launches (class = kernel chosen by the C dispatch x N x K x epilogue signature):
+    every `stride`-th launch of a class is bracketed by HIP events on the launch stream (events around every launch cost ~10 % of
+    the step).  Call before the warm-up steps (the kernel of each call signature is learnt on its first launch) and
+    gemm_profile_reset() at the start of the timed region."""
     global _gemm_prof
-    _gemm_prof = {"stride": int(stride), "glds": {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []},
-                  "k8": {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}}
+    _gemm_prof = {"stride": int(stride), "kid": {}, "classes": {}}
+
+
+def gemm_profile_reset():
+    if _gemm_prof is not None:
+        _gemm_prof["classes"] = {}
 
 
 def gemm_profile_stop():
-    """{kernel: {launches, flops, bytes, sampled, sampled_ms, sampled_flops}} for 'glds' and 'k8' since gemm_profile_start."""
+    """[{kernel, N, K, epi, launches, flops, bytes, sampled, sampled_ms, sampled_flops, sampled_bytes}] since the last reset."""
     global _gemm_prof
     prof, _gemm_prof = _gemm_prof, None
     torch.cuda.synchronize()
-    out = {}
-    for key in ("glds", "k8"):
-        pk = prof[key]
-        rec = pk["rec"]
-        out[key] = {"launches": pk["launches"], "flops": pk["flops"], "bytes": pk["bytes"], "sampled": len(rec),
-                    "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _ in rec), "sampled_flops": sum(f for _, _, f in rec)}
+    out = []
+    for (kid, N, Kd, epi), pc in prof["classes"].items():
+        rec = pc["rec"]
+        out.append({"kernel": GEMM_KERNEL_NAMES.get(kid, str(kid)), "N": N, "K": Kd, "epi": epi, "launches": pc["launches"],
+                    "flops": pc["flops"], "bytes": pc["bytes"], "sampled": len(rec),
+                    "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec), "sampled_flops": sum(r[2] for r in rec),
+                    "sampled_bytes": sum(r[3] for r in rec)})
     return out
 
 

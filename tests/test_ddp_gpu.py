@@ -44,7 +44,7 @@ def _models(gpu):
         lambda m: m(a_clip, v5, "fusion").float().square().mean()
     yield "swin_avs", Swin_AVSModel_Base.SwinTransformer2D_Adapter_AVS_Base(
         pretrained=None, num_frames=T, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], ftmode="fusion",
-        adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125], channel=256, vis_dim=[64, 128, 320, 512], tpavi_stages=[0, 1, 2, 3],
+        adapter_mlp_ratio=[0.5, 0.5, 0.25, 0.25], channel=256, vis_dim=[64, 128, 320, 512], tpavi_stages=[0, 1, 2, 3],
         tpavi_vv_flag=False, tpavi_va_flag=True), \
         lambda m: m(a, vt, "fusion")[0].float().square().mean()
     q = torch.randint(0, 93, (1, 14), generator=g).to(gpu)

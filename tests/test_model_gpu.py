@@ -227,13 +227,15 @@ def test_swin_b_fusion_full_model_matches_reference(stg, gpu):
     assert err <= 1.5e-2 * float(np.abs(z["logits"]).max()), f"logit deviation {err}"
 
 
-def test_swin_b_refinit_logits_within_1e2_abs(stg, gpu):
-    """Swin-B + STG-CMA at the reference's own initialisation scale (trunc_normal .02 Linears, unit LayerNorms,
-    Swin_AVE.py:1353-1361) with the zero-initialised D_fc2 / gates de-zeroed: max-abs logit deviation <= 1e-2
-    (BASELINE.json north_star) against the reference's fp32 CPU logits."""
+@pytest.mark.parametrize("case", ["swin_b_fusion_refinit", "swin_l_fusion_refinit"])
+def test_swin_refinit_logits_within_1e2_abs(stg, gpu, case):
+    """Swin-B and Swin-L + STG-CMA, full depth, at the reference's own initialisation scale (trunc_normal .02 Linears, unit
+    LayerNorms, Swin_AVE.py:1353-1361) with the zero-initialised D_fc2 / gates de-zeroed: max-abs logit deviation <= 1e-2
+    (BASELINE.json north_star) against the reference's fp32 CPU logits.  Swin-L (embed_dim 192, heads 6..48, adapters
+    [.5, .25, .125, .0625]: AVE/run_adapt_ave29.py:167-181) is the backbone geometry of the AVQA model of BASELINE config 5."""
     from stgcma.model import Swin_AVE as S
     from params import seeded_tensor, refinit_state
-    z, cfg, shapes, names = load_case("swin_b_fusion_refinit")
+    z, cfg, shapes, names = load_case(case)
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=refinit_state)
     m = _build_model(S, cfg, P, gpu)
     del P
@@ -244,7 +246,7 @@ def test_swin_b_refinit_logits_within_1e2_abs(stg, gpu):
     logits = m(a, v, "fusion")
     ref = torch.as_tensor(z["logits"])
     err = float((logits.detach().cpu() - ref).abs().max())
-    _report.append(f"swin_b refinit logits max abs err {err:.3e} (|logits| max {float(ref.abs().max()):.3g})")
+    _report.append(f"{case} logits max abs err {err:.3e} (|logits| max {float(ref.abs().max()):.3g})")
     assert err <= 1e-2, f"logit deviation {err}"
     tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1).to(gpu)
     loss = torch.nn.CrossEntropyLoss()(logits, tgt)
@@ -252,7 +254,7 @@ def test_swin_b_refinit_logits_within_1e2_abs(stg, gpu):
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
     d = dict(m.named_parameters())
     norms = torch.stack([d[n].grad.float().norm().cpu() for n in names])
-    _cmp(norms, z["grad_norms"], "swin_b refinit grad norms", max_rel=5e-2, l2_rel=3e-2)
+    _cmp(norms, z["grad_norms"], f"{case} grad norms", max_rel=5e-2, l2_rel=3e-2)
 
 
 def test_train_mode_droppath_and_dropout_run(stg, gpu):
@@ -316,7 +318,7 @@ def test_droppath_mask_semantics(stg, gpu, tag, monkeypatch):
     # the masks the block asked for: one per modality with B * N entries (temporal residual), then -- parallel mode -- B * T entries
     want = [B * N] * (2 if two else 1) + ([BT] if not two else [])
     assert [m.numel() for m in drawn] == want, [m.numel() for m in drawn]
-    assert all(set(m.unique().tolist()) <= {0.0, 1.0 / (1 - p_drop)} for m in drawn)
+    assert all(bool(((m == 0) | ((m - 1.0 / (1 - p_drop)).abs() < 1e-6)).all()) for m in drawn)
     assert all(0 < float((m == 0).float().mean()) < 1 for m in drawn), "the seeded masks must drop some rows and keep others"
     dps = {"t_v": drawn[0], "t_a": drawn[1]} if two else {"t_v": drawn[0], "ffn": drawn[1]}
     for n in P:
