@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="swin_b",
                     help="swin_b = the headline metric (default); vit_b = BASELINE configs[1]")
+    ap.add_argument("--fp8", action="store_true",
+                    help="frozen backbone Linears on the block-scaled e4m3 MFMA path (BASELINE config 5; opt-in, Swin workloads); the "
+                         "line then carries dtype 'fp8-e4m3(frozen weights + their inputs)/bf16' and is NOT the headline metric")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -234,6 +237,12 @@ def main():
 
     model = build_model(torch, device, args.workload)
     gflop_per_clip, workload_desc = WORKLOADS[args.workload]
+    if args.fp8:
+        from stgcma import fp8 as stg_fp8
+        if args.workload == "vit_b":
+            raise SystemExit("--fp8 covers the Swin workloads")
+        stg_fp8.enable(model)
+        workload_desc += "; frozen qkv / proj / fc1 / fc2 / reduction GEMMs (forward + dgrad) on block-scaled e4m3 MFMA"
     if world > 1:
         ddp.broadcast_parameters(model)
         ddp.attach(model)
@@ -368,7 +377,8 @@ def main():
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
                                               "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp8-e4m3 (frozen weights + their inputs, E8M0 block scales) / bf16" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": "fp32"},
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),

@@ -7,6 +7,7 @@ Layout
   ops.py        torch.autograd.Function glue (forward + hand-written backward kernels)
   model/        nn.Module mirror of the reference's AVE/AVQA/AVS model files (same ctor kwargs, forward, state_dict keys)
   ddp.py        one-process-per-GPU data parallelism: flat-bucket RCCL all-reduce of the trainable gradients
+  fp8.py        opt-in block-scaled e4m3 path of the frozen backbone Linears (BASELINE config 5)
 
 The directory name carries a hyphen, so import it as `import stgcma` (top-level alias module) or
 `importlib.import_module("stg-cma_amd")`.

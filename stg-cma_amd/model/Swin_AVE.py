@@ -261,6 +261,9 @@ class SwinTransformer2D_Adapter_New(nn.Module):
             self.mlp_head = nn.Sequential(nn.LayerNorm(self.num_features), nn.Linear(self.num_features, label_dim))
         self.initialize_weights(pretrained=self.pretrained)
         self._freeze_stages()
+        from .. import fp8 as _fp8
+        if _fp8.env_default():                  # STG_FP8=1: the opt-in fp8 frozen-weight path without touching the runner
+            _fp8.enable(self)
 
     # ------------------------------------------------------------------ init / checkpoint ingestion
     def _freeze_stages(self):

@@ -123,6 +123,30 @@ def clear_shadow_cache():
     _wintab_cache.clear()
 
 
+def shadow_fp8(p, transpose=False):
+    """Block-scaled e4m3 copy (K.Fp8) of a FROZEN fp32 weight, in the orientation given, cached next to its bf16 shadow (same
+    invalidation: parameter storage / version)."""
+    w = shadow(p, transpose)
+    slot = _shadow_cache[id(p)][1]
+    key = ("fp8", bool(transpose))
+    hit = slot.get(key)
+    tag = slot[bool(transpose)][0]
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    f = K.quant_fp8(w)
+    slot[key] = (tag, f)
+    return f
+
+
+def frozen_gemm(A, wp, bias=None, *, t=False, fp8=False, **kw):
+    """A . W^T (t=True: A . W, the dgrad) for a FROZEN Linear weight `wp`.  bf16 MFMA on the weight's bf16 shadow, or -- fp8 (BASELINE
+    config 5, opt-in: stgcma.fp8) -- the block-scaled e4m3 MFMA: the weight's cached e4m3 shadow and A quantised per 32-wide k-block
+    on the way in (stg_quant_fp8_mx); accumulation, epilogue and output are what they are on the bf16 path."""
+    if fp8:
+        return K.gemm_nt(K.quant_fp8(A), shadow_fp8(wp, t), bias, **kw)
+    return K.gemm_nt(A, shadow(wp, t), bias, **kw)
+
+
 # ------------------------------------------------------------------------------------------------ geometry caches
 _geom_cache = {}
 
@@ -515,8 +539,9 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, T)
     S = {}
     n1g, n1b = f32c(P["norm1.weight"]), f32c(P["norm1.bias"])
-    wqkv, bqkv = shadow(P["attn.qkv.weight"]), f32c(P["attn.qkv.bias"])
-    wproj, bproj = shadow(P["attn.proj.weight"]), f32c(P["attn.proj.bias"])
+    fp8 = bool(getattr(spec, "fp8", False))
+    wqkv, bqkv = P["attn.qkv.weight"], f32c(P["attn.qkv.bias"])
+    wproj, bproj = P["attn.proj.weight"], f32c(P["attn.proj.bias"])
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
 
     # ---------------- temporal attention + T_Adapter (even blocks; :705-716).  DropPath per (b, n) row.
@@ -524,7 +549,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         dps = [drop_scale(spec.drop_path, B * N, X.device, training, pool) for _ in spec.mods]
         Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X, n1g, n1b, want_stats=save)
         pre = None
-        QKV = K.gemm_nt(Y, wqkv, bqkv)
+        QKV = frozen_gemm(Y, wqkv, bqkv, fp8=fp8)
         del Y
         tbias = torch.empty((nm, H, T * T), dtype=F32, device=X.device)
         for i, m in enumerate(spec.mods):
@@ -535,7 +560,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
             AO, lse = K.tattn_fwd(tgeo, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]), tgeo    # backward recomputes: no O / LSE kept
         else:
             AO, lse = K.attn_fwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
-        PO = K.gemm_nt(AO, wproj, bproj)
+        PO = frozen_gemm(AO, wproj, bproj, fp8=fp8)
         if isinstance(lse, K.TGeom):
             AO = None
         X1 = torch.empty_like(X)
@@ -555,7 +580,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
 
     # ---------------- (shifted-)window attention + S_Adapter2 (window-level cross-modal when fusing) (:718-787)
     Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
-    QKV = K.gemm_nt(Y, wqkv, bqkv)
+    QKV = frozen_gemm(Y, wqkv, bqkv, fp8=fp8)
     del Y
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
         bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
@@ -564,7 +589,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     else:
         sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
         AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
-    PO = K.gemm_nt(AO, wproj, bproj)
+    PO = frozen_gemm(AO, wproj, bproj, fp8=fp8)
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
     HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
     xs = None
@@ -585,8 +610,8 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     Y, mean, rstd = ln2.triple() if ln2 is not None else \
         K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
     del ln2
-    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU, want_dact=True)
-    M = K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
+    Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=True)
+    M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8)
     del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
     X3 = torch.empty_like(X)
@@ -633,7 +658,8 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
     dgv, dga = G.buf("gate_v"), G.buf("gate_a")
     n1g = f32c(P["norm1.weight"])
-    wqkv_t, wproj_t = shadow(P["attn.qkv.weight"], True), shadow(P["attn.proj.weight"], True)
+    fp8 = bool(getattr(spec, "fp8", False))
+    wqkv, wproj = P["attn.qkv.weight"], P["attn.proj.weight"]
 
     # ---------------- FFN + S_Adapter
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
@@ -644,8 +670,8 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         dZa = K.act_bwd(dHa, Za_)
         _adapter_wgrad(G, A.name, dZa, Y, dX3, Ha_, rs=rs, rs_outer=N, rs_inner=1)
         dYa = K.gemm_nt(dZa, A.w1t)
-        dZm = K.gemm_nt(dX3, shadow(P["mlp.fc2.weight"], True), dact_src=Zm)
-        dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True), res1=dYa)
+        dZm = frozen_gemm(dX3, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
+        dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8, res1=dYa)
         del Y, Ha_, Za_, dHa, dZa, dYa, dZm, Zm
     else:
         X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
@@ -661,9 +687,9 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
         del HZ, H2, xs, dH2, dZs, M
-        dZm = K.gemm_nt(dM, shadow(P["mlp.fc2.weight"], True), dact_src=Zm)
+        dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
         del dM, Zm
-        dY = K.gemm_nt(dZm, shadow(P["mlp.fc1.weight"], True))
+        dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8)
         del dZm
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
     dX2, dH2 = _ln_bwd_join(dY, X2, f32c(P["norm2.weight"]), mean, rstd, dX3, sl, [A.w2t for A in ads])
@@ -684,7 +710,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
         K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
     del HZ, H2, xs, dH2, dZs, PO
-    dAO = K.gemm_nt(dPO, wproj_t)
+    dAO = frozen_gemm(dPO, wproj, t=True, fp8=fp8)
     del dPO
     dQKV = torch.empty_like(QKV)
     if isinstance(sbias, K.WinGeom):
@@ -694,7 +720,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         K.attn_bwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
                    dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
     del QKV, AO, dAO
-    dY = K.gemm_nt(dQKV, wqkv_t)
+    dY = frozen_gemm(dQKV, wqkv, t=True, fp8=fp8)
     del dQKV
     dH_prev = None
     if spec.t_attn:
@@ -716,7 +742,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
             K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
         del hz, PO
-        dAO = K.gemm_nt(dPO, wproj_t)
+        dAO = frozen_gemm(dPO, wproj, t=True, fp8=fp8)
         del dPO
         tabs = [G.buf("attn.temporal_position_bias_table" + ("_audio" if m else "")) for m in spec.mods]
         dtb = torch.zeros_like(tbias) if any(t is not None for t in tabs) else None
@@ -731,7 +757,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             if tabs[i] is not None:
                 K.bias_scatter(dtb[i], P["attn.t_relative_coords" + ("_a" if m else "")], tabs[i])
         del QKV, AO, dAO
-        dY = K.gemm_nt(dQKV, wqkv_t)
+        dY = frozen_gemm(dQKV, wqkv, t=True, fp8=fp8)
         del dQKV
         dX0, dH_prev = _ln_bwd_join(dY, X0, n1g, mean, rstd, dX1, sl, prev)
     else:
@@ -740,16 +766,16 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
 
 
 # ------------------------------------------------------------------------------------------------ patch merging / embedding / heads
-def merge_forward(X, H, W, P, save):
+def merge_forward(X, H, W, P, save, fp8=False):
     """PatchMerging.forward on every frame of the fused tensor (Swin_AVE.py:958-981): 2x2 gather + LN(4C) + Linear(4C->2C)."""
     Y, mean, rstd = K.layernorm_fwd(X, f32c(P["norm.weight"]), f32c(P["norm.bias"]), gather4=(H, W), want_stats=save)
-    out = K.gemm_nt(Y, shadow(P["reduction.weight"]), out_dtype=RESIDUAL_DTYPE)
+    out = frozen_gemm(Y, P["reduction.weight"], fp8=fp8, out_dtype=RESIDUAL_DTYPE)
     return out, ((X, mean, rstd) if save else None)
 
 
-def merge_backward(S, H, W, P, dout):
+def merge_backward(S, H, W, P, dout, fp8=False):
     X, mean, rstd = S
-    dY = K.gemm_nt(dout, shadow(P["reduction.weight"], True))
+    dY = frozen_gemm(dout, P["reduction.weight"], t=True, fp8=fp8)
     return K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd, gather4=(H, W))
 
 
@@ -915,7 +941,8 @@ def plain_block_forward(X, spec, P, training, pool=None):
     dp1 = drop_scale(spec.drop_path, BT, X.device, training, pool)
     dp2 = drop_scale(spec.drop_path, BT, X.device, training, pool)
     Y, _, _ = K.layernorm_fwd(X, f32c(P["norm1.weight"]), f32c(P["norm1.bias"]), want_stats=False)
-    QKV = K.gemm_nt(Y, shadow(P["attn.qkv.weight"]), f32c(P["attn.qkv.bias"]))
+    fp8 = bool(getattr(spec, "fp8", False))
+    QKV = frozen_gemm(Y, P["attn.qkv.weight"], f32c(P["attn.qkv.bias"]), fp8=fp8)
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
         bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
         wg = K.WinGeom(BT, H, spec.H, spec.W, spec.ws, spec.shift, spec.hd ** -0.5, bm, bmT)
@@ -923,12 +950,12 @@ def plain_block_forward(X, spec, P, training, pool=None):
     else:
         sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
         AO, _ = K.attn_fwd(_window_geom(spec, BT, g, sbias, 1), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=False)
-    X1 = K.gemm_nt(AO, shadow(P["attn.proj.weight"]), f32c(P["attn.proj.bias"]), out_dtype=RESIDUAL_DTYPE, res1=X,
+    X1 = frozen_gemm(AO, P["attn.proj.weight"], f32c(P["attn.proj.bias"]), fp8=fp8, out_dtype=RESIDUAL_DTYPE, res1=X,
                    row_scale=dp1, rs_outer=N, rs_inner=1)
     del QKV, AO
     Y, _, _ = K.layernorm_fwd(X1, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=False)
-    Hm = K.gemm_nt(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), act=ACT_GELU)
-    return K.gemm_nt(Hm, shadow(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]), out_dtype=RESIDUAL_DTYPE, res1=X1,
+    Hm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU)
+    return frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8, out_dtype=RESIDUAL_DTYPE, res1=X1,
                      row_scale=dp2, rs_outer=N, rs_inner=1)
 
 
@@ -974,6 +1001,7 @@ class SwinBackboneFn(torch.autograd.Function):
             if req:
                 pool = DropPool(req, dev)
         tape, tap_out = [], []
+        plan_fp8 = bool(getattr(plan, "fp8", False))
         for st in plan.stages:
             carry = None
             for j, (spec, pre) in enumerate(st["blocks"]):
@@ -989,10 +1017,10 @@ class SwinBackboneFn(torch.autograd.Function):
                 Pm = {n: P[pre + n] for n in ("norm.weight", "norm.bias", "reduction.weight")}
                 if taps:
                     tap_out.append(X[:X.shape[0] // 2])
-                X, S = merge_forward(X, H, W, Pm, save)
+                X, S = merge_forward(X, H, W, Pm, save, plan_fp8)
                 tape.append(("merge", (H, W), pre, Pm, S))
                 if Xn is not None:
-                    Xn, _ = merge_forward(Xn, H, W, Pm, False)
+                    Xn, _ = merge_forward(Xn, H, W, Pm, False, plan_fp8)
         ng, nb = f32c(P["norm.weight"]), f32c(P["norm.bias"])
         Fall, mean, rstd = K.layernorm_fwd(X, ng, nb, want_stats=save, out_dtype=F32)
         half = X.shape[0] // 2
@@ -1005,6 +1033,7 @@ class SwinBackboneFn(torch.autograd.Function):
         ctx.tape, ctx.final, ctx.P, ctx.need, ctx.names = tape, (X, mean, rstd), P, need, names
         ctx.n_tap, ctx.has_nega = len(tap_out), Xn is not None
         ctx.ddp = getattr(plan, "ddp", None)
+        ctx.fp8 = plan_fp8
         return tuple(outs)
 
     @staticmethod
@@ -1036,7 +1065,7 @@ class SwinBackboneFn(torch.autograd.Function):
                     grads[pre + k] = val
             else:
                 dH_carry = None
-                dX = merge_backward(S, spec[0], spec[1], Pl, dX)
+                dX = merge_backward(S, spec[0], spec[1], Pl, dX, ctx.fp8)
                 dt = dtaps.pop() if dtaps else None
                 if dt is not None:                                       # the tap's gradient joins the video rows
                     dv = dX[:dX.shape[0] // 2]
@@ -1079,6 +1108,7 @@ class SwinModelFn(torch.autograd.Function):
             if req:
                 pool = DropPool(req, src.device)
         tape = []
+        plan_fp8 = bool(getattr(plan, "fp8", False))
         for st in plan.stages:
             carry = None
             for j, (spec, pre) in enumerate(st["blocks"]):
@@ -1090,7 +1120,7 @@ class SwinModelFn(torch.autograd.Function):
             if st["merge"] is not None:
                 H, W, pre = st["merge"]
                 Pm = {n: P[pre + n] for n in ("norm.weight", "norm.bias", "reduction.weight")}
-                X, S = merge_forward(X, H, W, Pm, save)
+                X, S = merge_forward(X, H, W, Pm, save, plan_fp8)
                 tape.append(("merge", (H, W), pre, Pm, S))
         if len(mods) == 2:
             logits, S = head_fusion_forward(X, plan.n_tok_last, P, training, plan.head_drop, save, pool)
@@ -1098,6 +1128,7 @@ class SwinModelFn(torch.autograd.Function):
             logits, S = head_single_forward(X, plan.n_tok_last, P, save)
         ctx.tape, ctx.head, ctx.P, ctx.need, ctx.names, ctx.two = tape, S, P, need, names, len(mods) == 2
         ctx.ddp = getattr(plan, "ddp", None)
+        ctx.fp8 = plan_fp8
         return logits
 
     @staticmethod
@@ -1121,7 +1152,7 @@ class SwinModelFn(torch.autograd.Function):
                     grads[pre + k] = val
             else:
                 dH_carry = None
-                dX = merge_backward(S, spec[0], spec[1], Pl, dX)
+                dX = merge_backward(S, spec[0], spec[1], Pl, dX, ctx.fp8)
         if ctx.ddp is not None:
             ctx.ddp.allreduce_(arena.flat, arena.n_real)      # one collective for every trainable gradient of the step
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)

@@ -1,0 +1,111 @@
+"""-m gpu: the fp8 frozen-weight path at model level (BASELINE config 5).  The reference has no fp8 path: the criterion is
+BASELINE.json's max-abs logit deviation against the REFERENCE's fp32 logits, measured on the full-depth Swin-L fixture at the
+reference's initialisation scale (the backbone geometry of the AVQA model), next to the bf16 path's deviation on the same fixture;
+plus the AVQA model (backbone + QA head) with fp8 on against its reference golden, and a training loop that still converges."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import build_state, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(line):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/fp8_parity_report.txt", "a") as f:
+        f.write(line + "\n")
+    print(line)
+
+
+@pytest.mark.parametrize("case", ["swin_l_fusion_refinit", "swin_b_fusion_refinit"])
+def test_fp8_logit_deviation_on_refinit_models(stg, gpu, case):
+    from stgcma import fp8, recipe
+    from stgcma.model import Swin_AVE as S
+    from params import refinit_state, seeded_tensor
+    z, cfg, shapes, names = load_case(case)
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=refinit_state)
+    m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
+                                        embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"], window_size=7,
+                                        pretrained=None, ftmode=cfg["mode"], adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    sd = m.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point() and not k.endswith("attn_mask"):
+            sd[k] = P[k]
+    m.load_state_dict(sd, strict=True)
+    del P
+    m = m.to(gpu)
+    recipe.apply_freeze(m)
+    B, T = cfg["B"], cfg["num_frames"]
+    a = seeded_tensor((B, T, 224, 224), cfg["seed"] + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2).to(gpu)
+    tgt = torch.softmax(seeded_tensor((B * T, cfg["label_dim"]), cfg["seed"] + 3, 2.0), -1).to(gpu)
+    ref = torch.as_tensor(z["logits"])
+    ref_norms = np.asarray(z["grad_norms"])
+    res = {}
+    for tag, on in (("bf16", False), ("fp8", True)):
+        fp8.enable(m, on)
+        m.zero_grad(set_to_none=True)
+        logits = m(a, v, "fusion")
+        torch.nn.CrossEntropyLoss()(logits, tgt).backward()
+        err = float((logits.detach().cpu() - ref).abs().max())
+        d = dict(m.named_parameters())
+        norms = np.array([float(d[n].grad.float().norm()) for n in names])
+        live = ref_norms > 1e-3 * ref_norms.max()
+        gdev = float(np.abs(norms[live] / ref_norms[live] - 1).max())
+        gl2 = float(np.linalg.norm(norms[live] - ref_norms[live]) / np.linalg.norm(ref_norms[live]))
+        res[tag] = (err, gdev, gl2)
+        _report(f"{case} {tag}: max-abs logit deviation {err:.3e} (max |logit| {float(ref.abs().max()):.3g}); per-tensor gradient norms: "
+                f"worst deviation {gdev:.3e}, relL2 of the norm vector {gl2:.3e}")
+    assert res["bf16"][0] <= 1e-2
+    # e4m3 operands: measured, recorded, and bounded so that a broken kernel cannot pass (3 mantissa bits: ~3 % per GEMM)
+    assert res["fp8"][0] <= 5e-2 * max(1.0, float(ref.abs().max())), f"fp8 logit deviation {res['fp8'][0]:.3e}"
+    assert res["fp8"][2] <= 2.5e-1, f"fp8 gradient-norm vector relL2 {res['fp8'][2]:.3e}"
+
+
+def test_fp8_avqa_full_model_and_training(stg, gpu):
+    """AVQA model (three backbone streams + QA head) with the fp8 path on: outputs against the reference golden, then the AVQA
+    loop's loss goes down on a repeated batch (train mode, dropouts / DropPath active)."""
+    from stgcma import fp8, recipe
+    from stgcma.model import Swin_AVQAModel_V1 as Q
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avqa_full_tiny")
+    m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"], depths=cfg["depths"],
+                                         num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    sd = m.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point() and not k.endswith("attn_mask"):
+            sd[k] = P[k]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(gpu)
+    recipe.apply_freeze(m)
+    fp8.enable(m)
+    B, T, seed = cfg["B"], cfg["num_frames"], cfg["seed"]
+    a = seeded_tensor((B, T, 224, 224), seed + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, T, 3, 224, 224), seed + 2).to(gpu)
+    vn = seeded_tensor((B, T, 3, 224, 224), seed + 3).to(gpu)
+    question = torch.as_tensor(z["question"]).to(gpu)
+    outs = m(a, v, vn, question, "fusion")
+    for got, key in zip(outs, ("out_qa", "out_match_posi", "out_match_nega")):
+        ref = torch.as_tensor(np.asarray(z[key])).float()
+        e = float((got.detach().float().cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+        _report(f"avqa_full_tiny fp8 {key}: max err / scale {e:.3e}")
+        # a seeded O(1)-gain model: e4m3 noise through 8 blocks + the head.  The match logits are near-cancelling pairs (|.| <= 0.1,
+        # already 4 % off in a bf16 emulation of the head alone, test_avqa_head_gpu.py): reported, bounded only against garbage
+        assert e <= (2e-1 if key == "out_qa" else 1.0), f"{key}: {e:.3e}"
+    m.train()
+    opt = recipe.build_optimizer(m, lr=3e-4)
+    label = torch.tensor([3, 17]).to(gpu)
+    match_label = torch.tensor([1, 0] * (B * T)).to(gpu)
+    ce = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(6):
+        out_qa, mp, mn = m(a, v, vn, question, "fusion")
+        loss = ce(out_qa, label) + 0.5 * ce(torch.stack((mp, mn), dim=1).reshape(-1, 2), match_label)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
