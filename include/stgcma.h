@@ -25,10 +25,10 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 201
+#define STG_VERSION 202
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
-enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2 };
+enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
 
 int stg_version(void);
 const char* stg_last_error(void);
@@ -86,6 +86,12 @@ typedef struct {
      * Not combinable with conv_H > 0 or batch > 1. */
     int ab_dtype;
     const void* a_scale; const void* w_scale;
+    /* dact_dtype: storage of the saved activation derivative, both as output (`dact`) and as input (`dact_src`): STG_BF16 (or 0), or
+     * STG_U8_LIN -- one byte per element, code = round((act'(t) + 0.14) * 200) (GELU' and QuickGELU' lie in [-0.13, 1.13]; step
+     * 0.005, |error| <= 0.0025, the size of a bf16 rounding at 1).  Halves the bytes of the widest tensor of the step, the
+     * [rows, 4C] MLP hidden derivative (Swin_AVE.py:119-126 fc1 -> GELU; its backward reads it once).  ldp / ldd are then in bytes
+     * (multiples of 8).  Needs the row-layout epilogue, alpha == 1, no row_scale, bf16 C, and -- as input -- no activation / residual. */
+    int dact_dtype;
     /* out: which kernel the dispatch chose (STG_GEMM_KERNEL_*), for profilers that attribute time per kernel */
     int kernel_chosen;
 } stg_gemm_args;

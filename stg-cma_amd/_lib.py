@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so")   # env: an alternative build (kernel A/B runs)
 
-STG_F32, STG_BF16, STG_FP8_MX = 0, 1, 2
+STG_F32, STG_BF16, STG_FP8_MX, STG_U8_LIN = 0, 1, 2, 3
 (GEMM_KERNEL_REG, GEMM_KERNEL_GLDS, GEMM_KERNEL_BIG, GEMM_KERNEL_8PH, GEMM_KERNEL_GLDS_CONV, GEMM_KERNEL_GLDS_BATCH, GEMM_KERNEL_GLDS_KTAIL,
  GEMM_KERNEL_FP8) = range(8)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("conv_zero", c_vp),
         ("batch", C.c_int), ("a_bstride", c_i64), ("w_bstride", c_i64), ("c_bstride", c_i64),
         ("ab_dtype", C.c_int), ("a_scale", c_vp), ("w_scale", c_vp),
+        ("dact_dtype", C.c_int),
         ("kernel_chosen", C.c_int),
     ]
 
@@ -185,7 +186,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 201
+ABI_VERSION = 202
 _lib = None
 
 
@@ -212,7 +213,7 @@ def lib():
     _lib = handle
     # A/B knobs of tools/ (never set in production): forwarded ONCE from the environment to the library's explicit options
     for env, opt in (("STG_GEMM_EPI", "gemm_epi"), ("STG_GEMM_KTAIL", "gemm_ktail"), ("STG_GEMM_BIG", "gemm_big"),
-                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn")):
+                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn"), ("STG_WINATTN_BWD_OCC", "winattn_bwd_occ")):
         if env in os.environ:
             check(handle.stg_set_option(opt.encode(), int(os.environ[env])), f"stg_set_option({opt})")
     return _lib

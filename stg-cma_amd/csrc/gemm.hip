@@ -36,7 +36,7 @@ struct GemmParams {
     const float* bias;
     float alpha;
     int act;
-    bf16_t* dact; int64_t ldp;
+    bf16_t* dact; int64_t ldp;                // EV_*8 variants: uint8 codes, ldp / ldd in bytes
     const bf16_t* dact_src; int64_t ldd;
     const float* row_scale; int64_t rs_outer; int64_t rs_inner;
     const void* res1; int64_t ldr1; int res1_f32;
@@ -141,15 +141,34 @@ __device__ __forceinline__ uint4 pack_row8(const float* t) {
 // (spills at the 128-VGPR budget of 4 waves / SIMD) -- measured 555 us vs 369 us for the plain store of a
 // 125440 x 2048 x 512 GEMM.  The variants are the signatures that carry the training step (tools/step_gemm_shapes.py);
 // anything else takes EV_GENERIC, which keeps every test at run time.  Partial tiles are predicated, not branched.
-enum { EV_GENERIC = 0, EV_PLAIN, EV_GELU, EV_QGELU, EV_DSRC, EV_R16, EV_BRQ };
+enum { EV_GENERIC = 0, EV_PLAIN, EV_GELU, EV_QGELU, EV_DSRC, EV_R16, EV_BRQ, EV_GELU8, EV_QGELU8, EV_DSRC8 };   // *8: 8-bit saved derivative
+
+// saved-derivative byte code (STG_U8_LIN): code = round((d + 0.14) * 200), d = code * 0.005 - 0.14
+__device__ __forceinline__ uint2 pack_d8(const float* d) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        lo = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d[j], 200.f, 28.f), j, lo);          // v_cvt_pk_u8_f32: round to nearest, saturate to 0..255
+        hi = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d[4 + j], 200.f, 28.f), j, hi);
+    }
+    return make_uint2(lo, hi);
+}
+__device__ __forceinline__ void unpack_d8(const uint2 q, float* v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = fmaf((float)((q.x >> (8 * j)) & 0xffu), 0.005f, -0.14f);
+        v[4 + j] = fmaf((float)((q.y >> (8 * j)) & 0xffu), 0.005f, -0.14f);
+    }
+}
 
 template <int V>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
                                                    int lane, float* stg, int ngap = 0) {
     constexpr bool G = V == EV_GENERIC;
     const bool alpha_on = G ? p.alpha != 1.0f : false;
-    const int act = G ? p.act : (V == EV_GELU ? (int)STG_ACT_GELU : V == EV_QGELU ? (int)STG_ACT_QUICKGELU : (int)STG_ACT_NONE);
-    const bool dsrc_on = G ? p.dact_src != nullptr : V == EV_DSRC;
+    constexpr bool D8 = V == EV_GELU8 || V == EV_QGELU8 || V == EV_DSRC8;     // 8-bit saved derivative (byte leading dimensions)
+    const int act = G ? p.act : ((V == EV_GELU || V == EV_GELU8) ? (int)STG_ACT_GELU : (V == EV_QGELU || V == EV_QGELU8) ? (int)STG_ACT_QUICKGELU : (int)STG_ACT_NONE);
+    const bool dsrc_on = G ? p.dact_src != nullptr : (V == EV_DSRC || V == EV_DSRC8);
     const bool rs_on = G ? p.row_scale != nullptr : false;
     const bool r1_on = G ? p.res1 != nullptr : (V == EV_R16 || V == EV_BRQ);
     const int r1_f32 = G ? p.res1_f32 : 0;
@@ -186,7 +205,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
             const bool ok = m < p.M && col_ok;
             m = m < p.M ? m : p.M - 1;
             Row8 qd, q1, q2;
-            if (dsrc_on) qd = ld_row8(p.dact_src, 0, m * p.ldd + n);
+            uint2 qd8 = make_uint2(0u, 0u);
+            if (D8 && dsrc_on) qd8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.dact_src) + m * p.ldd + n);
+            else if (dsrc_on) qd = ld_row8(p.dact_src, 0, m * p.ldd + n);
             if (r1_on) q1 = ld_row8(p.res1, r1_f32, m * p.ldr1 + n);
             if (r2_on) q2 = ld_row8(p.res2, r2_f32, m * p.ldr2 + n);
             const float* src = stg + row * 64;
@@ -206,16 +227,19 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
                 float d[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) gelu_fast(t[j], t[j], d[j]);
-                if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
+                if (D8) { if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(p.dact) + m * p.ldp + n) = pack_d8(d); }
+                else if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
             } else if (act == STG_ACT_QUICKGELU) {
                 float d[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) quick_gelu_fast(t[j], t[j], d[j]);
-                if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
+                if (D8) { if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(p.dact) + m * p.ldp + n) = pack_d8(d); }
+                else if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
             }
             float v[8];
             if (dsrc_on) {
-                row8_to_f32(qd, 0, v);
+                if (D8) unpack_d8(qd8, v);
+                else row8_to_f32(qd, 0, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t[j] *= v[j];
             }
@@ -258,6 +282,9 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, cons
         case EV_DSRC: gemm_epilogue_rows<EV_DSRC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         case EV_R16: gemm_epilogue_rows<EV_R16>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         case EV_BRQ: gemm_epilogue_rows<EV_BRQ>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_GELU8: gemm_epilogue_rows<EV_GELU8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_QGELU8: gemm_epilogue_rows<EV_QGELU8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        case EV_DSRC8: gemm_epilogue_rows<EV_DSRC8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         case EV_GENERIC: gemm_epilogue_rows<EV_GENERIC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
         default: gemm_epilogue_elems(p, accs, m0, n0, wm, wn, lane & 15, lane >> 4); break;     // unaligned / N % 8 != 0
     }
@@ -1240,8 +1267,10 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         return ptr == nullptr || ((((uintptr_t)ptr) % need) == 0 && (ld * bytes_per) % need == 0);
     };
     p.vec_ok = 0;
+    const bool d8 = a->dact_dtype == STG_U8_LIN;
+    STG_CHECK(d8 || a->dact_dtype == 0 || a->dact_dtype == STG_BF16, -3, "stg_gemm_nt: unsupported dact_dtype %d", a->dact_dtype);
     const bool vec8 = a->N % 8 == 0 && al(a->C, a->ldc, p.c_f32 ? 4 : 2, 16) && al(a->bias, 4, 4, 16) &&
-                      al(a->dact, a->ldp, 2, 16) && al(a->dact_src, a->ldd, 2, 16) &&
+                      al(a->dact, a->ldp, d8 ? 1 : 2, d8 ? 8 : 16) && al(a->dact_src, a->ldd, d8 ? 1 : 2, d8 ? 8 : 16) &&
                       al(a->res1, a->ldr1, p.res1_f32 ? 4 : 2, 16) && al(a->res2, a->ldr2, p.res2_f32 ? 4 : 2, 16);
     p.epi_variant = -1;
     if (vec8) {
@@ -1255,7 +1284,16 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
             else if (p.c_f32 && !a->act && !a->dact_src && r1b && r2q) p.epi_variant = EV_BRQ;
         }
         if (stg_opt_gemm_epi.load(std::memory_order_relaxed) == 0) p.epi_variant = EV_GENERIC;   // A/B knob: every option a run-time test
+        if (d8 && (a->dact || a->dact_src)) {              // the 8-bit derivative exists in its dedicated variants only
+            const int v0 = p.epi_variant;
+            const bool out8 = a->dact && !a->dact_src && (a->alpha == 1.0f && !a->row_scale && !p.c_f32 && !a->res1 && !a->res2) && a->act != STG_ACT_NONE;
+            const bool in8 = a->dact_src && !a->dact && (a->alpha == 1.0f && !a->row_scale && !p.c_f32 && !a->res1 && !a->res2) && a->act == STG_ACT_NONE;
+            (void)v0;
+            STG_CHECK(out8 || in8, -3, "stg_gemm_nt: the 8-bit derivative needs a plain GELU / QuickGELU (+ bias) output or a plain derivative-source epilogue");
+            p.epi_variant = out8 ? (a->act == STG_ACT_GELU ? EV_GELU8 : EV_QGELU8) : EV_DSRC8;
+        }
     }
+    STG_CHECK(!(d8 && (a->dact || a->dact_src)) || vec8, -2, "stg_gemm_nt: the 8-bit derivative needs the row-layout epilogue (N %% 8 == 0, aligned operands)");
     if (fp8) {
         STG_CHECK(p.epi_variant >= 0, -2, "stg_gemm_nt: fp8 operands need the row-layout epilogue (N %% 8 == 0, 16-byte aligned outputs)");
         Fp8Scales e;
@@ -1277,7 +1315,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
-    const bool ph8_wide = a->K >= 512 && a->N >= 1536 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU);
+    const bool ph8_wide = a->K >= 512 && a->N >= 1536 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;

@@ -189,7 +189,10 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward (dQ, dK, dV)
-__global__ void __launch_bounds__(256, 2) winattn_bwd_kernel(WinP a) {
+// WPS = waves per SIMD the register allocation is held to: 2 (174 VGPRs, no spills) or 3 (<= 168: 12 spilled VGPRs, but the loads of one
+// problem hide behind two others; 3 x 51 KB of LDS still fit) -- option "winattn_bwd_occ"
+template <int WPS>
+__global__ void __launch_bounds__(256, WPS) winattn_bwd_kernel(WinP a) {
     // per wave: K tile, Q tile, dO tile ([64][32] bf16 each) + lse[64] + delta[64]
     constexpr int PER_WAVE = 3 * 64 * WD + 256;     // in bf16 units (2 * 64 floats = 256 bf16 slots)
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
@@ -397,7 +400,8 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    hipLaunchKernelGGL(winattn_bwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -156,11 +156,17 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     if want_dact:
         if act == ACT_NONE:
             raise RuntimeError("gemm_nt: want_dact needs an activation")
-        pre = torch.empty((M, N), dtype=BF16, device=dev)
+        d8 = want_dact == "u8"                              # 8-bit linear code of the derivative (STG_U8_LIN), else bf16
+        pre = torch.empty((M, N), dtype=torch.uint8 if d8 else BF16, device=dev)
         a.dact, a.ldp = _p(pre), _ld(pre)
+        a.dact_dtype = _lib.STG_U8_LIN if d8 else STG_BF16
     if dact_src is not None:
-        _chk2d(dact_src, "dact_src", BF16, cols=N, rows=M)
+        d8 = dact_src.dtype == torch.uint8
+        _chk2d(dact_src, "dact_src", torch.uint8 if d8 else BF16, cols=N, rows=M)
+        if want_dact and d8 != (want_dact == "u8"):
+            raise RuntimeError("gemm_nt: dact and dact_src must share one storage type")
         a.dact_src, a.ldd = _p(dact_src), _ld(dact_src)
+        a.dact_dtype = _lib.STG_U8_LIN if d8 else STG_BF16
     if row_scale is not None:
         if not row_scale.is_cuda or row_scale.dtype != F32 or not row_scale.is_contiguous():
             raise RuntimeError("row_scale: expected contiguous fp32 GPU tensor")
@@ -184,7 +190,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     if prof is not None and conv is None and M > 0:
         # per-class accounting for bench.py: class = (kernel the C dispatch chose, N, K, epilogue signature).  The kernel of a call
         # signature is learnt from stg_gemm_nt's `kernel_chosen` on its first launch (no host-side copy of the dispatch rules).
-        epi = ("b" if bias is not None else "") + ("a" if act else "") + ("p" if want_dact else "") + ("d" if dact_src is not None else "") + \
+        epi = ("b" if bias is not None else "") + ("a" if act else "") + (("p8" if want_dact == "u8" else "p") if want_dact else "") + \
+              ("" if dact_src is None else ("d8" if dact_src.dtype == torch.uint8 else "d")) + \
               ("" if res1 is None else ("r" if res1.dtype == BF16 else "q")) + ("" if res2 is None else ("R" if res2.dtype == BF16 else "Q")) + \
               ("s" if row_scale is not None else "") + ("A" if alpha != 1.0 else "") + ("" if out.dtype == BF16 else "F")
         sig = (M, N, K, epi, fp8)
@@ -195,8 +202,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             if pc is None:
                 pc = prof["classes"][ck] = {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}
             esz = 1.0 if fp8 else 2.0
-            nbytes = esz * M * K + esz * N * K + M * N * out.element_size() + (2.0 * M * N if want_dact else 0.0) + \
-                (2.0 * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
+            nbytes = esz * M * K + esz * N * K + M * N * out.element_size() + (pre.element_size() * M * N if want_dact else 0.0) + \
+                (dact_src.element_size() * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
                 (M * N * res2.element_size() if res2 is not None else 0.0)          # algorithmic HBM bytes: every operand / output once
             pc["launches"] += 1
             pc["flops"] += 2.0 * M * N * K

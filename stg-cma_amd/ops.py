@@ -22,6 +22,8 @@ from .kernels import ACT_GELU, ACT_NONE, BF16, F32
 
 import os as _os
 USE_UPLN = _os.environ.get("STG_UPLN", "1") != "0"     # fused up-projection + residual + LayerNorm (csrc/upln.hip)
+# the MLP hidden's saved GELU derivative ([rows, 4C], the widest tensor of the step) as one byte per element (STG_U8_LIN) instead of bf16
+MLP_DACT = "u8" if _os.environ.get("STG_MLP_DACT", "u8").lower() == "u8" else True
 RESIDUAL_DTYPE = BF16 if _os.environ.get("STG_RESIDUAL", "fp32").lower() == "bf16" else F32   # fp32 default; bf16 = A/B knob
 
 # ------------------------------------------------------------------------------------------------ weight shadows
@@ -610,7 +612,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     Y, mean, rstd = ln2.triple() if ln2 is not None else \
         K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
     del ln2
-    Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=True)
+    Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=MLP_DACT)
     M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8)
     del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]

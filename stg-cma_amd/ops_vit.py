@@ -172,7 +172,7 @@ def vit_block_forward(X, spec, P, training, save, pre=None, nxt=None):
     Y, mean, rstd = ln2.triple() if ln2 is not None else \
         K.layernorm_fwd(X2, f32c(P["ln_2.weight"]), f32c(P["ln_2.bias"]), want_stats=save)
     del ln2
-    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.c_fc.weight"]), f32c(P["mlp.c_fc.bias"]), act=ACT_QUICKGELU, want_dact=True)
+    Hm, Zm = K.gemm_nt(Y, shadow(P["mlp.c_fc.weight"]), f32c(P["mlp.c_fc.bias"]), act=ACT_QUICKGELU, want_dact=_ops.MLP_DACT)
     del Y
     M = K.gemm_nt(Hm, shadow(P["mlp.c_proj.weight"]), f32c(P["mlp.c_proj.bias"]))
     del Hm

@@ -5,6 +5,8 @@ result; tests use |err| <= 1e-2 * max(1, |ref|) (the north-star's bf16 tolerance
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -425,3 +427,36 @@ def test_gemm_batched(stg, gpu, nb, M, N, K):
     got = k.gemm_nt(A.to(gpu), W.to(gpu), alpha=0.2, batch=nb)
     ref = 0.2 * torch.einsum("bmk,bnk->bmn", A.float().view(nb, M, K), W.float()).reshape(nb * M, N)
     _close(got, ref, what="batched gemm")
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 512, 128, "gelu"), (8192, 2048, 512, "gelu"), (1000, 3072, 768, "qgelu")])
+def test_gemm_u8_saved_derivative(stg, gpu, M, N, K, act):
+    """The 8-bit linear code of the saved activation derivative (STG_U8_LIN: the [rows, 4C] MLP tensor, Swin_AVE.py:119-126): the
+    activation output is BIT-identical to the bf16-derivative variant's, the decoded derivative is within half a code step (0.0025)
+    of act'(t), and the backward epilogue (dact_src = the codes) equals the product with the decoded values."""
+    from stgcma import kernels as Kn
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(BF16).to(gpu)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF16).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    a = Kn.ACT_GELU if act == "gelu" else Kn.ACT_QUICKGELU
+    h16, d16 = Kn.gemm_nt(A, W, b, act=a, want_dact=True)
+    h8, d8 = Kn.gemm_nt(A, W, b, act=a, want_dact="u8")
+    assert d8.dtype == torch.uint8 and tuple(d8.shape) == (M, N)
+    assert torch.equal(h16, h8)
+    t = (A.float() @ W.float().t() + b).double()
+    if act == "gelu":
+        dref = 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * np.pi) ** 0.5
+    else:
+        sg = torch.sigmoid(1.702 * t)
+        dref = sg * (1 + 1.702 * t * (1 - sg))
+    dec = d8.double() * 0.005 - 0.14
+    assert float((dec - dref).abs().max()) <= 0.0025 + 2e-3          # half a code step + the bf16 operands' effect on t
+    assert float((dec - d16.double()).abs().max()) <= 0.0025 + 0.0045   # vs the bf16 derivative (its own rounding: 2^-8 at 1)
+    dM = torch.randn(M, K, generator=g).to(BF16).to(gpu)              # backward: dZ = (dM . W2^T) * act'  with W2^T := W (shape [N, K])
+    z16 = Kn.gemm_nt(dM, W, dact_src=d16)
+    z8 = Kn.gemm_nt(dM, W, dact_src=d8)
+    ref8 = (dM.float() @ W.float().t()).double() * dec
+    scale = float(ref8.abs().max())
+    assert float((z8.double() - ref8).abs().max()) <= 6e-3 * scale    # bf16 rounding of the stored product
+    assert float((z8.float() - z16.float()).norm() / z16.float().norm()) <= 6e-3
