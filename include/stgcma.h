@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 202
+#define STG_VERSION 203
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -127,6 +127,17 @@ int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int64_t ldx,
                     float* dW, int64_t lddw, float* db, int64_t M, int N1, int N2,
                     const float* row_scale, int64_t rs_outer, int64_t rs_inner,
                     float* ws, int64_t ws_floats, void* stream);
+/* n <= 16 such weight gradients in ONE pair of launches (the 8 / 12 adapter Linears of a Swin block, Swin_AVE.py:747-811: 64 MB
+ * streams that are launch-ramp bound on their own).  Every problem must be eligible for the workspace path and share one launch
+ * plan -- same M, same narrow width class (N rounded up to 16) and wide width -- else -7 is returned and nothing is launched
+ * (the caller then issues them one by one); the dW buffers must be distinct.  ws: n * stg_wgrad_ws_floats(M, N1, N2) floats. */
+typedef struct {
+    const void* dY; int64_t lddy; const void* X; int64_t ldx;
+    float* dW; int64_t lddw; float* db;
+    int64_t M; int N1; int N2;
+    const float* row_scale; int64_t rs_outer; int64_t rs_inner;
+} stg_wgrad_desc;
+int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* problems, int n, float* ws, int64_t ws_floats, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm; Swin_AVE.py:341,352 norm1/norm2, :960,976 PatchMerging.norm,

@@ -43,6 +43,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("dY", c_vp), ("lddy", c_i64), ("X", c_vp), ("ldx", c_i64), ("dW", c_vp), ("lddw", c_i64), ("db", c_vp),
+                ("M", c_i64), ("N1", C.c_int), ("N2", C.c_int), ("row_scale", c_vp), ("rs_outer", c_i64), ("rs_inner", c_i64)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", c_vp), ("ldq", c_i64),
@@ -125,6 +130,7 @@ SIGNATURES = {
     "stg_wgrad_ws_floats": (c_i64, [c_i64, C.c_int, C.c_int]),
     "stg_wgrad_tn_ws": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp, c_i64, c_i64,
                                   c_vp, c_i64, c_vp]),
+    "stg_wgrad_tn_ws_multi": (C.c_int, [C.POINTER(WgradDesc), C.c_int, c_vp, c_i64, c_vp]),
     "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, C.c_int, c_i64, c_vp, c_vp,
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_layernorm_bwd": (C.c_int, [c_vp, c_i64, c_vp, C.c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
@@ -186,7 +192,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 202
+ABI_VERSION = 203
 _lib = None
 
 

@@ -66,9 +66,15 @@ __device__ __forceinline__ void scale8(uint4& v, float rs) {
     v.w = pack_bf2(__uint_as_float(v.w << 16) * rs, __uint_as_float(v.w & 0xffff0000u) * rs);
 }
 
+// Up to WMAX problems of one plan (same NT1, column groups and row splits) per launch, blockIdx.z = problem: the twelve adapter
+// weight gradients of a Swin block are 64 MB streams of 25 us each on their own -- launch ramp and tail, not bandwidth.
+constexpr int WMAX = 16;
+struct WgMulti { Wg2 p[WMAX]; };
+
 // accumulators per lane: NT1 * 8 product tiles + 8 bias tiles (bias_on == 1 uses the first NT1), each f32x4
 template <int NT1>
-__global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(Wg2 p) {   // 48 / 64 wide: 160+ accumulator registers, one wave per SIMD
+__global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMulti pm) {   // 48 / 64 wide: 160+ accumulator registers, one wave per SIMD
+    const Wg2 p = pm.p[blockIdx.z];
     constexpr int TA = 16 * NT1;
     constexpr int NACC = NT1 * NTB + NTB;
     constexpr int CHA = NT1 > 4 ? 8 : (NT1 == 3 ? 4 : NT1);        // A-tile row pitch in 32-byte chunks (a power of two)
@@ -205,11 +211,13 @@ struct Wr2 {
     float* db; int bias_on;
     int NA, NB;
 };
+struct WrMulti { Wr2 p[WMAX]; };
 
 // Sum of the S partial tiles.  A block owns 16 consecutive float4 "quads" of the raw (lane-major) tile of column group cg;
 // its 16 row-split groups stride over S with independent 16-byte loads, fold through LDS, and 16 threads scatter the 64 sums:
 // raw element e = (tile * 64 + lane) * 4 + r  <->  D[16 ia + 4 (lane >> 4) + r][16 j + (lane & 15)].
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(Wr2 p) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WrMulti pm) {
+    const Wr2 p = pm.p[blockIdx.z];
     __shared__ float4 part[16][16];
     const int nacc = p.nt1 * NTB + NTB;
     const int per_cg = nacc * 256;
@@ -295,6 +303,40 @@ extern "C" int64_t stg_wgrad_ws_floats(int64_t M, int N1, int N2) {
     return pl.ok ? pl.ws_floats : 0;
 }
 
+namespace {
+
+void fill_problem(const Plan& pl, const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, float* db,
+                  int64_t M, int N1, int N2, const float* row_scale, int64_t rs_outer, int64_t rs_inner, float* ws, Wg2& p, Wr2& r) {
+    const bool yn = pl.y_narrow;
+    p.A = (const bf16_t*)(yn ? dY : X); p.lda = yn ? lddy : ldx; p.NA = yn ? N1 : N2;
+    p.B = (const bf16_t*)(yn ? X : dY); p.ldb = yn ? ldx : lddy; p.NB = yn ? N2 : N1;
+    p.ws = ws;
+    p.bias_on = db ? (yn ? 1 : 2) : 0;
+    p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
+    p.scale_on = yn ? 1 : 2;
+    p.M = M; p.rows_per_block = pl.rows_per_block; p.ncg = pl.ncg;
+    r.ws = ws; r.S = pl.S; r.ncg = pl.ncg; r.nt1 = pl.nt1;
+    r.dW = dW; r.lddw = lddw; r.transpose_out = yn ? 0 : 1;
+    r.db = db; r.bias_on = p.bias_on; r.NA = p.NA; r.NB = p.NB;
+}
+
+int launch_multi(const Plan& pl, const WgMulti& pm, const WrMulti& rm, int n, hipStream_t st) {
+    const dim3 grid(pl.ncg, pl.S, n);
+    if (pl.nt1 == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(256), 0, st, pm);
+    else if (pl.nt1 == 2) hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(256), 0, st, pm);
+    else if (pl.nt1 == 3) hipLaunchKernelGGL(wgrad_ws_kernel<3>, grid, dim3(256), 0, st, pm);
+    else if (pl.nt1 == 4) hipLaunchKernelGGL(wgrad_ws_kernel<4>, grid, dim3(256), 0, st, pm);
+    else if (pl.nt1 == 5) hipLaunchKernelGGL(wgrad_ws_kernel<5>, grid, dim3(256), 0, st, pm);
+    else hipLaunchKernelGGL(wgrad_ws_kernel<6>, grid, dim3(256), 0, st, pm);
+    STG_LAUNCH_CHECK();
+    const int per_cg = (pl.nt1 * NTB + NTB) * 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(per_cg / 64, pl.ncg, n), dim3(256), 0, st, rm);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, float* db,
                                int64_t M, int N1, int N2, const float* row_scale, int64_t rs_outer, int64_t rs_inner,
                                float* ws, int64_t ws_floats, void* stream) {
@@ -307,29 +349,30 @@ extern "C" int stg_wgrad_tn_ws(const void* dY, int64_t lddy, const void* X, int6
     if (!pl.ok || ws == nullptr || ws_floats < pl.ws_floats)          // shapes outside this path: the atomic kernels
         return stg_wgrad_tn(dY, lddy, X, ldx, dW, lddw, db, M, N1, N2, row_scale, rs_outer, rs_inner, stream);
     STG_CHECK((((uintptr_t)ws) & 15) == 0, -2, "stg_wgrad_tn_ws: workspace must be 16-byte aligned");
-    Wg2 p;
-    const bool yn = pl.y_narrow;
-    p.A = (const bf16_t*)(yn ? dY : X); p.lda = yn ? lddy : ldx; p.NA = yn ? N1 : N2;
-    p.B = (const bf16_t*)(yn ? X : dY); p.ldb = yn ? ldx : lddy; p.NB = yn ? N2 : N1;
-    p.ws = ws;
-    p.bias_on = db ? (yn ? 1 : 2) : 0;
-    p.row_scale = row_scale; p.rs_outer = row_scale ? rs_outer : 1; p.rs_inner = row_scale ? rs_inner : 1;
-    p.scale_on = yn ? 1 : 2;
-    p.M = M; p.rows_per_block = pl.rows_per_block; p.ncg = pl.ncg;
-    const dim3 grid(pl.ncg, pl.S);
-    if (pl.nt1 == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (pl.nt1 == 2) hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (pl.nt1 == 3) hipLaunchKernelGGL(wgrad_ws_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (pl.nt1 == 4) hipLaunchKernelGGL(wgrad_ws_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (pl.nt1 == 5) hipLaunchKernelGGL(wgrad_ws_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wgrad_ws_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    STG_LAUNCH_CHECK();
-    Wr2 r;
-    r.ws = ws; r.S = pl.S; r.ncg = pl.ncg; r.nt1 = pl.nt1;
-    r.dW = dW; r.lddw = lddw; r.transpose_out = yn ? 0 : 1;
-    r.db = db; r.bias_on = p.bias_on; r.NA = p.NA; r.NB = p.NB;
-    const int per_cg = (pl.nt1 * NTB + NTB) * 256;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(per_cg / 64, pl.ncg), dim3(256), 0, (hipStream_t)stream, r);
-    STG_LAUNCH_CHECK();
-    return 0;
+    WgMulti pm; WrMulti rm;
+    fill_problem(pl, dY, lddy, X, ldx, dW, lddw, db, M, N1, N2, row_scale, rs_outer, rs_inner, ws, pm.p[0], rm.p[0]);
+    return launch_multi(pl, pm, rm, 1, (hipStream_t)stream);
+}
+
+extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, int64_t ws_floats, void* stream) {
+    STG_CHECK(d && n >= 1 && n <= WMAX, -1, "stg_wgrad_tn_ws_multi: 1..%d problems", WMAX);
+    STG_CHECK(ws && (((uintptr_t)ws) & 15) == 0, -2, "stg_wgrad_tn_ws_multi: needs a 16-byte aligned workspace");
+    WgMulti pm; WrMulti rm;
+    Plan pl0 = {};
+    for (int i = 0; i < n; ++i) {
+        const stg_wgrad_desc& q = d[i];
+        STG_CHECK(q.dY && q.X && q.dW && q.M > 0 && q.N1 > 0 && q.N2 > 0 && q.lddy >= q.N1 && q.ldx >= q.N2 && q.lddw >= q.N2, -2,
+                  "stg_wgrad_tn_ws_multi: bad problem %d", i);
+        if (q.row_scale) STG_CHECK(q.rs_outer > 0 && q.rs_inner > 0, -2, "stg_wgrad_tn_ws_multi: bad row_scale params");
+        const Plan pl = plan_for(q.M, q.N1, q.N2, q.lddy, q.ldx, q.dY, q.X);
+        STG_CHECK(pl.ok, -7, "stg_wgrad_tn_ws_multi: problem %d is not eligible for the workspace path", i);
+        if (i == 0) pl0 = pl;
+        STG_CHECK(pl.nt1 == pl0.nt1 && pl.ncg == pl0.ncg && pl.S == pl0.S && pl.rows_per_block == pl0.rows_per_block, -7,
+                  "stg_wgrad_tn_ws_multi: problem %d has a different launch plan than problem 0", i);
+        for (int j = 0; j < i; ++j) STG_CHECK(d[j].dW != q.dW, -2, "stg_wgrad_tn_ws_multi: problems %d and %d share dW", j, i);
+        fill_problem(pl, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, q.M, q.N1, q.N2, q.row_scale, q.rs_outer, q.rs_inner,
+                     ws + (int64_t)i * pl.ws_floats, pm.p[i], rm.p[i]);
+    }
+    STG_CHECK(ws_floats >= (int64_t)n * pl0.ws_floats, -2, "stg_wgrad_tn_ws_multi: workspace too small");
+    return launch_multi(pl0, pm, rm, n, (hipStream_t)stream);
 }

@@ -285,6 +285,7 @@ def bmm_tn(A, B, rows):
 _gemm_prof = None
 import os as _os
 USE_WGRAD_WS = _os.environ.get("STG_WGRAD_WS", "1") != "0"    # 0 = atomic wgrad kernels only (A/B knob)
+USE_WGRAD_MULTI = _os.environ.get("STG_WGRAD_MULTI", "1") != "0"   # 0 = one launch pair per adapter Linear (A/B knob)
 
 
 GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GLDS: "gemm_nt_glds_kernel<1, false, false, false>",
@@ -366,6 +367,44 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         return
     _lib.check(L.stg_wgrad_tn(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
                               _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
+
+
+def wgrad_tn_multi(problems):
+    """Several wgrad_tn calls at once: problems = [(dY, X, dW, db, row_scale, rs_outer, rs_inner)].  Problems that share a launch
+    plan of the workspace path (same M, narrow-width class, wide width) go out as ONE pair of launches (stg_wgrad_tn_ws_multi);
+    the rest one by one.  Same results as the individual calls (same kernels, same row splits)."""
+    L = _lib.lib()
+    groups, single = {}, []
+    for pr in problems:
+        dY, X, dW, db, rs, ro, ri = pr
+        M, N1, N2 = dY.shape[0], dY.shape[1], X.shape[1]
+        nws = L.stg_wgrad_ws_floats(M, N1, N2) if (USE_WGRAD_WS and USE_WGRAD_MULTI) else 0
+        if nws > 0 and dW.is_contiguous() and dY.dtype == BF16 and X.dtype == BF16 and X.shape[0] == M and dY.stride(1) == 1 and X.stride(1) == 1 \
+                and tuple(dW.shape) == (N1, N2):
+            groups.setdefault((M, (min(N1, N2) + 15) // 16, max(N1, N2), nws), []).append(pr)
+        else:
+            single.append(pr)
+    for (M, _, _, nws), prs in groups.items():
+        if len(prs) == 1:
+            single.append(prs[0])
+            continue
+        for i0 in range(0, len(prs), 16):
+            chunk = prs[i0:i0 + 16]
+            n = len(chunk)
+            descs = (_lib.WgradDesc * n)()
+            for d, (dY, X, dW, db, rs, ro, ri) in zip(descs, chunk):
+                d.dY, d.lddy, d.X, d.ldx = _p(dY), _ld(dY), _p(X), _ld(X)
+                d.dW, d.lddw, d.db = _p(dW), _ld(dW), _p(db)
+                d.M, d.N1, d.N2 = M, dY.shape[1], X.shape[1]
+                d.row_scale, d.rs_outer, d.rs_inner = _p(rs), int(ro), int(ri)
+            ws = torch.empty((n * nws,), dtype=F32, device=chunk[0][0].device)
+            rc = L.stg_wgrad_tn_ws_multi(descs, n, _p(ws), n * nws, _stream())
+            if rc == -7:                                  # not one plan after all (alignment of a view): one by one
+                single.extend(chunk)
+            else:
+                _lib.check(rc, "stg_wgrad_tn_ws_multi")
+    for dY, X, dW, db, rs, ro, ri in single:
+        wgrad_tn(dY, X, dW, db, row_scale=rs, rs_outer=ro, rs_inner=ri)
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None, out_dtype=BF16):

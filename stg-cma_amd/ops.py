@@ -364,6 +364,13 @@ class _Grads:
     def __init__(self, P, need, prefix="", arena=None):
         self.P, self.need, self.prefix, self.arena = P, need, prefix, arena
         self.g = {}
+        self.pending = []        # deferred weight-gradient problems (operands stay referenced until flush)
+
+    def flush(self):
+        """Issue the deferred adapter weight gradients of a block: one launch pair per launch plan (K.wgrad_tn_multi)."""
+        if self.pending:
+            K.wgrad_tn_multi(self.pending)
+            self.pending = []
 
     def buf(self, name):
         if not self.need.get(self.prefix + name, False):
@@ -402,12 +409,12 @@ def _adapter_wgrad(G, name, dZ, X, dY2, H2, *, rs=None, rs_outer=1, rs_inner=1):
     if w1 is not None or b1 is not None:
         if w1 is None or b1 is None:
             raise NotImplementedError("adapter weight and bias must be frozen/trained together")
-        K.wgrad_tn(dZ, X, w1, b1)
+        G.pending.append((dZ, X, w1, b1, None, 1, 1))
     w2, b2 = G.buf(name + ".D_fc2.weight"), G.buf(name + ".D_fc2.bias")
     if w2 is not None or b2 is not None:
         if w2 is None or b2 is None:
             raise NotImplementedError("adapter weight and bias must be frozen/trained together")
-        K.wgrad_tn(dY2, H2, w2, b2, row_scale=rs, rs_outer=rs_outer, rs_inner=rs_inner)
+        G.pending.append((dY2, H2, w2, b2, rs, rs_outer, rs_inner))
 
 
 def _xattn_geom(spec, BT, dh, window, g):
@@ -764,6 +771,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         dX0, dH_prev = _ln_bwd_join(dY, X0, n1g, mean, rstd, dX1, sl, prev)
     else:
         dX0 = dX1
+    G.flush()
     return dX0, G.g, dH_prev
 
 

@@ -264,6 +264,7 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
     dY = K.gemm_nt(dQKV, wqkv_t)
     del dQKV
     dX0 = K.layernorm_bwd(dY, X0, n1g, mean, rstd, add_to=dX1)
+    G.flush()
     return dX0, G.g
 
 

@@ -460,3 +460,35 @@ def test_gemm_u8_saved_derivative(stg, gpu, M, N, K, act):
     scale = float(ref8.abs().max())
     assert float((z8.double() - ref8).abs().max()) <= 6e-3 * scale    # bf16 rounding of the stored product
     assert float((z8.float() - z16.float()).norm() / z16.float().norm()) <= 6e-3
+
+
+def test_wgrad_multi_matches_single_calls(stg, gpu):
+    """stg_wgrad_tn_ws_multi (the adapter weight gradients of a block in one launch pair) against the same problems issued one by
+    one: bit-identical (same kernels, same row splits), incl. the DropPath row scale and both operand orientations; a problem with a
+    different launch plan is carried out on its own."""
+    from stgcma import kernels as Kn
+    g = torch.Generator().manual_seed(11)
+    M, C_, dh = 8192, 256, 32
+    T, N = 2, 64
+    probs, refs = [], []
+    for i in range(5):
+        narrow_first = i % 2 == 0
+        dY = torch.randn(M, dh if narrow_first else C_, generator=g).to(BF16).to(gpu)
+        X = torch.randn(M, C_ if narrow_first else dh, generator=g).to(BF16).to(gpu)
+        rs = (torch.rand(M // (T * N) * N, generator=g) < 0.7).float().to(gpu) / 0.7 if i == 3 else None
+        shp = (dY.shape[1], X.shape[1])
+        dW = torch.randn(shp, generator=g).to(gpu)
+        db = torch.randn(shp[0], generator=g).to(gpu)
+        dW1, db1 = dW.clone(), db.clone()
+        Kn.wgrad_tn(dY, X, dW1, db1, row_scale=rs, rs_outer=T * N, rs_inner=N)
+        probs.append((dY, X, dW, db, rs, T * N, N))
+        refs.append((dW1, db1))
+    # an odd one out: other M (another launch plan) -- must still come out right
+    dY = torch.randn(4096, dh, generator=g).to(BF16).to(gpu); X = torch.randn(4096, C_, generator=g).to(BF16).to(gpu)
+    dW = torch.zeros(dh, C_, device=gpu); db = torch.zeros(dh, device=gpu)
+    dW1, db1 = dW.clone(), db.clone()
+    Kn.wgrad_tn(dY, X, dW1, db1)
+    probs.append((dY, X, dW, db, None, 1, 1)); refs.append((dW1, db1))
+    Kn.wgrad_tn_multi(probs)
+    for (dY, X, dW, db, *_), (dW1, db1) in zip(probs, refs):
+        assert torch.equal(dW, dW1) and torch.equal(db, db1)
