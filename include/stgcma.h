@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 203
+#define STG_VERSION 204
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -107,6 +107,16 @@ int stg_gemm_nt(stg_gemm_args* args, void* stream);
  *       pad rows / blocks hold 127.  stg_quant_fp8_scale_bytes(rows, K) returns its size. */
 int64_t stg_quant_fp8_scale_bytes(int64_t rows, int K);
 int stg_quant_fp8_mx(const void* X, int64_t ldx, int64_t rows, int K, void* Q, int64_t ldq, void* S, void* stream);
+
+/* Swin MLP in one kernel, narrow stages (stg_mlp_fused_supported(C): C = 128): Out = fc2(GELU(fc1(Y))) with the [rows, 4C] hidden
+ * tensor kept in accumulator registers between the two products (replaces Mlp.forward, Swin_AVE.py:111-127 as called at :790-794).
+ *   Y [rows, C] bf16, W1 [4C, C] bf16, b1 [4C] fp32, W2p [C, 4C] bf16 = fc2.weight with its hidden index permuted by stg_mlp_w2_perm
+ *   (position h' holds original column perm[h']: the accumulator layout of the first product then IS the operand layout of the
+ *   second), b2 [C] fp32, Out [rows, C] bf16.  Same arithmetic as two stg_gemm_nt calls (bf16 operands, fp32 accumulate, bf16 hidden). */
+int stg_mlp_fused_supported(int C);
+int stg_mlp_w2_perm(int hidden, int* perm);
+int stg_mlp_fwd(const void* Y, int64_t ldy, const void* W1, const float* b1, const void* W2p, const float* b2,
+                void* Out, int64_t ldo, int64_t rows, int C, void* stream);
 
 /* Weight gradient of a trainable nn.Linear y = x W^T + b   (autograd of Swin_AVE.py:15-16 D_fc1/D_fc2, :1319-1322 head)
  *   dW[N1,N2] (+)= sum_m dY[m,N1] * X[m,N2]      fp32, atomically accumulated (dW must be zeroed or hold a prior grad)

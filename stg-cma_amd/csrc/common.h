@@ -60,6 +60,31 @@ __device__ __forceinline__ void gelu_fast(float x, float& y, float& dy) {
     dy = fmaf(x * e, 0.3989422804014327f, phi);
     y = x * phi;
 }
+// GELU for bf16 destinations at half the VALU cost: Phi(x) ~ sigmoid(a1 x + a3 x^3 + a5 x^5) (a minimax fit of the logistic form of
+// Page 1977 with one more term: |Phi error| <= 1.9e-5, |x Phi error| <= 5.5e-5 over all x, 1/35 of a bf16 half-ulp at 1; derivative of
+// the fit within 1.4e-4 of GELU').  7 VALU + exp2 + rcp per value (the erfc form above: ~20 + exp2 + rcp), 6 more for the derivative:
+// the fc1 epilogues and the fused MLP kernel are VALU-bound on this function (10^9 values per stage-0 block).  The odd polynomial
+// turns over at |x| = 11.6, so its argument is clamped to [-8, 8] (sigmoid is 1 - 1e-13 / 1e-13 there).
+__device__ __forceinline__ float gelu_sig_core(float x, float& x2, float& xc) {
+    xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    x2 = xc * xc;
+    float pl = fmaf(x2, 0.000911226f, -0.106178f);          // -log2(e) * (a5 x^2 + a3)
+    pl = fmaf(pl, x2, -2.30172f);                            // ... + a1
+    const float e = __builtin_amdgcn_exp2f(pl * xc);         // exp(-u)
+    return __builtin_amdgcn_rcpf(1.0f + e);                  // sigmoid(u) ~ Phi(x)
+}
+__device__ __forceinline__ float gelu_sig(float x) {
+    float x2, xc;
+    return x * gelu_sig_core(x, x2, xc);
+}
+__device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
+    float x2, xc;
+    const float sg = gelu_sig_core(x, x2, xc);
+    float up = fmaf(x2, -0.0031580704f, 0.2207895358f);      // u'(x) = a1 + 3 a3 x^2 + 5 a5 x^4
+    up = fmaf(up, x2, 1.5954356678f);
+    dy = fmaf(sg * (1.0f - sg), x * up, sg);
+    y = x * sg;
+}
 __device__ __forceinline__ void quick_gelu_fast(float x, float& y, float& dy) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930157f));   // sigmoid(1.702 x)
     dy = s * fmaf(1.702f * x, 1.0f - s, 1.0f);

@@ -225,8 +225,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
             }
             if (act == STG_ACT_GELU) {
                 float d[8];
+                if (!G && !c_f32) {                    // bf16 destinations: the cheaper logistic form (common.h)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gelu_fast(t[j], t[j], d[j]);
+                    for (int j = 0; j < 8; ++j) gelu_sig_both(t[j], t[j], d[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gelu_fast(t[j], t[j], d[j]);
+                }
                 if (D8) { if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(p.dact) + m * p.ldp + n) = pack_d8(d); }
                 else if (p.dact && ok) *reinterpret_cast<uint4*>(p.dact + m * p.ldp + n) = pack_row8(d);
             } else if (act == STG_ACT_QUICKGELU) {

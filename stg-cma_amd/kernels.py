@@ -369,6 +369,42 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
                               _p(row_scale), int(rs_outer), int(rs_inner), _stream()), "stg_wgrad_tn")
 
 
+_mlp_perm_cache = {}
+
+
+def mlp_fused_supported(C_):
+    return bool(_lib.lib().stg_mlp_fused_supported(int(C_)))
+
+
+def mlp_w2_perm(hidden, device):
+    """Index tensor `perm` with W2p = W2[:, perm] (stg_mlp_w2_perm)."""
+    key = (int(hidden), str(device))
+    t = _mlp_perm_cache.get(key)
+    if t is None:
+        buf = (C.c_int * hidden)()
+        _lib.check(_lib.lib().stg_mlp_w2_perm(hidden, buf), "stg_mlp_w2_perm")
+        t = torch.tensor(list(buf), dtype=torch.long, device=device)
+        _mlp_perm_cache[key] = t
+    return t
+
+
+def mlp_fwd(Y, W1, b1, W2p, b2, out=None):
+    """out = fc2(GELU(fc1(Y))) in one kernel (stg_mlp_fwd).  Y [rows, C] bf16, W1 [4C, C] bf16, W2p [C, 4C] bf16 = W2[:, mlp_w2_perm]."""
+    rows, C_ = Y.shape
+    _chk2d(Y, "Y", BF16)
+    _chk2d(W1, "W1", BF16, cols=C_, rows=4 * C_)
+    _chk2d(W2p, "W2p", BF16, cols=4 * C_, rows=C_)
+    _chk1d(b1, "b1", F32, 4 * C_)
+    _chk1d(b2, "b2", F32, C_)
+    if not W1.is_contiguous() or not W2p.is_contiguous():
+        raise RuntimeError("mlp_fwd: weights must be contiguous")
+    if out is None:
+        out = torch.empty((rows, C_), dtype=BF16, device=Y.device)
+    _chk2d(out, "out", BF16, cols=C_, rows=rows)
+    _lib.check(_lib.lib().stg_mlp_fwd(_p(Y), _ld(Y), _p(W1), _p(b1), _p(W2p), _p(b2), _p(out), _ld(out), rows, C_, _stream()), "stg_mlp_fwd")
+    return out
+
+
 def wgrad_tn_multi(problems):
     """Several wgrad_tn calls at once: problems = [(dY, X, dW, db, row_scale, rs_outer, rs_inner)].  Problems that share a launch
     plan of the workspace path (same M, narrow-width class, wide width) go out as ONE pair of launches (stg_wgrad_tn_ws_multi);

@@ -492,3 +492,29 @@ def test_wgrad_multi_matches_single_calls(stg, gpu):
     Kn.wgrad_tn_multi(probs)
     for (dY, X, dW, db, *_), (dW1, db1) in zip(probs, refs):
         assert torch.equal(dW, dW1) and torch.equal(db, db1)
+
+
+@pytest.mark.parametrize("rows", [1, 300, 4096, 70000])
+def test_mlp_fused_forward(stg, gpu, rows):
+    """stg_mlp_fwd (fc1 -> GELU -> fc2 in one kernel, the hidden tensor never in HBM; Swin_AVE.py:111-127) against (i) the two-GEMM path
+    of the same library -- same operands, fp32 accumulation, bf16 hidden: agreement to summation-order / rounding-boundary level --
+    and (ii) the fp32 PyTorch statement with erf GELU."""
+    from stgcma import kernels as Kn
+    C_ = 128
+    assert Kn.mlp_fused_supported(C_)
+    g = torch.Generator().manual_seed(rows)
+    Y = torch.randn(rows, C_, generator=g).to(BF16)
+    W1 = (torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5).to(BF16)
+    W2 = (torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5).to(BF16)
+    b1, b2 = torch.randn(4 * C_, generator=g) * 0.2, torch.randn(C_, generator=g) * 0.2
+    perm = Kn.mlp_w2_perm(4 * C_, gpu)
+    assert sorted(perm.tolist()) == list(range(4 * C_))
+    Yg, W1g, W2g, b1g, b2g = (t.to(gpu) for t in (Y, W1, W2, b1, b2))
+    out = Kn.mlp_fwd(Yg, W1g, b1g, W2g[:, perm].contiguous(), b2g)
+    two = Kn.gemm_nt(Kn.gemm_nt(Yg, W1g, b1g, act=Kn.ACT_GELU), W2g, b2g)
+    ref = torch.nn.functional.gelu(Y.float() @ W1.float().t() + b1) @ W2.float().t() + b2
+    scale = float(ref.abs().max())
+    assert float((out.float() - two.float()).abs().max()) <= 8e-3 * scale           # a bf16 ulp of the output where the hidden rounds differently
+    assert float((out.float() - two.float()).norm() / two.float().norm()) <= 2e-4
+    assert float((out.float().cpu() - ref).abs().max()) <= 1e-2 * max(1.0, scale)
+    assert float((out.float().cpu() - ref).norm() / ref.norm()) <= 4e-3
