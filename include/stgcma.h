@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 204
+#define STG_VERSION 205
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -117,6 +117,12 @@ int stg_mlp_fused_supported(int C);
 int stg_mlp_w2_perm(int hidden, int* perm);
 int stg_mlp_fwd(const void* Y, int64_t ldy, const void* W1, const float* b1, const void* W2p, const float* b2,
                 void* Out, int64_t ldo, int64_t rows, int C, void* stream);
+/* Its backward, also one kernel: dY = ((dM . W2) * GELU'(Y . W1^T + b1)) . W1 with the pre-activation recomputed from Y (the forward
+ * saves nothing of the hidden tensor; the weights are frozen, so there is no weight gradient -- Swin_AVE.py:119-126 under the
+ * freeze filter of traintest_adapt_ave29.py:52-61).  W2T [4C, C] bf16 = fc2.weight^T; W1 is read once per chunk and used both
+ * row-wise (first product) and transposed (third product, ds_read_b64_tr_b16). */
+int stg_mlp_bwd(const void* Y, int64_t ldy, const void* dM, int64_t ldm, const void* W1, const float* b1, const void* W2T,
+                void* dY, int64_t ldo, int64_t rows, int C, void* stream);
 
 /* Weight gradient of a trainable nn.Linear y = x W^T + b   (autograd of Swin_AVE.py:15-16 D_fc1/D_fc2, :1319-1322 head)
  *   dW[N1,N2] (+)= sum_m dY[m,N1] * X[m,N2]      fp32, atomically accumulated (dW must be zeroed or hold a prior grad)

@@ -133,6 +133,7 @@ SIGNATURES = {
     "stg_mlp_fused_supported": (C.c_int, [C.c_int]),
     "stg_mlp_w2_perm": (C.c_int, [C.c_int, c_vp]),
     "stg_mlp_fwd": (C.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp]),
+    "stg_mlp_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, C.c_int, c_vp]),
     "stg_wgrad_tn_ws_multi": (C.c_int, [C.POINTER(WgradDesc), C.c_int, c_vp, c_i64, c_vp]),
     "stg_layernorm_fwd": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, c_vp, C.c_float, c_vp, C.c_int, c_i64, c_vp, c_vp,
                                     c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -195,7 +196,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 204
+ABI_VERSION = 205
 _lib = None
 
 

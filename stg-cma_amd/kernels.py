@@ -405,6 +405,24 @@ def mlp_fwd(Y, W1, b1, W2p, b2, out=None):
     return out
 
 
+def mlp_bwd(Y, dM, W1, b1, W2T, out=None):
+    """dY = ((dM @ W2) * GELU'(Y @ W1.T + b1)) @ W1 in one kernel (stg_mlp_bwd).  W2T [4C, C] bf16 = fc2.weight.T."""
+    rows, C_ = Y.shape
+    _chk2d(Y, "Y", BF16)
+    _chk2d(dM, "dM", BF16, cols=C_, rows=rows)
+    _chk2d(W1, "W1", BF16, cols=C_, rows=4 * C_)
+    _chk2d(W2T, "W2T", BF16, cols=C_, rows=4 * C_)
+    _chk1d(b1, "b1", F32, 4 * C_)
+    if not W1.is_contiguous() or not W2T.is_contiguous():
+        raise RuntimeError("mlp_bwd: weights must be contiguous")
+    if out is None:
+        out = torch.empty((rows, C_), dtype=BF16, device=Y.device)
+    _chk2d(out, "out", BF16, cols=C_, rows=rows)
+    _lib.check(_lib.lib().stg_mlp_bwd(_p(Y), _ld(Y), _p(dM), _ld(dM), _p(W1), _p(b1), _p(W2T), _p(out), _ld(out), rows, C_, _stream()),
+               "stg_mlp_bwd")
+    return out
+
+
 def wgrad_tn_multi(problems):
     """Several wgrad_tn calls at once: problems = [(dY, X, dW, db, row_scale, rs_outer, rs_inner)].  Problems that share a launch
     plan of the workspace path (same M, narrow-width class, wide width) go out as ONE pair of launches (stg_wgrad_tn_ws_multi);

@@ -140,6 +140,24 @@ def shadow_fp8(p, transpose=False):
     return f
 
 
+def shadow_mlp_w2(p):
+    """fc2.weight as the fused MLP kernel wants it: bf16, hidden index permuted (K.mlp_w2_perm), cached like the plain shadow."""
+    w = shadow(p)
+    slot = _shadow_cache[id(p)][1]
+    tag = slot[False][0]
+    hit = slot.get("mlp_w2p")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wp = w[:, K.mlp_w2_perm(w.shape[1], w.device)].contiguous()
+    slot["mlp_w2p"] = (tag, wp)
+    return wp
+
+
+# fc1 -> GELU -> fc2 (and its backward, pre-activation recomputed) as ONE kernel where csrc/mlp.hip is built (C = 128: Swin-B stage 0):
+# the [rows, 4C] hidden tensor and its saved derivative never reach HBM
+MLP_FUSED = _os.environ.get("STG_MLP_FUSED", "1") != "0"
+
+
 def frozen_gemm(A, wp, bias=None, *, t=False, fp8=False, **kw):
     """A . W^T (t=True: A . W, the dgrad) for a FROZEN Linear weight `wp`.  bf16 MFMA on the weight's bf16 shadow, or -- fp8 (BASELINE
     config 5, opt-in: stgcma.fp8) -- the block-scaled e4m3 MFMA: the weight's cached e4m3 shadow and A quantised per 32-wide k-block
@@ -619,9 +637,14 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     Y, mean, rstd = ln2.triple() if ln2 is not None else \
         K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
     del ln2
-    Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=MLP_DACT)
-    M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8)
-    del Hm
+    fused_mlp = MLP_FUSED and not fp8 and K.mlp_fused_supported(C)
+    if fused_mlp:
+        M = K.mlp_fwd(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow_mlp_w2(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
+        Zm = ("recompute", Y)                 # backward recomputes GELU' from norm2(x): Y stays alive instead of the 4C-wide derivative
+    else:
+        Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=MLP_DACT)
+        M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8)
+        del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
     X3 = torch.empty_like(X)
     ln3 = _LnOut(X, nxt["gamma"], nxt["beta"]) if nxt is not None and _ln_fusable(X, ads) else None
@@ -652,6 +675,10 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     return X3, (S if save else None)
 
 
+def _mlp_bwd_fused(P, Y, dM):
+    return K.mlp_bwd(Y, dM, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow(P["mlp.fc2.weight"], True))
+
+
 def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=None):
     """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad}, dH_prev).
     dH_in: this block's S_Adapter dgrad (dX3 . D_fc2), already computed by the LayerNorm backward that produced dX3.
@@ -679,9 +706,13 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         dZa = K.act_bwd(dHa, Za_)
         _adapter_wgrad(G, A.name, dZa, Y, dX3, Ha_, rs=rs, rs_outer=N, rs_inner=1)
         dYa = K.gemm_nt(dZa, A.w1t)
-        dZm = frozen_gemm(dX3, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
-        dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8, res1=dYa)
-        del Y, Ha_, Za_, dHa, dZa, dYa, dZm, Zm
+        if isinstance(Zm, tuple):
+            dY = K.add(_mlp_bwd_fused(P, Zm[1], dX3), dYa)
+        else:
+            dZm = frozen_gemm(dX3, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
+            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8, res1=dYa)
+            del dZm
+        del Y, Ha_, Za_, dHa, dZa, dYa, Zm
     else:
         X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
         dH2 = dH_in if dH_in is not None else [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
@@ -696,10 +727,13 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
             K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
         del HZ, H2, xs, dH2, dZs, M
-        dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
+        if isinstance(Zm, tuple):
+            dY = _mlp_bwd_fused(P, Zm[1], dM)
+        else:
+            dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
+            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8)
+            del dZm
         del dM, Zm
-        dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8)
-        del dZm
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
     dX2, dH2 = _ln_bwd_join(dY, X2, f32c(P["norm2.weight"]), mean, rstd, dX3, sl, [A.w2t for A in ads])
     del dY, X2, dX3

@@ -518,3 +518,29 @@ def test_mlp_fused_forward(stg, gpu, rows):
     assert float((out.float() - two.float()).norm() / two.float().norm()) <= 2e-4
     assert float((out.float().cpu() - ref).abs().max()) <= 1e-2 * max(1.0, scale)
     assert float((out.float().cpu() - ref).norm() / ref.norm()) <= 4e-3
+
+
+@pytest.mark.parametrize("rows", [1, 130, 4096, 70000])
+def test_mlp_fused_backward(stg, gpu, rows):
+    """stg_mlp_bwd (dY of the frozen MLP with the pre-activation recomputed in-kernel) against the library's own two-GEMM backward
+    (saved bf16 derivative) and against fp32 autograd of fc2(gelu(fc1(y)))."""
+    from stgcma import kernels as Kn
+    C_ = 128
+    g = torch.Generator().manual_seed(rows + 5)
+    Y = torch.randn(rows, C_, generator=g).to(BF16)
+    dM = torch.randn(rows, C_, generator=g).to(BF16)
+    W1 = (torch.randn(4 * C_, C_, generator=g) / C_ ** 0.5).to(BF16)
+    W2 = (torch.randn(C_, 4 * C_, generator=g) / (4 * C_) ** 0.5).to(BF16)
+    b1 = torch.randn(4 * C_, generator=g) * 0.2
+    Yg, dMg, W1g, W2g, b1g = (t.to(gpu) for t in (Y, dM, W1, W2, b1))
+    W2T = W2g.t().contiguous()
+    out = Kn.mlp_bwd(Yg, dMg, W1g, b1g, W2T)
+    _, Z = Kn.gemm_nt(Yg, W1g, b1g, act=Kn.ACT_GELU, want_dact=True)
+    two = Kn.gemm_nt(Kn.gemm_nt(dMg, W2T, dact_src=Z), W1g.t().contiguous())
+    y32 = Y.float().requires_grad_(True)
+    (torch.nn.functional.gelu(y32 @ W1.float().t() + b1) @ W2.float().t() * dM.float()).sum().backward()
+    ref = y32.grad
+    scale = float(ref.abs().max())
+    assert float((out.float() - two.float()).norm() / two.float().norm()) <= 4e-3         # the two-GEMM path rounds GELU' and dZ to bf16 too
+    assert float((out.float().cpu() - ref).abs().max()) <= 1.5e-2 * max(1.0, scale)
+    assert float((out.float().cpu() - ref).norm() / ref.norm()) <= 6e-3

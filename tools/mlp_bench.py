@@ -30,3 +30,14 @@ print(f"max |fused - two-GEMM| = {float(d.abs().max()):.4e} (scale {float(ref.fl
 t2, t1 = t(two), t(lambda: K.mlp_fwd(Y, W1, b1, W2p, b2))
 fl = 2.0 * rows * C_ * 4 * C_ * 2
 print(f"rows {rows}: two GEMMs {t2:8.1f} us   fused {t1:8.1f} us ({fl / t1 / 1e6:6.1f} TF/s, {(rows * C_ * 4) / t1 / 1e3:5.0f} GB/s in+out)")
+dM = torch.randn(rows, C_, generator=g, device=dev).bfloat16()
+W2T, W1T = W2.t().contiguous(), W1.t().contiguous()
+H, Z = K.gemm_nt(Y, W1, b1, act=K.ACT_GELU, want_dact="u8")
+def two_b():
+    return K.gemm_nt(K.gemm_nt(dM, W2T, dact_src=Z), W1T)
+rb = two_b()
+ob = K.mlp_bwd(Y, dM, W1, b1, W2T)
+db = ob.float() - rb.float()
+print(f"bwd: max |fused - two-GEMM| = {float(db.abs().max()):.4e} (scale {float(rb.float().abs().max()):.3f}), relL2 {float(db.norm() / rb.float().norm()):.3e}")
+t2, t1 = t(two_b), t(lambda: K.mlp_bwd(Y, dM, W1, b1, W2T))
+print(f"bwd rows {rows}: two GEMMs {t2:8.1f} us   fused {t1:8.1f} us ({1.5 * fl / t1 / 1e6:6.1f} TF/s)")
