@@ -24,6 +24,12 @@
 #define DIAG_ON(p, v) false
 #endif
 
+#ifdef STG_GEMM_DIAG
+// clock stamps around the 8-phase main loop (option gemm_dbg = 4): per workgroup {s_memtime, s_memrealtime} before and after, written
+// to a buffer of their own that no other code reads (MI355X_MICROARCH.md, DVFS give-back item 6); read with stg_diag_read_stamps
+__device__ unsigned long long stg_diag_stamps[4 * 8192];
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -756,6 +762,12 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) af[0][mi][0] = *reinterpret_cast<const bf16x8_t*>(smem8 + HA0 * SLOT + offA[mi][0]);
     if (wr == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run one barrier behind
+#ifdef STG_GEMM_DIAG
+    if (p.dbg == 4 && tid == 0 && blockIdx.x < 8192) {
+        stg_diag_stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        stg_diag_stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
     for (int kt2 = 0; kt2 < nk; kt2 += 2) {
 #pragma unroll
@@ -807,6 +819,12 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
             }
         }
     }
+#ifdef STG_GEMM_DIAG
+    if (p.dbg == 4 && tid == 0 && blockIdx.x < 8192) {
+        stg_diag_stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        stg_diag_stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();           // pairs with the late group's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy tail DMAs land before the staging regions reuse the slots
     __builtin_amdgcn_s_barrier();
@@ -1415,3 +1433,10 @@ extern "C" int stg_wgrad_tn(const void* dY, int64_t lddy, const void* X, int64_t
     STG_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef STG_GEMM_DIAG
+extern "C" int stg_diag_read_stamps(unsigned long long* host, int n_workgroups) {
+    if (!host || n_workgroups <= 0 || n_workgroups > 8192) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(stg_diag_stamps), sizeof(unsigned long long) * 4 * n_workgroups) == hipSuccess ? 0 : -100;
+}
+#endif
