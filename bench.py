@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="frozen backbone Linears on the block-scaled e4m3 MFMA path (BASELINE config 5; opt-in, Swin workloads); the "
                          "line then carries dtype 'fp8-e4m3(frozen weights + their inputs)/bf16' and is NOT the headline metric")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra HIP-graph replay measurement (N = 1)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -247,7 +248,7 @@ def main():
         ddp.broadcast_parameters(model)
         ddp.attach(model)
     from stgcma import recipe
-    opt = recipe.build_optimizer(model, lr=1e-4, head_lr=0.1)       # reference recipe: Adam(0.95, 0.999), wd 5e-7, two groups
+    opt = recipe.build_optimizer(model, lr=1e-4, head_lr=0.1, capturable=(world == 1))   # reference recipe: Adam(0.95, 0.999), wd 5e-7, two groups
     loss_fn = torch.nn.CrossEntropyLoss()
     a, v, labels = synth_batch(torch, args.batch, device, rank, args.workload)
 
@@ -327,6 +328,29 @@ def main():
     dt = time.perf_counter() - t0
     gp = kernels.gemm_profile_stop()
     final_loss = float(loss)
+    # the same step replayed from a HIP graph (N = 1): reported next to the eager number, which stays `value` -- the roofline
+    # sampling above needs eager launches (HIP events around individual kernels)
+    graph_replay = None
+    if world == 1 and not args.no_graph:
+        import gc
+        loss = None                       # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream:
+        gc.collect()                      # kept alive, they drag that stream into the capture and invalidate it
+        try:
+            replay, static_loss = recipe.capture_train_step(step, warmup=1)
+            for _ in range(2):
+                replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                replay()
+            th = time.perf_counter() - tg
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            graph_replay = {"value": round(args.batch * args.steps / tg, 3), "unit": "clips/s", "ms_per_step": round(tg / args.steps * 1e3, 3),
+                            "host_ms_per_step": round(th / args.steps * 1e3, 3), "final_loss": round(float(static_loss), 4),
+                            "what": "the identical step (forward + loss + backward + Adam) captured once with torch.cuda.graph and replayed"}
+        except Exception as e:                                   # a capture failure must not take the headline number with it
+            graph_replay = {"error": repr(e)[:200]}
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -384,7 +408,7 @@ def main():
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),
             "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
-            "roofline": roofline, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms,
+            "roofline": roofline, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms, "graph_replay": graph_replay,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
             out["cpu_baseline"] = cpu_baseline()
