@@ -33,7 +33,7 @@ enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
 int stg_version(void);
 const char* stg_last_error(void);
 /* Dispatch options for A/B measurements (tools/, tests): "gemm_epi" (0: generic epilogue), "gemm_ktail" (0: register-staged
- * kernel for K % 64 != 0), "gemm_big" (0 off / 1 auto / 2 whenever legal), "gemm_8ph" (0 off / 1 auto / 2 every legal shape /
+ * kernel for K % 64 != 0, 1: LDS-DMA k-tail kernel for K > 64 only, 2 = default: for every K), "gemm_big" (0 off / 1 auto / 2 whenever legal), "gemm_8ph" (0 off / 1 auto / 2 every legal shape /
  * 3 long-K only), "xattn" (0: frame-global cross-modal attention on the generic kernels), "gemm_dbg" (diagnostics build only).
  * Returns -2 for an unknown name.  The product never calls it. */
 int stg_set_option(const char* name, int value);

@@ -1328,7 +1328,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         STG_LAUNCH_CHECK();
         return 0;
     }
-    const bool ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed) != 0;
+    const int ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed);
     const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
     const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
@@ -1363,7 +1363,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     } else if (a->K % BK == 0) {
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS;
         hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (ktail_on && a->K > BK && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail
+    } else if (ktail_on && (a->K > BK || ktail_on >= 2) && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail (option gemm_ktail = 2: K < 64 too)
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS_KTAIL;
         hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     } else {

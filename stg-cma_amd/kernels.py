@@ -181,7 +181,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
-    if not fp8 and K % 64 != 0 and K > 64:                # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
+    if not fp8 and K % 64 != 0:                           # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
         a.conv_zero = _p(_zero_line(dev))
     if conv is not None:
         zl = _zero_line(dev)

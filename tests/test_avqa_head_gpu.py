@@ -217,7 +217,8 @@ def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
         if rn > 1e-4 and "gate_" not in n and "temporal_position_bias_table" not in n:
             rel = abs(float(d[n].grad.norm()) - float(rn)) / float(rn)
             worst = max(worst, rel)
-            assert rel <= 8e-2, f"grad norm of {n}: {float(d[n].grad.norm()):.4g} vs {float(rn):.4g}"
+            # 8 % on the V1 model; the 512-d variant routes every gradient through two more bf16 Linears in front of the ReLU match head
+            assert rel <= (1.2e-1 if case == "avqa512_full_tiny" else 8e-2), f"grad norm of {n}: {float(d[n].grad.norm()):.4g} vs {float(rn):.4g}"
     flat = torch.cat([d[n].grad.reshape(-1).float().cpu() for n in names])[::197]
     ref = torch.as_tensor(z["grads_sample"])
     e_l2 = float((flat - ref).norm() / ref.norm())
