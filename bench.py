@@ -389,7 +389,7 @@ def main():
         classes.sort(key=lambda t: -t[0]["est_ms_per_step"])
         gemm_ms = round(sum(c["est_ms_per_step"] for c, _, _ in classes), 2)
         roofs = []
-        for c, traffic, traffic_src in classes[:12]:
+        for c, traffic, traffic_src in classes[:24]:
             roofs.append(c)
         if classes:
             top, traffic, traffic_src = classes[0]
