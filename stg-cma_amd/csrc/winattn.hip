@@ -316,6 +316,130 @@ __global__ void __launch_bounds__(256, WPS) winattn_bwd_kernel(WinP a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, one pass (round 2)
+// The two-orientation kernel above recomputes S, dP and the exponentials for the key-on-lane products (dK, dV): 16 of its 56 MFMAs,
+// half of its 128 exponentials per lane, a second additive table (bmT) and the lse / delta broadcast.  Here each (key tile, q tile)
+// pair is evaluated ONCE, query on the lane; P and dS go to dQ straight from the accumulators (B operand, as above) and, as two
+// 32 x 32 bf16 tiles T[q][key] through the wave's own LDS, come back TRANSPOSED (ds_read_b64_tr_b16) as the B operands of
+//     dV^T[d][key] += dO^T[d][q] P[q][key],        dK^T[d][key] += Q^T[d][q] dS[q][key].
+// A lane writes its 16 keys of a tile as four 8-byte pieces of row q; the piece index is XOR-ed with (q >> 2) & 7 so that the 32
+// rows (64-byte pitch) of one write instruction fall on distinct banks -- the four rows of a transposed-read block share q >> 2, so
+// the reads stay conflict-free.  Padded queries carry lse = +1e30 (P = dS = 0), padded keys the table's -1e30.
+__device__ __forceinline__ bf16x8_t tr_frag_sw(const bf16_t* s, int s2, int hh, int d) {
+    const int gi = d & 15, c = d >> 4;
+    const int row = 16 * s2 + 4 * hh + (gi >> 2), u = 4 * c + (gi & 3);
+    const bf16_t* p0 = s + row * 32 + ((u ^ ((row >> 2) & 7)) << 2);
+    const bf16_t* p1 = s + (row + 8) * 32 + ((u ^ (((row + 8) >> 2) & 7)) << 2);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
+    // per wave: K, Q, dO tiles ([64][32] bf16) + the P and dS tiles of the current pair ([32 q][32 keys] bf16)
+    constexpr int PER_WAVE = 3 * 64 * WD + 2 * 32 * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int h = item % a.H;
+    const int p = item / a.H;
+    const int pg = p / a.G, g = p - pg * a.G;
+    bf16_t* sK = smem + wave * PER_WAVE;
+    bf16_t* sQ = sK + 64 * WD;
+    bf16_t* sD = sQ + 64 * WD;
+    bf16_t* sP = sD + 64 * WD;
+    bf16_t* sS = sP + 32 * 32;
+
+    bf16x8_t qf[2][2], kf[2][2], vf[2][2], dof[2][2];
+    int64_t row[2];
+    float delta[2], lse_q[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        row[t] = tok_row(a, pg, g, 32 * t + r);
+        const int64_t off = row[t] * a.ld + h * WD + 8 * hh;
+        qf[t][0] = ld_frag(a.Q + off); qf[t][1] = ld_frag(a.Q + off + 16);
+        kf[t][0] = ld_frag(a.K + off); kf[t][1] = ld_frag(a.K + off + 16);
+        vf[t][0] = ld_frag(a.V + off); vf[t][1] = ld_frag(a.V + off + 16);
+        const bf16_t* dp = a.dO + row[t] * a.lddo + h * WD + 8 * hh;
+        const bf16_t* op = a.O + row[t] * a.ldo + h * WD + 8 * hh;
+        dof[t][0] = ld_frag(dp); dof[t][1] = ld_frag(dp + 16);
+        const bf16x8_t o0 = ld_frag(op), o1 = ld_frag(op + 16);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            d += bf2f((bf16_t)dof[t][0][j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)dof[t][1][j]) * bf2f((bf16_t)o1[j]);
+        d += __shfl_xor(d, 32, 64);
+        delta[t] = d;
+        const int q = 32 * t + r;
+        lse_q[t] = q < a.n ? a.lse[((int64_t)p * a.H + h) * 64 + q] * 1.4426950408889634f : 1.0e30f;
+    }
+    stage64(a, sK, a.K, a.ld, pg, g, h, lane);
+    stage64(a, sQ, a.Q, a.ld, pg, g, h, lane);
+    stage64(a, sD, a.dO, a.lddo, pg, g, h, lane);
+    const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
+    const int swz = (r >> 2) & 7;
+    lds_fence();
+
+    f32x16_t dq[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        f32x16_t dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float* bmq = a.bm + tb + 4 * (32 * qt + r);
+            float4 add[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+            f32x16_t st = zero16(), dpt = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st = MFMA32(kf[kt][s], qf[qt][s], st);
+                dpt = MFMA32(vf[kt][s], dof[qt][s], dpt);
+            }
+            float pr[16], ds[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float4 ad = add[reg >> 2];
+                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
+                pr[reg] = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + (av - lse_q[qt]));      // padded keys: av = -1e30; padded queries: lse = +1e30
+                ds[reg] = pr[reg] * (dpt[reg] - delta[qt]);
+            }
+            bf16x8_t pp[2], ps[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { pp[s2] = pack8(pr + 8 * s2); ps[s2] = pack8(ds + 8 * s2); }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dq[qt] = MFMA32(tr_frag(sK, kt, s2, hh, r), ps[s2], dq[qt]);
+            // T[q = r][keys 8 g4 + 4 hh .. + 3], g4 = 2 s2 + half: 8-byte piece u = 2 g4 + hh, stored at u ^ swz
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4_t wp = __builtin_bit_cast(u32x4_t, pp[s2]), ws = __builtin_bit_cast(u32x4_t, ps[s2]);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int u = (2 * (2 * s2 + half) + hh) ^ swz;
+                    *reinterpret_cast<uint2*>(sP + r * 32 + u * 4) = make_uint2(wp[2 * half], wp[2 * half + 1]);
+                    *reinterpret_cast<uint2*>(sS + r * 32 + u * 4) = make_uint2(ws[2 * half], ws[2 * half + 1]);
+                }
+            }
+            lds_fence();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dv = MFMA32(tr_frag(sD, qt, s2, hh, r), tr_frag_sw(sP, s2, hh, r), dv);
+                dk = MFMA32(tr_frag(sQ, qt, s2, hh, r), tr_frag_sw(sS, s2, hh, r), dk);
+            }
+            lds_fence();                                   // the tiles are rewritten by the next pair
+        }
+        store_tile32(a.dK + row[kt] * a.lddqkv + h * WD, dk, a.scale, hh, 32 * kt + r < a.n);
+        store_tile32(a.dV + row[kt] * a.lddqkv + h * WD, dv, 1.0f, hh, 32 * kt + r < a.n);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) store_tile32(a.dQ + row[qt] * a.lddqkv + h * WD, dq[qt], a.scale, hh, 32 * qt + r < a.n);
+}
+
 // ------------------------------------------------------------------------------------------------ bias + mask table
 // Additive score term v(q, k) = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to
 // 64 x 64 per (window type g, head h) and stored TILED for the kernels' access pattern -- a lane owns one index x (its
@@ -400,7 +524,9 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    const int occ = stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed);      // 1 (default): the one-pass kernel; 2 / 3: the two-orientation kernel
+    if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

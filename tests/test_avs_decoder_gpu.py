@@ -201,14 +201,33 @@ def test_avs_full_model_matches_reference(stg, gpu):
     assert cos >= 0.85 and 0.9 <= med <= 1.1 and share >= 0.6, f"gradient sample cosine {cos:.4f}, median norm ratio {med:.3f}, share within 25 % {share:.3f}"
 
 
+def _relcos(a, b):
+    a = a.detach().float().cpu().reshape(-1); b = b.detach().float().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm()), float(a.norm() / b.norm()), float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
 def test_avs_full_model_eval_batchnorm_gradients(stg, gpu):
-    """Whole-model gradient parity on the WELL-CONDITIONED fixture (ADVICE r1 / VERDICT r1 item 8): eval-mode BatchNorm on
-    calibrated running statistics (a fixed per-channel affine map with O(1) outputs), upstream gradient on pred.  Every trainable
-    tensor: per-tensor norm within 10 %, strided gradient sample within 5 % relative L2 of the reference's."""
+    """Whole-model gradient parity of the AVS model on the eval-BatchNorm fixture (ADVICE r1 / VERDICT r1 item 8), SPLIT at the
+    backbone / decoder boundary (the four video taps + the audio feature) with the fp32 oracle run beside the HIP path -- the oracle
+    reproduces the reference's gradients of this fixture to 2e-3 (tests/test_oracle_cpu.py), so it stands in for the reference on
+    either side of the cut:
+      1. the taps themselves (forward)                                        tight: <= 1.5e-2 relative L2
+      2. the HIP BACKBONE driven by the oracle's d(taps)                      tight: median per-tensor relL2 <= 3e-2 (measured 1.0e-2)
+      3. the HIP DECODER on the oracle's taps: pred tight (<= 2e-2), d(taps) and its parameter gradients in AGGREGATE only
+      4. end to end against the golden                                        aggregate only
+    Why 3 / 4 are aggregate bounds (round-2 finding, tools/avs_grad_conditioning.py reproduces it on the CPU in fp32): the decoder is a
+    ReLU network (ResidualConvUnit, output_conv), and a ReLU network's gradient is DISCONTINUOUS in its activations -- a forward
+    perturbation of relative size eps flips ~eps of the masks, and the gradient moves by ~sqrt(eps).  Rounding ONE decoder tensor of
+    the fp32 oracle to bf16 (eps = 2^-9) moves the oracle's own d(taps) by 4-8 % and single parameter gradients by up to 35 %; all
+    decoder activations rounded: 8-11 % on d(taps), 92 % on the worst tensor (TPAVI block 1's W_z, a sum over 15 680 positions per clip
+    that mostly cancels).  The backbone (GELU, LayerNorm: smooth) does not have this: 1 % (check 2).  The reference trains this decoder
+    under fp16 autocast (AVS/traintest_adapt_avs.py), whose gradients scatter the same way at half the size."""
     from stgcma import recipe
     from stgcma.model import Swin_AVSModel_Base
+    from stgcma.ops_dec import avs_decoder_forward
     from params import seeded_tensor
-    import json
+    import oracle.avs_decoder as OD
+    from oracle.swin import swin_backbone
     z, cfg, shapes, names = load_case("avs_full_tiny_evalbn")
     m = Swin_AVSModel_Base.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                                                               num_heads=cfg["num_heads"], ftmode="fusion",
@@ -228,61 +247,86 @@ def test_avs_full_model_eval_batchnorm_gradients(stg, gpu):
     recipe.apply_freeze(m)
     assert [n for n, p in m.named_parameters() if p.requires_grad] == names
     B, seed = cfg["B"], cfg["seed"]
-    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5).to(gpu)
-    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2).to(gpu)
-    pred, _, _ = m(a, v, "fusion")
-    e_max, e_l2 = _rel(pred, z["pred"])
-    (pred * seeded_tensor(pred.shape, seed + 3, 1e-2).to(gpu)).sum().backward()
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    w = seeded_tensor(tuple(np.asarray(z["pred"]).shape), seed + 3, 1e-2)
     d = dict(m.named_parameters())
-    ref_norms = np.asarray(z["grad_norms"])
-    # TPAVI's inner branch (theta / phi / g -> y -> W_z.0 -> BatchNorm): with the audio constant over a frame every position's y is a
-    # scalar multiple of ONE vector per clip, so the rows entering BatchNorm are nearly collinear -- |mean| >> spread per channel --
-    # and a fixed (eval) normalisation divides the bf16 rounding of that tensor by the small spread.  Those tensors are pinned at
-    # module level (test_tpavi_module_matches_reference); here they get a loose bound, everything else the tight one.
-    # The same amplification acts on the way back (d(pre-BN) = dOut * gamma / sigma with a tiny calibrated sigma), strongest at the
-    # 56 x 56 stage (15 680 positions per clip), so the tensors in FRONT of TPAVI block 1 -- its own inner branch and the stage-1
-    # ASPP / tap Linear that feed it -- inherit it.
-    def inner(n):
-        return ("avstask_tpavi" in n and any(t in n for t in (".W_z.", ".g.", ".theta.", ".phi.", ".align_channel."))) or \
-            n.startswith(("avstask_conv1.", "avstask_x1_linear."))
-    sizes = [d[n].numel() for n in names]
-    owner = np.repeat(np.arange(len(names)), sizes)[::97]
-    is_inner = np.array([inner(n) for n in names])[owner]
+    rep = []
+
+    def zero():
+        for p_ in m.parameters():
+            p_.grad = None
+
+    # ---- the oracle, cut at the taps
+    Po = {k: t.clone() for k, t in P.items()}
+    for n in names:
+        Po[n].requires_grad_(True)
+    out = swin_backbone(Po, a, v, cfg)
+    taps_o = [t.detach().clone().requires_grad_(True) for t in out["taps"]] + [out["f_a"].detach().clone().requires_grad_(True)]
+    pred_o, _, _ = OD.avs_decoder(Po, taps_o[:4], taps_o[4], B, 5, bn_training=False)
+    assert _rel(pred_o, z["pred"])[1] <= 1e-4                         # the oracle IS the reference here
+    (pred_o * w).sum().backward()
+    dtaps_o = [t.grad.clone() for t in taps_o]
+    dec_o = {n: Po[n].grad.clone() for n in names if Po[n].grad is not None and float(Po[n].grad.norm()) > 0}
+    for n in names:
+        Po[n].grad = None
+    torch.autograd.backward(out["taps"] + [out["f_a"]], dtaps_o)
+    bb_o = {n: Po[n].grad.clone() for n in names if Po[n].grad is not None and not n.startswith("avstask_") and float(Po[n].grad.norm()) > 1e-12}
+
+    # ---- 1. taps, 2. the backbone alone
+    ms, a_feat = m.forward_features(a.to(gpu), v.to(gpu))
+    hip_taps = list(ms) + [a_feat]
+    e_taps = [_relcos(t, to.reshape(t.shape))[0] for t, to in zip(hip_taps, taps_o)]
+    rep.append("taps relL2 " + " ".join(f"{e:.2e}" for e in e_taps))
+    assert max(e_taps) <= 1.5e-2, rep[-1]
+    zero()
+    torch.autograd.backward(hip_taps, [g.reshape(t.shape).to(gpu) for g, t in zip(dtaps_o, hip_taps)])
+    rows = sorted(((_relcos(d[n].grad, g)[0], n) for n, g in bb_o.items()), reverse=True)
+    assert all(d[n].grad is not None and torch.isfinite(d[n].grad).all() for n in bb_o)
+    med_bb = float(np.median([r for r, _ in rows]))
+    plain = [(r, n) for r, n in rows if "gate_" not in n and "temporal_position_bias_table" not in n]
+    rep.append(f"backbone alone (oracle d(taps) in): median per-tensor relL2 {med_bb:.3e} over {len(rows)} tensors, worst {rows[0][0]:.3e} ({rows[0][1]}), "
+               f"worst outside gates / bias tables {plain[0][0]:.3e} ({plain[0][1]})")
+    assert med_bb <= 3e-2 and plain[0][0] <= 8e-2 and rows[0][0] <= 0.3, rep[-1]
+
+    # ---- 3. the decoder alone
+    zero()
+    in2 = [to.detach().reshape(t.shape).to(gpu).requires_grad_(True) for t, to in zip(hip_taps, taps_o)]
+    pred2, _, _ = avs_decoder_forward(m, in2[:4], in2[4], B, 5, False)
+    e_pred2 = _relcos(pred2, pred_o)[0]
+    (pred2 * w.to(gpu)).sum().backward()
+    dt = [_relcos(t.grad, g.reshape(t.shape)) for t, g in zip(in2, dtaps_o)]
+    decs = sorted(((_relcos(d[n].grad, g)[0], n) for n, g in dec_o.items() if d[n].grad is not None), reverse=True)
+    med_dec = float(np.median([r for r, _ in decs]))
+    rep.append(f"decoder alone (oracle taps in): pred relL2 {e_pred2:.3e}; d(taps) relL2 " + " ".join(f"{x[0]:.3f}" for x in dt) + "; norm ratio " +
+               " ".join(f"{x[1]:.3f}" for x in dt) + "; cos " + " ".join(f"{x[2]:.4f}" for x in dt) +
+               f"; parameter gradients median relL2 {med_dec:.3e}, worst {decs[0][0]:.3e} ({decs[0][1]})")
+    assert e_pred2 <= 2e-2, rep[-1]
+    assert min(x[2] for x in dt) >= 0.93 and all(0.85 <= x[1] <= 1.15 for x in dt) and med_dec <= 0.35, rep[-1]
+
+    # ---- 4. end to end against the golden
+    zero()
+    pred, _, _ = m(a.to(gpu), v.to(gpu), "fusion")
+    e_max, e_l2 = _rel(pred, z["pred"])
+    (pred * w.to(gpu)).sum().backward()
     flat = torch.cat([(d[n].grad if d[n].grad is not None else torch.zeros_like(d[n])).reshape(-1).float().cpu() for n in names])[::97]
     ref = torch.as_tensor(z["grads_sample"])
-    sel = torch.as_tensor(~is_inner)
-    g_l2 = float((flat[sel] - ref[sel]).norm() / ref[sel].norm())
-    g_l2_inner = float((flat[~sel] - ref[~sel]).norm() / ref[~sel].norm())
-    devs = []
+    cos = float(torch.dot(flat, ref) / (flat.norm() * ref.norm()))
+    ref_norms = np.asarray(z["grad_norms"])
+    ratios = [float(d[n].grad.norm()) / float(rn) for n, rn in zip(names, ref_norms) if d[n].grad is not None and rn > 1e-3 * ref_norms.max()]
     for n, rn in zip(names, ref_norms):
         if d[n].grad is None:
             assert rn == 0, n
-            continue
-        assert torch.isfinite(d[n].grad).all(), n
-        if rn > 1e-3 * ref_norms.max() and "gate_" not in n and "temporal_position_bias_table" not in n:
-            devs.append((abs(float(d[n].grad.norm()) / float(rn) - 1.0), n))
-    worst, worst_n = max((r, n) for r, n in devs if not inner(n))
-    worst_i, worst_in = max((r, n) for r, n in devs if inner(n))
+        else:
+            assert torch.isfinite(d[n].grad).all(), n
+    med_ratio = float(np.median(ratios))
+    rep.append(f"end to end: pred max/scale={e_max:.3e} relL2={e_l2:.3e}; gradient sample cosine {cos:.4f}, per-tensor norm ratio median {med_ratio:.3f} "
+               f"(min {min(ratios):.3f}, max {max(ratios):.3f})")
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/model_parity_report.txt", "a") as f:
-        f.write(f"avs_full_tiny_evalbn pred: max/scale={e_max:.3e} relL2={e_l2:.3e}; grads outside TPAVI's inner branch: sample relL2={g_l2:.3e}, "
-                f"worst per-tensor norm deviation {worst:.3e} ({worst_n}); inner branch: sample relL2={g_l2_inner:.3e}, worst {worst_i:.3e} ({worst_in})\n")
-        for r, n in sorted((rn for rn in devs if not inner(rn[1])), reverse=True)[:12]:
-            f.write(f"    {r:.3e} {n}\n")
-    assert e_max <= 4.5e-2 and e_l2 <= 3.5e-2, f"pred: max/scale={e_max:.3e} relL2={e_l2:.3e}"
-    # Round-2 finding: eval-mode BatchNorm does NOT make the whole-model gradient well conditioned at bf16.  The rows entering TPAVI's
-    # BatchNorm are nearly collinear (|mean| >> spread), a FIXED normalisation divides the bf16 rounding of that tensor by the small
-    # calibrated spread in both directions, and the result moves with any change of rounding elsewhere: the same binary gave 13 %
-    # sample relL2 before and 31 % after the GELU polynomial was exchanged (both far below a bf16 ulp per element).  What holds across
-    # such changes is direction and size in aggregate -- asserted here like on the train-mode fixture; the per-module tests above pin
-    # every building block's backward at 1-6 %, the oracle reproduces the reference's gradients of THIS fixture to 2e-3 on CPU.
-    cos = float(torch.dot(flat, ref) / (flat.norm() * ref.norm()))
-    rr = np.array([1.0 + r if True else r for r, _ in devs])
-    med_dev = float(np.median([r for r, _ in devs]))
-    with open("gpurun_out/model_parity_report.txt", "a") as f:
-        f.write(f"avs_full_tiny_evalbn grads: cosine of the strided sample {cos:.4f}, median per-tensor norm deviation {med_dev:.3e}\n")
-    assert cos >= 0.85 and med_dev <= 1e-1, f"gradient sample cosine {cos:.4f}, median per-tensor norm deviation {med_dev:.3e}"
-    assert g_l2_inner <= 1.0 and worst_i <= 1.0, f"TPAVI inner branch: sample relL2 {g_l2_inner:.3e}, norm off by {worst_i:.3e} at {worst_in}"
+        f.write("avs_full_tiny_evalbn (split at the taps)\n" + "".join("    " + r + "\n" for r in rep))
+    assert e_max <= 4.5e-2 and e_l2 <= 3.5e-2, rep[-1]
+    assert cos >= 0.9 and 0.7 <= med_ratio <= 1.4, rep[-1]
 
 
 def test_avs_train_mode_loop(stg, gpu):
