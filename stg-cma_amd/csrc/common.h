@@ -146,7 +146,8 @@ extern std::atomic<int> stg_opt_gemm_ktail;   // K % 64 != 0 shapes: 0 register-
 extern std::atomic<int> stg_opt_gemm_big;     // 256 x 256 simple-loop kernel: 0 off, 1 auto, 2 whenever legal
 extern std::atomic<int> stg_opt_gemm_8ph;     // 8-phase kernel: 0 off, 1 auto (default), 2 every legal shape, 3 long-K shapes only
 extern std::atomic<int> stg_opt_gemm_dbg;     // diagnostics build only (-DSTG_GEMM_DIAG)
-extern std::atomic<int> stg_opt_winattn_bwd_occ;   // register budget of winattn_bwd_kernel: 2 or 3 waves per SIMD
+extern std::atomic<int> stg_opt_winattn_bwd_occ;   // window attention: 1 (default) the coalesced round-2 kernels (winattn_fwd1 / winattn_bwd1); 2 / 3: the round-1
+                                                   // kernels, backward held to 2 / 3 waves per SIMD
 extern std::atomic<int> stg_opt_xattn;        // 0: frame-global cross-modal attention on the generic attention kernels
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: `done` (one static per kernel instantiation) remembers the

@@ -317,15 +317,37 @@ __global__ void __launch_bounds__(256, WPS) winattn_bwd_kernel(WinP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward, one pass (round 2)
-// The two-orientation kernel above recomputes S, dP and the exponentials for the key-on-lane products (dK, dV): 16 of its 56 MFMAs,
-// half of its 128 exponentials per lane, a second additive table (bmT) and the lse / delta broadcast.  Here each (key tile, q tile)
-// pair is evaluated ONCE, query on the lane; P and dS go to dQ straight from the accumulators (B operand, as above) and, as two
-// 32 x 32 bf16 tiles T[q][key] through the wave's own LDS, come back TRANSPOSED (ds_read_b64_tr_b16) as the B operands of
-//     dV^T[d][key] += dO^T[d][q] P[q][key],        dK^T[d][key] += Q^T[d][q] dS[q][key].
-// A lane writes its 16 keys of a tile as four 8-byte pieces of row q; the piece index is XOR-ed with (q >> 2) & 7 so that the 32
-// rows (64-byte pitch) of one write instruction fall on distinct banks -- the four rows of a transposed-read block share q >> 2, so
-// the reads stay conflict-free.  Padded queries carry lse = +1e30 (P = dS = 0), padded keys the table's -1e30.
-__device__ __forceinline__ bf16x8_t tr_frag_sw(const bf16_t* s, int s2, int hh, int d) {
+// Two things the two-orientation kernel above pays for, removed:
+//  (1) It recomputes S, dP and the exponentials for the key-on-lane products (dK, dV): 16 of its 56 MFMAs, half of its 128
+//      exponentials per lane, a second additive table (bmT) and the lse / delta broadcast.  Here each (key tile, q tile) pair is
+//      evaluated ONCE, query on the lane; P and dS go to dQ straight from the accumulators (B operand, as above) and, as two 32 x 32
+//      bf16 tiles T[q][key] through the wave's own LDS, come back TRANSPOSED (ds_read_b64_tr_b16) as the B operands of
+//          dV^T[d][key] += dO^T[d][q] P[q][key],        dK^T[d][key] += Q^T[d][q] dS[q][key].
+//  (2) Its operand fragments and its stores are ROW-PER-LANE accesses (a lane reads / writes 16 bytes of its own token row): 64
+//      separate requests per wave-instruction, ~64 clocks each in the CU's address path -- 30 such instructions per problem, with 8
+//      waves sharing the path, were more than half of the kernel's time.  Here every global access is coalesced (4 lanes cover the
+//      64 bytes of a head's row): Q, K, V, dO, O are read once, 16 rows per instruction, into swizzled LDS tiles (O only into the
+//      delta dot product), the MFMA operand fragments are read from those tiles, and dQ / dK / dV leave through a 32 x 32 LDS
+//      transposition.
+// LDS tiles [64 tokens][32] bf16: 16-byte chunk c of row R sits at chunk c ^ ((R >> 2) & 3) -- conflict-free for the row-fragment
+// ds_read_b128 (its 16-lane groups mix four values of R >> 2), for the staging writes and for the transposed reads (the four rows of
+// a block share R >> 2).  P / dS / output tiles [32][32]: 8-byte piece u of row q at u ^ ((q >> 2) & 7).
+// Padded queries carry lse = +1e30 (P = dS = 0), padded keys the table's -1e30; padded rows of the tiles duplicate token n - 1.
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * WD + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+__device__ __forceinline__ bf16x8_t tr_frag64(const bf16_t* s, int kt, int s2, int hh, int d) {     // tr_frag on a swizzled [64][32] tile
+    const int gi = d & 15, c = d >> 4;
+    const int row = 32 * kt + 16 * s2 + 4 * hh + (gi >> 2), u = 4 * c + (gi & 3);
+    const bf16_t* p0 = s + sw_off(row, u >> 1) + ((u & 1) << 2);
+    const bf16_t* p1 = s + sw_off(row + 8, u >> 1) + ((u & 1) << 2);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+__device__ __forceinline__ bf16x8_t tr_frag32(const bf16_t* s, int s2, int hh, int d) {              // on a [32][32] piece-swizzled tile
     const int gi = d & 15, c = d >> 4;
     const int row = 16 * s2 + 4 * hh + (gi >> 2), u = 4 * c + (gi & 3);
     const bf16_t* p0 = s + row * 32 + ((u ^ ((row >> 2) & 7)) << 2);
@@ -337,10 +359,29 @@ __device__ __forceinline__ bf16x8_t tr_frag_sw(const bf16_t* s, int s2, int hh, 
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
+// accumulator tile (lane = token r, rows = head dims) -> [32 tokens][32 dims] bf16 piece-swizzled LDS tile
+__device__ __forceinline__ void put_tile32(bf16_t* T, const f32x16_t& acc, float sc, int r, int hh) {
+    const int swz = (r >> 2) & 7;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<uint2*>(T + r * 32 + (((2 * g4 + hh) ^ swz) << 2)) =
+            make_uint2(pack_bf2(acc[4 * g4] * sc, acc[4 * g4 + 1] * sc), pack_bf2(acc[4 * g4 + 2] * sc, acc[4 * g4 + 3] * sc));
+}
+// ... and out of it, 16 token rows x 64 bytes per store instruction; rowoff[j]: element offset of token 32 t + (lane >> 2) + 16 j
+__device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const int64_t (&rowoff)[2], int t, int n, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tl = (lane >> 2) + 16 * j, cq = lane & 3, sw = (tl >> 2) & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
+        if (32 * t + tl < n) *reinterpret_cast<uint4*>(dst + rowoff[j] + cq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
 
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
-    // per wave: K, Q, dO tiles ([64][32] bf16) + the P and dS tiles of the current pair ([32 q][32 keys] bf16)
-    constexpr int PER_WAVE = 3 * 64 * WD + 2 * 32 * 32;
+    // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
+    // pair, then the output transpositions), delta[64]
+    constexpr int PER_WAVE = 4 * 64 * WD + 128;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -354,53 +395,77 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     bf16_t* sD = sQ + 64 * WD;
     bf16_t* sP = sD + 64 * WD;
     bf16_t* sS = sP + 32 * 32;
+    float* sDel = reinterpret_cast<float*>(sP + 64 * WD);
 
-    bf16x8_t qf[2][2], kf[2][2], vf[2][2], dof[2][2];
-    int64_t row[2];
-    float delta[2], lse_q[2];
+    // ---- coalesced staging by LDS-DMA: instruction i of a tile fills rows 16 i .. + 15 (1 KiB), lane -> row 16 i + (lane >> 2), LDS
+    // chunk lane & 3, which holds SOURCE chunk (lane & 3) ^ ((row >> 2) & 3) (the swizzle lives on the source address; (row >> 2) & 3
+    // = (lane >> 4) & 3 for every i).  No registers, nothing for the compiler to serialise: 16 DMAs + 6 loads in flight at once.
+    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t trow[4];
+    uint4 vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
+        const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(sP + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dO + trow[i] * a.lddo + h * WD + cs * 8),
+                                         (__attribute__((address_space(3))) void*)(sD + i * 512), 16, 0, 0);
+        vo[i] = *reinterpret_cast<const uint4*>(a.O + trow[i] * a.ldo + h * WD + cs * 8);
+    }
+    float lse_q[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        row[t] = tok_row(a, pg, g, 32 * t + r);
-        const int64_t off = row[t] * a.ld + h * WD + 8 * hh;
-        qf[t][0] = ld_frag(a.Q + off); qf[t][1] = ld_frag(a.Q + off + 16);
-        kf[t][0] = ld_frag(a.K + off); kf[t][1] = ld_frag(a.K + off + 16);
-        vf[t][0] = ld_frag(a.V + off); vf[t][1] = ld_frag(a.V + off + 16);
-        const bf16_t* dp = a.dO + row[t] * a.lddo + h * WD + 8 * hh;
-        const bf16_t* op = a.O + row[t] * a.ldo + h * WD + 8 * hh;
-        dof[t][0] = ld_frag(dp); dof[t][1] = ld_frag(dp + 16);
-        const bf16x8_t o0 = ld_frag(op), o1 = ld_frag(op + 16);
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            d += bf2f((bf16_t)dof[t][0][j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)dof[t][1][j]) * bf2f((bf16_t)o1[j]);
-        d += __shfl_xor(d, 32, 64);
-        delta[t] = d;
         const int q = 32 * t + r;
         lse_q[t] = q < a.n ? a.lse[((int64_t)p * a.H + h) * 64 + q] * 1.4426950408889634f : 1.0e30f;
     }
-    stage64(a, sK, a.K, a.ld, pg, g, h, lane);
-    stage64(a, sQ, a.Q, a.ld, pg, g, h, lane);
-    stage64(a, sD, a.dO, a.lddo, pg, g, h, lane);
     const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
-    const int swz = (r >> 2) & 7;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_fence();
+    // delta[q] = sum_d dO[q][d] O[q][d]: the lane's own 16-byte piece of dO (back from LDS) times the same piece of O, summed over the
+    // four lanes of the row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 vd = *reinterpret_cast<const uint4*>(sD + i * 512 + lane * 8);
+        const uint32_t dw[4] = {vd.x, vd.y, vd.z, vd.w}, ow[4] = {vo[i].x, vo[i].y, vo[i].z, vo[i].w};
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            d += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16) + __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if ((lane & 3) == 0) sDel[(lane >> 2) + 16 * i] = d;
+    }
+    lds_fence();
+    bf16x8_t vf[2][2];
+    float delta[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        vf[t][0] = ld_frag(sP + sw_off(32 * t + r, hh)); vf[t][1] = ld_frag(sP + sw_off(32 * t + r, hh + 2));
+        delta[t] = sDel[32 * t + r];
+    }
+    lds_fence();                                           // the V tile becomes the P / dS tiles
+    const int swz = (r >> 2) & 7;
 
     f32x16_t dq[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         f32x16_t dv = zero16(), dk = zero16();
+        const bf16x8_t kf0 = ld_frag(sK + sw_off(32 * kt + r, hh)), kf1 = ld_frag(sK + sw_off(32 * kt + r, hh + 2));
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const float* bmq = a.bm + tb + 4 * (32 * qt + r);
             float4 add[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+            const bf16x8_t qf0 = ld_frag(sQ + sw_off(32 * qt + r, hh)), qf1 = ld_frag(sQ + sw_off(32 * qt + r, hh + 2));
+            const bf16x8_t df0 = ld_frag(sD + sw_off(32 * qt + r, hh)), df1 = ld_frag(sD + sw_off(32 * qt + r, hh + 2));
             f32x16_t st = zero16(), dpt = zero16();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                st = MFMA32(kf[kt][s], qf[qt][s], st);
-                dpt = MFMA32(vf[kt][s], dof[qt][s], dpt);
-            }
+            st = MFMA32(kf0, qf0, st);
+            dpt = MFMA32(vf[kt][0], df0, dpt);
+            st = MFMA32(kf1, qf1, st);
+            dpt = MFMA32(vf[kt][1], df1, dpt);
             float pr[16], ds[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -413,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) { pp[s2] = pack8(pr + 8 * s2); ps[s2] = pack8(ds + 8 * s2); }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) dq[qt] = MFMA32(tr_frag(sK, kt, s2, hh, r), ps[s2], dq[qt]);
+            for (int s2 = 0; s2 < 2; ++s2) dq[qt] = MFMA32(tr_frag64(sK, kt, s2, hh, r), ps[s2], dq[qt]);
             // T[q = r][keys 8 g4 + 4 hh .. + 3], g4 = 2 s2 + half: 8-byte piece u = 2 g4 + hh, stored at u ^ swz
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -428,16 +493,130 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
             lds_fence();
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                dv = MFMA32(tr_frag(sD, qt, s2, hh, r), tr_frag_sw(sP, s2, hh, r), dv);
-                dk = MFMA32(tr_frag(sQ, qt, s2, hh, r), tr_frag_sw(sS, s2, hh, r), dk);
+                dv = MFMA32(tr_frag64(sD, qt, s2, hh, r), tr_frag32(sP, s2, hh, r), dv);
+                dk = MFMA32(tr_frag64(sQ, qt, s2, hh, r), tr_frag32(sS, s2, hh, r), dk);
             }
             lds_fence();                                   // the tiles are rewritten by the next pair
         }
-        store_tile32(a.dK + row[kt] * a.lddqkv + h * WD, dk, a.scale, hh, 32 * kt + r < a.n);
-        store_tile32(a.dV + row[kt] * a.lddqkv + h * WD, dv, 1.0f, hh, 32 * kt + r < a.n);
+        put_tile32(sP, dk, a.scale, r, hh);
+        put_tile32(sS, dv, 1.0f, r, hh);
+        lds_fence();
+        const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * WD, trow[2 * kt + 1] * a.lddqkv + h * WD};
+        flush_tile32(sP, a.dK, ro, kt, a.n, lane);
+        flush_tile32(sS, a.dV, ro, kt, a.n, lane);
+        lds_fence();
     }
+    put_tile32(sP, dq[0], a.scale, r, hh);
+    put_tile32(sS, dq[1], a.scale, r, hh);
+    lds_fence();
+    {
+        const int64_t r0[2] = {trow[0] * a.lddqkv + h * WD, trow[1] * a.lddqkv + h * WD};
+        const int64_t r1[2] = {trow[2] * a.lddqkv + h * WD, trow[3] * a.lddqkv + h * WD};
+        flush_tile32(sP, a.dQ, r0, 0, a.n, lane);
+        flush_tile32(sS, a.dQ, r1, 1, a.n, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
+// winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
+// fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
+__global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
+    constexpr int PER_WAVE = 3 * 64 * WD;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int h = item % a.H;
+    const int p = item / a.H;
+    const int pg = p / a.G, g = p - pg * a.G;
+    bf16_t* sQ = smem + wave * PER_WAVE;
+    bf16_t* sK = sQ + 64 * WD;
+    bf16_t* sV = sK + 64 * WD;
+
+    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t trow[4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) store_tile32(a.dQ + row[qt] * a.lddqkv + h * WD, dq[qt], a.scale, hh, 32 * qt + r < a.n);
+    for (int i = 0; i < 4; ++i) {
+        trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
+        const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
+    }
+    const float* bmq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + r);       // tiled: see win_table_kernel
+    float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_fence();
+
+    bf16x8_t qf[2][2], kf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[t][s] = ld_frag(sQ + sw_off(32 * t + r, hh + 2 * s));
+            kf[t][s] = ld_frag(sK + sw_off(32 * t + r, hh + 2 * s));
+        }
+    f32x16_t st[2][2];               // [q tile][key tile]: St[key][q]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[qt][kt] = zero16();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st[qt][kt] = MFMA32(kf[kt][s], qf[qt][s], st[qt][kt]);
+        }
+    lds_fence();                     // the Q and K tiles are free: O leaves through them
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float x[2][16];
+        float m = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float4 ad = add[qt][kt][reg >> 2];
+                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
+                x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
+                m = fmaxf(m, x[kt][reg]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
+                l += x[kt][reg];
+            }
+        l += __shfl_xor(l, 32, 64);
+        f32x16_t o = zero16();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) o = MFMA32(tr_frag64(sV, kt, s2, hh, r), pack8(x[kt] + 8 * s2), o);
+        bf16_t* T = qt == 0 ? sQ : sK;
+        put_tile32(T, o, 1.0f / l, r, hh);
+        const int q = 32 * qt + r;
+        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
+    }
+    lds_fence();
+    {
+        const int64_t r0[2] = {trow[0] * a.ldo + h * WD, trow[1] * a.ldo + h * WD};
+        const int64_t r1[2] = {trow[2] * a.ldo + h * WD, trow[3] * a.ldo + h * WD};
+        flush_tile32(sQ, a.O, r0, 0, a.n, lane);
+        flush_tile32(sK, a.O, r1, 1, a.n, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ bias + mask table
@@ -507,7 +686,8 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
-    hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) hipLaunchKernelGGL(winattn_fwd1_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
