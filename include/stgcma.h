@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 205
+#define STG_VERSION 206
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -353,6 +353,19 @@ int stg_cast_bf16(const float* in, void* out, int64_t R, int64_t Cc, int transpo
  * arena first.  max_elems = the largest R*C (sizes the grid). */
 typedef struct { const float* in; int64_t off; int64_t offT; int R, C, ld, ldT; } stg_cast_desc;
 int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_elems, void* arena, void* stream);
+/* torch.optim.Adam's update (the reference's optimizer, AVE/traintest_adapt_ave29.py:63-69: betas (0.95, 0.999), weight_decay 5e-7 as
+ * L2 folded into the gradient, no amsgrad, not maximize) for MANY tensors in one launch, and capturable in a HIP graph: nothing of a
+ * step lives on the host.  `descs`: n descriptors IN DEVICE MEMORY (p / m / v updated in place, g read; all fp32, n elements).
+ * `st` of a descriptor: that tensor's own {step, lr / bias_correction1, sqrt(bias_correction2), -} (device, fp32) -- torch counts
+ * steps per parameter (a parameter that receives its first gradient later starts later).  `hyper`: device DOUBLE [n_groups][8] =
+ * {lr, beta1, beta2, eps, weight_decay, -, -, -} (double: torch evaluates 1 - beta and the corrections from Python floats; beta2 =
+ * 0.999 rounded to fp32 first would move 1 - beta2 by 1.3e-5).  The call first advances `step` of every LISTED tensor by one and
+ * refreshes its step size and correction (one small launch), then applies, per element and in torch's order of operations,
+ *     g' = g + wd p;  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g' g';  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+ * max_elems = the largest tensor (sizes the grid).  ATen runs this as ~13 multi-tensor launches, and its graph-capturable form as
+ * ~1 000 single-element launches per step. */
+typedef struct { float* p; const float* g; float* m; float* v; float* st; int64_t n; int group; int pad_; } stg_adam_desc;
+int stg_adam_multi(const stg_adam_desc* descs, int n, int64_t max_elems, const double* hyper, int n_groups, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 

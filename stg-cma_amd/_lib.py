@@ -107,6 +107,10 @@ class CastDesc(C.Structure):
     _fields_ = [("in_", c_vp), ("off", c_i64), ("offT", c_i64), ("R", C.c_int), ("C", C.c_int), ("ld", C.c_int), ("ldT", C.c_int)]
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("st", c_vp), ("n", c_i64), ("group", C.c_int), ("pad_", C.c_int)]
+
+
 class TAttnArgs(C.Structure):
     _fields_ = [
         ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
@@ -160,6 +164,7 @@ SIGNATURES = {
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_cast_bf16": (C.c_int, [c_vp, c_vp, c_i64, c_i64, C.c_int, c_i64, c_vp]),
     "stg_cast_bf16_multi": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, c_vp]),
+    "stg_adam_multi": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_vp]),
     "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
@@ -196,7 +201,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 205
+ABI_VERSION = 206
 _lib = None
 
 
@@ -223,7 +228,7 @@ def lib():
     _lib = handle
     # A/B knobs of tools/ (never set in production): forwarded ONCE from the environment to the library's explicit options
     for env, opt in (("STG_GEMM_EPI", "gemm_epi"), ("STG_GEMM_KTAIL", "gemm_ktail"), ("STG_GEMM_BIG", "gemm_big"),
-                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn"), ("STG_WINATTN_BWD_OCC", "winattn_bwd_occ")):
+                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn"), ("STG_WINATTN_BWD_OCC", "winattn_bwd_occ"), ("STG_TATTN", "tattn")):
         if env in os.environ:
             check(handle.stg_set_option(opt.encode(), int(os.environ[env])), f"stg_set_option({opt})")
     return _lib

@@ -192,6 +192,36 @@ __global__ void cast_bf16_multi_kernel(const stg_cast_desc* descs, bf16_t* arena
     }
 }
 
+// ---- fused multi-tensor Adam (stg_adam_multi)
+__global__ void adam_bump_kernel(const stg_adam_desc* descs, int n, const double* hyper) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* st = descs[i].st;
+    const double* h = hyper + 8 * descs[i].group;
+    const float step = st[0] + 1.0f;
+    st[0] = step;
+    st[1] = (float)(h[0] / (1.0 - pow(h[1], (double)step)));      // lr / bias_correction1
+    st[2] = (float)sqrt(1.0 - pow(h[2], (double)step));           // sqrt(bias_correction2)
+}
+__global__ void adam_multi_kernel(const stg_adam_desc* descs, const double* hyper) {
+    const stg_adam_desc d = descs[blockIdx.y];
+    const double* h = hyper + 8 * d.group;
+    const float b2 = (float)h[2], eps = (float)h[3], wd = (float)h[4], step_size = d.st[1], bc2s = d.st[2];
+    const float w1 = (float)(1.0 - h[1]), w2 = (float)(1.0 - h[2]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = d.p[i];
+        float g = d.g[i];
+        if (wd != 0.f) g = g + wd * p;
+        float m = d.m[i], v = d.v[i];
+        m = m + w1 * (g - m);
+        v = v * b2 + w2 * g * g;
+        const float denom = sqrtf(v) / bc2s + eps;
+        d.p[i] = p - step_size * (m / denom);
+        d.m[i] = m;
+        d.v[i] = v;
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* in, bf16_t* out, int64_t R, int64_t Cc, int64_t ld) {
     const int64_t total = R * ld;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -418,6 +448,19 @@ extern "C" int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_el
     int gx = (max_elems + 1023) / 1024;          // <= 4 elements per thread for the largest tensor
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(gx, n), dim3(256), 0, ST, descs, (bf16_t*)arena);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_adam_multi(const stg_adam_desc* descs, int n, int64_t max_elems, const double* hyper, int n_groups, void* stream) {
+    STG_CHECK(descs && hyper, -1, "stg_adam_multi: null pointer");
+    STG_CHECK(n >= 0 && n < 65536 && max_elems >= 0 && n_groups > 0, -2, "stg_adam_multi: bad count");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_bump_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, descs, n, hyper);
+    STG_LAUNCH_CHECK();
+    if (max_elems == 0) return 0;
+    int64_t gx = (max_elems + 1023) / 1024;      // <= 4 elements per thread for the largest tensor
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, ST, descs, hyper);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -299,6 +299,278 @@ __global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ coalesced kernels (round 2)
+// The kernels above fetch their operand fragments and store their results ROW-PER-LANE (a lane moves 16 bytes of its own token row):
+// 64 separate requests per wave-instruction, ~64 clocks each in the CU's address path, 8 / 14 such instructions per group.  Here every
+// global access is coalesced -- four lanes cover the 64 bytes of a head's row: the operand tiles of the NEXT group arrive by LDS-DMA
+// (two instructions per 32-row tile) in a second set of LDS tiles while the current group is computed, fragments are read from LDS, and
+// the results leave through a 32 x 32 LDS transposition.  The backward is ONE pass, query on the lane: P and dS feed dQ from the
+// accumulators and come back transposed (ds_read_b64_tr_b16) from two LDS tiles as the B operands of dV^T = dO^T P, dK^T = Q^T dS --
+// no second orientation, no lse / delta broadcast, half the exponentials, no key-major table.
+// Tiles [32][32] bf16 hold SOURCE chunk c of row R at chunk c ^ ((R >> 2) & 3) (operand tiles: conflict-free row fragments and
+// transposed reads); P / dS / output tiles hold 8-byte piece u of row q at u ^ ((q >> 2) & 7).
+__device__ __forceinline__ int sw_off(int row, int chunk) { return row * TD + ((chunk ^ ((row >> 2) & 3)) << 3); }
+__device__ __forceinline__ bf16x8_t tr_frag_sw(const bf16_t* s, int s2, int hh, int d) {       // tr_frag on an sw_off tile
+    const int gi = d & 15, c = d >> 4;
+    const int row = 16 * s2 + 4 * hh + (gi >> 2), u = 4 * c + (gi & 3);
+    const bf16_t* p0 = s + sw_off(row, u >> 1) + ((u & 1) << 2);
+    const bf16_t* p1 = s + sw_off(row + 8, u >> 1) + ((u & 1) << 2);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+__device__ __forceinline__ bf16x8_t tr_frag_pc(const bf16_t* s, int s2, int hh, int d) {       // ... on a piece-swizzled tile
+    const int gi = d & 15, c = d >> 4;
+    const int row = 16 * s2 + 4 * hh + (gi >> 2), u = 4 * c + (gi & 3);
+    const bf16_t* p0 = s + row * 32 + ((u ^ ((row >> 2) & 7)) << 2);
+    const bf16_t* p1 = s + (row + 8) * 32 + ((u ^ (((row + 8) >> 2) & 7)) << 2);
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+__device__ __forceinline__ void put_pieces(bf16_t* T, const bf16x8_t& lo8, const bf16x8_t& hi8, int r, int hh) {   // packed regs 0..7, 8..15
+    const int swz = (r >> 2) & 7;
+    const u32x4_t w0 = __builtin_bit_cast(u32x4_t, lo8), w1 = __builtin_bit_cast(u32x4_t, hi8);
+    *reinterpret_cast<uint2*>(T + r * 32 + (((0 + hh) ^ swz) << 2)) = make_uint2(w0[0], w0[1]);
+    *reinterpret_cast<uint2*>(T + r * 32 + (((2 + hh) ^ swz) << 2)) = make_uint2(w0[2], w0[3]);
+    *reinterpret_cast<uint2*>(T + r * 32 + (((4 + hh) ^ swz) << 2)) = make_uint2(w1[0], w1[1]);
+    *reinterpret_cast<uint2*>(T + r * 32 + (((6 + hh) ^ swz) << 2)) = make_uint2(w1[2], w1[3]);
+}
+__device__ __forceinline__ void put_acc(bf16_t* T, const f32x16_t& acc, float sc, int r, int hh) {
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = acc[i] * sc;
+    put_pieces(T, pack8(x), pack8(x + 8), r, hh);
+}
+// 16 token rows x 64 bytes per store instruction; rowoff[j]: element offset of tile row (lane >> 2) + 16 j
+__device__ __forceinline__ void flush_rows(const bf16_t* T, bf16_t* dst, const int64_t (&rowoff)[2], int nvalid, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tl = (lane >> 2) + 16 * j, cq = lane & 3, sw = (tl >> 2) & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
+        if (tl < nvalid) *reinterpret_cast<uint4*>(dst + rowoff[j] + cq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+#define TATTN_DMA(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                                             (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__global__ void __launch_bounds__(256, 2) tattn_fwd1_kernel(TP a) {
+    constexpr int SET = 3 * 32 * TD;                  // Q, K, V tiles
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 2 * SET];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    bf16_t* base = smem + wave * 2 * SET;
+    const float* bmq = a.bm + ((int64_t)(m * a.H + h) * 32 + r) * 32;
+    float4 add[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 8 * g4 + 4 * hh);
+    // staging lanes: tile row R = (lane >> 2) + 16 j <-> (sequence s, frame t), source chunk (lane & 3) ^ ((R >> 2) & 3)
+    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
+    int ss[2], tt[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (lane >> 2) + 16 * j;
+        ss[j] = R / a.T; tt[j] = R - ss[j] * a.T;
+        if (R >= nv) { ss[j] = 0; tt[j] = 0; }
+    }
+    int64_t nrow[2] = {0, 0}, crow[2];                // token row of the staging lane's two tile rows: next / current group
+    int ncnt = 0;
+    auto issue = [&](int g, int set) {
+        const int b = g / a.gpb, jg = g - b * a.gpb;
+        const int n0 = jg * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        ncnt = cnt;
+        bf16_t* d = base + set * SET;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t row = ((int64_t)(m * a.B + b) * a.T + tt[j]) * a.N + n0 + (ss[j] < cnt ? ss[j] : cnt - 1);
+            nrow[j] = row;
+            const int64_t off = row * a.ld + h * TD + cs * 8;
+            TATTN_DMA(a.Q + off, d + j * 512);
+            TATTN_DMA(a.K + off, d + 32 * TD + j * 512);
+            TATTN_DMA(a.V + off, d + 64 * TD + j * 512);
+        }
+    };
+    int set = 0;
+    if ((int)blockIdx.x < a.ngroups) issue(blockIdx.x, 0);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x, set ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this group's tiles have landed (and the last group's stores are out)
+        lds_fence();
+        crow[0] = nrow[0]; crow[1] = nrow[1];
+        const int nvalid = ncnt * a.T;
+        if (g + (int)gridDim.x < a.ngroups) issue(g + gridDim.x, set ^ 1);
+        const bf16_t* sQ = base + set * SET;
+        const bf16_t* sK = sQ + 32 * TD;
+        const bf16_t* sV = sK + 32 * TD;
+        f32x16_t st = zero16();                       // St[key][q]
+        st = MFMA32(ld_frag(sK + sw_off(r, hh)), ld_frag(sQ + sw_off(r, hh)), st);
+        st = MFMA32(ld_frag(sK + sw_off(r, hh + 2)), ld_frag(sQ + sw_off(r, hh + 2)), st);
+        float x[16];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
+            mx = fmaxf(mx, x[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+            l += x[reg];
+        }
+        l += __shfl_xor(l, 32, 64);
+        f32x16_t o = zero16();                        // O^T[d][q]
+        o = MFMA32(tr_frag_sw(sV, 0, hh, r), pack8(x), o);
+        o = MFMA32(tr_frag_sw(sV, 1, hh, r), pack8(x + 8), o);
+        lds_fence();                                  // every read of the Q tile is done: O leaves through it
+        bf16_t* T = base + set * SET;
+        put_acc(T, o, 1.0f / l, r, hh);
+        lds_fence();
+        const int64_t ro[2] = {crow[0] * a.ldo + h * TD, crow[1] * a.ldo + h * TD};
+        flush_rows(T, a.O, ro, nvalid, lane);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) tattn_bwd1_kernel(TP a) {
+    constexpr int SET = 4 * 32 * TD;                  // K, Q, dO, V tiles
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 2 * SET];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
+    if (h >= a.H) return;
+    const int nv = a.per * a.T;
+    bf16_t* base = smem + wave * 2 * SET;
+    const int64_t tb = ((int64_t)(m * a.H + h) * 32 + r) * 32;
+    float4 add[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(a.bm + tb + 8 * g4 + 4 * hh);      // lane = query, float4 along keys
+    f32x16_t dbacc = zero16();                        // sum of dS^T[key][q] over this wave's groups
+    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
+    int ss[2], tt[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (lane >> 2) + 16 * j;
+        ss[j] = R / a.T; tt[j] = R - ss[j] * a.T;
+        if (R >= nv) { ss[j] = 0; tt[j] = 0; }
+    }
+    int64_t nrow[2] = {0, 0}, crow[2];
+    int ncnt = 0;
+    auto issue = [&](int g, int set) {
+        const int b = g / a.gpb, jg = g - b * a.gpb;
+        const int n0 = jg * a.per;
+        const int cnt = min(a.per, a.N - n0);
+        ncnt = cnt;
+        bf16_t* d = base + set * SET;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t row = ((int64_t)(m * a.B + b) * a.T + tt[j]) * a.N + n0 + (ss[j] < cnt ? ss[j] : cnt - 1);
+            nrow[j] = row;
+            const int64_t off = row * a.ld + h * TD + cs * 8;
+            TATTN_DMA(a.K + off, d + j * 512);
+            TATTN_DMA(a.Q + off, d + 32 * TD + j * 512);
+            TATTN_DMA(a.dO + row * a.lddo + h * TD + cs * 8, d + 64 * TD + j * 512);
+            TATTN_DMA(a.V + off, d + 96 * TD + j * 512);
+        }
+    };
+    int set = 0;
+    if ((int)blockIdx.x < a.ngroups) issue(blockIdx.x, 0);
+    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x, set ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_fence();
+        crow[0] = nrow[0]; crow[1] = nrow[1];
+        const int nvalid = ncnt * a.T;
+        if (g + (int)gridDim.x < a.ngroups) issue(g + gridDim.x, set ^ 1);
+        bf16_t* sK = base + set * SET;
+        bf16_t* sQ = sK + 32 * TD;
+        bf16_t* sD = sQ + 32 * TD;
+        bf16_t* sV = sD + 32 * TD;
+        f32x16_t st = zero16(), dpt = zero16();       // St[key][q], dPt[key][q]
+        st = MFMA32(ld_frag(sK + sw_off(r, hh)), ld_frag(sQ + sw_off(r, hh)), st);
+        dpt = MFMA32(ld_frag(sV + sw_off(r, hh)), ld_frag(sD + sw_off(r, hh)), dpt);
+        st = MFMA32(ld_frag(sK + sw_off(r, hh + 2)), ld_frag(sQ + sw_off(r, hh + 2)), st);
+        dpt = MFMA32(ld_frag(sV + sw_off(r, hh + 2)), ld_frag(sD + sw_off(r, hh + 2)), dpt);
+        float x[16], pr[16];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
+            mx = fmaxf(mx, x[reg]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
+            l += x[reg];
+        }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = (r < nvalid) ? 1.0f / l : 0.f;          // padded / absent sequences contribute nothing
+        float delta = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            pr[reg] = x[reg] * inv;
+            delta += pr[reg] * dpt[reg];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            x[reg] = pr[reg] * (dpt[reg] - delta);                  // dS^T[key][q]
+            dbacc[reg] += x[reg];
+        }
+        const bf16x8_t ps0 = pack8(x), ps1 = pack8(x + 8), pp0 = pack8(pr), pp1 = pack8(pr + 8);
+        f32x16_t dq = zero16();
+        dq = MFMA32(tr_frag_sw(sK, 0, hh, r), ps0, dq);
+        dq = MFMA32(tr_frag_sw(sK, 1, hh, r), ps1, dq);
+        lds_fence();                                  // the K and V tiles are dead: they take dS and P (T[q][key], piece-swizzled)
+        put_pieces(sK, ps0, ps1, r, hh);
+        put_pieces(sV, pp0, pp1, r, hh);
+        lds_fence();
+        f32x16_t dv = zero16(), dk = zero16();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dv = MFMA32(tr_frag_sw(sD, s2, hh, r), tr_frag_pc(sV, s2, hh, r), dv);
+            dk = MFMA32(tr_frag_sw(sQ, s2, hh, r), tr_frag_pc(sK, s2, hh, r), dk);
+        }
+        lds_fence();                                  // all four tiles are dead: dQ, dK, dV leave through three of them
+        put_acc(sK, dq, a.scale, r, hh);
+        put_acc(sQ, dk, a.scale, r, hh);
+        put_acc(sD, dv, 1.0f, r, hh);
+        lds_fence();
+        const int64_t ro[2] = {crow[0] * a.lddqkv + h * TD, crow[1] * a.lddqkv + h * TD};
+        flush_rows(sK, a.dQ, ro, nvalid, lane);
+        flush_rows(sQ, a.dK, ro, nvalid, lane);
+        flush_rows(sD, a.dV, ro, nvalid, lane);
+    }
+
+    if (a.dbias) {
+        // fold the `per` diagonal T x T blocks of the accumulated dS^T[key][q] and add them to dbias[m][h][tq][tk]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_fence();
+        float* tile = reinterpret_cast<float*>(base);   // 32 x 32 fp32 = two tiles of set 0
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) tile[ACC_ROW(reg, hh) * 32 + r] = dbacc[reg];
+        lds_fence();
+        const int TT = a.T * a.T;
+        for (int idx = lane; idx < TT; idx += 64) {
+            const int tq = idx / a.T, tk = idx - tq * a.T;
+            float acc = 0.f;
+            for (int sq = 0; sq < a.per; ++sq) acc += tile[(sq * a.T + tk) * 32 + sq * a.T + tq];
+            atomicAdd(a.dbias + (int64_t)(m * a.H + h) * TT + idx, acc);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ wide heads, no bias (ViT)
 // The CLIP ViT blocks run the same temporal attention (ResidualAttentionBlock, CLIP_AVE.py:369-377: 'n (b t) d -> t (b n) d') through
 // nn.MultiheadAttention: no additive bias, head dim 96 (ViT-B built with 8 heads) or 64 (ViT-L).  Same packing and one-pass backward;
@@ -558,7 +830,8 @@ extern "C" int stg_tattn_fwd(const stg_tattn_args* f, void* stream) {
     hipLaunchKernelGGL(tattn_table_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, f->bias, f->bm, f->bmT, p.nm * p.H, p.T, p.per);
     STG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tattn_fwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    if (stg_opt_tattn.load(std::memory_order_relaxed) >= 1) hipLaunchKernelGGL(tattn_fwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tattn_fwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -587,7 +860,8 @@ extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t ld
         STG_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(tattn_bwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    if (stg_opt_tattn.load(std::memory_order_relaxed) >= 1) hipLaunchKernelGGL(tattn_bwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(tattn_bwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -708,6 +708,36 @@ def cast_bf16_multi(desc, n, max_elems, arena):
     _lib.check(_lib.lib().stg_cast_bf16_multi(_p(desc), int(n), int(max_elems), _p(arena), _stream()), "stg_cast_bf16_multi")
 
 
+def adam_desc_table(entries, device, host=None):
+    """entries: [(p, g, m, v, per-tensor state data_ptrs, numel, group)] -> (uint8 GPU tensor holding the stg_adam_desc array, its
+    pinned host source).  `host`: a pinned uint8 buffer to stage through (nothing is allocated on the host then -- a pinned
+    allocation is not allowed while a HIP graph is being captured); it must stay alive and unchanged as long as a captured graph
+    replays the copy."""
+    arr = (_lib.AdamDesc * len(entries))()
+    for i, (pp, gp, mp, vp, sp, n, grp) in enumerate(entries):
+        arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].st, arr[i].n, arr[i].group = pp, gp, mp, vp, sp, n, grp
+    nbytes = C.sizeof(arr)
+    if host is None:
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    if host.numel() < nbytes or not host.is_pinned():
+        raise RuntimeError("adam_desc_table: the staging buffer must be pinned and large enough")
+    C.memmove(host.data_ptr(), C.addressof(arr), nbytes)
+    dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev.copy_(host[:nbytes], non_blocking=True)
+    return dev, host
+
+
+def adam_multi(desc, n, max_elems, hyper):
+    """One optimizer step of torch.optim.Adam's arithmetic over n fp32 tensors (device-resident descriptor table from adam_desc_table);
+    hyper: fp64 [groups, 8] = lr, beta1, beta2, eps, weight_decay, -, -, -; each tensor's own {step, lr / bc1, sqrt(bc2)} triple (the
+    descriptor's `st`) is advanced by the call."""
+    if desc.dtype != torch.uint8 or not desc.is_cuda or desc.numel() != n * C.sizeof(_lib.AdamDesc):
+        raise RuntimeError("adam_multi: bad descriptor table")
+    if hyper.dtype != torch.float64 or hyper.dim() != 2 or hyper.shape[1] != 8 or not hyper.is_contiguous() or not hyper.is_cuda:
+        raise RuntimeError("adam_multi: hyper must be a contiguous fp64 [groups, 8] device tensor")
+    _lib.check(_lib.lib().stg_adam_multi(_p(desc), int(n), int(max_elems), _p(hyper), int(hyper.shape[0]), _stream()), "stg_adam_multi")
+
+
 def cast_f32(x):
     _chk_flat(x, "x")
     out = torch.empty(x.shape, dtype=F32, device=x.device)

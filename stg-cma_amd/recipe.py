@@ -37,14 +37,155 @@ def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epoch
     return table
 
 
-def build_optimizer(model, lr, head_lr=1.0, weight_decay=5e-7, betas=(0.95, 0.999), capturable=False):
+def build_optimizer(model, lr, head_lr=1.0, weight_decay=5e-7, betas=(0.95, 0.999), capturable=False, fused=None):
     """The reference's optimizer (traintest_adapt_ave29.py:38-69): freeze the backbone by name, Adam over two groups --
-    adapters / gates / temporal tables at `lr`, the newly initialised mlp_head at lr * head_lr.  capturable=True keeps Adam's step
-    counters on the device, so the whole training step can be captured in a HIP graph (capture_train_step)."""
+    adapters / gates / temporal tables at `lr`, the newly initialised mlp_head at lr * head_lr.
+    fused (default: whenever the parameters live on the GPU): FusedAdam below -- torch.optim.Adam's arithmetic as ONE launch of
+    stg_adam_multi, nothing of a step on the host, so the whole training step can be captured in a HIP graph (capture_train_step).
+    fused=False: torch.optim.Adam itself (capturable=True keeps its step counters on the device for graph capture)."""
     import torch
     adapt, head = apply_freeze(model)
     groups = [{"params": adapt, "lr": lr}] + ([{"params": head, "lr": lr * head_lr}] if head else [])   # backbones carry no mlp_head
+    if fused is None:
+        fused = all(p.is_cuda for g in groups for p in g["params"])
+    if fused:
+        return FusedAdam(groups, weight_decay=weight_decay, betas=betas)
     return torch.optim.Adam(groups, weight_decay=weight_decay, betas=betas, capturable=capturable)
+
+
+def _fused_adam_class():
+    import torch
+    from . import kernels as K
+
+    class FusedAdam(torch.optim.Optimizer):
+        """torch.optim.Adam (L2 weight decay, no amsgrad) on the HIP path: every trainable tensor updated by one launch of
+        stg_adam_multi (+ one single-thread launch that advances the step counters and bias corrections on the device).
+        param_groups carry the usual keys (lr, betas, eps, weight_decay): a loop that writes group["lr"] every iteration
+        (traintest_adapt_ave29.py:139-144) works unchanged -- changed values reach the device as fill kernels, no synchronisation.
+        state[p] = {step, exp_avg, exp_avg_sq} like torch's, so state_dict() / load_state_dict() interchange with torch.optim.Adam.
+        Step counters are per parameter, on the device.  Under HIP-graph capture nothing is written from the host: set
+        `lr_tensor(group)` (a device scalar) between replays instead."""
+
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+            super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+            ps = [p for g in self.param_groups for p in g["params"]]
+            if not ps or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+                raise RuntimeError("FusedAdam: contiguous fp32 parameters on the GPU only (use torch.optim.Adam elsewhere)")
+            dev = ps[0].device
+            total = sum((p.numel() + 3) // 4 * 4 for p in ps)
+            self._m = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._v = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._hyper = torch.zeros((len(self.param_groups), 8), dtype=torch.float64, device=dev)
+            self._st = torch.zeros((len(ps), 4), dtype=torch.float32, device=dev)      # per tensor: step, bc1, sqrt(bc2), -
+            self._sent = [None] * len(self.param_groups)
+            off = 0
+            self._idx = {}
+            for gi, g in enumerate(self.param_groups):
+                for p in g["params"]:
+                    n = p.numel()
+                    self._idx[p] = len(self._idx)
+                    self.state[p] = {"step": self._st[self._idx[p], 0], "exp_avg": self._m[off:off + n].view(p.shape),
+                                     "exp_avg_sq": self._v[off:off + n].view(p.shape)}
+                    off += (n + 3) // 4 * 4
+            self._sig, self._desc, self._n, self._max, self._tables = None, None, 0, 0, {}
+            # pinned staging for the descriptor tables, allocated here (not under graph capture): 4 slots recycled by eager address sets,
+            # 4 that tables built during a capture keep for good (a captured copy node re-reads its slot on every replay)
+            self._slot_bytes = (len(ps) * 56 + 63) // 64 * 64
+            self._pinned = torch.empty(8 * self._slot_bytes, dtype=torch.uint8).pin_memory()
+            self._eager_slot, self._graph_slots = 0, 0
+
+        def lr_tensor(self, group=0):
+            return self._hyper[group, 0]
+
+        def _push_hyper(self):
+            for gi, g in enumerate(self.param_groups):
+                vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+                if g.get("amsgrad") or g.get("maximize"):
+                    raise RuntimeError("FusedAdam: amsgrad / maximize are not implemented")
+                old = self._sent[gi]
+                if old == vals:
+                    continue
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedAdam: a hyper-parameter changed during graph capture; write lr_tensor(group) between replays")
+                for k, x in enumerate(vals):
+                    if old is None or old[k] != x:
+                        self._hyper[gi, k].fill_(x)
+                self._sent[gi] = vals
+
+        def _table(self):
+            live = [(gi, p) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.grad is not None]
+            sig = tuple((p.data_ptr(), p.grad.data_ptr()) for _, p in live)
+            if sig != self._sig:
+                # one table per (parameter, gradient) address set, kept: eager steps and a captured graph (whose gradients live in the
+                # graph's own memory pool) each keep theirs; the table goes up from pinned memory, which capture allows
+                if sig not in self._tables:
+                    for _, p in live:
+                        if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.is_sparse:
+                            raise RuntimeError("FusedAdam: dense contiguous fp32 gradients only")
+                    ent = [(p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                            self._st[self._idx[p]].data_ptr(), p.numel(), gi) for gi, p in live]
+                    cap = torch.cuda.is_current_stream_capturing()
+                    if cap:
+                        if self._graph_slots >= 4:
+                            raise RuntimeError("FusedAdam: more than 4 captured address sets")
+                        slot = 4 + self._graph_slots
+                        self._graph_slots += 1
+                    else:
+                        slot = self._eager_slot
+                        self._eager_slot = (self._eager_slot + 1) % 4
+                        for k in [k for k, t in self._tables.items() if t[3] == slot]:
+                            torch.cuda.current_stream().synchronize()      # its upload may still be in flight: rare (addresses moved 4 times)
+                            self._tables.pop(k)
+                    host = self._pinned[slot * self._slot_bytes:(slot + 1) * self._slot_bytes]
+                    self._tables[sig] = (K.adam_desc_table(ent, self._m.device, host) if ent else (None, None), len(ent), max([e[5] for e in ent], default=0), slot)
+                (self._desc, _), self._n, self._max, _ = self._tables[sig]
+                self._sig = sig
+            return self._desc
+
+        @torch.no_grad()
+        def step(self, closure=None):
+            loss = None
+            if closure is not None:
+                with torch.enable_grad():
+                    loss = closure()
+            self._push_hyper()
+            desc = self._table()
+            if desc is not None:
+                with torch.cuda.device(self._m.device):
+                    K.adam_multi(desc, self._n, self._max, self._hyper)
+                # an in-place write outside autograd's sight: bump the version counters the bf16 weight shadows are keyed on (ops.shadow)
+                torch.autograd.graph.increment_version([p for g in self.param_groups for p in g["params"] if p.grad is not None])
+            return loss
+
+        def load_state_dict(self, state_dict):
+            mine = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
+            super().load_state_dict(state_dict)
+            self._sent = [None] * len(self.param_groups)
+            for gi, g in enumerate(self.param_groups):
+                for p in g["params"]:
+                    st = self.state.get(p, {})
+                    m, v = mine[p]
+                    if "exp_avg" in st and st["exp_avg"] is not m:
+                        m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    if "step" in st and st["step"] is not self._st[self._idx[p], 0]:
+                        self._st[self._idx[p], 0].fill_(float(st["step"]))
+                    self.state[p] = {"step": self._st[self._idx[p], 0], "exp_avg": m, "exp_avg_sq": v}
+            self._sig = None
+
+    return FusedAdam
+
+
+class _Lazy:
+    def __init__(self):
+        self._cls = None
+
+    def __call__(self, *a, **kw):
+        if self._cls is None:
+            self._cls = _fused_adam_class()
+        return self._cls(*a, **kw)
+
+
+FusedAdam = _Lazy()
 
 
 def capture_train_step(step, warmup=3):

@@ -33,4 +33,4 @@ for res, heads in [rh for rh in ((56, 4), (28, 8), (14, 16), (7, 32)) if rh[0] i
         f = t(lambda: K.winattn_fwd(wg, qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out=O))
         b = t(lambda: K.winattn_bwd(wg, qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], O, lse, dO, dQ=d[:, :C], dK=d[:, C:2 * C], dV=d[:, 2 * C:]))
         U = rows * C * 2
-        print(f"res {res:2d} heads {heads:2d} shift {shift}: fwd {f:7.1f} us ({4*U/f/1e6:5.0f} GB/s)  bwd {b:7.1f} us ({8*U/b/1e6:5.0f} GB/s)  tables {bm.numel()*8/1e6:.2f} MB")
+        print(f"res {res:2d} heads {heads:2d} shift {shift}: fwd {f:7.1f} us ({4*U/f/1e6:5.0f} TB/s)  bwd {b:7.1f} us ({8*U/b/1e6:5.2f} TB/s)  tables {bm.numel()*8/1e6:.2f} MB")
