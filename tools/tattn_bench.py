@@ -1,5 +1,5 @@
 """Temporal attention kernels (head dim 32, T = 10) at the four Swin-B stage shapes, B = 32 clips x 2 modalities:
-python tools/tattn_bench.py   (STG_TATTN=0/1 selects the round-1 / coalesced kernels)"""
+python tools/tattn_bench.py   (STG_TATTN_KERNELS=0/1 selects the round-1 / coalesced kernels)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, stgcma
