@@ -189,9 +189,9 @@ FusedAdam = _Lazy()
 
 
 def capture_train_step(step, warmup=3):
-    """Capture one call of `step()` (forward + loss + zero_grad + backward + optimizer.step, the optimizer built with capturable=True)
-    in a HIP graph and return (replay, static_loss): every launch of the step -- ~2 000 for Swin-B -- then costs one graph launch
-    (host time 140 ms -> 2 ms per step, measured).  The library's launches go to torch's current stream, so torch.cuda.graph records
+    """Capture one call of `step()` (forward + loss + zero_grad + backward + optimizer.step; the optimizer is build_optimizer's
+    FusedAdam, or torch.optim.Adam built with capturable=True) in a HIP graph and return (replay, static_loss): every launch of the
+    step -- ~1 700 for Swin-B -- then costs one graph launch (host time 95 ms -> 0.4 ms per step, measured).  The library's launches go to torch's current stream, so torch.cuda.graph records
     them like ATen's; `step` must not synchronise (no .item() / float(loss)) and its inputs must be static tensors (copy new batches
     into them).  A few eager calls on a side stream first: graph capture needs every lazily built table / shadow / LDS reservation in
     place."""
