@@ -85,6 +85,34 @@ __device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
     dy = fmaf(sg * (1.0f - sg), x * up, sg);
     y = x * sg;
 }
+// The same two functions on PAIRS of values: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 carry two fp32 lanes per issue slot, so the
+// polynomial part costs half (the clamp, exp2 and rcp stay per value): 2 x (13 VALU + 2 transcendentals) -> 14 + 4 for value and
+// derivative.  Same operations in the same order as the scalar forms: bit-identical results.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2_t pk_splat(float v) { return (f32x2_t){v, v}; }
+__device__ __forceinline__ f32x2_t gelu_sig_core2(f32x2_t x, f32x2_t& x2, f32x2_t& xc) {
+    xc = (f32x2_t){__builtin_amdgcn_fmed3f(x.x, -8.0f, 8.0f), __builtin_amdgcn_fmed3f(x.y, -8.0f, 8.0f)};
+    x2 = xc * xc;
+    f32x2_t pl = pk_fma(x2, pk_splat(0.000911226f), pk_splat(-0.106178f));
+    pl = pk_fma(pl, x2, pk_splat(-2.30172f));
+    const f32x2_t u = pl * xc;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+    const f32x2_t d = pk_splat(1.0f) + e;
+    return (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
+    f32x2_t x2, xc;
+    return x * gelu_sig_core2(x, x2, xc);
+}
+__device__ __forceinline__ void gelu_sig_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
+    f32x2_t x2, xc;
+    const f32x2_t sg = gelu_sig_core2(x, x2, xc);
+    f32x2_t up = pk_fma(x2, pk_splat(-0.0031580704f), pk_splat(0.2207895358f));
+    up = pk_fma(up, x2, pk_splat(1.5954356678f));
+    dy = pk_fma(sg * (pk_splat(1.0f) - sg), x * up, sg);
+    y = x * sg;
+}
 __device__ __forceinline__ void quick_gelu_fast(float x, float& y, float& dy) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930157f));   // sigmoid(1.702 x)
     dy = s * fmaf(1.702f * x, 1.0f - s, 1.0f);

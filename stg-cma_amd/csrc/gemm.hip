@@ -233,7 +233,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
                 float d[8];
                 if (!G && !c_f32) {                    // bf16 destinations: the cheaper logistic form (common.h)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) gelu_sig_both(t[j], t[j], d[j]);
+                    for (int j = 0; j < 8; j += 2) {   // packed fp32 pairs (common.h): bit-identical to gelu_sig_both
+                        f32x2_t y2, d2;
+                        gelu_sig_both2((f32x2_t){t[j], t[j + 1]}, y2, d2);
+                        t[j] = y2.x; t[j + 1] = y2.y; d[j] = d2.x; d[j + 1] = d2.y;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) gelu_fast(t[j], t[j], d[j]);

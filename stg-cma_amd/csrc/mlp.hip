@@ -150,9 +150,11 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_kernel(MlpP p) {
                 for (int mt = 0; mt < 2; ++mt) {
                     float x[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        x[r] = DIAG == 1 ? S[2 * q][mt][r] + bv[r] : gelu_sig(S[2 * q][mt][r] + bv[r]);
-                        x[4 + r] = DIAG == 1 ? S[2 * q + 1][mt][r] + bv[4 + r] : gelu_sig(S[2 * q + 1][mt][r] + bv[4 + r]);
+                    for (int r = 0; r < 4; r += 2) {     // packed fp32 pairs (common.h): bit-identical to gelu_sig
+                        const f32x2_t a2 = {S[2 * q][mt][r] + bv[r], S[2 * q][mt][r + 1] + bv[r + 1]};
+                        const f32x2_t b2 = {S[2 * q + 1][mt][r] + bv[4 + r], S[2 * q + 1][mt][r + 1] + bv[4 + r + 1]};
+                        const f32x2_t ya = DIAG == 1 ? a2 : gelu_sig2(a2), yb = DIAG == 1 ? b2 : gelu_sig2(b2);
+                        x[r] = ya.x; x[r + 1] = ya.y; x[4 + r] = yb.x; x[4 + r + 1] = yb.y;
                     }
                     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
                     const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
