@@ -175,9 +175,11 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
         }
         float pA[16], pB[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            pA[reg] = __builtin_amdgcn_exp2f(fmaf(sA[reg], a.c2, -m2));
-            pB[reg] = __builtin_amdgcn_exp2f(fmaf(sB[reg], a.c2, -m2));
+        for (int reg = 0; reg < 16; reg += 2) {                 // the FMA on packed fp32 pairs (v_pk_fma_f32: two scores per issue slot)
+            const f32x2_t xa = pk_fma((f32x2_t){sA[reg], sA[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
+            const f32x2_t xb = pk_fma((f32x2_t){sB[reg], sB[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
+            pA[reg] = __builtin_amdgcn_exp2f(xa.x); pA[reg + 1] = __builtin_amdgcn_exp2f(xa.y);
+            pB[reg] = __builtin_amdgcn_exp2f(xb.x); pB[reg + 1] = __builtin_amdgcn_exp2f(xb.y);
         }
         lds_sync();                                             // tile writes visible to the transposed reads
 #pragma unroll
@@ -284,15 +286,19 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
         if (k0 + 64 < a.n_kv) load_pair(k0 + 64);
         float dA[16], dB[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float xa = fmaf(sA[reg], a.c2, -lse2), xb = fmaf(sB[reg], a.c2, -lse2);
+        for (int reg = 0; reg < 16; reg += 2) {                 // FMA, subtraction and product on packed fp32 pairs
+            f32x2_t xa = pk_fma((f32x2_t){sA[reg], sA[reg + 1]}, pk_splat(a.c2), pk_splat(-lse2));
+            f32x2_t xb = pk_fma((f32x2_t){sB[reg], sB[reg + 1]}, pk_splat(a.c2), pk_splat(-lse2));
             if (MASKED) {
                 const int key = k0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                xa = key < a.n_kv ? xa : -INFINITY;
-                xb = key + 32 < a.n_kv ? xb : -INFINITY;
+                xa.x = key < a.n_kv ? xa.x : -INFINITY;          xa.y = key + 1 < a.n_kv ? xa.y : -INFINITY;
+                xb.x = key + 32 < a.n_kv ? xb.x : -INFINITY;     xb.y = key + 33 < a.n_kv ? xb.y : -INFINITY;
             }
-            dA[reg] = __builtin_amdgcn_exp2f(xa) * (dpA[reg] - delta);
-            dB[reg] = __builtin_amdgcn_exp2f(xb) * (dpB[reg] - delta);
+            const f32x2_t ea = {__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
+            const f32x2_t eb = {__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+            const f32x2_t ra = ea * ((f32x2_t){dpA[reg], dpA[reg + 1]} - pk_splat(delta));
+            const f32x2_t rb = eb * ((f32x2_t){dpB[reg], dpB[reg + 1]} - pk_splat(delta));
+            dA[reg] = ra.x; dA[reg + 1] = ra.y; dB[reg] = rb.x; dB[reg + 1] = rb.y;
         }
         lds_sync();
 #pragma unroll
@@ -393,10 +399,12 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
             const float4 d4 = *reinterpret_cast<const float4*>(sStat + 32 + 8 * g + 4 * hh);
             const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {                     // packed fp32 pairs
                 const int reg = 4 * g + e;
-                pr[reg] = __builtin_amdgcn_exp2f(fmaf(sc[reg], a.c2, -lv[e]));
-                ds[reg] = pr[reg] * (dp[reg] - dl[e]);
+                const f32x2_t x = pk_fma((f32x2_t){sc[reg], sc[reg + 1]}, pk_splat(a.c2), (f32x2_t){-lv[e], -lv[e + 1]});
+                const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                const f32x2_t dv2 = pv * ((f32x2_t){dp[reg], dp[reg + 1]} - (f32x2_t){dl[e], dl[e + 1]});
+                pr[reg] = pv.x; pr[reg + 1] = pv.y; ds[reg] = dv2.x; ds[reg + 1] = dv2.y;
             }
         }
 #pragma unroll
