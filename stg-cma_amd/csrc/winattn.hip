@@ -421,6 +421,15 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         lse_q[t] = q < a.n ? a.lse[((int64_t)p * a.H + h) * 64 + q] * 1.4426950408889634f : 1.0e30f;
     }
     const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
+    // the additive table of a (key tile, q tile) pair is fetched one pair ahead (L2 hits, but ~1 us each when waited for in place);
+    // the fences around the P / dS tiles keep the compiler from sinking the loads back to their use
+    float4 addc[4], addn[4];
+    auto load_add = [&](float4 (&dst)[4], int kt, int qt) {
+        const float* bmq = a.bm + tb + 4 * (32 * qt + r);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+    };
+    load_add(addc, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_fence();
     // delta[q] = sum_d dO[q][d] O[q][d]: the lane's own 16-byte piece of dO (back from LDS) times the same piece of O, summed over the
@@ -455,10 +464,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         const bf16x8_t kf0 = ld_frag(sK + sw_off(32 * kt + r, hh)), kf1 = ld_frag(sK + sw_off(32 * kt + r, hh + 2));
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const float* bmq = a.bm + tb + 4 * (32 * qt + r);
-            float4 add[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+            if (kt * 2 + qt < 3) load_add(addn, (kt * 2 + qt + 1) >> 1, (kt * 2 + qt + 1) & 1);
             const bf16x8_t qf0 = ld_frag(sQ + sw_off(32 * qt + r, hh)), qf1 = ld_frag(sQ + sw_off(32 * qt + r, hh + 2));
             const bf16x8_t df0 = ld_frag(sD + sw_off(32 * qt + r, hh)), df1 = ld_frag(sD + sw_off(32 * qt + r, hh + 2));
             f32x16_t st = zero16(), dpt = zero16();
@@ -469,7 +475,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
             float pr[16], ds[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const float4 ad = add[reg >> 2];
+                const float4 ad = addc[reg >> 2];
                 const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
                 pr[reg] = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + (av - lse_q[qt]));      // padded keys: av = -1e30; padded queries: lse = +1e30
                 ds[reg] = pr[reg] * (dpt[reg] - delta[qt]);
@@ -497,6 +503,8 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
                 dk = MFMA32(tr_frag64(sQ, qt, s2, hh, r), tr_frag32(sS, s2, hh, r), dk);
             }
             lds_fence();                                   // the tiles are rewritten by the next pair
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) addc[g4] = addn[g4];
         }
         put_tile32(sP, dk, a.scale, r, hh);
         put_tile32(sS, dv, 1.0f, r, hh);

@@ -348,3 +348,19 @@ def test_product_path_has_no_cpu_fallback(stg):
                                         ftmode="fusion", adapter_mlp_ratio=[0.5, 0.25])
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 2, 224, 224), torch.zeros(1, 3, 2, 224, 224), "fusion")
+
+
+def test_use_checkpoint_flag_is_accepted(stg, gpu):
+    """use_checkpoint=True (Swin_AVE.py:1049-1050) trades memory for recompute in the reference and leaves results unchanged; here it
+    is accepted and a no-op: same logits as without it."""
+    from stgcma.model import Swin_AVE
+    kw = dict(pretrained=None, num_frames=2, embed_dim=32, depths=[2, 2], num_heads=[1, 2], ftmode="fusion", label_dim=5,
+              adapter_mlp_ratio=[0.5, 0.5])
+    torch.manual_seed(0)
+    m0 = Swin_AVE.SwinTransformer2D_Adapter_New(**kw).to(gpu).eval()
+    m1 = Swin_AVE.SwinTransformer2D_Adapter_New(use_checkpoint=True, **kw).to(gpu).eval()
+    m1.load_state_dict(m0.state_dict())
+    a = torch.randn(2, 2, 224, 224, device=gpu) * 0.5
+    v = torch.randn(2, 3, 2, 224, 224, device=gpu)
+    with torch.no_grad():
+        assert torch.equal(m0(a, v, "fusion"), m1(a, v, "fusion"))
