@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 206
+#define STG_VERSION 207
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -366,6 +366,10 @@ int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_elems, void* 
  * ~1 000 single-element launches per step. */
 typedef struct { float* p; const float* g; float* m; float* v; float* st; int64_t n; int group; int pad_; } stg_adam_desc;
 int stg_adam_multi(const stg_adam_desc* descs, int n, int64_t max_elems, const double* hyper, int n_groups, void* stream);
+/* x[((b T + t) N + n), :] += emb[t, :]  -- the absolute temporal embedding of t_relative=False, '(b t) n c -> (b n) t c' + embedding
+ * (AVE/model/Swin_AVE.py:1483-1487, :1569-1576): x fp32 [B*T*N, C] in place, emb fp32 [T, C].  Its gradient is a token mean
+ * (stg_meanpool_fwd over the N rows of every frame) summed over the clips. */
+int stg_add_temporal(float* x, const float* emb, int64_t B, int T, int64_t N, int C, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 

@@ -281,6 +281,12 @@ def swin_forward(P, a, v, cfg, mode):
                   "fusion": "fusion_adapt"}[mode]
     xv = patch_embed(P, "patch_embed", v) if mode != "audioonly" else None
     xa = patch_embed(P, "patch_embed_audio", a.unsqueeze(1)) if mode != "videoonly" else None
+    if "temporal_embedding" in P:                     # t_relative=False (:1207-1212): '(b t) n c -> (b n) t c' + embedding (:1483-1487, :1569-1576)
+        def add_t(x, e):
+            BT, N, C = x.shape
+            return (x.view(BT // T, T, N, C) + e.view(1, T, 1, C)).view(BT, N, C)
+        xv = add_t(xv, P["temporal_embedding"]) if xv is not None else None
+        xa = add_t(xa, P["temporal_embedding_audio"]) if xa is not None else None
     x = xv if mode == "videoonly" else xa if mode == "audioonly" else (xv, xa)
     for s, depth in enumerate(depths):
         H = W = res // (2 ** s)

@@ -192,6 +192,17 @@ __global__ void cast_bf16_multi_kernel(const stg_cast_desc* descs, bf16_t* arena
     }
 }
 
+__global__ void add_temporal_kernel(float* x, const float* emb, int64_t total4, int T, int64_t N, int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / C4;
+        const int c4 = (int)(i - row * C4), t = (int)((row / N) % T);
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        const float4 e = reinterpret_cast<const float4*>(emb)[(int64_t)t * C4 + c4];
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+
 // ---- fused multi-tensor Adam (stg_adam_multi)
 __global__ void adam_bump_kernel(const stg_adam_desc* descs, int n, const double* hyper) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,6 +459,16 @@ extern "C" int stg_cast_bf16_multi(const stg_cast_desc* descs, int n, int max_el
     int gx = (max_elems + 1023) / 1024;          // <= 4 elements per thread for the largest tensor
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(gx, n), dim3(256), 0, ST, descs, (bf16_t*)arena);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_add_temporal(float* x, const float* emb, int64_t B, int T, int64_t N, int C, void* stream) {
+    STG_CHECK(x && emb, -1, "stg_add_temporal: null pointer");
+    STG_CHECK(B >= 0 && T > 0 && N > 0 && C > 0 && C % 4 == 0, -2, "stg_add_temporal: bad shape (C % 4 == 0)");
+    STG_CHECK((((uintptr_t)x | (uintptr_t)emb) & 15) == 0, -2, "stg_add_temporal: pointers must be 16-byte aligned");
+    const int64_t total4 = B * T * N * (C / 4);
+    if (total4 == 0) return 0;
+    hipLaunchKernelGGL(add_temporal_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, ST, x, emb, total4, T, N, C / 4);
     STG_LAUNCH_CHECK();
     return 0;
 }

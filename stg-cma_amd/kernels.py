@@ -708,6 +708,16 @@ def cast_bf16_multi(desc, n, max_elems, arena):
     _lib.check(_lib.lib().stg_cast_bf16_multi(_p(desc), int(n), int(max_elems), _p(arena), _stream()), "stg_cast_bf16_multi")
 
 
+def add_temporal(x, emb, B, T, N):
+    """x fp32 [B*T*N, C] (a contiguous row slice) += emb fp32 [T, C] broadcast over clips and tokens, in place."""
+    _chk_flat(x, "x", F32)
+    Cc = x.shape[-1]
+    if x.shape[0] != B * T * N or emb.dtype != F32 or not emb.is_contiguous() or emb.numel() != T * Cc:
+        raise RuntimeError("add_temporal: shape mismatch")
+    _lib.check(_lib.lib().stg_add_temporal(_p(x), _p(emb), B, T, N, Cc, _stream()), "stg_add_temporal")
+    return x
+
+
 def adam_desc_table(entries, device, host=None):
     """entries: [(p, g, m, v, per-tensor state data_ptrs, numel, group)] -> (uint8 GPU tensor holding the stg_adam_desc array, its
     pinned host source).  `host`: a pinned uint8 buffer to stage through (nothing is allocated on the host then -- a pinned

@@ -355,7 +355,7 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         last = self.layers[-1].input_resolution
         plan.n_tok_last = last[0] * last[1]
         plan.head_drop = self.mlp_head[1].p if (len(plan.mods) == 2 and hasattr(self, 'mlp_head')) else 0.
-        train_ok = ("Adapter", "gate_", "temporal_position_bias_table", "mlp_head.")
+        train_ok = ("Adapter", "gate_", "temporal_position_bias_table", "mlp_head.", "temporal_embedding")
         plan.trainable_ok = lambda n: any(t in n for t in train_ok)
         self._plan_cache = plan
         return plan
@@ -380,7 +380,7 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         if self.ftmode != 'fusion':
             raise TypeError('ftmode is not expected !!!')
         if not self.t_relative:
-            raise NotImplementedError("t_relative=False (absolute temporal embedding) is not on the HIP path yet")
+            raise NotImplementedError("t_relative=False (absolute temporal embedding): built for the AVE model only")
         if not v.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
         names, tensors = self._flat_tensors()
@@ -392,8 +392,6 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         (Swin_AVE.py:1479-1599).  Runs entirely on the HIP path; raises when inputs / parameters are not on a GPU."""
         if mode not in ('audioonly', 'videoonly', 'multimodal', 'fusion') or mode != self.ftmode:
             raise TypeError('ftmode is not expected !!!')
-        if not self.t_relative:
-            raise NotImplementedError("t_relative=False (absolute temporal embedding) is not on the HIP path yet")
         ref = v if mode != 'audioonly' else a
         if not ref.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")

@@ -1144,6 +1144,9 @@ class SwinModelFn(torch.autograd.Function):
             x5 = a.unsqueeze(1) if m else v
             nw = P.get(pe + ".norm.weight")
             patch_embed_into(x5, P[pe + ".proj.weight"], P[pe + ".proj.bias"], nw, P.get(pe + ".norm.bias"), X[i * Rm:(i + 1) * Rm])
+            te = P.get("temporal_embedding_audio" if m else "temporal_embedding")
+            if te is not None:                       # t_relative=False: absolute temporal embedding behind the patch embedding (:1569-1576)
+                K.add_temporal(X[i * Rm:(i + 1) * Rm], f32c(te).reshape(T, -1), B, T, N0)
         pool = None
         if training:
             req = [r for st in plan.stages for spec, _ in st["blocks"] for r in block_drop_requests(spec, B)]
@@ -1173,6 +1176,7 @@ class SwinModelFn(torch.autograd.Function):
         ctx.tape, ctx.head, ctx.P, ctx.need, ctx.names, ctx.two = tape, S, P, need, names, len(mods) == 2
         ctx.ddp = getattr(plan, "ddp", None)
         ctx.fp8 = plan_fp8
+        ctx.geom0 = (mods, B, T, N0)
         return logits
 
     @staticmethod
@@ -1197,6 +1201,15 @@ class SwinModelFn(torch.autograd.Function):
             else:
                 dH_carry = None
                 dX = merge_backward(S, spec[0], spec[1], Pl, dX, ctx.fp8)
+        mods, B, T, N0 = ctx.geom0
+        for i, m in enumerate(mods):                 # t_relative=False: d emb[t] = sum over clips and tokens of dX (token mean x N0, then clips)
+            name = "temporal_embedding_audio" if m else "temporal_embedding"
+            if need.get(name, False):
+                Rm = B * T * N0
+                pooled = K.meanpool_fwd(dX[i * Rm:(i + 1) * Rm], B * T, N0, out_dtype=F32)
+                g = arena.view(name, P[name])
+                g.copy_(pooled.view(B, T, -1).sum(0).mul_(float(N0)).view(g.shape))
+                grads[name] = g
         if ctx.ddp is not None:
             ctx.ddp.allreduce_(arena.flat, arena.n_real)      # one collective for every trainable gradient of the step
         return (None, None, None, None, None, None) + tuple(grads.get(n) for n in ctx.names)

@@ -124,7 +124,8 @@ def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True, state_f
     m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
                                         embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
                                         window_size=7, pretrained=None, ftmode=mode,
-                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+                                        **({"t_relative": cfg["t_relative"]} if "t_relative" in cfg else {})).eval()
     shapes = seed_module(m, seed, state_fn)
     names = apply_freeze(m)
     T = cfg["num_frames"]
@@ -620,6 +621,8 @@ def main(argv):
         "swin_tiny_fusion": lambda: swin_model_case(S, "swin_tiny_fusion", cfg=SWIN_TINY, B=1, mode="fusion", seed=200),
         "swin_tiny_multimodal": lambda: swin_model_case(S, "swin_tiny_multimodal", cfg=SWIN_TINY, B=1, mode="multimodal", seed=210),
         "swin_tiny_videoonly": lambda: swin_model_case(S, "swin_tiny_videoonly", cfg=SWIN_TINY, B=1, mode="videoonly", seed=220),
+        # t_relative=False (Swin_AVE.py:1207-1212, :1569-1576): trainable absolute temporal embeddings added behind the patch embedding
+        "swin_tiny_fusion_tabs": lambda: swin_model_case(S, "swin_tiny_fusion_tabs", cfg=dict(SWIN_TINY, t_relative=False), B=2, mode="fusion", seed=230),
         "swin_b_fusion": lambda: swin_model_case(S, "swin_b_fusion", cfg=SWIN_B, B=1, mode="fusion", seed=300, store_all_grads=False),
         "swin_b_fusion_refinit": lambda: swin_model_case(S, "swin_b_fusion_refinit", cfg=SWIN_B, B=1, mode="fusion", seed=310,
                                                          store_all_grads=False, state_fn=GP.refinit_state),

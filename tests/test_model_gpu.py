@@ -99,7 +99,8 @@ def test_single_stream_block_matches_reference(stg, gpu, tag):
             assert d[n].grad is None or float(d[n].grad.abs().max()) == 0
 
 
-@pytest.mark.parametrize("tag,mode", [("swin_tiny_multimodal", "multimodal"), ("swin_tiny_videoonly", "videoonly")])
+@pytest.mark.parametrize("tag,mode", [("swin_tiny_multimodal", "multimodal"), ("swin_tiny_videoonly", "videoonly"),
+                                      ("swin_tiny_fusion_tabs", "fusion")])      # _tabs: t_relative=False, absolute temporal embeddings (B = 2)
 def test_swin_tiny_other_modes_match_reference(stg, gpu, tag, mode):
     from stgcma.model import Swin_AVE as S
     from params import seeded_tensor
@@ -119,6 +120,14 @@ def test_swin_tiny_other_modes_match_reference(stg, gpu, tag, mode):
     _report.append(f"{tag} logits max abs err {err:.3e}")
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
     _cmp(_flat_grads(m, names), z["grads"], f"{tag} grads", max_rel=5e-2, l2_rel=3e-2)
+    if "t_relative" in cfg:                                    # the embeddings' own gradients, not hidden behind the adapters'
+        d = dict(m.named_parameters())
+        off = 0
+        for n in names:
+            k = d[n].numel()
+            if n.startswith("temporal_embedding"):
+                _cmp(d[n].grad, z["grads"][off:off + k], f"{tag} grad[{n}]", max_rel=5e-2, l2_rel=3e-2)
+            off += k
 
 
 @pytest.mark.parametrize("tag", ["swin_block_even", "swin_block_odd", "swin_block_s0", "swin_block_s3", "swin_block_nofusion",
@@ -166,7 +175,7 @@ def _build_model(S, cfg, P, gpu, train=False):
     m = S.SwinTransformer2D_Adapter_New(label_dim=cfg["label_dim"], patch_size=[1, 4, 4], num_frames=cfg["num_frames"],
                                         embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
                                         window_size=7, pretrained=None, ftmode=cfg["mode"],
-                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"])
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"], t_relative=cfg.get("t_relative", True))
     _load_into(m, P)
     m = m.to(gpu)
     m.train(train)

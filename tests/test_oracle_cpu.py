@@ -60,7 +60,7 @@ def test_swin_block_matches_reference(tag):
     _close(_grads(P, ["blk." + n for n in names]), z["grads"], what="param grads")
 
 
-@pytest.mark.parametrize("tag", ["swin_tiny_fusion", "swin_tiny_multimodal", "swin_tiny_videoonly"])
+@pytest.mark.parametrize("tag", ["swin_tiny_fusion", "swin_tiny_multimodal", "swin_tiny_videoonly", "swin_tiny_fusion_tabs"])
 def test_swin_tiny_model_matches_reference(tag):
     z, cfg, shapes, names = load_case(tag)
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
