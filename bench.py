@@ -327,7 +327,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gp = kernels.gemm_profile_stop()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     # the same step replayed from a HIP graph (N = 1): reported next to the eager number, which stays `value` -- the roofline
     # sampling above needs eager launches (HIP events around individual kernels)
     graph_replay = None
