@@ -278,6 +278,8 @@ typedef struct {
 int stg_winattn_table(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT,
                       int L, int H, int n, int Gt, void* stream);
 int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
+/* dV == NULL: K and V are the same tensor (the adapters' window-level cross-modal attention softmax(h hother^T) hother,
+ * AVE/model/Swin_AVE.py:750-760, run with H = 1 and an all-zero bias table) and dK receives dK + dV. */
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
 

@@ -506,12 +506,20 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) addc[g4] = addn[g4];
         }
-        put_tile32(sP, dk, a.scale, r, hh);
-        put_tile32(sS, dv, 1.0f, r, hh);
-        lds_fence();
         const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * WD, trow[2 * kt + 1] * a.lddqkv + h * WD};
-        flush_tile32(sP, a.dK, ro, kt, a.n, lane);
-        flush_tile32(sS, a.dV, ro, kt, a.n, lane);
+        if (a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dk[i] = fmaf(dk[i], a.scale, dv[i]);
+            put_tile32(sP, dk, 1.0f, r, hh);
+            lds_fence();
+            flush_tile32(sP, a.dK, ro, kt, a.n, lane);
+        } else {
+            put_tile32(sP, dk, a.scale, r, hh);
+            put_tile32(sS, dv, 1.0f, r, hh);
+            lds_fence();
+            flush_tile32(sP, a.dK, ro, kt, a.n, lane);
+            flush_tile32(sS, a.dV, ro, kt, a.n, lane);
+        }
         lds_fence();
     }
     put_tile32(sP, dq[0], a.scale, r, hh);
@@ -706,13 +714,13 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     WinP p = {};
     int rc = fill(f, p, "stg_winattn_bwd");
     if (rc) return rc;
-    STG_CHECK(f->O && f->lse && dO && dQ && dK && dV, -1, "stg_winattn_bwd: null pointer");
+    const int occ = stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed);      // 1 (default): the one-pass kernel; 2 / 3: the two-orientation kernel
+    STG_CHECK(f->O && f->lse && dO && dQ && dK && (dV || occ <= 1), -1, "stg_winattn_bwd: null pointer (dV == NULL -> dK receives dK + dV: round-2 kernel only)");
     STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_winattn_bwd: bad leading dims");
     STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    const int occ = stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed);      // 1 (default): the one-pass kernel; 2 / 3: the two-orientation kernel
     if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);

@@ -991,11 +991,11 @@ def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     if lse is None or lse.dtype != F32 or lse.numel() != g.P * g.H * 64:
         raise RuntimeError("winattn_bwd: bad lse")
     rows = (g.P // g.G) * g.outer
-    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK"), (dV, "dV")):
+    for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK")) + (((dV, "dV"),) if dV is not None else ()):      # dV None: K is V, dK <- dK + dV
         _chk2d(t, name, BF16)
         if t.shape[1] < g.H * 32 or t.shape[0] < rows:
             raise RuntimeError(f"winattn_bwd {name}: needs >= {rows} rows x {g.H * 32} columns")
-    if not (_ld(dQ) == _ld(dK) == _ld(dV)):
+    if not (_ld(dQ) == _ld(dK) == (_ld(dV) if dV is not None else _ld(dK))):
         raise RuntimeError("winattn_bwd: dQ, dK, dV must share one leading dimension")
     a = _win_fill(g, Q, K, V, O, lse)
     _lib.check(_lib.lib().stg_winattn_bwd(C.byref(a), _p(dO), _ld(dO), _p(dQ), _p(dK), _p(dV), _ld(dQ), _stream()),

@@ -443,6 +443,22 @@ def _xattn_geom(spec, BT, dh, window, g):
     return K.AttnGeom(BT, 1, spec.N, dh, G=1, outer=spec.N, n_kv=spec.N, outer_kv=spec.N, scale=1.0)
 
 
+USE_XWIN = _os.environ.get("STG_XWIN", "1") != "0"     # 0 = window-level cross-modal attention on the generic kernels (A/B knob)
+_xwin_tabs = {}
+
+
+def _xwin_geom(spec, BT, dev):
+    """The window-level cross-modal pair on the whole-window kernels of winattn.hip: one head of width 32, K = V = the other
+    modality's hidden states, scale 1, no bias and no shift mask (an all-zero additive table, -1e30 on the padding keys)."""
+    n = spec.ws * spec.ws
+    key = (dev, spec.ws)
+    tabs = _xwin_tabs.get(key)
+    if tabs is None:
+        L = (2 * spec.ws - 1) ** 2
+        tabs = _xwin_tabs[key] = K.winattn_table(torch.zeros((L, 1), dtype=F32, device=dev), torch.zeros(n * n, dtype=torch.int64, device=dev), None, n)
+    return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
+
+
 def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=None):
     """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808).
     geoms = (video-queries geometry, audio-queries geometry) when the two token counts differ (ViT)."""
@@ -452,6 +468,11 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
         ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
         return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a), (rv, ra, lse_v, lse_a, mg)
+    if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
+        wg = _xwin_geom(spec, BT, hv.device)
+        rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
+        ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
+        return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a), (rv, ra, lse_v, lse_a, wg)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
     ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
@@ -465,6 +486,19 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     the adapters' D_fc1, the gradients wrt the D_fc1 pre-activations instead (the join and the activation backward in one pass)."""
     mg = saved[4] if len(saved) == 5 else None
     rv, ra, lse_v, lse_a = saved[:4]
+    if isinstance(mg, K.WinGeom):                                                     # whole-window kernels, dK <- dK + dV
+        if dgate_v is None:
+            dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
+        if dgate_a is None:
+            dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
+        drv = K.gate_bwd(dhv2, rv, gate_v, dgate_v)
+        dra = K.gate_bwd(dha2, ra, gate_a, dgate_a)
+        dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
+        K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v
+        K.winattn_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)      # direction v -> a
+        if zs is not None:
+            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
+        return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
     if mg is None:
         ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     if dgate_v is None:

@@ -115,3 +115,33 @@ def test_winattn_rejects_bad_geometry(stg, gpu):
     q = torch.zeros(14 * 14 - 1, 192, dtype=BF16, device=gpu)
     with pytest.raises(RuntimeError):
         k.winattn_fwd(wg, q[:, :64], q[:, 64:128], q[:, 128:])          # too few rows
+
+
+def test_window_shared_kv_single_head_sums_dk_dv(stg, gpu):
+    """The cross-modal use (H = 1, K = V = the other modality's hidden states, zero bias, scale 1): dV = None makes the backward
+    write dK + dV into dK -- the same numbers as the two separate gradients added in fp32, up to one bf16 rounding."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(11)
+    images, Himg, ws, shift = 3, 14, 7, 3
+    n, N = ws * ws, Himg * Himg
+    q = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    kv = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    dO = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    bm, bmT = k.winattn_table(torch.zeros(((2 * ws - 1) ** 2, 1), device=gpu), torch.zeros(n * n, dtype=torch.int64, device=gpu), None, n)
+    wg = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, bm, bmT)
+    O, lse = k.winattn_fwd(wg, q, kv, kv)
+    dQ, dK, dV, dQ2, dKV = (torch.full_like(q, float("nan")) for _ in range(5))
+    k.winattn_bwd(wg, q, kv, kv, O, lse, dO, dQ=dQ, dK=dK, dV=dV)
+    k.winattn_bwd(wg, q, kv, kv, O, lse, dO, dQ=dQ2, dK=dKV, dV=None)
+    assert torch.equal(dQ, dQ2)
+    want = dK.float() + dV.float()
+    assert torch.isfinite(dKV.float()).all()
+    scale = float(want.abs().max())
+    assert float((dKV.float() - want).abs().max()) <= 1.2e-2 * scale
+    # and against the generic gather-mapped kernels on the same problem
+    ag = k.AttnGeom(images * wg.G, 1, n, 32, G=wg.G, outer=N, n_kv=n, outer_kv=N, scale=1.0, window=(Himg, Himg, ws, shift))
+    O2, lse2 = k.attn_fwd(ag, q, kv, kv)
+    _close(O, O2.float(), what="O vs generic")
+    dq_g, dkv_g, _ = k.attn_bwd(ag, q, kv, kv, O2, lse2, dO, shared_kv=True)
+    _close(dQ2.float() / scale, dq_g.float() / scale, tol=1.5e-2, what="dQ vs generic")
+    _close(dKV.float() / scale, dkv_g.float() / scale, tol=1.5e-2, what="dK + dV vs generic")
