@@ -1344,7 +1344,9 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
     // (r2, measured inside the step: K = 512 -> N = 512 projections 101 -> 88 us with bias, 96 -> 91 us plain; the derivative-source
     // epilogue stays on the 128 x 128 kernel: 403 vs 473 us)
-    const bool ph8_wide = a->K >= 512 && a->N >= 512 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
+    // (r2, stage-1 shapes, microbenchmark: 501 760 x 768 x 256 + bias 437 -> 388 us, x 256 x 768 343 -> 297, x 1024 x 256 with GELU +
+    // derivative 814 -> 763, x 256 x 256 156 -> 149: the 128 x 128 kernel's main loop is L2-bandwidth-bound there)
+    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
