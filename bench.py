@@ -195,7 +195,14 @@ def pmc_traffic(kernel):
     if summ is None:
         return None, None
     # the plain instantiation is the one with (by far) the most dispatches; the PMC csv truncates names and writes ',' as ';'
-    hits = [(v.get("dispatches", 0), v) for name, v in summ.items() if kernel in name.replace(";", ",") and "hbm_bytes_per_launch" in v]
+    def same(name):                                   # `name`: at most 60 characters of the demangled kernel name
+        n = name.replace(";", ",")
+        base = kernel.split("<")[0].split("(")[0]
+        if base not in n:
+            return False
+        tail = n[n.index(base):]
+        return kernel.startswith(tail) or tail.startswith(kernel)
+    hits = [(v.get("dispatches", 0), v) for name, v in summ.items() if same(name) and "hbm_bytes_per_launch" in v]
     if hits:
         return int(max(hits, key=lambda t: t[0])[1]["hbm_bytes_per_launch"]), f"profiles/{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     return None, None

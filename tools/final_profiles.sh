@@ -2,7 +2,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 mkdir -p gpurun_out/final
-bash tools/profile_bench.sh r02_b32_v3 --steps 6 --warmup 2 --no-graph > gpurun_out/final/prof_v3.txt 2>&1
+bash tools/profile_bench.sh r02_b32_v4 --steps 6 --warmup 2 --no-graph > gpurun_out/final/prof_v3.txt 2>&1
 echo prof done
 bash tools/pmc_run.sh r02_fetch "FETCH_SIZE" bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/final/pmc_fetch.txt 2>&1
 echo fetch done

@@ -14,7 +14,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in agg.values() for c in k})
 with open(sys.argv[2], "w") as f:
     f.write("kernel,dispatches," + ",".join(names) + "\n")
