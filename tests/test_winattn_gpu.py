@@ -117,6 +117,12 @@ def test_winattn_rejects_bad_geometry(stg, gpu):
         k.winattn_fwd(wg, q[:, :64], q[:, 64:128], q[:, 128:])          # too few rows
 
 
+def test_window_partial_workgroups(stg, gpu):
+    """(window, head) problems not a multiple of the four waves of a workgroup: 9 problems, and a single one."""
+    _case(gpu, images=3, heads=3, Himg=7, ws=7, shift=0, seed=6)
+    _case(gpu, images=1, heads=1, Himg=7, ws=7, shift=0, seed=7)
+
+
 def test_window_shared_kv_single_head_sums_dk_dv(stg, gpu):
     """The cross-modal use (H = 1, K = V = the other modality's hidden states, zero bias, scale 1): dV = None makes the backward
     write dK + dV into dK -- the same numbers as the two separate gradients added in fp32, up to one bf16 rounding."""
