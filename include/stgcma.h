@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 207
+#define STG_VERSION 208
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -372,6 +372,15 @@ int stg_adam_multi(const stg_adam_desc* descs, int n, int64_t max_elems, const d
  * (AVE/model/Swin_AVE.py:1483-1487, :1569-1576): x fp32 [B*T*N, C] in place, emb fp32 [T, C].  Its gradient is a token mean
  * (stg_meanpool_fwd over the N rows of every frame) summed over the clips. */
 int stg_add_temporal(float* x, const float* emb, int64_t B, int T, int64_t N, int C, void* stream);
+/* Audio front end (AVE/dataloader.py:204-272 `_wav2fbank`): Kaldi-compatible log-mel filterbank features of S
+ * waveform segments -- torchaudio.compliance.kaldi.fbank(htk_compat=True, use_energy=False, window_type='hanning', dither=0,
+ * num_mel_bins, frame_shift; other options at their defaults: frame DC removal, pre-emphasis, power spectrum of the frame zero-padded
+ * to `padded` samples, log with the fp32-epsilon floor) -- then (x - norm_mean) / (2 norm_std) and zero padding / cropping to
+ * target_frames rows.  wave fp32 [S, n_samples] (row stride wave_stride), window fp32 [size], melw fp32 [num_mel_bins, padded/2 + 1]
+ * (the caller builds both once: stg-cma_amd/audio.py), out fp32 [S, target_frames, num_mel_bins] = the models' spectrogram input. */
+int stg_fbank(const float* wave, int64_t n_samples, int64_t wave_stride, int S, int shift, int size, int padded,
+              const float* window, const float* melw, int num_mel_bins, float preemphasis, float norm_mean, float norm_std,
+              int target_frames, float* out, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 

@@ -166,6 +166,8 @@ SIGNATURES = {
     "stg_cast_bf16_multi": (C.c_int, [c_vp, C.c_int, C.c_int, c_vp, c_vp]),
     "stg_adam_multi": (C.c_int, [c_vp, C.c_int, c_i64, c_vp, C.c_int, c_vp]),
     "stg_add_temporal": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, c_i64, C.c_int, c_vp]),
+    "stg_fbank": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int, C.c_float, C.c_float, C.c_float,
+                            C.c_int, c_vp, c_vp]),
     "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
@@ -202,7 +204,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 207
+ABI_VERSION = 208
 _lib = None
 
 
