@@ -179,33 +179,35 @@ def cpu_baseline(timeout_s=240):
     return dict(fail, error=(r.stderr or "no output")[-300:])
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/
-    r01_pmc_summary.json: (2 * FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
-    cannot be collected from inside the process, so the bench line quotes the last committed pass; None when absent."""
-    summ = path = None
-    for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+PMC_BY_CLASS = ("r03_pmc_by_class.json",)      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
+
+
+def pmc_traffic(kernel, N, K, epi):
+    """HBM bytes per launch of THIS class (kernel x N x K x epilogue; at the bench's row count) from the committed rocprofv3 PMC
+    passes of this same command: (2 * FETCH_SIZE + WRITE_SIZE) KiB per dispatch, the gfx950 correction of MI355X_MICROARCH.md,
+    dispatches matched to classes by launch order (bench.py --gemm-seq + tools/ledger.py -> profiles/r03_pmc_by_class.json).  PMC
+    counters cannot be read from inside the process, so the line quotes the last committed pass; None when the class is absent."""
+    for cand in PMC_BY_CLASS:
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
-                summ = json.load(f)["kernels"]
-            path = cand
-            break
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        c = d.get("classes", {}).get(f"{kernel}|{N}|{K}|{epi}")
+        if c is not None:
+            return int(c["hbm_bytes_per_launch"]), f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {c['launches_per_step']} launches of this class per step)"
+    return None, None
+
+
+def pmc_step():
+    """Whole-step HBM traffic and the GEMM / non-GEMM split of the kernel time from the same committed passes (None when absent)."""
+    for cand in PMC_BY_CLASS:
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                return dict(json.load(f)["step"], source=f"profiles/{cand}")
         except (OSError, ValueError, KeyError):
             continue
-    if summ is None:
-        return None, None
-    # the plain instantiation is the one with (by far) the most dispatches; the PMC csv truncates names and writes ',' as ';'
-    def same(name):                                   # `name`: at most 60 characters of the demangled kernel name
-        n = name.replace(";", ",")
-        base = kernel.split("<")[0].split("(")[0]
-        if base not in n:
-            return False
-        tail = n[n.index(base):]
-        return kernel.startswith(tail) or tail.startswith(kernel)
-    hits = [(v.get("dispatches", 0), v) for name, v in summ.items() if same(name) and "hbm_bytes_per_launch" in v]
-    if hits:
-        return int(max(hits, key=lambda t: t[0])[1]["hbm_bytes_per_launch"]), f"profiles/{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-    return None, None
+    return None
 
 
 def main():
@@ -220,7 +222,13 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="frozen backbone Linears on the block-scaled e4m3 MFMA path (BASELINE config 5; opt-in, Swin workloads); the "
                          "line then carries dtype 'fp8-e4m3(frozen weights + their inputs)/bf16' and is NOT the headline metric")
-    ap.add_argument("--no-graph", action="store_true", help="skip the extra HIP-graph replay measurement (N = 1)")
+    ap.add_argument("--graph", action="store_true",
+                    help="after the eager measurement (which stays `value`), also time the identical step replayed from a HIP graph (N = 1); "
+                         "opt-in: a fault inside capture / replay must not be able to take the headline line with it")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # accepted for older command lines: the default now
+    ap.add_argument("--gemm-seq", default=None, metavar="PATH",
+                    help="write the launch-ordered GEMM class list of ONE step (kernel, M, N, K, epilogue, algorithmic bytes) as JSON: "
+                         "tools/ledger.py joins it with a rocprofv3 trace of the same command")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -323,7 +331,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernels.gemm_profile_start()            # learns, during the warm-up, which kernel the C dispatch picks per call signature
+    kernels.gemm_profile_start(log_sequence=args.gemm_seq is not None)   # learns, during the warm-up, which kernel the C dispatch picks per call signature
     for _ in range(args.warmup):
         step()
     fence()
@@ -333,31 +341,13 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if args.gemm_seq is not None and rank == 0:
+        seq = kernels.gemm_profile_sequence()
+        per = len(seq) // max(args.steps, 1)
+        with open(args.gemm_seq, "w") as f:
+            json.dump({"steps": args.steps, "launches_per_step": per, "step": seq[-per:] if per else []}, f)
     gp = kernels.gemm_profile_stop()
     final_loss = float(loss.detach())
-    # the same step replayed from a HIP graph (N = 1): reported next to the eager number, which stays `value` -- the roofline
-    # sampling above needs eager launches (HIP events around individual kernels)
-    graph_replay = None
-    if world == 1 and not args.no_graph:
-        import gc
-        loss = None                       # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream:
-        gc.collect()                      # kept alive, they drag that stream into the capture and invalidate it
-        try:
-            replay, static_loss = recipe.capture_train_step(step, warmup=1)
-            for _ in range(2):
-                replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(args.steps):
-                replay()
-            th = time.perf_counter() - tg
-            torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-            graph_replay = {"value": round(args.batch * args.steps / tg, 3), "unit": "clips/s", "ms_per_step": round(tg / args.steps * 1e3, 3),
-                            "host_ms_per_step": round(th / args.steps * 1e3, 3), "final_loss": round(float(static_loss), 4),
-                            "what": "the identical step (forward + loss + backward + Adam) captured once with torch.cuda.graph and replayed"}
-        except Exception as e:                                   # a capture failure must not take the headline number with it
-            graph_replay = {"error": repr(e)[:200]}
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -383,7 +373,7 @@ def main():
             intensity = pc["sampled_flops"] / max(pc["sampled_bytes"], 1.0)
             tf, tbs = pc["sampled_flops"] / sec / 1e12, pc["sampled_bytes"] / sec / 1e12
             bound = "mfma" if intensity > RIDGE else "hbm"
-            traffic, traffic_src = pmc_traffic(pc["kernel"])
+            traffic, traffic_src = pmc_traffic(pc["kernel"], pc["N"], pc["K"], pc["epi"])
             c = {"bound": bound, "kernel": pc["kernel"], "N": pc["N"], "K": pc["K"], "epilogue": pc["epi"],
                  "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
@@ -397,10 +387,11 @@ def main():
         gemm_ms = round(sum(c["est_ms_per_step"] for c, _, _ in classes), 2)
         roofs = []
         for c, traffic, traffic_src in classes[:24]:
-            roofs.append(c)
+            roofs.append(dict(c, traffic=traffic))
         if classes:
             top, traffic, traffic_src = classes[0]
-            roofline = dict(top, traffic=traffic, traffic_unit="bytes/launch (average over the kernel's launches)", traffic_source=traffic_src)
+            roofline = dict(top, traffic=traffic, traffic_unit="bytes/launch, PMC, of THIS class's dispatches (same N, K, epilogue, row count)",
+                            traffic_source=traffic_src)
         else:
             roofline = None
         out = {
@@ -415,11 +406,45 @@ def main():
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),
             "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
-            "roofline": roofline, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms, "graph_replay": graph_replay,
+            "roofline": roofline, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms,
+            "non_gemm_est_ms_per_step": round(dt / args.steps * 1e3 - gemm_ms, 2), "step_traffic": pmc_step(),
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        # the same step replayed from a HIP graph (N = 1, --graph): reported next to the eager number, which stays `value` -- the roofline
+        # sampling above needs eager launches (HIP events around individual kernels).  It runs AFTER the headline object is complete and
+        # the line is printed in `finally`, so nothing in here can lose the measurement.
+        try:
+            if world == 1 and args.graph:
+                import gc
+                loss = None                   # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream:
+                gc.collect()                  # kept alive, they drag that stream into the capture and invalidate it
+                try:
+                    replay, static_loss = recipe.capture_train_step(step, warmup=1)
+                    for _ in range(2):
+                        replay()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    replay()                  # ONE replay from an idle stream: the host cost of launching a step
+                    host_one = time.perf_counter() - t1
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter()
+                    for _ in range(args.steps):
+                        replay()
+                    th = time.perf_counter() - tg
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter() - tg
+                    out["graph_replay"] = {
+                        "value": round(args.batch * args.steps / tg, 3), "unit": "clips/s", "ms_per_step": round(tg / args.steps * 1e3, 3),
+                        "host_ms_one_replay": round(host_one * 1e3, 3), "host_ms_per_step_back_to_back": round(th / args.steps * 1e3, 3),
+                        "final_loss": round(float(static_loss.detach()), 4),
+                        "what": "the identical step (forward + loss + backward + Adam) captured once with torch.cuda.graph and replayed; "
+                                "host_ms_one_replay = launching one replay on an idle stream; back to back the host blocks on the launch "
+                                "queue once a few replays are in flight, so that figure tends to the GPU time per step"}
+                except Exception as e:                               # a capture failure must not take the headline number with it
+                    out["graph_replay"] = {"error": repr(e)[:200]}
+            if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
+                out["cpu_baseline"] = cpu_baseline()
+        finally:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -43,6 +43,7 @@ class GradSync:
         self.calls = 0
         self.last_numel = 0
         self.extra = []
+        self._hooked = set()
         self._acc = 0
         self._armed = -1                       # id of the backward pass whose end-of-pass callback is queued
 
@@ -62,6 +63,8 @@ class GradSync:
         self.calls += 1
         self._acc += flat.numel() if n_real is None else n_real
         self._average(flat)
+        if len(self._hooked) != len(self.extra):
+            self.rewatch()
         self._arm()
         return flat
 
@@ -92,17 +95,29 @@ class GradSync:
         self.last_numel, self._acc = self._acc, 0
 
     def watch(self, params):
-        """Route parameters whose gradients do not pass through the backbone arena into the end-of-backward bucket."""
+        """Route parameters whose gradients do not pass through the backbone arena into the end-of-backward bucket.  Frozen
+        parameters (requires_grad=False: an ablation or a linear probe that freezes part of a task head before attach) are
+        recorded without a hook -- autograd refuses a hook on a tensor that needs no gradient -- and picked up by rewatch()."""
         for p in params:
             if not any(p is q for q in self.extra):
                 self.extra.append(p)
+        self.rewatch()
+
+    def rewatch(self):
+        """Hook every recorded parameter that requires a gradient now and has no hook yet.  Runs at every arena all-reduce (each
+        backward pass of a model with trainable backbone tensors), so a parameter unfrozen after attach() is synchronised from
+        the NEXT backward pass on; call it by hand after unfreezing when the backbone itself is entirely frozen."""
+        for p in self.extra:
+            if p.requires_grad and id(p) not in self._hooked:
                 p.register_post_accumulate_grad_hook(self._arm)
+                self._hooked.add(id(p))
 
 
 def attach(model, group=None):
     """Enable gradient averaging for a stg-cma_amd model: the backbone arena inside its autograd node plus -- for the AVS / AVQA
     mirrors -- every task-head parameter (`avstask_*` / `avqatask_*`, AVS/traintest_adapt_avs.py:55, AVQA/traintest_adapt_avqa.py:72)
-    through the end-of-backward bucket.  Call once after construction (before or after the loop's freeze).
+    through the end-of-backward bucket.  Call once after construction, before or after the loop's freeze: frozen task-head
+    tensors are recorded and hooked when they are unfrozen (GradSync.rewatch).
 
     BatchNorm of the AVS decoder (TPAVI `W_z`, AVS/model/TPAVI.py:57-61): batch statistics stay PER RANK, which is what the
     reference's nn.DataParallel does (each replica normalises its own chunk, AVS/traintest_adapt_avs.py:35-38); its affine

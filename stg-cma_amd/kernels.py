@@ -15,18 +15,30 @@ F32 = torch.float32
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_ptr_dev = -1      # device index of the last tensor whose pointer was taken (_p): every wrapper takes its pointers before _stream()
 
 
 def _stream():
-    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than building a
-    torch.cuda.Stream object per launch: 2 900 launches per step)."""
+    """hipStream_t of torch's current stream on the device of the launch's tensors (the raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object per launch: 1 500 launches per step).  A HIP launch goes to the CURRENT device, so the tensors must
+    live there: the module entry points enter torch.cuda.device(input.device) (nn.DataParallel replicas and autograd's backward
+    threads do the same), and a call that reaches a kernel from another device fails here instead of launching on the wrong
+    device's stream with foreign pointers."""
+    dev = torch.cuda.current_device()
+    if _ptr_dev >= 0 and _ptr_dev != dev:
+        raise RuntimeError(f"stg-cma_amd: operands live on cuda:{_ptr_dev} but the current device is cuda:{dev}; wrap the call in "
+                           f"torch.cuda.device(tensor.device) (the model / block modules do)")
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(dev)
     return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
-    return None if t is None else t.data_ptr()
+    global _ptr_dev
+    if t is None:
+        return None
+    _ptr_dev = t.device.index if t.is_cuda else -1
+    return t.data_ptr()
 
 
 def _chk2d(t, name, dtype, cols=None, rows=None):
@@ -208,6 +220,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             pc["launches"] += 1
             pc["flops"] += 2.0 * M * N * K
             pc["bytes"] += nbytes
+            if prof["seq"] is not None:                    # launch-ordered class log (bench.py --gemm-seq; tools/ledger.py joins it with a trace)
+                prof["seq"].append((kid, M, N, K, epi, nbytes))
             if pc["launches"] % prof["stride"] == 0:       # HIP events around every stride-th launch of the class, on the launch stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -295,18 +309,27 @@ GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GL
                      _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel"}
 
 
-def gemm_profile_start(stride=7):
+def gemm_profile_start(stride=7, log_sequence=False):
     """Start per-class accounting of stg_gemm_nt launches (class = kernel chosen by the C dispatch x N x K x epilogue signature):
     every `stride`-th launch of a class is bracketed by HIP events on the launch stream (events around every launch cost ~10 % of
     the step).  Call before the warm-up steps (the kernel of each call signature is learnt on its first launch) and
     gemm_profile_reset() at the start of the timed region."""
     global _gemm_prof
-    _gemm_prof = {"stride": int(stride), "kid": {}, "classes": {}}
+    _gemm_prof = {"stride": int(stride), "kid": {}, "classes": {}, "seq": [] if log_sequence else None}
 
 
 def gemm_profile_reset():
     if _gemm_prof is not None:
         _gemm_prof["classes"] = {}
+        if _gemm_prof["seq"] is not None:
+            _gemm_prof["seq"] = []
+
+
+def gemm_profile_sequence():
+    """[(kernel name, M, N, K, epilogue signature, algorithmic bytes)] of every stg_gemm_nt launch since the last reset, in launch order
+    (gemm_profile_start(log_sequence=True))."""
+    seq = _gemm_prof["seq"] if _gemm_prof is not None else None
+    return [(GEMM_KERNEL_NAMES.get(k, str(k)), M, N, Kd, epi, nb) for k, M, N, Kd, epi, nb in (seq or [])]
 
 
 def gemm_profile_stop():

@@ -7,6 +7,8 @@ lazily, only when a pretrained directory is given) and the dead ablation code.
 """
 from collections import OrderedDict
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -77,7 +79,8 @@ class ResidualAttentionBlock(nn.Module):
         spec = self.spec(n_tok)
         names = vit_block_param_names(spec)
         sd = dict(self.named_parameters())
-        return VitBlockFn.apply(X, spec, tuple(names), self.training, torch.is_grad_enabled(), *[sd[n] for n in names])
+        with torch.cuda.device(X.device) if X.is_cuda else contextlib.nullcontext():
+            return VitBlockFn.apply(X, spec, tuple(names), self.training, torch.is_grad_enabled(), *[sd[n] for n in names])
 
 
 class Transformer(nn.Module):

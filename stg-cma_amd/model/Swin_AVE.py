@@ -10,6 +10,8 @@ Reference bugs handled deliberately: ftmode='audioonly' de
 `self.layers_audio` (Swin_AVE.py:1521) -- here it works; `temporal_embedding_audio` is never initialised when
 t_relative=False (:1211-1212) -- here it is.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -149,7 +151,8 @@ class SwinTransformerBlock(nn.Module):
         names = self.tensor_names()
         sd = dict(self.named_parameters())
         sd.update(dict(self.named_buffers()))
-        return SwinBlockFn.apply(X, self._spec, tuple(names), self.training, torch.is_grad_enabled(), *[sd[n] for n in names])
+        with torch.cuda.device(X.device) if X.is_cuda else contextlib.nullcontext():
+            return SwinBlockFn.apply(X, self._spec, tuple(names), self.training, torch.is_grad_enabled(), *[sd[n] for n in names])
 
     def extra_repr(self):
         return f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, " \
@@ -390,20 +393,39 @@ class SwinTransformer2D_Adapter_New(nn.Module):
     def forward(self, a, v, mode):
         """a: [B, T, H, W] spectrogram segments, v: [B, 3, T, H, W] frames -> fp32 logits [(B*T), label_dim]
         (Swin_AVE.py:1479-1599).  Runs entirely on the HIP path; raises when inputs / parameters are not on a GPU."""
-        if mode not in ('audioonly', 'videoonly', 'multimodal', 'fusion') or mode != self.ftmode:
+        # `mode` picks the reference's forward path (:1479-1599), the blocks were built for `ftmode` (:1220-1309).  The 'multimodal'
+        # and 'fusion' paths are the same code over a (v, a) tuple, so either string drives a two-stream model; a single-stream
+        # path through two-stream blocks (or the reverse) crashes in the reference, and an unknown string makes it return None:
+        # both raise here.
+        two = ('multimodal', 'fusion')
+        if mode not in ('audioonly', 'videoonly') + two or (mode != self.ftmode and not (mode in two and self.ftmode in two)):
             raise TypeError('ftmode is not expected !!!')
         ref = v if mode != 'audioonly' else a
         if not ref.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
         # use_checkpoint=True (Swin_AVE.py:1049-1050) is accepted and changes nothing: checkpointing trades memory for recompute and
         # leaves outputs and gradients as they are; this node keeps its activations (80 GB at B = 32 of 288 GB).
-        names, tensors = [], []
-        for n, p in self.named_parameters():
-            names.append(n)
-            tensors.append(p)
-        for n, b in self.named_buffers():
-            if not n.endswith("attn_mask"):
-                names.append(n)
-                tensors.append(b)
+        names, tensors = self._all_tensors()
         with torch.cuda.device(ref.device):     # launches go to the current device's stream: make that the tensors' device
-            return SwinModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), tuple(names), *tensors)
+            return SwinModelFn.apply(a, v, self._plan(), self.training, torch.is_grad_enabled(), names, *tensors)
+
+    def _all_tensors(self):
+        """(names, tensors) of every parameter and buffer the whole-model node takes, in a fixed order.  The NAME walk is cached
+        (it cost a named_parameters() traversal of 946 entries per call); the tensors are re-read from the modules' own
+        dictionaries on every call, so .to() / load_state_dict / requires_grad_ / DataParallel replicas are always seen."""
+        cache = self.__dict__.get("_tensor_walk")
+        if cache is not None and cache[2] != id(self):       # a DataParallel replica copies __dict__: its walk must name ITS submodules
+            cache = None
+        if cache is None:
+            mods = dict(self.named_modules())
+            cache = []
+            for n, _ in self.named_parameters():
+                owner, _, leaf = n.rpartition(".")
+                cache.append((n, mods[owner], leaf, True))
+            for n, _ in self.named_buffers():
+                if not n.endswith("attn_mask"):
+                    owner, _, leaf = n.rpartition(".")
+                    cache.append((n, mods[owner], leaf, False))
+            self.__dict__["_tensor_walk"] = cache = (tuple(c[0] for c in cache), cache, id(self))
+        names, walk = cache[0], cache[1]
+        return names, [(m._parameters if is_p else m._buffers)[leaf] for _, m, leaf, is_p in walk]

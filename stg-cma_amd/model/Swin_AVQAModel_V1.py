@@ -152,7 +152,8 @@ class SwinTransformer2D_Adapter_AVQA(SwinTransformer2D_Adapter_New):
         if f_v.shape[-1] != 1536 or f_v.shape[1] != 49:
             raise NotImplementedError("the QA head is hard-wired to 49 tokens x 1536 channels (Swin-L at 224 x 224, :1776-1777)")
         from ..ops_head import avqa_head_forward
-        return avqa_head_forward(self, f_v, f_a, f_n, question, v.shape[0], v.shape[1], self.training)
+        with torch.cuda.device(f_v.device):     # the head's launches follow the backbone's device (kernels._stream)
+            return avqa_head_forward(self, f_v, f_a, f_n, question, v.shape[0], v.shape[1], self.training)
 
 
 class QstEncoder(nn.Module):

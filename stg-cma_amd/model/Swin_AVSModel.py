@@ -149,7 +149,8 @@ class SwinTransformer2D_Adapter_AVS(SwinTransformer2D_Adapter_New):
         if int(round(ms[0].shape[1] ** 0.5)) ** 2 != ms[0].shape[1]:
             raise NotImplementedError("the dense decoder expects square token maps (:1838-1841)")
         from ..ops_dec import avs_decoder_forward
-        return avs_decoder_forward(self, ms, a_feat, v.shape[0], v.shape[1], self.training)
+        with torch.cuda.device(a_feat.device):  # the decoder's launches follow the backbone's device (kernels._stream)
+            return avs_decoder_forward(self, ms, a_feat, v.shape[0], v.shape[1], self.training)
 
 
 class SwinTransformer2D_Adapter_AVS_Base(SwinTransformer2D_Adapter_AVS):

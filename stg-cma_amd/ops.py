@@ -158,6 +158,14 @@ def shadow_mlp_w2(p):
 MLP_FUSED = _os.environ.get("STG_MLP_FUSED", "1") != "0"
 
 
+def _f8(sel, site, bwd=False):
+    """Is the frozen Linear `site` ('qkv' / 'proj' / 'fc1' / 'fc2' / 'merge'; bwd: its data-gradient GEMM) on the e4m3 path?
+    sel: False / True (every site, both directions) / a set of 'site.f' and 'site.b' tags (stgcma.fp8.enable(model, sites=...))."""
+    if not sel or sel is True:
+        return bool(sel)
+    return (site + (".b" if bwd else ".f")) in sel
+
+
 def frozen_gemm(A, wp, bias=None, *, t=False, fp8=False, **kw):
     """A . W^T (t=True: A . W, the dgrad) for a FROZEN Linear weight `wp`.  bf16 MFMA on the weight's bf16 shadow, or -- fp8 (BASELINE
     config 5, opt-in: stgcma.fp8) -- the block-scaled e4m3 MFMA: the weight's cached e4m3 shadow and A quantised per 32-wide k-block
@@ -600,7 +608,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, T)
     S = {}
     n1g, n1b = f32c(P["norm1.weight"]), f32c(P["norm1.bias"])
-    fp8 = bool(getattr(spec, "fp8", False))
+    fp8 = getattr(spec, "fp8", False)
     wqkv, bqkv = P["attn.qkv.weight"], f32c(P["attn.qkv.bias"])
     wproj, bproj = P["attn.proj.weight"], f32c(P["attn.proj.bias"])
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
@@ -610,7 +618,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         dps = [drop_scale(spec.drop_path, B * N, X.device, training, pool) for _ in spec.mods]
         Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X, n1g, n1b, want_stats=save)
         pre = None
-        QKV = frozen_gemm(Y, wqkv, bqkv, fp8=fp8)
+        QKV = frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
         del Y
         tbias = torch.empty((nm, H, T * T), dtype=F32, device=X.device)
         for i, m in enumerate(spec.mods):
@@ -621,7 +629,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
             AO, lse = K.tattn_fwd(tgeo, QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:]), tgeo    # backward recomputes: no O / LSE kept
         else:
             AO, lse = K.attn_fwd(_temporal_geom(spec, B, g, tbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
-        PO = frozen_gemm(AO, wproj, bproj, fp8=fp8)
+        PO = frozen_gemm(AO, wproj, bproj, fp8=_f8(fp8, "proj"))
         if isinstance(lse, K.TGeom):
             AO = None
         X1 = torch.empty_like(X)
@@ -641,7 +649,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
 
     # ---------------- (shifted-)window attention + S_Adapter2 (window-level cross-modal when fusing) (:718-787)
     Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
-    QKV = frozen_gemm(Y, wqkv, bqkv, fp8=fp8)
+    QKV = frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
     del Y
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
         bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
@@ -650,7 +658,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     else:
         sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
         AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
-    PO = frozen_gemm(AO, wproj, bproj, fp8=fp8)
+    PO = frozen_gemm(AO, wproj, bproj, fp8=_f8(fp8, "proj"))
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
     HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
     xs = None
@@ -671,13 +679,13 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     Y, mean, rstd = ln2.triple() if ln2 is not None else \
         K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
     del ln2
-    fused_mlp = MLP_FUSED and not fp8 and K.mlp_fused_supported(C)
+    fused_mlp = MLP_FUSED and not any(_f8(fp8, s_, b_) for s_ in ("fc1", "fc2") for b_ in (False, True)) and K.mlp_fused_supported(C)
     if fused_mlp:
         M = K.mlp_fwd(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow_mlp_w2(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
         Zm = ("recompute", Y)                 # backward recomputes GELU' from norm2(x): Y stays alive instead of the 4C-wide derivative
     else:
-        Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU, want_dact=MLP_DACT)
-        M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8)
+        Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=_f8(fp8, "fc1"), act=ACT_GELU, want_dact=MLP_DACT)
+        M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=_f8(fp8, "fc2"))
         del Hm
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
     X3 = torch.empty_like(X)
@@ -713,10 +721,12 @@ def _mlp_bwd_fused(P, Y, dM):
     return K.mlp_bwd(Y, dM, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow(P["mlp.fc2.weight"], True))
 
 
-def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=None):
+def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=None, need_dx0=True):
     """Backward of block_forward.  dX3: bf16 [R, C].  Returns (dX0 bf16, {param name: fp32 grad}, dH_prev).
     dH_in: this block's S_Adapter dgrad (dX3 . D_fc2), already computed by the LayerNorm backward that produced dX3.
-    prev: transposed D_fc2 shadows of the PREVIOUS block's S_Adapters; dH_prev is then their dgrad of dX0 (else None)."""
+    prev: transposed D_fc2 shadows of the PREVIOUS block's S_Adapters; dH_prev is then their dgrad of dX0 (else None).
+    need_dx0=False: nothing trainable lies below this block (the first block behind the frozen patch embedding): the qkv
+    data-gradient GEMM and the LayerNorm backward of its FIRST attention pass, which only produce dX0, are skipped (dX0 = None)."""
     R, C = dX3.shape
     Rm, sl = _slices(spec, R)
     nm = len(spec.mods)
@@ -728,7 +738,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
     dgv, dga = G.buf("gate_v"), G.buf("gate_a")
     n1g = f32c(P["norm1.weight"])
-    fp8 = bool(getattr(spec, "fp8", False))
+    fp8 = getattr(spec, "fp8", False)
     wqkv, wproj = P["attn.qkv.weight"], P["attn.proj.weight"]
 
     # ---------------- FFN + S_Adapter
@@ -743,8 +753,8 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         if isinstance(Zm, tuple):
             dY = K.add(_mlp_bwd_fused(P, Zm[1], dX3), dYa)
         else:
-            dZm = frozen_gemm(dX3, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
-            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8, res1=dYa)
+            dZm = frozen_gemm(dX3, P["mlp.fc2.weight"], t=True, fp8=_f8(fp8, "fc2", True), dact_src=Zm)
+            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=_f8(fp8, "fc1", True), res1=dYa)
             del dZm
         del Y, Ha_, Za_, dHa, dZa, dYa, Zm
     else:
@@ -764,8 +774,8 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         if isinstance(Zm, tuple):
             dY = _mlp_bwd_fused(P, Zm[1], dM)
         else:
-            dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=fp8, dact_src=Zm)
-            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=fp8)
+            dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=_f8(fp8, "fc2", True), dact_src=Zm)
+            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=_f8(fp8, "fc1", True))
             del dZm
         del dM, Zm
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
@@ -787,7 +797,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
         K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
     del HZ, H2, xs, dH2, dZs, PO
-    dAO = frozen_gemm(dPO, wproj, t=True, fp8=fp8)
+    dAO = frozen_gemm(dPO, wproj, t=True, fp8=_f8(fp8, "proj", True))
     del dPO
     dQKV = torch.empty_like(QKV)
     if isinstance(sbias, K.WinGeom):
@@ -797,9 +807,12 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         K.attn_bwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], AO, lse, dAO,
                    dQ=dQKV[:, :C], dK=dQKV[:, C:2 * C], dV=dQKV[:, 2 * C:])
     del QKV, AO, dAO
-    dY = frozen_gemm(dQKV, wqkv, t=True, fp8=fp8)
-    del dQKV
     dH_prev = None
+    if not spec.t_attn and not need_dx0:
+        G.flush()
+        return None, G.g, None
+    dY = frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
+    del dQKV
     if spec.t_attn:
         tads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
         dX1, dHts = _ln_bwd_join(dY, X1, n1g, mean, rstd, dX2, sl, [A.w2t for A in tads], S["t"][9], rs_outer=T * N, rs_inner=N)
@@ -819,7 +832,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
             K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
         del hz, PO
-        dAO = frozen_gemm(dPO, wproj, t=True, fp8=fp8)
+        dAO = frozen_gemm(dPO, wproj, t=True, fp8=_f8(fp8, "proj", True))
         del dPO
         tabs = [G.buf("attn.temporal_position_bias_table" + ("_audio" if m else "")) for m in spec.mods]
         dtb = torch.zeros_like(tbias) if any(t is not None for t in tabs) else None
@@ -834,7 +847,10 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             if tabs[i] is not None:
                 K.bias_scatter(dtb[i], P["attn.t_relative_coords" + ("_a" if m else "")], tabs[i])
         del QKV, AO, dAO
-        dY = frozen_gemm(dQKV, wqkv, t=True, fp8=fp8)
+        if not need_dx0:
+            G.flush()
+            return None, G.g, None
+        dY = frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
         del dQKV
         dX0, dH_prev = _ln_bwd_join(dY, X0, n1g, mean, rstd, dX1, sl, prev)
     else:
@@ -847,13 +863,13 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
 def merge_forward(X, H, W, P, save, fp8=False):
     """PatchMerging.forward on every frame of the fused tensor (Swin_AVE.py:958-981): 2x2 gather + LN(4C) + Linear(4C->2C)."""
     Y, mean, rstd = K.layernorm_fwd(X, f32c(P["norm.weight"]), f32c(P["norm.bias"]), gather4=(H, W), want_stats=save)
-    out = frozen_gemm(Y, P["reduction.weight"], fp8=fp8, out_dtype=RESIDUAL_DTYPE)
+    out = frozen_gemm(Y, P["reduction.weight"], fp8=_f8(fp8, "merge"), out_dtype=RESIDUAL_DTYPE)
     return out, ((X, mean, rstd) if save else None)
 
 
 def merge_backward(S, H, W, P, dout, fp8=False):
     X, mean, rstd = S
-    dY = frozen_gemm(dout, P["reduction.weight"], t=True, fp8=fp8)
+    dY = frozen_gemm(dout, P["reduction.weight"], t=True, fp8=_f8(fp8, "merge", True))
     return K.layernorm_bwd(dY, X, f32c(P["norm.weight"]), mean, rstd, gather4=(H, W))
 
 
@@ -1019,8 +1035,8 @@ def plain_block_forward(X, spec, P, training, pool=None):
     dp1 = drop_scale(spec.drop_path, BT, X.device, training, pool)
     dp2 = drop_scale(spec.drop_path, BT, X.device, training, pool)
     Y, _, _ = K.layernorm_fwd(X, f32c(P["norm1.weight"]), f32c(P["norm1.bias"]), want_stats=False)
-    fp8 = bool(getattr(spec, "fp8", False))
-    QKV = frozen_gemm(Y, P["attn.qkv.weight"], f32c(P["attn.qkv.bias"]), fp8=fp8)
+    fp8 = getattr(spec, "fp8", False)
+    QKV = frozen_gemm(Y, P["attn.qkv.weight"], f32c(P["attn.qkv.bias"]), fp8=_f8(fp8, "qkv"))
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
         bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
         wg = K.WinGeom(BT, H, spec.H, spec.W, spec.ws, spec.shift, spec.hd ** -0.5, bm, bmT)
@@ -1028,12 +1044,12 @@ def plain_block_forward(X, spec, P, training, pool=None):
     else:
         sbias = K.bias_gather(f32c(P["attn.relative_position_bias_table"]), P["attn.relative_position_index"].reshape(-1))
         AO, _ = K.attn_fwd(_window_geom(spec, BT, g, sbias, 1), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=False)
-    X1 = frozen_gemm(AO, P["attn.proj.weight"], f32c(P["attn.proj.bias"]), fp8=fp8, out_dtype=RESIDUAL_DTYPE, res1=X,
+    X1 = frozen_gemm(AO, P["attn.proj.weight"], f32c(P["attn.proj.bias"]), fp8=_f8(fp8, "proj"), out_dtype=RESIDUAL_DTYPE, res1=X,
                    row_scale=dp1, rs_outer=N, rs_inner=1)
     del QKV, AO
     Y, _, _ = K.layernorm_fwd(X1, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=False)
-    Hm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=fp8, act=ACT_GELU)
-    return frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=fp8, out_dtype=RESIDUAL_DTYPE, res1=X1,
+    Hm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=_f8(fp8, "fc1"), act=ACT_GELU)
+    return frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=_f8(fp8, "fc2"), out_dtype=RESIDUAL_DTYPE, res1=X1,
                      row_scale=dp2, rs_outer=N, rs_inner=1)
 
 
@@ -1079,7 +1095,7 @@ class SwinBackboneFn(torch.autograd.Function):
             if req:
                 pool = DropPool(req, dev)
         tape, tap_out = [], []
-        plan_fp8 = bool(getattr(plan, "fp8", False))
+        plan_fp8 = getattr(plan, "fp8", False)
         for st in plan.stages:
             carry = None
             for j, (spec, pre) in enumerate(st["blocks"]):
@@ -1138,7 +1154,7 @@ class SwinBackboneFn(torch.autograd.Function):
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape))
+                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape), need_dx0=bool(tape))
                 for k, val in g.items():
                     grads[pre + k] = val
             else:
@@ -1189,7 +1205,7 @@ class SwinModelFn(torch.autograd.Function):
             if req:
                 pool = DropPool(req, src.device)
         tape = []
-        plan_fp8 = bool(getattr(plan, "fp8", False))
+        plan_fp8 = getattr(plan, "fp8", False)
         for st in plan.stages:
             carry = None
             for j, (spec, pre) in enumerate(st["blocks"]):
@@ -1226,10 +1242,14 @@ class SwinModelFn(torch.autograd.Function):
         ctx.head = None
         tape = ctx.tape
         dH_carry = None
+        need_emb = need.get("temporal_embedding", False) or need.get("temporal_embedding_audio", False)
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape))
+                # the bottom block's input gradient feeds only the absolute temporal embeddings (t_relative=False); otherwise nothing
+                # trainable lies below it (frozen patch embedding, inputs without gradient)
+                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape),
+                                                 need_dx0=bool(tape) or need_emb)
                 for k, val in g.items():
                     grads[pre + k] = val
             else:

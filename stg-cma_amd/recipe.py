@@ -165,10 +165,16 @@ def _fused_adam_class():
                 for p in g["params"]:
                     st = self.state.get(p, {})
                     m, v = mine[p]
-                    if "exp_avg" in st and st["exp_avg"] is not m:
-                        m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
-                    if "step" in st and st["step"] is not self._st[self._idx[p], 0]:
-                        self._st[self._idx[p], 0].fill_(float(st["step"]))
+                    if "exp_avg" in st:
+                        if st["exp_avg"] is not m:
+                            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    else:                                   # not covered by the checkpoint: torch.optim.Adam starts it from scratch
+                        m.zero_(); v.zero_()
+                    if "step" in st:
+                        if st["step"] is not self._st[self._idx[p], 0]:
+                            self._st[self._idx[p], 0].fill_(float(st["step"]))
+                    else:
+                        self._st[self._idx[p]].zero_()
                     self.state[p] = {"step": self._st[self._idx[p], 0], "exp_avg": m, "exp_avg_sq": v}
             self._sig = None
 
@@ -188,14 +194,22 @@ class _Lazy:
 FusedAdam = _Lazy()
 
 
-def capture_train_step(step, warmup=3):
+def capture_train_step(step, warmup=3, params=None):
     """Capture one call of `step()` (forward + loss + zero_grad + backward + optimizer.step; the optimizer is build_optimizer's
     FusedAdam, or torch.optim.Adam built with capturable=True) in a HIP graph and return (replay, static_loss): every launch of the
-    step -- ~1 700 for Swin-B -- then costs one graph launch (host time 95 ms -> 0.4 ms per step, measured).  The library's launches go to torch's current stream, so torch.cuda.graph records
-    them like ATen's; `step` must not synchronise (no .item() / float(loss)) and its inputs must be static tensors (copy new batches
-    into them).  A few eager calls on a side stream first: graph capture needs every lazily built table / shadow / LDS reservation in
-    place."""
+    step -- ~1 500 for Swin-B -- then costs one graph launch (host time of ONE replay from an idle stream: 0.4 ms instead of ~95;
+    back-to-back replays block on the launch queue once a few are in flight, so a loop's host time per replay tends to the
+    GPU time).  The library's launches go to torch's current stream, so torch.cuda.graph records them like ATen's; `step` must
+    not synchronise (no .item() / float(loss)) and its inputs must be static tensors (copy new batches into them).
+    `warmup` >= 1 eager calls run on a side stream first: capture needs every lazily built table / shadow / LDS reservation in
+    place, and a first call would leave the one-off casts of the frozen weights OUT of the graph's steady state.
+    `params`: the tensors the captured optimizer updates (default: those of the optimizers / modules `step` closes over that hold a .grad).  replay() bumps
+    their version counters after each launch -- FusedAdam.step's own bump is host code, which a replay does not run -- so an
+    eager forward between replays re-casts its bf16 weight shadows (ops.shadow keys on the version) instead of reusing the
+    ones written inside the last replay's forward."""
     import torch
+    if warmup < 1:
+        raise ValueError("capture_train_step: warmup must be >= 1 (lazily built tables and shadows must exist before the capture)")
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -206,7 +220,23 @@ def capture_train_step(step, warmup=3):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         static_loss = step()
-    return g.replay, static_loss
+    if params is None:                   # the optimizers / modules `step` closes over
+        params = []
+        for cell in (getattr(step, "__closure__", None) or ()):
+            o = cell.cell_contents
+            if isinstance(o, torch.optim.Optimizer):
+                params += [p for grp in o.param_groups for p in grp["params"]]
+            elif isinstance(o, torch.nn.Module):
+                params += [p for p in o.parameters() if p.requires_grad]
+    params = list({id(p): p for p in params if p.grad is not None}.values())
+
+    def replay():
+        g.replay()
+        if params:
+            torch.autograd.graph.increment_version(params)
+
+    replay.graph = g
+    return replay, static_loss
 
 
 def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, global_step=0):

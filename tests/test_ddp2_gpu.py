@@ -1,0 +1,57 @@
+"""-m gpu: the REAL data-parallel path under a 2-rank process group (AVE/traintest_adapt_ave29.py:32-35 is what
+it replaces).  Two fresh child processes (started, not exec'ed; both on cuda:0, gloo -- RCCL refuses two ranks on one device) run
+the HIP forward / backward of a small Swin AVE model, an AVS model and an AVQA model with ddp.attach; the parent then checks that
+every trainable .grad (a) is identical on the two ranks and (b) equals the mean of the two ranks' own single-clip gradients."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_hip_backward_gradients_are_averaged(gpu, tmp_path):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "helpers", "ddp2_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=800)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+    for tag in ("swin_ave", "swin_avs", "swin_avqa"):
+        r0 = torch.load(tmp_path / f"{tag}_r0.pt")
+        r1 = torch.load(tmp_path / f"{tag}_r1.pt")
+        assert r0["synced"].keys() == r1["synced"].keys() and len(r0["synced"]) > 0
+        worst = 0.0
+        for n in r0["synced"]:
+            assert torch.equal(r0["synced"][n], r1["synced"][n]), f"{tag}: ranks disagree on {n} after the exchange"
+            mean = 0.5 * (r0["local"][n] + r1["local"][n])
+            # the two backward passes of a rank are separate launches (fp32 atomics in the gate / bias-table gradients): equal up to
+            # summation order
+            err = float((r0["synced"][n] - mean).norm()) / max(float(mean.norm()), 1e-12)
+            worst = max(worst, err)
+            assert err <= 1e-3 or float((r0["synced"][n] - mean).abs().max()) <= 1e-7, f"{tag}: {n} is not the rank mean (rel {err:.2e})"
+        # the ranks saw different clips, so their own gradients differ: the exchange did something
+        assert any(not torch.equal(r0["local"][n], r1["local"][n]) for n in r0["local"]), tag
+        print(f"{tag}: {len(r0['synced'])} trainable tensors identical across ranks; worst rel deviation from the rank mean {worst:.2e}")
