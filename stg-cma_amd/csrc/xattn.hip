@@ -14,7 +14,14 @@
 //     tile: it is written once to a wave-private LDS tile and read back transposed with ds_read_b64_tr_b16 (the k-strided
 //     V^T / K^T / Q^T / dO^T operands), 2 reads per fragment instead of 8 16-bit reads + packing;
 //   * two 32-key tiles per loop trip, next trip's fragments prefetched into registers; tails are handled in a separate,
-//     masked instantiation of the loop body so the steady state carries no bounds logic.
+//     masked instantiation of the loop body so the steady state carries no bounds logic;
+//   * (round 3) the per-score arithmetic around the exponential rides the MATRIX pipe, which has slack here: the wave's constant
+//     operand (its queries, or its keys in the dK + dV kernel) is pre-multiplied by scale * log2 e and split into a bf16 hi + lo
+//     pair (two score MFMAs instead of one: the product keeps ~16 mantissa bits, the fp32 multiply it replaces had 24 against bf16
+//     operands), and -max / -lse / -delta enter as the MFMA's C operand, so a score leaves the MFMA as the exp2 argument and dP
+//     leaves it as dP - delta: backward exp + mul + cvt per score (was fma + exp + sub + mul + cvt).  Applied to the two backward
+//     kernels (dQ -9 %, dK + dV -4 %); in the forward kernel the 16 extra live registers of the C operand cost more than the FMA saved
+//     (+7 %), so it keeps the fp32 FMA.
 // One wave owns 32 queries (fwd, dQ) or 32 keys (dK+dV); waves never synchronise with each other.
 //
 // MFMA v_mfma_f32_32x32x16_bf16, lane l = (r = l & 31, hh = l >> 5): A[row r][k = 8 hh + j], B[k = 8 hh + j][col r];
@@ -45,6 +52,22 @@ __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpr
 __device__ __forceinline__ bf16x8_t pack_frag(const float* x) {
     const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
     return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ f32x16_t splat16(float v) {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = v;
+    return z;
+}
+// c * f as a bf16 (hi, lo) fragment pair: hi = rn(c f), lo = rn(c f - hi)
+__device__ __forceinline__ void scale_split(const bf16x8_t f, float c, bf16x8_t& hi, bf16x8_t& lo) {
+    float v[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf2f((bf16_t)f[j]) * c;
+    hi = pack_frag(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = v[j] - bf2f((bf16_t)hi[j]);
+    lo = pack_frag(l);
 }
 __device__ __forceinline__ void lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -116,7 +139,7 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
     const int tr_stride = ones_lane ? 0 : D;                    // rows advance only for real tiles
 
     f32x16_t o = zero16(), lacc = zero16();
-    float m2 = -INFINITY;
+    float m2 = 0.f;                                             // running max (log2 domain); the first trip adopts its tile's maximum
     bf16x8_t ones_frag;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones_frag[j] = (short)0x3F80;
@@ -134,8 +157,9 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
     };
     load_pair(0);
 
-    auto body = [&](int k0, auto masked_tag) {
+    auto body = [&](int k0, auto masked_tag, auto first_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         lds_sync();                                             // previous trip's transposed reads are done
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -157,30 +181,38 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
                 sB[reg] = key + 32 < a.n_kv ? sB[reg] : -INFINITY;
             }
         }
-        float mt = fmaxf(sA[0], sB[0]);
+        // x = c2 s - m2 FIRST (packed FMA: two scores per issue slot), the maximum over x afterwards: taken on the raw MFMA outputs
+        // every fmaxf is preceded by a canonicalising v_max_f32 (hipcc cannot know an MFMA result is not a signalling NaN) -- 50
+        // v_max per trip instead of 16 v_max3
+        float xA[16], xB[16];
 #pragma unroll
-        for (int reg = 1; reg < 16; ++reg) mt = fmaxf(mt, fmaxf(sA[reg], sB[reg]));
+        for (int reg = 0; reg < 16; reg += 2) {
+            const f32x2_t xa = pk_fma((f32x2_t){sA[reg], sA[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
+            const f32x2_t xb = pk_fma((f32x2_t){sB[reg], sB[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
+            xA[reg] = xa.x; xA[reg + 1] = xa.y; xB[reg] = xb.x; xB[reg + 1] = xb.y;
+        }
+        float mt = fmaxf(xA[0], xB[0]);                         // the tile's maximum RELATIVE to the running one
+#pragma unroll
+        for (int reg = 1; reg < 16; ++reg) mt = fmaxf(mt, fmaxf(xA[reg], xB[reg]));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mt2 = mt * a.c2;
-        if (__builtin_amdgcn_ballot_w64(mt2 > m2 + RESCALE_THRESHOLD) != 0) {
-            const float mn = fmaxf(m2, mt2);
-            const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
+        if (FIRST || __builtin_amdgcn_ballot_w64(mt > RESCALE_THRESHOLD) != 0) {
+            const float shift = FIRST ? mt : fmaxf(mt, 0.f);     // lazy rescale; the first trip adopts the tile's maximum (o, l are zero)
+            if (!FIRST) {
+                const float alpha = __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) o[reg] *= alpha;
-            if (D == 32) {
+                for (int reg = 0; reg < 16; ++reg) o[reg] *= alpha;
+                if (D == 32) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) lacc[reg] *= alpha;
+                    for (int reg = 0; reg < 16; ++reg) lacc[reg] *= alpha;
+                }
             }
-            m2 = mn;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) { xA[reg] -= shift; xB[reg] -= shift; }
+            m2 += shift;
         }
         float pA[16], pB[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; reg += 2) {                 // the FMA on packed fp32 pairs (v_pk_fma_f32: two scores per issue slot)
-            const f32x2_t xa = pk_fma((f32x2_t){sA[reg], sA[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
-            const f32x2_t xb = pk_fma((f32x2_t){sB[reg], sB[reg + 1]}, pk_splat(a.c2), pk_splat(-m2));
-            pA[reg] = __builtin_amdgcn_exp2f(xa.x); pA[reg + 1] = __builtin_amdgcn_exp2f(xa.y);
-            pB[reg] = __builtin_amdgcn_exp2f(xb.x); pB[reg + 1] = __builtin_amdgcn_exp2f(xb.y);
-        }
+        for (int reg = 0; reg < 16; ++reg) { pA[reg] = __builtin_amdgcn_exp2f(xA[reg]); pB[reg] = __builtin_amdgcn_exp2f(xB[reg]); }
         lds_sync();                                             // tile writes visible to the transposed reads
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -194,10 +226,11 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
         }
     };
 
-    const int full = a.n_kv & ~63;
-    int k0 = 0;
-    for (; k0 < full; k0 += 64) body(k0, std::false_type{});
-    if (k0 < a.n_kv) body(k0, std::true_type{});
+    const int full = a.n_kv & ~63;                              // n_kv >= 64 (stg_xattn_eligible): the first trip is a full one
+    body(0, std::false_type{}, std::true_type{});
+    int k0 = 64;
+    for (; k0 < full; k0 += 64) body(k0, std::false_type{}, std::false_type{});
+    if (k0 < a.n_kv) body(k0, std::true_type{}, std::false_type{});
 
     if (okq) {
         const float l = (D == 16) ? o[8] : lacc[0];
@@ -253,6 +286,11 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
     const bf16_t* trA = tA + tr_off;
     const bf16_t* trB = tB + tr_off;
 
+    bf16x8_t qh[KS], ql[KS];                                    // scale * log2 e folded into the queries (hi + lo)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) scale_split(qf[s], a.c2, qh[s], ql[s]);
+    const f32x16_t cl = splat16(-lse2), cd = splat16(-delta);   // C operands: scores leave the MFMA as c2 s - lse2, dP as dP - delta
+
     f32x16_t dq = zero16();
     bf16x8_t kfA[KS], kfB[KS];
     auto load_pair = [&](int k0) {
@@ -275,20 +313,20 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
             *reinterpret_cast<bf16x8_t*>(tA + wr_off + 16 * s) = kfA[s];
             *reinterpret_cast<bf16x8_t*>(tB + wr_off + 16 * s) = kfB[s];
         }
-        f32x16_t sA = zero16(), sB = zero16(), dpA = zero16(), dpB = zero16();
+        f32x16_t sA = MFMA32(kfA[0], qh[0], cl), sB = MFMA32(kfB[0], qh[0], cl);
+        sA = MFMA32(kfA[0], ql[0], sA); sB = MFMA32(kfB[0], ql[0], sB);
+        f32x16_t dpA = MFMA32(kfA[0], dof[0], cd), dpB = MFMA32(kfB[0], dof[0], cd);       // V == K
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            sA = MFMA32(kfA[s], qf[s], sA);
-            sB = MFMA32(kfB[s], qf[s], sB);
-            dpA = MFMA32(kfA[s], dof[s], dpA);                  // V == K
-            dpB = MFMA32(kfB[s], dof[s], dpB);
+        for (int s = 1; s < KS; ++s) {
+            sA = MFMA32(kfA[s], qh[s], sA); sB = MFMA32(kfB[s], qh[s], sB);
+            sA = MFMA32(kfA[s], ql[s], sA); sB = MFMA32(kfB[s], ql[s], sB);
+            dpA = MFMA32(kfA[s], dof[s], dpA); dpB = MFMA32(kfB[s], dof[s], dpB);
         }
         if (k0 + 64 < a.n_kv) load_pair(k0 + 64);
         float dA[16], dB[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; reg += 2) {                 // FMA, subtraction and product on packed fp32 pairs
-            f32x2_t xa = pk_fma((f32x2_t){sA[reg], sA[reg + 1]}, pk_splat(a.c2), pk_splat(-lse2));
-            f32x2_t xb = pk_fma((f32x2_t){sB[reg], sB[reg + 1]}, pk_splat(a.c2), pk_splat(-lse2));
+        for (int reg = 0; reg < 16; reg += 2) {                 // exp2 + one packed multiply per pair of scores
+            f32x2_t xa = {sA[reg], sA[reg + 1]}, xb = {sB[reg], sB[reg + 1]};
             if (MASKED) {
                 const int key = k0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
                 xa.x = key < a.n_kv ? xa.x : -INFINITY;          xa.y = key + 1 < a.n_kv ? xa.y : -INFINITY;
@@ -296,8 +334,8 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
             }
             const f32x2_t ea = {__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
             const f32x2_t eb = {__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
-            const f32x2_t ra = ea * ((f32x2_t){dpA[reg], dpA[reg + 1]} - pk_splat(delta));
-            const f32x2_t rb = eb * ((f32x2_t){dpB[reg], dpB[reg + 1]} - pk_splat(delta));
+            const f32x2_t ra = ea * (f32x2_t){dpA[reg], dpA[reg + 1]};
+            const f32x2_t rb = eb * (f32x2_t){dpB[reg], dpB[reg + 1]};
             dA[reg] = ra.x; dA[reg + 1] = ra.y; dB[reg] = rb.x; dB[reg + 1] = rb.y;
         }
         lds_sync();
@@ -358,6 +396,10 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
     const bf16_t* trQ = tQ + tr_off;
     const bf16_t* trD = tD + tr_off;
 
+    bf16x8_t kh[KS], kl[KS];                                    // scale * log2 e folded into the wave's keys (hi + lo); V stays kf
+#pragma unroll
+    for (int s = 0; s < KS; ++s) scale_split(kf[s], a.c2, kh[s], kl[s]);
+
     f32x16_t dk = zero16(), dv = zero16();
     bf16x8_t qf[KS], dof[KS];
     float stat;
@@ -371,8 +413,8 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
             dof[s] = ld_frag(dop + (int64_t)qq * a.lddo + 16 * s);
         }
         const float v = statp[qq];
-        // padded queries: lse2 = +inf -> p = 0, delta = 0
-        stat = hh == 0 ? (ok ? v * LOG2E : INFINITY) : (ok ? v : 0.f);
+        // NEGATED (they are the MFMAs' C operands); padded queries: -lse2 = -inf -> p = 0, delta = 0
+        stat = hh == 0 ? (ok ? -v * LOG2E : -INFINITY) : (ok ? -v : 0.f);
     };
     load_tile(0);
 
@@ -384,28 +426,31 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
             *reinterpret_cast<bf16x8_t*>(tD + wr_off + 16 * s) = dof[s];
         }
         sStat[lane] = stat;
-        f32x16_t sc = zero16(), dp = zero16();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            sc = MFMA32(qf[s], kf[s], sc);                      // S[q][key]: query on the accumulator row, key on the lane
-            dp = MFMA32(dof[s], kf[s], dp);                     // dP[q][key] = dO[q] . V[key],  V == K
-        }
-        if (q0 + 32 < a.n) load_tile(q0 + 32);
         lds_sync();
-        float pr[16], ds[16];
+        f32x16_t cl, cd;                                        // -lse2 / -delta of the query on each accumulator row
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 l4 = *reinterpret_cast<const float4*>(sStat + 8 * g + 4 * hh);
             const float4 d4 = *reinterpret_cast<const float4*>(sStat + 32 + 8 * g + 4 * hh);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+            cl[4 * g] = l4.x; cl[4 * g + 1] = l4.y; cl[4 * g + 2] = l4.z; cl[4 * g + 3] = l4.w;
+            cd[4 * g] = d4.x; cd[4 * g + 1] = d4.y; cd[4 * g + 2] = d4.z; cd[4 * g + 3] = d4.w;
+        }
+        f32x16_t sc = MFMA32(qf[0], kh[0], cl);                 // c2 S[q][key] - lse2[q]: query on the accumulator row, key on the lane
+        sc = MFMA32(qf[0], kl[0], sc);
+        f32x16_t dp = MFMA32(dof[0], kf[0], cd);                // dP[q][key] - delta[q],  V == K
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {                     // packed fp32 pairs
-                const int reg = 4 * g + e;
-                const f32x2_t x = pk_fma((f32x2_t){sc[reg], sc[reg + 1]}, pk_splat(a.c2), (f32x2_t){-lv[e], -lv[e + 1]});
-                const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                const f32x2_t dv2 = pv * ((f32x2_t){dp[reg], dp[reg + 1]} - (f32x2_t){dl[e], dl[e + 1]});
-                pr[reg] = pv.x; pr[reg + 1] = pv.y; ds[reg] = dv2.x; ds[reg + 1] = dv2.y;
-            }
+        for (int s = 1; s < KS; ++s) {
+            sc = MFMA32(qf[s], kh[s], sc);
+            sc = MFMA32(qf[s], kl[s], sc);
+            dp = MFMA32(dof[s], kf[s], dp);
+        }
+        if (q0 + 32 < a.n) load_tile(q0 + 32);
+        float pr[16], ds[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; reg += 2) {                 // exp2 + one packed multiply per pair of scores
+            const f32x2_t pv = {__builtin_amdgcn_exp2f(sc[reg]), __builtin_amdgcn_exp2f(sc[reg + 1])};
+            const f32x2_t dv2 = pv * (f32x2_t){dp[reg], dp[reg + 1]};
+            pr[reg] = pv.x; pr[reg + 1] = pv.y; ds[reg] = dv2.x; ds[reg + 1] = dv2.y;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
