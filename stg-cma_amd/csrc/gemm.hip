@@ -167,7 +167,13 @@ __device__ __forceinline__ void unpack_d8(const uint2 q, float* v) {
     }
 }
 
-template <int V>
+// FULL: the wave's 64 x 64 piece lies entirely inside C (decided once per wave by the caller): no bounds tests at all.  With the tests the
+// compiler wraps every 8-row step in an exec-mask branch (s_and_saveexec / s_cbranch_execz), sinks the step's LDS reads into it, and --
+// because its wait-count bookkeeping is merged conservatively at every join -- puts `s_waitcnt vmcnt(0)` in front of every step's first
+// use of the bias registers: each wave then waits for its PREVIOUS global store to complete before it issues the next one (16 steps x a
+// full store latency per wave: that, not the memory system, was the 8.9 us "un-overlapped epilogue" of a 256 x 256 tile; a pure-store
+// kernel writes the same tile in 5 us with every CU storing at once, tools/probe/store_probe.hip).
+template <int V, bool FULL>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm, int wn,
                                                    int lane, float* stg, int ngap = 0) {
     constexpr bool G = V == EV_GENERIC;
@@ -185,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
     const int lrow = lane & 15, lk = lane >> 4;
     const int rr = lane >> 3, cc = lane & 7;
     int n = n0 + wn * 64 + cc * 8 + ((cc & 4) ? ngap : 0);     // ngap: the tile's right 32 columns sit ngap further right (8-phase kernel)
-    const bool col_ok = n < p.N;
+    const bool col_ok = FULL || n < p.N;
     if (!col_ok) n = 0;                                // clamped: loads stay unconditional, stores are predicated
     float bias[8];
 #pragma unroll
@@ -195,8 +201,37 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
         bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
         bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
+    // Row operands (saved derivative, residuals) are loaded for ALL steps of a group BEFORE the group's first store: vmcnt counts
+    // loads and stores together, in order, so a wait for a load that was issued behind a store is also a wait for that store's
+    // completion (one full store latency per 8-row step: see FULL above).  Group = the whole 64 x 64 piece (8 steps) for the byte-wide
+    // derivative, one 32-row half for the bf16 operands, a single step where fp32 residuals would not fit the 128-VGPR kernels.
+    constexpr int LG = (V == EV_DSRC8) ? 8 : (V == EV_DSRC || V == EV_R16) ? 4 : 1;     // steps per load group (register budget)
+    Row8 qdv[2][4], q1v[2][4], q2v[2][4];
+    uint2 qd8v[2][4];
+    auto row_of = [&](int half, int it) -> int64_t {
+        int64_t m = m0 + wm * 64 + half * 32 + it * 8 + rr;
+        if (!FULL) m = m < p.M ? m : p.M - 1;
+        return m;
+    };
+    auto load_step = [&](int half, int it) {
+        const int64_t m = row_of(half, it);
+        if (D8 && dsrc_on) qd8v[half][it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.dact_src) + m * p.ldd + n);
+        else if (dsrc_on) qdv[half][it] = ld_row8(p.dact_src, 0, m * p.ldd + n);
+        if (r1_on) q1v[half][it] = ld_row8(p.res1, r1_f32, m * p.ldr1 + n);
+        if (r2_on) q2v[half][it] = ld_row8(p.res2, r2_f32, m * p.ldr2 + n);
+    };
+    if (LG == 8) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) load_step(hh, it);
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        if (LG == 4) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) load_step(half, it);
+        }
         if (half) lds_wave_sync();                     // the previous half's reads are done before it is overwritten
 #pragma unroll
         for (int mi2 = 0; mi2 < 2; ++mi2)
@@ -207,15 +242,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + rr;
-            int64_t m = m0 + wm * 64 + half * 32 + row;
-            const bool ok = m < p.M && col_ok;
-            m = m < p.M ? m : p.M - 1;
-            Row8 qd, q1, q2;
-            uint2 qd8 = make_uint2(0u, 0u);
-            if (D8 && dsrc_on) qd8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.dact_src) + m * p.ldd + n);
-            else if (dsrc_on) qd = ld_row8(p.dact_src, 0, m * p.ldd + n);
-            if (r1_on) q1 = ld_row8(p.res1, r1_f32, m * p.ldr1 + n);
-            if (r2_on) q2 = ld_row8(p.res2, r2_f32, m * p.ldr2 + n);
+            const int64_t m = row_of(half, it);
+            const bool ok = FULL || (m0 + wm * 64 + half * 32 + row < p.M && col_ok);
+            if (LG == 1) load_step(half, it);
+            const Row8& qd = qdv[half][it];
+            const Row8& q1 = q1v[half][it];
+            const Row8& q2 = q2v[half][it];
+            const uint2 qd8 = qd8v[half][it];
             const float* src = stg + row * 64;
             const int c0 = (2 * cc) ^ (row & 15);
             const f32x4_t u0 = *reinterpret_cast<const f32x4_t*>(src + (c0 << 2));
@@ -290,19 +323,24 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
 __device__ __forceinline__ void gemm_epilogue_dispatch(const GemmParams& p, const AccTile accs, int64_t m0, int n0, int wm,
                                                        int wn, int lane, float* stg, int ngap = 0) {
     if (DIAG_ON(p, 3) && accs.v[0][0][0] != 12345.678f) return;
+    // wave-uniform: does the wave's 64 x 64 piece (its right half ngap further right) lie inside C?
+    const bool full = m0 + wm * 64 + 64 <= p.M && n0 + wn * 64 + 64 + ngap <= p.N;
+#define STG_EPI_CASE(V) case V: if (full) gemm_epilogue_rows<V, true>(p, accs, m0, n0, wm, wn, lane, stg, ngap); \
+                                else gemm_epilogue_rows<V, false>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
     switch (p.epi_variant) {
-        case EV_PLAIN: gemm_epilogue_rows<EV_PLAIN>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_GELU: gemm_epilogue_rows<EV_GELU>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_QGELU: gemm_epilogue_rows<EV_QGELU>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_DSRC: gemm_epilogue_rows<EV_DSRC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_R16: gemm_epilogue_rows<EV_R16>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_BRQ: gemm_epilogue_rows<EV_BRQ>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_GELU8: gemm_epilogue_rows<EV_GELU8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_QGELU8: gemm_epilogue_rows<EV_QGELU8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_DSRC8: gemm_epilogue_rows<EV_DSRC8>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
-        case EV_GENERIC: gemm_epilogue_rows<EV_GENERIC>(p, accs, m0, n0, wm, wn, lane, stg, ngap); break;
+        STG_EPI_CASE(EV_PLAIN)
+        STG_EPI_CASE(EV_GELU)
+        STG_EPI_CASE(EV_QGELU)
+        STG_EPI_CASE(EV_DSRC)
+        STG_EPI_CASE(EV_R16)
+        STG_EPI_CASE(EV_BRQ)
+        STG_EPI_CASE(EV_GELU8)
+        STG_EPI_CASE(EV_QGELU8)
+        STG_EPI_CASE(EV_DSRC8)
+        STG_EPI_CASE(EV_GENERIC)
         default: gemm_epilogue_elems(p, accs, m0, n0, wm, wn, lane & 15, lane >> 4); break;     // unaligned / N % 8 != 0
     }
+#undef STG_EPI_CASE
 }
 
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmParams p) {
