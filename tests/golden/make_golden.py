@@ -219,7 +219,7 @@ def avqa_backbone_case(Q, tag, *, cfg, B, seed):
          grads=flat_grads(m, names), f_v=f_v, f_a=f_a, f_nega=f_n)
 
 
-def avqa_full_case(Q, tag, *, cfg, B, seed):
+def avqa_full_case(Q, tag, *, cfg, B, seed, state_fn=None):
     """The whole SwinTransformer2D_Adapter_AVQA.forward[fusion] (AVQA/model/Swin_AVQAModel_V1.py:1740-1903): backbone + QA head
     (question LSTM, grounding on the positive and the negative clip, two single-query attentions, fusion MLPs), eval mode,
     every trainable tensor of the AVQA loop's name filter (traintest_adapt_avqa.py:72: adapters + `avqatask_`) with a gradient.
@@ -227,7 +227,7 @@ def avqa_full_case(Q, tag, *, cfg, B, seed):
     m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, grounding_pretrained=None, num_frames=cfg["num_frames"],
                                          embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
                                          adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
-    shapes = seed_module(m, seed)
+    shapes = seed_module(m, seed, state_fn)
     names = apply_freeze(m)
     T = cfg["num_frames"]
     a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
@@ -563,6 +563,9 @@ AVS_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_f
 AVQA_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
 AVS_FULL_TINY = dict(embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32], num_frames=5, adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
 AVQA_FULL_TINY = dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
+# BASELINE config 5's model beyond depths [2, 2, 2, 2]: Swin-L widths, the AVQA runner's adapter ratios (AVQA/run_adapt_avqa.py:288-301), six
+# stage-2 blocks (three temporal + three shifted), B = 1, reference-initialised backbone (GP.avqa_deep_state)
+AVQA_FULL_D6 = dict(embed_dim=192, depths=[2, 2, 6, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.0625])
 SWIN_B = dict(label_dim=29, embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=10,
               adapter_mlp_ratio=[0.125, 0.125, 0.0625, 0.0625])
 # AVE/run_adapt_ave29.py:167-181 (MM-Swin-AVE-Large) = the backbone geometry of AVQA/run_adapt_avqa.py:288-301 (BASELINE config 5)
@@ -640,6 +643,7 @@ def main(argv):
                                                                 res=224, audio_length=3200, seed=730),
         "avqa_full_tiny": lambda: avqa_full_case(ref_avqa(), "avqa_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=620),
         # the 512-d head variant that AVQA/test.py:8 imports (yb_fc_v / yb_fc_a projections, fc_a1)
+        "avqa_full_d6": lambda: avqa_full_case(ref_avqa(), "avqa_full_d6", cfg=AVQA_FULL_D6, B=1, seed=640, state_fn=GP.avqa_deep_state),
         "avqa512_full_tiny": lambda: avqa_full_case(ref_avqa512(), "avqa512_full_tiny", cfg=AVQA_FULL_TINY, B=2, seed=630),
         # full-depth Swin-L at the reference's initialisation scale: the fixture the fp8 frozen-weight path is measured on
         "swin_l_fusion_refinit": lambda: swin_model_case(S, "swin_l_fusion_refinit", cfg=SWIN_L, B=1, mode="fusion", seed=320,

@@ -100,6 +100,15 @@ def refinit_state(shapes, seed):
     return out
 
 
+def avqa_deep_state(shapes, seed):
+    """The deeper AVQA fixture (avqa_full_d6): backbone at the REFERENCE's initialisation scale (refinit_state: a 12-block Swin-L with
+    O(1)-gain "hot" parameters would put the bf16 floor far above the 1e-2 logit bound the fixture is there to check), task head
+    (`avqatask_*`: question LSTM, grounding, attentions, MLPs) at the seeded O(1) scale so that its outputs are not all ~0."""
+    ref = refinit_state(shapes, seed)
+    hot = seeded_state(shapes, seed + 1)
+    return {k: (hot[k] if k.startswith("avqatask_") else ref[k]) for k, _ in shapes}
+
+
 def swin2d_checkpoint(state_dict, seed, patch_depth_one=True):
     """A synthetic stand-in for swin_*_patch4_window7_224_22k.pth: {'model': sd} holding what an image Swin checkpoint holds --
     the backbone keys of `state_dict` (a Swin+STG-CMA model's: everything except adapters, gates, temporal tables, the audio

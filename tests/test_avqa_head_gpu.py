@@ -2,6 +2,8 @@
   * unit: every head.hip kernel pair (forward + backward) against fp32 PyTorch-CPU autograd of the same op;
   * model: SwinTransformer2D_Adapter_AVQA.forward (backbone + head) against the golden produced by the REFERENCE model
     (tests/golden/avqa_full_tiny.npz): the three outputs, per-tensor gradient norms, a strided gradient sample."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,7 +168,8 @@ def _rel(got, ref):
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6), float((got - ref).norm() / max(float(ref.norm()), 1e-12))
 
 
-@pytest.mark.parametrize("case,modname", [("avqa_full_tiny", "Swin_AVQAModel_V1"), ("avqa512_full_tiny", "Swin_AVQAModel")])
+@pytest.mark.parametrize("case,modname", [("avqa_full_tiny", "Swin_AVQAModel_V1"), ("avqa512_full_tiny", "Swin_AVQAModel"),
+                                          ("avqa_full_d6", "Swin_AVQAModel_V1")])      # d6: Swin-L widths, depths [2, 2, 6, 2], B = 1, reference-init backbone
 def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
     """backbone + QA head against the reference model's outputs and gradients (eval mode: every dropout off): the runner's V1
     model (AVQA/run_adapt_avqa.py:20) and the 512-d variant of AVQA/test.py:8."""
@@ -178,7 +181,8 @@ def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
     m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
                                                  depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
                                                  adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
-    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    from params import avqa_deep_state
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=avqa_deep_state if case == "avqa_full_d6" else None)
     sd = m.state_dict()
     assert [k for k in sd if sd[k].is_floating_point() and not k.endswith("attn_mask")] == [k for k, _ in shapes], \
         "state_dict float keys (incl. avqatask_*) differ from the reference's"
@@ -203,6 +207,10 @@ def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
     assert out_qa.dtype == F32 and tuple(out_qa.shape) == (B, 42) and tuple(mp.shape) == (B * T, 2) and tuple(mn.shape) == (B * T, 2)
     for got, key in ((out_qa, "out_qa"), (mp, "out_match_posi"), (mn, "out_match_nega")):
         e_max, e_l2 = _rel(got, z[key])
+        e_abs = float((got.detach().float().cpu() - torch.as_tensor(np.asarray(z[key])).float()).abs().max())
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/model_parity_report.txt", "a") as f:
+            f.write(f"{case} {key}: max/scale={e_max:.3e} relL2={e_l2:.3e} max-abs={e_abs:.3e} scale={float(np.abs(np.asarray(z[key])).max()):.3g}\n")
         # the 512-d variant's positive match logits are a near-cancelling pair (|.| <= 0.07): a bf16 emulation of the HEAD alone on
         # the fp32 oracle features (every Linear on bf16 inputs / weights / outputs) already deviates 3.9 % / 4.4 % there, 1.4 % elsewhere
         lim = 8e-2 if (case == "avqa512_full_tiny" and key == "out_match_posi") else 3e-2

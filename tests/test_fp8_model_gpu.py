@@ -45,8 +45,8 @@ def test_fp8_logit_deviation_on_refinit_models(stg, gpu, case):
     ref = torch.as_tensor(z["logits"])
     ref_norms = np.asarray(z["grad_norms"])
     res = {}
-    for tag, on in (("bf16", False), ("fp8", True)):
-        fp8.enable(m, on)
+    for tag, on in (("bf16", False), ("fp8", True), ("fp8-bwd", fp8.BACKWARD_ONLY)):
+        fp8.enable(m, bool(on), sites=None if on is True or not on else on)
         m.zero_grad(set_to_none=True)
         logits = m(a, v, "fusion")
         torch.nn.CrossEntropyLoss()(logits, tgt).backward()
@@ -60,9 +60,29 @@ def test_fp8_logit_deviation_on_refinit_models(stg, gpu, case):
         _report(f"{case} {tag}: max-abs logit deviation {err:.3e} (max |logit| {float(ref.abs().max()):.3g}); per-tensor gradient norms: "
                 f"worst deviation {gdev:.3e}, relL2 of the norm vector {gl2:.3e}")
     assert res["bf16"][0] <= 1e-2
-    # e4m3 operands: measured, recorded, and bounded so that a broken kernel cannot pass (3 mantissa bits: ~3 % per GEMM)
-    assert res["fp8"][0] <= 5e-2 * max(1.0, float(ref.abs().max())), f"fp8 logit deviation {res['fp8'][0]:.3e}"
+    # e4m3 operands on every frozen GEMM: FAILS BASELINE's 1e-2 bound by 4-5 x (measured 4.5e-2 Swin-L / 3.7e-2 Swin-B; per-site table
+    # profiles/r03_fp8_sites.txt: no forward subset beyond stage 0 fits) -- the strict assertion lives in the xfail test below; here
+    # the deviation is recorded and bounded at 1.5 x measured so that a broken kernel cannot pass (3 mantissa bits: ~3 % per GEMM)
+    assert res["fp8"][0] <= 7e-2, f"fp8 logit deviation {res['fp8'][0]:.3e}"
     assert res["fp8"][2] <= 2.5e-1, f"fp8 gradient-norm vector relL2 {res['fp8'][2]:.3e}"
+    # data-gradient GEMMs only: the forward is the bf16 path's, so the logit bound holds; gradients within 1.5 x measured (7.5e-2 worst tensor)
+    assert res["fp8-bwd"][0] <= 1e-2 and abs(res["fp8-bwd"][0] - res["bf16"][0]) <= 1e-6
+    assert res["fp8-bwd"][1] <= 1.2e-1, f"fp8 (bwd only) worst gradient-norm deviation {res['fp8-bwd'][1]:.3e}"
+    _strict[case] = res["fp8"][0]
+
+
+_strict = {}
+
+
+@pytest.mark.xfail(reason="config 5 fp8: every frozen GEMM on e4m3 deviates 3.7e-2 .. 4.7e-2 from the reference logits (bound 1e-2); "
+                          "measured infeasible per site, profiles/r03_fp8_sites.txt -- the path stays opt-in", strict=False)
+@pytest.mark.parametrize("case", ["swin_l_fusion_refinit", "swin_b_fusion_refinit"])
+def test_fp8_logit_bound_strict(case):
+    """BASELINE.json's acceptance bound for the fp8 weight path, asserted as it is written (<= 1e-2 max-abs): expected to fail; it shows
+    up as XPASS the day the path meets its contract."""
+    if case not in _strict:
+        pytest.skip("runs after test_fp8_logit_deviation_on_refinit_models")
+    assert _strict[case] <= 1e-2, f"fp8 logit deviation {_strict[case]:.3e} > 1e-2"
 
 
 def test_fp8_avqa_full_model_and_training(stg, gpu):

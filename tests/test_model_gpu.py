@@ -22,6 +22,25 @@ _report = []
 # fused kernel (csrc/upln.hip: x equal to 4e-6, 579 of 32 M bf16 outputs one ulp apart, tools/dbg_upln.py) moved single small
 # tensors by up to +-40 % of their deviation while the mean over the 393 compared tensors stayed put (-2 %; 184 closer, 96
 # farther).  Scalars / 16-element biases and the tiny models' logits therefore carry ~20 % headroom over the first realisation.
+# Per-tensor gradient bounds of the block fixtures = 1.5 x the worst deviation measured on MI355X (profiles/r03_parity_report.txt:
+# per case the worst trainable tensor and the worst scalar gate; a bf16 pipeline against the fp32 reference), never below 1.5e-2.
+# (max-abs / tensor max, relative L2) for tensors, one number for the scalar gates.
+_BLOCK_GRAD_MEASURED = {
+    "swin_block_audio": ((9.1e-3, 8.6e-3), 0.0), "swin_block_video": ((8.3e-3, 8.0e-3), 0.0),
+    "swin_block_even": ((1.59e-2, 1.18e-2), 9.5e-3), "swin_block_odd": ((9.7e-3, 8.5e-3), 1.01e-2),
+    "swin_block_s0": ((9.3e-3, 8.2e-3), 3.6e-3), "swin_block_s3": ((3.41e-2, 2.54e-2), 2.43e-2),
+    "swin_block_nofusion": ((1.34e-2, 1.13e-2), 0.0), "swin_block_wide64": ((2.19e-2, 1.66e-2), 1.16e-2),
+    "swin_block_wide96": ((8.5e-3, 8.5e-3), 2.0e-2),
+}
+
+
+def _block_grad_bounds(tag, scalar):
+    (mx, l2), gate = _BLOCK_GRAD_MEASURED[tag]
+    if scalar:
+        return (max(1.5 * gate, 1.5e-2),) * 2
+    return max(1.5 * mx, 1.5e-2), max(1.5 * l2, 1.5e-2)
+
+
 def _cmp(got, ref, what, max_rel=2e-2, l2_rel=1e-2):
     got = got.detach().float().cpu().reshape(-1)
     ref = torch.as_tensor(np.asarray(ref)).float().reshape(-1)
@@ -86,7 +105,7 @@ def test_single_stream_block_matches_reference(stg, gpu, tag):
     assert out.dtype == torch.float32
     _cmp(out, z["out"], f"{tag} out")
     out.backward(gx.reshape(-1, C).to(gpu))
-    _cmp(X.grad, z["din"], f"{tag} din", max_rel=3e-2, l2_rel=2e-2)
+    _cmp(X.grad, z["din"], f"{tag} din", max_rel=1.5e-2, l2_rel=1.2e-2)                # 1.5 x measured (9.9e-3 / 6.8e-3)
     d = dict(blk.named_parameters())
     off = 0
     for n in names:
@@ -94,7 +113,8 @@ def test_single_stream_block_matches_reference(stg, gpu, tag):
         ref = z["grads"][off:off + k]
         off += k
         if np.abs(ref).max() > 0:
-            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=6e-2, l2_rel=5e-2 if k == 1 else 4e-2)      # NOISE (scalars: gates)
+            mr, lr = _block_grad_bounds(tag, k == 1)
+            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=mr, l2_rel=lr)
         else:
             assert d[n].grad is None or float(d[n].grad.abs().max()) == 0
 
@@ -119,14 +139,14 @@ def test_swin_tiny_other_modes_match_reference(stg, gpu, tag, mode):
     err = float((logits.detach().cpu() - torch.as_tensor(z["logits"])).abs().max())
     _report.append(f"{tag} logits max abs err {err:.3e}")
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
-    _cmp(_flat_grads(m, names), z["grads"], f"{tag} grads", max_rel=5e-2, l2_rel=3e-2)
+    _cmp(_flat_grads(m, names), z["grads"], f"{tag} grads", max_rel=1.5e-2, l2_rel=1.7e-2)   # 1.5 x measured (9.3e-3 / 1.13e-2)
     if "t_relative" in cfg:                                    # the embeddings' own gradients, not hidden behind the adapters'
         d = dict(m.named_parameters())
         off = 0
         for n in names:
             k = d[n].numel()
             if n.startswith("temporal_embedding"):
-                _cmp(d[n].grad, z["grads"][off:off + k], f"{tag} grad[{n}]", max_rel=5e-2, l2_rel=3e-2)
+                _cmp(d[n].grad, z["grads"][off:off + k], f"{tag} grad[{n}]", max_rel=3e-2, l2_rel=3.6e-2)   # 1.5 x measured (2.0e-2 / 2.4e-2)
             off += k
 
 
@@ -157,9 +177,9 @@ def test_fusion_block_matches_reference(stg, gpu, tag):
     _cmp(out[BT * N:], z["out_a"], f"{tag} out_a")
     dO = torch.cat([gv.reshape(-1, C), ga.reshape(-1, C)]).to(BF16).to(gpu)
     out.backward(dO)
-    _cmp(X.grad[:BT * N], z["din_v"], f"{tag} din_v", max_rel=3e-2, l2_rel=2e-2)
-    _cmp(X.grad[BT * N:], z["din_a"], f"{tag} din_a", max_rel=3e-2, l2_rel=2e-2)
-    _cmp(_flat_grads(blk, names), z["grads"], f"{tag} param grads", max_rel=3e-2, l2_rel=2e-2)
+    _cmp(X.grad[:BT * N], z["din_v"], f"{tag} din_v", max_rel=1.6e-2, l2_rel=1.2e-2)   # 1.5 x measured (1.06e-2 / 7.8e-3)
+    _cmp(X.grad[BT * N:], z["din_a"], f"{tag} din_a", max_rel=1.6e-2, l2_rel=1.2e-2)
+    _cmp(_flat_grads(blk, names), z["grads"], f"{tag} param grads", max_rel=1.3e-2, l2_rel=1.3e-2)   # 1.5 x measured (8.5e-3 / 8.6e-3)
     # per-tensor view of the same gradients (a small tensor must not hide behind a large one)
     d = dict(blk.named_parameters())
     off = 0
@@ -168,7 +188,8 @@ def test_fusion_block_matches_reference(stg, gpu, tag):
         ref = z["grads"][off:off + k]
         off += k
         if np.abs(ref).max() > 0:
-            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=6e-2, l2_rel=5e-2 if k == 1 else 4e-2)      # NOISE (scalars: gates)
+            mr, lr = _block_grad_bounds(tag, k == 1)
+            _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=mr, l2_rel=lr)
 
 
 def _build_model(S, cfg, P, gpu, train=False):
@@ -201,7 +222,7 @@ def test_swin_tiny_fusion_model_matches_reference(stg, gpu):
     loss.backward()
     _cmp(logits, z["logits"], "swin_tiny logits")
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
-    _cmp(_flat_grads(m, names), z["grads"], "swin_tiny grads", max_rel=5e-2, l2_rel=3e-2)
+    _cmp(_flat_grads(m, names), z["grads"], "swin_tiny grads", max_rel=1.5e-2, l2_rel=1.5e-2)     # 1.5 x measured (6.3e-3 / 8.5e-3)
     assert err <= 1e-2 * max(1.0, float(np.abs(z["logits"]).max())), f"logit deviation {err}"
 
 
@@ -227,8 +248,9 @@ def test_swin_b_fusion_full_model_matches_reference(stg, gpu):
     loss.backward()
     d = dict(m.named_parameters())
     norms = torch.stack([d[n].grad.float().norm().cpu() for n in names])
-    _cmp(norms, z["grad_norms"], "swin_b grad norms", max_rel=5e-2, l2_rel=3e-2)
-    _cmp(_flat_grads(m, names)[::97], z["grads_sample"], "swin_b grad sample", max_rel=8e-2, l2_rel=5e-2)
+    # bounds = 1.5 x measured (norms 1.0e-3 / 2.2e-3, sample 2.0e-2 / 1.3e-2: profiles/r03_parity_report.txt)
+    _cmp(norms, z["grad_norms"], "swin_b grad norms", max_rel=5e-3, l2_rel=5e-3)
+    _cmp(_flat_grads(m, names)[::97], z["grads_sample"], "swin_b grad sample", max_rel=3e-2, l2_rel=2e-2)
     assert abs(float(loss) - float(z["loss"][0])) <= 1e-2
     # This fixture uses deliberately "hot" parameters (every Linear at gain ~1, |logits| up to 2.1) so that a wrong kernel
     # cannot hide; through 24 blocks that puts the bf16-operand floor (2^-9 per GEMM input) at ~1.3 % of the logit scale.

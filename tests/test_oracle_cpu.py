@@ -233,15 +233,17 @@ def test_avqa_backbone_matches_reference():
     assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("case", ["avqa_full_tiny", "avqa512_full_tiny"])
+@pytest.mark.parametrize("case", ["avqa_full_tiny", "avqa512_full_tiny", "avqa_full_d6"])
 def test_avqa_full_model_matches_reference(case):
     """backbone + QA head (question LSTM, grounding on the positive / negative clip, single-query attentions, fusion
     MLPs) of the reference's SwinTransformer2D_Adapter_AVQA, outputs and every trainable gradient; the V1 (1536-d) model of the
     runner and the 512-d variant of AVQA/test.py."""
     import oracle.avqa_head as OH
     from params import seeded_tensor
+    from params import avqa_deep_state
     z, cfg, shapes, names = load_case(case)
-    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    # avqa_full_d6: Swin-L widths with six stage-2 blocks (BASELINE config 5's model beyond depths [2, 2, 2, 2]), reference-initialised backbone
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=avqa_deep_state if case == "avqa_full_d6" else None)
     for n in names:
         P[n].requires_grad_(True)
     B, T, seed = cfg["B"], cfg["num_frames"], cfg["seed"]

@@ -76,8 +76,8 @@ def test_vit_block_matches_reference(stg, gpu, tag):
     out.backward(torch.cat([gv, ga]).to(gpu))
     dv = X.grad[:BT * nv].view(BT, nv, d).permute(1, 0, 2)
     da = X.grad[BT * nv:].view(BT, na, d).permute(1, 0, 2)
-    _cmp(dv[::st], z["din_v"], f"{tag} din_v", max_rel=3e-2, l2_rel=2e-2)
-    _cmp(da[::st], z["din_a"], f"{tag} din_a", max_rel=3e-2, l2_rel=2e-2)
+    _cmp(dv[::st], z["din_v"], f"{tag} din_v", max_rel=1.3e-2, l2_rel=1.2e-2)          # 1.5 x measured (8.3e-3 / 7.7e-3)
+    _cmp(da[::st], z["din_a"], f"{tag} din_a", max_rel=1.3e-2, l2_rel=1.2e-2)
     dct = dict(blk.named_parameters())
     off = 0
     for n in names:
@@ -93,7 +93,7 @@ def test_vit_block_matches_reference(stg, gpu, tag):
             _report.append(f"{tag} grad[{n}]: err {err:.3g} (ref {float(ref[0]):.3g}, tol {tol:.3g})")
             assert err <= tol, f"{tag} grad[{n}]: {float(dct[n].grad)} vs {float(ref[0])} (tol {tol})"
         elif np.abs(ref).max() > 0:
-            _cmp(dct[n].grad, ref, f"{tag} grad[{n}]", max_rel=6e-2, l2_rel=4e-2)
+            _cmp(dct[n].grad, ref, f"{tag} grad[{n}]", max_rel=1.7e-2, l2_rel=1.4e-2)     # 1.5 x measured (1.1e-2 / 8.9e-3)
 
 
 def test_vit_tiny_fusion_model_matches_reference(stg, gpu):
@@ -135,7 +135,7 @@ def test_vit_tiny_fusion_model_matches_reference(stg, gpu):
             tol = 8e-2 * abs(float(ref[0])) + 5e-3 * terms ** 0.5
             assert abs(float(g) - float(ref[0])) <= tol, f"vit_tiny grad[{n}]: {float(g)} vs {float(ref[0])} (tol {tol})"
         elif np.abs(ref).max() > 0:
-            _cmp(g, ref, f"vit_tiny grad[{n}]", max_rel=8e-2, l2_rel=5e-2)
+            _cmp(g, ref, f"vit_tiny grad[{n}]", max_rel=2.3e-2, l2_rel=2.1e-2)       # 1.5 x measured (1.48e-2 / 1.38e-2, profiles/r03_parity_report.txt)
 
 
 def test_vit_train_mode_and_no_cpu_fallback(stg, gpu):
