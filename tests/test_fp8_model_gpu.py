@@ -66,7 +66,8 @@ def test_fp8_logit_deviation_on_refinit_models(stg, gpu, case):
     assert res["fp8"][0] <= 7e-2, f"fp8 logit deviation {res['fp8'][0]:.3e}"
     assert res["fp8"][2] <= 2.5e-1, f"fp8 gradient-norm vector relL2 {res['fp8'][2]:.3e}"
     # data-gradient GEMMs only: the forward is the bf16 path's, so the logit bound holds; gradients within 1.5 x measured (7.5e-2 worst tensor)
-    assert res["fp8-bwd"][0] <= 1e-2 and abs(res["fp8-bwd"][0] - res["bf16"][0]) <= 1e-6
+    # (Swin-B: the stage-0 one-kernel MLP steps aside for the two-GEMM path when its dgrad is on e4m3 -- the forward moves by ~3e-4)
+    assert res["fp8-bwd"][0] <= 1e-2 and abs(res["fp8-bwd"][0] - res["bf16"][0]) <= 1e-3
     assert res["fp8-bwd"][1] <= 1.2e-1, f"fp8 (bwd only) worst gradient-norm deviation {res['fp8-bwd'][1]:.3e}"
     _strict[case] = res["fp8"][0]
 
