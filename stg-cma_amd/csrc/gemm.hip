@@ -49,6 +49,7 @@ struct GemmParams {
     const void* res2; int64_t ldr2; int res2_f32;
     int64_t M; int N; int K;
     int nbm, nbn;
+    int ntl;           // multi-tile 8-phase kernel: consecutive column tiles per workgroup (divides nbn)
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
     int conv_H, conv_W, conv_d, conv_C; const bf16_t* conv_zero;     // implicit 3x3 convolution (conv_H > 0), see stgcma.h
@@ -888,6 +889,191 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-tile form of the 8-phase kernel (round 3): one workgroup computes `ntl` CONSECUTIVE COLUMN TILES of one 256-row panel and the
+// half-tile pipeline keeps running across the tile boundary.  In the one-tile kernel a K = 512 tile costs 12.9 us of main loop plus
+// ~4.8 us in which the matrix pipe has nothing to do before the epilogue even starts (workgroup turnover + the first DMAs' trip to L2 /
+// HBM + the drain of the dummy tail loads: 271 us for 15.3 tiles per CU with the epilogue compiled out) -- here the schedule's own
+// look-ahead (A1, W0 of k-tile kt + 1 and A0, W1 of kt + 2) simply addresses the NEXT tile's first k-tiles once kt runs past K, so a
+// tile's epilogue runs while the next tile's six prologue half-tiles land, and the next main loop starts on operands that are already
+// in LDS.  Same MFMA / k order: bit-identical to the one-tile kernel.
+//   * LDS: the ring's 8 slots (128 KiB) + 32 KiB.  After the last k-tile the slots parity-1 A1 and W0 (slots 5, 6) are the last ones read
+//     and the only ones the look-ahead has not re-staged: they and the extra 32 KiB are the eight 8 KiB epilogue staging regions.
+//   * the epilogue variant is a template parameter (one variant per instantiation: the register allocator sees one epilogue, and the
+//     main loop's per-lane offsets stay live across it without spills);
+//   * before the next main loop: s_waitcnt vmcnt(NST) with NST = the global stores the epilogue issued behind the DMAs (in-order
+//     completion: everything older than the NST youngest operations has landed), then the workgroup barrier.
+template <int V>
+__global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 16 KiB + 32 KiB of epilogue staging
+    const int ntl = p.ntl;
+    const int gpr = p.nbn / ntl;                         // tile groups per row panel
+    const int ngrp = p.nbm * gpr;
+    int gid = blockIdx.x;
+    {
+        const int q = ngrp >> 3, r = ngrp & 7;
+        const int xcd = gid & 7, idx = gid >> 3;
+        gid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = gid / gpr, bn0 = (gid % gpr) * ntl;
+    const int64_t m0 = (int64_t)bm * GBM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lrow = lane & 15, lk = lane >> 4;
+    constexpr int SLOT = 128 * BK;
+    enum { HA0 = 0, HA1 = 1, HW0 = 2, HW1 = 3 };
+
+    uint32_t oa[2][2], ow[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = j * 512 + tid;
+            const int row = hf * 128 + (q >> 3), c = (q & 7) ^ ((q >> 3) & 7);
+            const int64_t rm = p.M - 1 - m0;
+            const int ra = row < rm ? row : (int)rm;
+            oa[hf][j] = (uint32_t)(((int64_t)ra * p.lda + c * 8) * 2);
+            ow[hf][j] = (uint32_t)(((int64_t)row * p.ldw + c * 8) * 2);
+        }
+    const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda);
+    const int nk = p.K / BK;
+
+    int offA[4][2], offW[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { const int r = wr * 64 + mi * 16 + lrow; offA[mi][s2] = r * BK + swz(r, 4 * s2 + lk) * 8; }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { const int r = wc * 32 + ni * 16 + lrow; offW[ni][s2] = r * BK + swz(r, 4 * s2 + lk) * 8; }
+    }
+    // staging regions: waves 0-3 in slots 5 and 6 (contiguous 32 KiB), waves 4-7 behind the ring
+    float* stg = reinterpret_cast<float*>(smem8 + (wave < 4 ? 5 * SLOT : 8 * SLOT)) + (wave & 3) * 2048;
+
+#pragma unroll 1
+    for (int t = 0; t < ntl; ++t) {
+        const int n0 = (bn0 + t) * GBN;
+        const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+        const bool has_next = t + 1 < ntl;
+        const char* baseWn = reinterpret_cast<const char*>(p.W + (int64_t)(n0 + (has_next ? GBN : 0)) * p.ldw);
+        // which: HA0 / HA1 / HW0 / HW1 of k-tile kt; past the end of K: the next tile's k-tile kt - nk (same A panel, next W tile), or --
+        // behind the group's last tile -- a dummy re-load of the last k-tile (keeps the counted waits exact)
+        auto issue = [&](int which, int kt) {
+            const bool isw = which >= HW0;
+            const int hf = which & 1;
+            const int par = kt & 1;                      // nk is even: the slot parity continues across the tile boundary
+            const char* g = isw ? baseW : baseA;
+            if (kt >= nk) {
+                if (has_next) { kt -= nk; g = isw ? baseWn : baseA; } else kt = nk - 1;
+            }
+            bf16_t* dst = smem8 + (par * 4 + which) * SLOT + wave * 512;
+            g += (size_t)kt * (BK * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (isw ? ow[hf][j] : oa[hf][j])),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+        };
+        f32x4_t acc[2][2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[a][b][c][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (t == 0) {                                    // the group's first tile: explicit prologue, the last two half-tiles stay in flight
+            issue(HA0, 0); issue(HW0, 0); issue(HW1, 0); issue(HA1, 0); issue(HA0, 1); issue(HW1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        bf16x8_t af[2][4][2], wf[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[0][mi][0] = *reinterpret_cast<const bf16x8_t*>(smem8 + HA0 * SLOT + offA[mi][0]);
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // waves 4-7 run one barrier behind
+
+        for (int kt2 = 0; kt2 < nk; kt2 += 2) {
+#pragma unroll
+            for (int cur = 0; cur < 2; ++cur) {
+                const int kt = kt2 + cur;
+                const bf16_t* sl = smem8 + cur * 4 * SLOT;
+                const bf16_t* sn = smem8 + (cur ^ 1) * 4 * SLOT;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int mh = ph >> 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
+                    if (ph != 2) {
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2)
+                                wf[ni][s2] = *reinterpret_cast<const bf16x8_t*>(sl + (HW0 + nh) * SLOT + offW[ni][s2]);
+                    }
+                    if (ph == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) af[cur][mi][1] = *reinterpret_cast<const bf16x8_t*>(sl + HA0 * SLOT + offA[mi][1]);
+                    } else if (ph == 2) {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) af[cur][mi][s2] = *reinterpret_cast<const bf16x8_t*>(sl + HA1 * SLOT + offA[mi][s2]);
+                    } else if (ph == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        // the next k-tile's A0, k-step 0 -- past the tile's last k-tile these registers are re-read at the top of the next tile
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) af[cur ^ 1][mi][0] = *reinterpret_cast<const bf16x8_t*>(sn + HA0 * SLOT + offA[mi][0]);
+                    }
+                    if (ph == 0) issue(HA1, kt + 1);
+                    if (ph == 1) issue(HW0, kt + 1);
+                    if (ph == 2) issue(HA0, kt + 2);
+                    if (ph == 3) { issue(HW1, kt + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < 4; ++mi)
+                                acc[mh][nh][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][s2], af[cur][mi][s2], acc[mh][nh][ni][mi], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // pairs with the late group's last barrier: every wave is past its last ring read
+        __builtin_amdgcn_s_barrier();
+
+        // epilogue of tile t through the wave's 8 KiB staging region (slots 5 / 6 and the extra 32 KiB: nothing in flight writes them)
+        const bool full = m0 + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            AccTile tl;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) tl.v[nh * 2 + ni][mi] = acc[mh][nh][ni][mi];
+            if (mh) lds_wave_sync();
+            if (full) gemm_epilogue_rows<V, true>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+            else gemm_epilogue_rows<V, false>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+        }
+        if (has_next) {
+            // the next tile's four k-tile-0 half-tiles (and its first two of k-tile 1) were issued before this epilogue's stores:
+            // all but the wave's youngest NST operations done = every DMA landed (vmcnt counts in issue order)
+            // every variant stores >= 16 times per wave and tile (8 steps x 2 calls); the byte-derivative variants always 32
+            constexpr int NST = (V == EV_GELU8 || V == EV_QGELU8) ? 32 : 16;
+            if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dummy tail DMAs must land before the workgroup's LDS is handed on
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp8 variant (ab_dtype == STG_FP8_MX): A and W are OCP e4m3 bytes with one E8M0 scale per 32-wide k-block of a row (stg_quant_fp8_mx).
 // Same 128 x 128 block tile, 2 x 2 waves of 64 x 64 and the same LDS geometry as gemm_nt_glds_kernel -- a k-tile is 128 BYTES per row,
 // now 128 k-elements -- but ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 output tile and k-tile instead of two bf16 16x16x32:
@@ -1267,7 +1453,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
     }
 }
 
-std::atomic<uint64_t> lds_8ph_done{0}, lds_big_done{0};
+std::atomic<uint64_t> lds_8ph_done{0}, lds_big_done{0}, lds_8phm_done[6];
 
 }  // namespace
 
@@ -1386,9 +1572,39 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // derivative 814 -> 763, x 256 x 256 156 -> 149: the 128 x 128 kernel's main loop is L2-bandwidth-bound there)
     const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
-        STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
+        // multi-tile form (option gemm_8phm, default on): ntl >= 3 consecutive column tiles per workgroup where the tile is short
+        // (K <= 512: turnover + epilogue are a third of it; at K = 768 -- ViT-B, Swin-L stage 2 -- the whole-model A/B is neutral to -0.8 %) and the group count still fills the chip twice.  Measured per class of the
+        // step, one process, interleaved (tools/gemm_route_ab.py ... gemm_8phm): qkv 125440 x 1536 x 512 247 -> 217 us (ntl = 3), fc1 with
+        // GELU + byte derivative x 2048 x 512 426 -> 396 (ntl = 4), stage-1 qkv 327 -> 312; PAIRS of tiles (N = 512) lose 6 .. 25 %:
+        // half as many, twice as long workgroups end on a longer tail, and the next tile's first counted wait also waits for the
+        // epilogue's own stores (vmcnt is one in-order counter), which a fresh workgroup does not.
+        int ntl = 1;
+        const int m8 = stg_opt_gemm_8phm.load(std::memory_order_relaxed);
+        if (m8 > 0 && gbn >= 3 && (a->K <= 512 || m8 >= 2)) {
+            for (int c = (int)(gbn < 8 ? gbn : 8); c >= (m8 >= 2 ? 2 : 3); --c)
+                if (gbn % c == 0 && (m8 >= 2 ? c <= m8 : true) && gbm * (gbn / c) >= 2 * 256) { ntl = c; break; }
+        }
+        if (ntl > 1) {
+            p.ntl = ntl;
+            const int lds = 8 * 128 * BK * 2 + 8 * 4096;
+            const unsigned grid = (unsigned)(gbm * (gbn / ntl));
+#define STG_8PHM(V, slot) case V: STG_CHECK(stg_reserve_lds(gemm_nt_8phm_kernel<V>, lds, lds_8phm_done[slot]), -101, "stg_gemm_nt: cannot reserve 160 KiB of LDS"); \
+                              hipLaunchKernelGGL(gemm_nt_8phm_kernel<V>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p); launched = true; break;
+            bool launched = false;
+            switch (p.epi_variant) {
+                STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2)
+                default: break;
+            }
+#undef STG_8PHM
+            if (launched) {
+                a->kernel_chosen = STG_GEMM_KERNEL_8PH;
+                STG_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+        STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         a->kernel_chosen = STG_GEMM_KERNEL_8PH;
         hipLaunchKernelGGL(gemm_nt_8ph_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
         STG_LAUNCH_CHECK();

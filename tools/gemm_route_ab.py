@@ -9,6 +9,8 @@ from stgcma import kernels as K, _lib  # noqa: E402
 
 dev = "cuda"
 seq = json.load(open(sys.argv[1]))["step"]
+OPT = (sys.argv[2] if len(sys.argv) > 2 else "gemm_8ph").encode()          # the option to sweep (values 0, 1, 2), e.g. gemm_8phm
+VALS = [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "0,1,2".split(","))]
 cls = collections.Counter((M, N, Kd, epi) for _, M, N, Kd, epi, _ in seq)
 L = _lib.lib()
 
@@ -47,15 +49,15 @@ def make(M, N, Kd, epi):
 
 tot = collections.defaultdict(float)
 best_tot = 0.0
-print(f"{'M':>8s} {'N':>5s} {'K':>5s} {'epi':6s} {'x/step':>6s} | {'8ph=0':>8s} {'8ph=1':>8s} {'8ph=2':>8s}  best")
+print(f"{'M':>8s} {'N':>5s} {'K':>5s} {'epi':6s} {'x/step':>6s} | " + " ".join(f"{OPT.decode()[5:]}={v:<3d}" for v in VALS) + "  best")
 for (M, N, Kd, epi), n in sorted(cls.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
     if M * N * Kd < 1e9 or Kd % 64 != 0:
         continue
     A, W, bias, kw = make(M, N, Kd, epi)
-    times = {0: [], 1: [], 2: []}
+    times = {v: [] for v in VALS}
     for rnd in range(5):
-        for mode in (0, 1, 2):
-            L.stg_set_option(b"gemm_8ph", mode)
+        for mode in VALS:
+            L.stg_set_option(OPT, mode)
             K.gemm_nt(A, W, bias, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -69,7 +71,7 @@ for (M, N, Kd, epi), n in sorted(cls.items(), key=lambda kv: -kv[1] * kv[0][0] *
     for m in med:
         tot[m] += med[m] * n
     best_tot += med[b] * n
-    print(f"{M:8d} {N:5d} {Kd:5d} {epi:6s} {n:6d} | {med[0]:8.1f} {med[1]:8.1f} {med[2]:8.1f}  {b}" + ("  <-- differs from the shipped rule" if abs(med[b] - med[1]) > 0.02 * med[1] else ""), flush=True)
+    print(f"{M:8d} {N:5d} {Kd:5d} {epi:6s} {n:6d} | " + " ".join(f"{med[v]:8.1f}" for v in VALS) + f"  {b}" + ("  <-- differs from the shipped rule" if abs(med[b] - med[1]) > 0.02 * med[1] else ""), flush=True)
     del A, W, bias, kw
-L.stg_set_option(b"gemm_8ph", 1)
-print(f"step totals (ms): 8ph=0 {tot[0]/1e3:.2f}   8ph=1 (shipped) {tot[1]/1e3:.2f}   8ph=2 {tot[2]/1e3:.2f}   per-class best {best_tot/1e3:.2f}")
+L.stg_set_option(OPT, 1)
+print("step totals (ms): " + "   ".join(f"{OPT.decode()}={v} {tot[v]/1e3:.2f}" for v in VALS) + f"   per-class best {best_tot/1e3:.2f}")
