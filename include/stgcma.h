@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 208
+#define STG_VERSION 209
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -34,7 +34,7 @@ int stg_version(void);
 const char* stg_last_error(void);
 /* Dispatch options for A/B measurements (tools/, tests): "gemm_epi" (0: generic epilogue), "gemm_ktail" (0: register-staged
  * kernel for K % 64 != 0, 1: LDS-DMA k-tail kernel for K > 64 only, 2 = default: for every K), "gemm_big" (0 off / 1 auto / 2 whenever legal), "gemm_8ph" (0 off / 1 auto / 2 every legal shape /
- * 3 long-K only), "xattn" (0: frame-global cross-modal attention on the generic kernels), "gemm_dbg" (diagnostics build only).
+ * 3 long-K only), "gemm_8phm" (multi-tile 8-phase kernel: 0 off / 1 auto / n >= 2: at most n column tiles per workgroup, any K), "xattn" (0: frame-global cross-modal attention on the generic kernels), "gemm_dbg" (diagnostics build only).
  * Returns -2 for an unknown name.  The product never calls it. */
 int stg_set_option(const char* name, int value);
 
@@ -96,7 +96,7 @@ typedef struct {
     int kernel_chosen;
 } stg_gemm_args;
 enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
-       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7 };
+       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8 };
 int stg_gemm_nt(stg_gemm_args* args, void* stream);
 
 /* Block-scaled e4m3 quantisation of a bf16 matrix (the producer side of ab_dtype == STG_FP8_MX): for every row r and 32-wide
@@ -201,6 +201,16 @@ int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, c
                     const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt,
                     const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
                     int64_t M, int C, int J, void* stream);
+
+/* The two LayerNorm backwards from the NORMALISED row (round 3).  A frozen LayerNorm in front of a frozen Linear (Swin_AVE.py:703 / :718
+ * norm1 -> attn.qkv, :790 norm2 -> mlp.fc1) never needs its affine: y W^T + b = x_hat (W gamma)^T + (b + W beta), so the caller folds
+ * gamma / beta into the frozen weight once, the forward writes x_hat (bf16) where it wrote y, and the backward reads that bf16 row
+ * instead of the fp32 residual row + mean (per row 2C bytes instead of 4C; gamma == 1 in the formula above, dy is the gradient wrt x_hat). */
+int stg_layernorm_bwd_xhat(const void* dy, int64_t lddy, const void* xhat, int64_t ldx, const float* rstd, const void* add_to,
+                           int64_t ldadd, void* dx, int64_t lddx, int64_t rows, int C, void* stream);
+int stg_ln_bwd_down_xhat(const void* dy, int64_t lddy, const void* xhat, int64_t ldx, const float* rstd, const void* add_to,
+                         int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt, const float* row_scale,
+                         int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh, int64_t M, int C, int J, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic gather-mapped multi-head attention (flash-style, MFMA 32x32x16, scores never hit HBM).

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so
 
 STG_F32, STG_BF16, STG_FP8_MX, STG_U8_LIN = 0, 1, 2, 3
 (GEMM_KERNEL_REG, GEMM_KERNEL_GLDS, GEMM_KERNEL_BIG, GEMM_KERNEL_8PH, GEMM_KERNEL_GLDS_CONV, GEMM_KERNEL_GLDS_BATCH, GEMM_KERNEL_GLDS_KTAIL,
- GEMM_KERNEL_FP8) = range(8)
+ GEMM_KERNEL_FP8, GEMM_KERNEL_8PHM) = range(9)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 
 c_i64 = C.c_int64
@@ -149,6 +149,9 @@ SIGNATURES = {
     "stg_ln_bwd_down_supported": (C.c_int, [C.c_int, C.c_int]),
     "stg_ln_bwd_down": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                   c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_layernorm_bwd_xhat": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, C.c_int, c_vp]),
+    "stg_ln_bwd_down_xhat": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                       c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -204,7 +207,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 208
+ABI_VERSION = 209
 _lib = None
 
 

@@ -1599,7 +1599,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
             }
 #undef STG_8PHM
             if (launched) {
-                a->kernel_chosen = STG_GEMM_KERNEL_8PH;
+                a->kernel_chosen = STG_GEMM_KERNEL_8PHM;
                 STG_LAUNCH_CHECK();
                 return 0;
             }

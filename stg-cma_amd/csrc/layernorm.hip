@@ -21,6 +21,7 @@ struct LnParams {
     const bf16_t* add_to; int64_t ldadd;
     bf16_t* dx; int64_t lddx;
     float* dgamma; float* dbeta;
+    int xhat;          // backward: `x` holds the NORMALISED row (bf16 x_hat, saved by the forward in place of y), gamma == 1: no mean
 };
 
 // source element offset (in elements) of logical (row, col8) chunk start
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnParams p) {
     const bool valid = row < p.rows;
     const int nch = p.C / 8;
     float xh[MAXCH][8], gd[MAXCH][8];
-    const float mu = valid ? p.mean[row] : 0.f;
+    const float mu = (valid && !p.xhat) ? p.mean[row] : 0.f;
     const float rs = valid ? p.rstd[row] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -137,12 +138,18 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnParams p) {
             float xv[8], dv[8];
             load8(p, p.x, p.x_f32, src_off(p, row, ch * 8, p.ldx), xv);
             load8(p, p.dy, 0, row * p.lddy + ch * 8, dv);
-            const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
-            const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
-            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float g[8];
+            if (p.xhat) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = 1.0f;
+            } else {
+                const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
+                const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
+                g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                xh[c][j] = (xv[j] - mu) * rs;
+                xh[c][j] = p.xhat ? xv[j] : (xv[j] - mu) * rs;
                 gd[c][j] = g[j] * dv[j];
                 s1 += gd[c][j];
                 s2 += gd[c][j] * xh[c][j];
@@ -248,5 +255,23 @@ extern "C" int stg_layernorm_bwd(const void* dy, int64_t lddy, const void* x, in
     p.rows = rows; p.C = C; p.gather4 = gather4; p.Csrc = gather4 ? C / 4 : C; p.H = H; p.W = W;
     p.dy = (const bf16_t*)dy; p.lddy = lddy; p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd;
     p.dx = (bf16_t*)dx; p.lddx = lddx; p.dgamma = dgamma; p.dbeta = dbeta;
+    return dispatch_ln(true, p, (hipStream_t)stream);
+}
+
+// The same backward from the NORMALISED row: x_hat [rows, C] bf16 is what the forward saved (it feeds the frozen GEMM whose weight has
+// gamma / beta folded in, so the affine never ran), gamma == 1, no mean -- the fp32 residual row is not re-read (4C -> 2C bytes per row).
+extern "C" int stg_layernorm_bwd_xhat(const void* dy, int64_t lddy, const void* xhat, int64_t ldx, const float* rstd, const void* add_to,
+                                      int64_t ldadd, void* dx, int64_t lddx, int64_t rows, int C, void* stream) {
+    STG_CHECK(dy && xhat && rstd && dx, -1, "stg_layernorm_bwd_xhat: null pointer");
+    int rc = check_common("stg_layernorm_bwd_xhat", rows, C, 0, 0, 0, ldx, STG_BF16);
+    if (rc) return rc;
+    STG_CHECK(lddy % 8 == 0 && lddx % 8 == 0 && (add_to == nullptr || ldadd % 8 == 0), -2, "stg_layernorm_bwd_xhat: bad ld");
+    if (rows == 0) return 0;
+    LnParams p = {};
+    p.x = xhat; p.ldx = ldx; p.x_f32 = 0; p.xhat = 1;
+    p.rstd = (float*)rstd;
+    p.rows = rows; p.C = C; p.gather4 = 0; p.Csrc = C;
+    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd;
+    p.dx = (bf16_t*)dx; p.lddx = lddx;
     return dispatch_ln(true, p, (hipStream_t)stream);
 }

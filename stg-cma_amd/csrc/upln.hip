@@ -243,7 +243,7 @@ int dispatch_ks(const UpLnP& p, hipStream_t st) {
 // down-projection costs the row no second trip through HBM (as a separate GEMM it re-read all of dx to produce J <= 64 columns).
 struct LnDownP {
     const bf16_t* dy; int64_t lddy;
-    const float* x; int64_t ldx;
+    const float* x; int64_t ldx;                 // XH: bf16 x_hat rows (ldx in bf16 elements), gamma == 1, no mean
     const float* gamma; const float* mean; const float* rstd;
     const bf16_t* add_to; int64_t ldadd;
     bf16_t* dx; int64_t lddx;
@@ -253,7 +253,7 @@ struct LnDownP {
     int64_t M; int C; int J;
 };
 
-template <int NT, int NH, int NJ, bool ADD, int NW = 4>
+template <int NT, int NH, int NJ, bool ADD, int NW = 4, bool XH = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(LnDownP p) {
     extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
     constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16, NP = NT / 2, NPT = TT / 2;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
     float* gam = reinterpret_cast<float*>(wfrag + NJ * NPT * 64);
     float2* xch = reinterpret_cast<float2*>(gam + CC);               // [NW waves][16 rows]
     float* hx = reinterpret_cast<float*>(xch + NW * 16);             // [NW / 2 groups][NJ * 4][64 lanes]  (NH == 2)
-    for (int c = tid; c < CC; c += NW * 64) gam[c] = p.gamma[c];
+    if (!XH) for (int c = tid; c < CC; c += NW * 64) gam[c] = p.gamma[c];
     __syncthreads();
 
     constexpr int GPB = NW / NH;
@@ -292,29 +292,46 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
         f32x4_t xh[NT];
         uint4 adq[ADD ? NP : 1];
         const bf16_t* dyp = p.dy + rc * p.lddy + 8 * g + half * CW;
-        const float* xp = p.x + rc * p.ldx + 8 * g + half * CW;
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) dyq[pr] = *reinterpret_cast<const uint4*>(dyp + 32 * pr);
+        if (XH) {                                           // the lane's 8 columns of x_hat are ONE 16-byte bf16 piece (the layout of dy)
+            const bf16_t* xq = reinterpret_cast<const bf16_t*>(p.x) + rc * p.ldx + 8 * g + half * CW;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xh[t] = *reinterpret_cast<const f32x4_t*>(xp + 32 * (t >> 1) + 4 * (t & 1));
+            for (int pr = 0; pr < NP; ++pr) {
+                float xv[8];
+                unpack8(*reinterpret_cast<const uint4*>(xq + 32 * pr), xv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xh[2 * pr][j] = xv[j]; xh[2 * pr + 1][j] = xv[4 + j]; }
+            }
+        } else {
+            const float* xp = p.x + rc * p.ldx + 8 * g + half * CW;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) xh[t] = *reinterpret_cast<const f32x4_t*>(xp + 32 * (t >> 1) + 4 * (t & 1));
+        }
         if (ADD) {
             const bf16_t* ap = p.add_to + rc * p.ldadd + 8 * g + half * CW;
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) adq[pr] = *reinterpret_cast<const uint4*>(ap + 32 * pr);
         }
-        const float mu = p.mean[rc], rs = p.rstd[rc];
+        const float mu = XH ? 0.f : p.mean[rc], rs = p.rstd[rc];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-            const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
-            const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
-            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float ga[8];
+            if (XH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ga[j] = 1.0f;
+            } else {
+                const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
+                const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
+                ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+            }
             float dv[8];
             unpack8(dyq[pr], dv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a0 = (xh[2 * pr][j] - mu) * rs, a1 = (xh[2 * pr + 1][j] - mu) * rs;
+                const float a0 = XH ? xh[2 * pr][j] : (xh[2 * pr][j] - mu) * rs, a1 = XH ? xh[2 * pr + 1][j] : (xh[2 * pr + 1][j] - mu) * rs;
                 xh[2 * pr][j] = a0; xh[2 * pr + 1][j] = a1;
                 const float e0 = ga[j] * dv[j], e1 = ga[4 + j] * dv[4 + j];
                 s1 += e0 + e1;
@@ -337,9 +354,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             if ((pr & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-            const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
-            const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
-            const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float ga[8];
+            if (XH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ga[j] = 1.0f;
+            } else {
+                const float4 g0 = *reinterpret_cast<const float4*>(gam + 32 * pr + go);
+                const float4 g1 = *reinterpret_cast<const float4*>(gam + 32 * pr + go + 4);
+                ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+            }
             float dv[8], o[8];
             unpack8(dyq[pr], dv);
 #pragma unroll
@@ -397,7 +420,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
     }
 }
 
-template <int NT, int NH, int NJ, int NW = 4>
+template <int NT, int NH, int NJ, int NW = 4, bool XH = false>
 int launch_lnbd(const LnDownP& p, hipStream_t st) {
     constexpr int GPB = NW / NH;
     const int64_t ngroups = (p.M + 15) / 16;
@@ -406,20 +429,20 @@ int launch_lnbd(const LnDownP& p, hipStream_t st) {
     const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + NW * 16 * sizeof(float2) + (size_t)(NW / 2) * NJ * 4 * 64 * 4;
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> d1{0}, d0{0};
-        const bool ok = stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, true, NW>, (int)lds, d1) && stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, false, NW>, (int)lds, d0);
+        const bool ok = stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, true, NW, XH>, (int)lds, d1) && stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, false, NW, XH>, (int)lds, d0);
         STG_CHECK(ok, -101, "stg_ln_bwd_down: cannot reserve %d bytes of LDS", (int)lds);
     }
-    if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
-    else hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, false, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
+    if (p.add_to) hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, true, NW, XH>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
+    else hipLaunchKernelGGL((ln_bwd_down_kernel<NT, NH, NJ, false, NW, XH>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
 
-template <int NT, int NH>
+template <int NT, int NH, bool XH = false>
 int dispatch_nj(const LnDownP& p, hipStream_t st) {
-    if (p.J == 16) return launch_lnbd<NT, NH, 1>(p, st);
-    if (p.J == 32) return launch_lnbd<NT, NH, 2>(p, st);
-    return launch_lnbd<NT, NH, 4>(p, st);
+    if (p.J == 16) return launch_lnbd<NT, NH, 1, 4, XH>(p, st);
+    if (p.J == 32) return launch_lnbd<NT, NH, 2, 4, XH>(p, st);
+    return launch_lnbd<NT, NH, 4, 4, XH>(p, st);
 }
 
 }  // namespace
@@ -487,5 +510,32 @@ extern "C" int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int
         case 8: return dispatch_nj<8, 1>(p, st);
         case 16: return dispatch_nj<16, 1>(p, st);
         default: return dispatch_nj<16, 2>(p, st);
+    }
+}
+
+// stg_ln_bwd_down from the NORMALISED row (see stg_layernorm_bwd_xhat): xhat [M, C] bf16 in place of the fp32 residual row, gamma == 1.
+extern "C" int stg_ln_bwd_down_xhat(const void* dy, int64_t lddy, const void* xhat, int64_t ldx, const float* rstd, const void* add_to,
+                                    int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt, const float* row_scale,
+                                    int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh, int64_t M, int C, int J, void* stream) {
+    STG_CHECK(dy && xhat && rstd && dx && wt && dh, -1, "stg_ln_bwd_down_xhat: null pointer");
+    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "stg_ln_bwd_down_xhat: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", C, J);
+    STG_CHECK(M >= 0, -2, "stg_ln_bwd_down_xhat: bad M");
+    STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % 8 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "stg_ln_bwd_down_xhat: bad lddy / ldx / lddx");
+    STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "stg_ln_bwd_down_xhat: bad ldadd");
+    STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "stg_ln_bwd_down_xhat: bad ldwt / lddh");
+    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_ln_bwd_down_xhat: bad row_scale geometry");
+    STG_CHECK(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)add_to | (uintptr_t)dx | (uintptr_t)wt) % 16 == 0 &&
+              (uintptr_t)dh % 8 == 0 && (J == 16 || (uintptr_t)dh % 16 == 0), -2, "stg_ln_bwd_down_xhat: operands must be 16-byte aligned");
+    if (M == 0) return 0;
+    LnDownP p = {};
+    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const float*)xhat; p.ldx = ldx; p.rstd = rstd;
+    p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd; p.dx = (bf16_t*)dx; p.lddx = lddx; p.wt = (const bf16_t*)wt; p.ldwt = ldwt;
+    p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner; p.dh = (bf16_t*)dh; p.lddh = lddh;
+    p.M = M; p.C = C; p.J = J;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C / 16) {
+        case 8: return dispatch_nj<8, 1, true>(p, st);
+        case 16: return dispatch_nj<16, 1, true>(p, st);
+        default: return dispatch_nj<16, 2, true>(p, st);
     }
 }

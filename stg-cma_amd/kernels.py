@@ -303,7 +303,7 @@ USE_WGRAD_MULTI = _os.environ.get("STG_WGRAD_MULTI", "1") != "0"   # 0 = one lau
 
 
 GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GLDS: "gemm_nt_glds_kernel<1, false, false, false>",
-                     _lib.GEMM_KERNEL_BIG: "gemm_nt_big_kernel", _lib.GEMM_KERNEL_8PH: "gemm_nt_8ph_kernel",
+                     _lib.GEMM_KERNEL_BIG: "gemm_nt_big_kernel", _lib.GEMM_KERNEL_8PH: "gemm_nt_8ph_kernel", _lib.GEMM_KERNEL_8PHM: "gemm_nt_8phm_kernel",
                      _lib.GEMM_KERNEL_GLDS_CONV: "gemm_nt_glds_kernel<1, true, false, false>",
                      _lib.GEMM_KERNEL_GLDS_BATCH: "gemm_nt_glds_kernel<1, false, true, false>",
                      _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel"}
@@ -617,6 +617,49 @@ def ln_bwd_down(dy, x, gamma, mean, rstd, wt, *, add_to=None, row_scale=None, rs
                                           _p(row_scale), int(rs_outer), int(rs_inner), _p(dh), _ld(dh), M, Cc, J, _stream()),
                "stg_ln_bwd_down")
     return dx, dh
+
+
+def ln_bwd_down_xhat(dy, xhat, rstd, wt, *, add_to=None, row_scale=None, rs_outer=1, rs_inner=1, dx_out=None):
+    """ln_bwd_down from the NORMALISED row: xhat [M, C] bf16 (what the forward wrote in place of y; gamma / beta live in the frozen
+    GEMM weight behind it), rstd [M].  Returns (dx, dh)."""
+    _chk2d(xhat, "xhat", BF16)
+    M, Cc = xhat.shape
+    _chk2d(dy, "dy", BF16, cols=Cc, rows=M)
+    J = wt.shape[0]
+    _chk2d(wt, "wt", BF16, rows=J)
+    if wt.shape[1] < Cc:
+        raise RuntimeError("ln_bwd_down_xhat: wt has fewer columns than xhat")
+    _chk1d(rstd, "rstd", F32, M)
+    if add_to is not None:
+        _chk2d(add_to, "add_to", BF16, cols=Cc, rows=M)
+    if row_scale is not None:
+        if row_scale.dtype != F32 or not row_scale.is_cuda or not row_scale.is_contiguous():
+            raise RuntimeError("ln_bwd_down_xhat: row_scale must be a contiguous fp32 GPU vector")
+        if M > 0 and ((M - 1) // rs_outer) * rs_inner + rs_inner > row_scale.numel():
+            raise RuntimeError("ln_bwd_down_xhat: row_scale too short for (M, rs_outer, rs_inner)")
+    dx = torch.empty((M, Cc), dtype=BF16, device=xhat.device) if dx_out is None else dx_out
+    _chk2d(dx, "dx", BF16, cols=Cc, rows=M)
+    dh = torch.empty((M, J), dtype=BF16, device=xhat.device)
+    _lib.check(_lib.lib().stg_ln_bwd_down_xhat(_p(dy), _ld(dy), _p(xhat), _ld(xhat), _p(rstd), _p(add_to),
+                                               _ld(add_to) if add_to is not None else 0, _p(dx), _ld(dx), _p(wt), _ld(wt),
+                                               _p(row_scale), int(rs_outer), int(rs_inner), _p(dh), _ld(dh), M, Cc, J, _stream()),
+               "stg_ln_bwd_down_xhat")
+    return dx, dh
+
+
+def layernorm_bwd_xhat(dy, xhat, rstd, add_to=None):
+    """LayerNorm backward wrt the input from the NORMALISED row (gamma == 1): dx bf16 = rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add_to)."""
+    _chk2d(xhat, "xhat", BF16)
+    M, Cc = xhat.shape
+    _chk2d(dy, "dy", BF16, cols=Cc, rows=M)
+    _chk1d(rstd, "rstd", F32, M)
+    if add_to is not None:
+        _chk2d(add_to, "add_to", BF16, cols=Cc, rows=M)
+    dx = torch.empty((M, Cc), dtype=BF16, device=xhat.device)
+    _lib.check(_lib.lib().stg_layernorm_bwd_xhat(_p(dy), _ld(dy), _p(xhat), _ld(xhat), _p(rstd), _p(add_to),
+                                                 _ld(add_to) if add_to is not None else 0, _p(dx), _ld(dx), M, Cc, _stream()),
+               "stg_layernorm_bwd_xhat")
+    return dx
 
 
 def _chk_flat(t, name, dtype=BF16):

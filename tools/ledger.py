@@ -45,7 +45,7 @@ def by_class(tr, fe, wr, seq_path, dst, summary):
         raise SystemExit(f"{len(gd)} gemm dispatches in the step, {len(seq)} in the sequence file")
     cls = collections.OrderedDict()
     for (a, b, c), (kern, M, N, K, epi, nbytes) in zip(gd, seq):
-        if short(a["Kernel_Name"]) != kern:
+        if short(a["Kernel_Name"]).split("<")[0] != kern.split("<")[0] or (("<" in kern) and short(a["Kernel_Name"]) != kern):
             raise SystemExit(f"sequence mismatch: trace {short(a['Kernel_Name'])} vs log {kern}")
         d = cls.setdefault(f"{kern}|{N}|{K}|{epi}", {"n": 0, "ns": 0, "bytes": 0.0, "alg": 0.0, "flops": 0.0, "rows": set()})
         d["n"] += 1
