@@ -94,6 +94,12 @@ typedef struct {
     int dact_dtype;
     /* out: which kernel the dispatch chose (STG_GEMM_KERNEL_*), for profilers that attribute time per kernel */
     int kernel_chosen;
+    /* Two row groups in one launch (split_m > 0; round 3): rows m >= split_m take W2 / bias2 (same ldw, same N, K) instead of W / bias;
+     * everything else -- A, C, the saved derivative, residuals, row_scale -- is addressed by the global row as usual.  This is the
+     * video | audio layout of the fused token tensor: the two modalities' adapters (S_Adapter / S_Adapter_Audio ..., Swin_AVE.py:747-748,
+     * 796-797) are separate Linears over the two halves of the rows, and their narrow GEMMs (N = d_h or K = d_h, 490 workgroups each at
+     * stage 2) fill the chip only together.  split_m % 128 == 0; bf16 operands, no convolution / batch; the 128 x 128 LDS-DMA kernels. */
+    int64_t split_m; const void* W2; const float* bias2;
 } stg_gemm_args;
 enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
        STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8 };

@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("ab_dtype", C.c_int), ("a_scale", c_vp), ("w_scale", c_vp),
         ("dact_dtype", C.c_int),
         ("kernel_chosen", C.c_int),
+        ("split_m", c_i64), ("W2", c_vp), ("bias2", c_vp),
     ]
 
 

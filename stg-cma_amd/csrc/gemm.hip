@@ -50,6 +50,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int nbm, nbn;
     int ntl;           // multi-tile 8-phase kernel: consecutive column tiles per workgroup (divides nbn)
+    int64_t split_m; const bf16_t* W2; const float* bias2;           // two row groups (see stgcma.h): rows >= split_m use W2 / bias2
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
     int conv_H, conv_W, conv_d, conv_C; const bf16_t* conv_zero;     // implicit 3x3 convolution (conv_H > 0), see stgcma.h
@@ -484,6 +485,7 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
     const int bm = bid / p.nbn, bn = bid % p.nbn;
     const int64_t m0 = (int64_t)bm * BM;
     const int n0 = bn * BN;
+    if (!CONV && !BATCH && p.split_m > 0 && m0 >= p.split_m) { p.W = p.W2; p.bias = p.bias2; }   // second row group (block-uniform)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 15, lk = lane >> 4;
@@ -1496,6 +1498,15 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     p.conv_H = a->conv_H; p.conv_W = a->conv_W; p.conv_d = a->conv_d; p.conv_C = a->conv_C; p.conv_zero = (const bf16_t*)a->conv_zero;
     const bool conv = a->conv_H > 0;
     p.batch = a->batch > 1 ? a->batch : 1; p.a_bstride = a->a_bstride; p.w_bstride = a->w_bstride; p.c_bstride = a->c_bstride;
+    p.split_m = a->split_m > 0 ? a->split_m : 0; p.W2 = (const bf16_t*)a->W2; p.bias2 = a->bias2;
+    const bool split = p.split_m > 0;
+    if (split) {
+        STG_CHECK(a->W2 && (a->bias == nullptr) == (a->bias2 == nullptr) && a->split_m % BM == 0 && a->split_m < a->M, -2,
+                  "stg_gemm_nt: split mode needs W2, bias2 like bias, split_m %% 128 == 0 and split_m < M");
+        STG_CHECK(a->conv_H <= 0 && a->batch <= 1 && a->ab_dtype != STG_FP8_MX && ((uintptr_t)a->W2 & 15) == 0 && ((uintptr_t)a->bias2 & 15) == 0, -3,
+                  "stg_gemm_nt: split mode takes bf16 operands, no convolution / batch, 16-byte aligned W2 / bias2");
+        STG_CHECK(a->K % BK == 0 || (a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0), -2, "stg_gemm_nt: split mode with K %% 64 != 0 needs the zero line (conv_zero)");
+    }
     if (p.batch > 1) {
         STG_CHECK(!conv && !a->dact && !a->dact_src && !a->res1 && !a->res2 && !a->row_scale, -3, "stg_gemm_nt: batched mode takes bias / alpha / activation only");
         STG_CHECK(a->K % BK == 0 && a->a_bstride % 8 == 0 && a->w_bstride % 8 == 0 && a->c_bstride % 8 == 0 && p.batch <= 65535, -2,
@@ -1558,11 +1569,11 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     }
     const int ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed);
     const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
-    const bool big_ok = !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
+    const bool big_ok = !split && !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
     const int ph8_mode = stg_opt_gemm_8ph.load(std::memory_order_relaxed);   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
-    const bool ph8_ok = !conv && p.batch == 1 && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
+    const bool ph8_ok = !split && !conv && p.batch == 1 && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
@@ -1625,7 +1636,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     } else if (a->K % BK == 0) {
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS;
         hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (ktail_on && (a->K > BK || ktail_on >= 2) && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail (option gemm_ktail = 2: K < 64 too)
+    } else if ((split || (ktail_on && (a->K > BK || ktail_on >= 2))) && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail (option gemm_ktail = 2: K < 64 too)
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS_KTAIL;
         hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     } else {

@@ -120,7 +120,7 @@ def quant_fp8(x):
 
 
 def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NONE, want_dact=False, dact_src=None,
-            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None, batch=None):
+            row_scale=None, rs_outer=1, rs_inner=1, res1=None, res2=None, conv=None, batch=None, split=None):
     """C = epi(A @ W.T); see stg_gemm_nt in include/stgcma.h.  Returns C or (C, dact) with dact = bf16(act'(pre-activation)),
     the tensor a later call takes as dact_src (or act_bwd as its second argument).  A and W are bf16 tensors, or both Fp8
     (quant_fp8): the block-scaled e4m3 MFMA path."""
@@ -193,6 +193,17 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         _chk2d(res2, "res2", res2.dtype, cols=N, rows=M)
         a.res2, a.ldr2, a.res2_dtype = _p(res2), _ld(res2), _dt(res2)
     a.M, a.N, a.K = M, N, K
+    if split is not None:                                 # two row groups: rows >= split_m take (W2, bias2) -- the video | audio adapters
+        split_m, W2, bias2 = split
+        if fp8 or conv is not None:
+            raise RuntimeError("gemm_nt(split=...): bf16 operands, no implicit convolution")
+        _chk2d(W2, "W2", BF16, cols=K, rows=N)
+        if _ld(W2) != _ld(W) or (bias is None) != (bias2 is None) or split_m % 128 != 0 or not 0 < split_m < M:
+            raise RuntimeError("gemm_nt(split=...): W2 must match W's layout, bias2 come with bias, 0 < split_m < M, split_m % 128 == 0")
+        if bias2 is not None:
+            _chk1d(bias2, "bias2", F32, N)
+        a.split_m, a.W2, a.bias2 = int(split_m), _p(W2), _p(bias2)
+        a.conv_zero = _p(_zero_line(dev))
     if not fp8 and K % 64 != 0:                           # k tail of the LDS-DMA kernel reads zeros from here (csrc/gemm.hip KTAIL)
         a.conv_zero = _p(_zero_line(dev))
     if conv is not None:
@@ -704,23 +715,34 @@ def add(a, b, c=None, out=None):
     return out
 
 
-def add3_mul(a, b, c, z):
+def add3_mul(a, b, c, z, out=None):
     """(a + b + c) * z, bf16, one pass."""
     for t, n in ((a, "a"), (b, "b"), (c, "c"), (z, "z")):
         _chk_flat(t, n)
         if t.shape != a.shape:
             raise RuntimeError("add3_mul: shape mismatch")
-    out = torch.empty_like(a)
+    if out is None:
+        out = torch.empty_like(a)
+    else:
+        _chk_flat(out, "out")
+        if out.shape != a.shape:
+            raise RuntimeError("add3_mul: shape mismatch")
     _lib.check(_lib.lib().stg_add3_mul(_p(a), _p(b), _p(c), _p(z), _p(out), a.numel(), _stream()), "stg_add3_mul")
     return out
 
 
-def act_bwd(dh, z):
+def act_bwd(dh, z, out=None):
     """dz = dh * z, z = the activation derivative saved by gemm_nt(want_dact=True)."""
     _chk_flat(dh, "dh"); _chk_flat(z, "z")
     if dh.shape != z.shape:
         raise RuntimeError("act_bwd: shape mismatch")
-    dz = torch.empty_like(dh)
+    if out is None:
+        dz = torch.empty_like(dh)
+    else:
+        _chk_flat(out, "out")
+        if out.shape != dh.shape:
+            raise RuntimeError("act_bwd: shape mismatch")
+        dz = out
     _lib.check(_lib.lib().stg_act_bwd(_p(dh), _p(z), _p(dz), dh.numel(), _stream()), "stg_act_bwd")
     return dz
 

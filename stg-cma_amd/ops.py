@@ -545,7 +545,7 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
     return hv2, ha2, (rv, ra, lse_v, lse_a)
 
 
-def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None, zs=None):
+def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, dha2, dgate_v, dgate_a, geoms=None, zs=None, outs=None):
     """Returns (dhv, dha) = gradients wrt the pre-fusion hidden states; with zs = (Z_v, Z_a), the saved activation derivatives of
     the adapters' D_fc1, the gradients wrt the D_fc1 pre-activations instead (the join and the activation backward in one pass)."""
     mg = saved[4] if len(saved) == 5 else None
@@ -561,7 +561,8 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v
         K.winattn_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)      # direction v -> a
         if zs is not None:
-            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
+            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
+                K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
         return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
     if mg is None:
         ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
@@ -576,12 +577,14 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
         K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
         if zs is not None:
-            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
+            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
+                K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
         return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
     dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
     dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
     if zs is not None:
-        return K.add3_mul(dhv2, dq_v, dkv_v, zs[0]), K.add3_mul(dha2, dq_a, dkv_a, zs[1])
+        return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
+            K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
     return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
 
 
@@ -651,6 +654,39 @@ def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
     return dX, dH
 
 
+GEMM_SPLIT = _os.environ.get("STG_GEMM_SPLIT", "1") != "0"     # 0 = one adapter GEMM launch per modality (A/B knob)
+
+
+def _pairable(sl, ads):
+    return GEMM_SPLIT and len(ads) == 2 and sl[0].start == 0 and sl[0].stop % 128 == 0 and sl[1].start == sl[0].stop and ads[0].dh == ads[1].dh
+
+
+def _down_pair(src, sl, ads):
+    """[(H, Z)] per modality: H = GELU(src[rows] D_fc1^T + b) and its saved derivative.  The two modalities' adapters are separate
+    Linears over the two halves of the rows: ONE launch with two row groups (stg_gemm_nt split mode) where the halves are 128-aligned."""
+    if _pairable(sl, ads):
+        H, Z = K.gemm_nt(src, ads[0].w1, ads[0].b1, act=ACT_GELU, want_dact=True, split=(sl[0].stop, ads[1].w1, ads[1].b1))
+        return [(H[r], Z[r]) for r in sl]
+    return [K.gemm_nt(src[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
+
+
+def _dz_buffers(like, sl, ads):
+    """One [rows, d_h] buffer for both modalities' D_fc1 pre-activation gradients (so that their dgrad is one split launch), or None."""
+    if not _pairable(sl, ads):
+        return None, None
+    buf = torch.empty((sl[1].stop, ads[0].dh), dtype=BF16, device=like.device)
+    return buf, [buf[r] for r in sl]
+
+
+def _up_dgrad_pair(dZ_all, dZs, ads, sl, out, res):
+    """out[rows] = (res[rows] +) dZ D_fc1 -- the adapters' input gradient joined with the branch gradient it rides on."""
+    if dZ_all is not None:
+        K.gemm_nt(dZ_all, ads[0].w1t, out=out, res1=res, split=(sl[0].stop, ads[1].w1t, None))
+        return
+    for i, A in enumerate(ads):
+        K.gemm_nt(dZs[i], A.w1t, out=out[sl[i]], res1=None if res is None else res[sl[i]])
+
+
 def _ln_fusable(X, ads):
     return USE_UPLN and X.dtype == F32 and all(K.up_ln_supported(X.shape[1], A.dh) for A in ads)
 
@@ -709,10 +745,9 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         hz = []
         ads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
         pre = _LnOut(X, n1g, n1b) if _ln_fusable(X, ads) else None          # norm1 of the spatial pass
+        hz = _down_pair(PO, sl, ads)
         for i, A in enumerate(ads):
-            Ht, Zt = K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True)
-            _join(Ht, A, X1, sl[i], X, None, pre, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
-            hz.append((Ht, Zt))
+            _join(hz[i][0], A, X1, sl[i], X, None, pre, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
         pre = pre.triple() if pre is not None else None
         if save:
             S["t"] = (Yt if xh else X, None if xh else mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
@@ -734,7 +769,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         AO, lse = K.attn_fwd(_window_geom(spec, BT, g, sbias, nm), QKV[:, :C], QKV[:, C:2 * C], QKV[:, 2 * C:], want_lse=save)
     PO = frozen_gemm(AO, wproj, bproj, fp8=_f8(fp8, "proj"))
     ads = [_Adapter(P, "S_Adapter2" + _SFX[m]) for m in spec.mods]
-    HZ = [K.gemm_nt(PO[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
+    HZ = _down_pair(PO, sl, ads)
     xs = None
     if spec.fuse:
         Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, save)
@@ -779,7 +814,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
             S["f"] = (X2, mean, rstd, Zm, Y, Ha_, Za_, rs)
     else:
         del Y
-        HZ = [K.gemm_nt(M[sl[i]], A.w1, A.b1, act=ACT_GELU, want_dact=True) for i, A in enumerate(ads)]
+        HZ = _down_pair(M, sl, ads)
         xs = None
         if spec.fuse:
             Hv2, Ha2, xs = _cross_modal_fwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, save)
@@ -843,17 +878,17 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     else:
         X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
         dH2 = dH_in if dH_in is not None else [K.gemm_nt(dX3[sl[i]], A.w2t) for i, A in enumerate(ads)]
+        dZ_all, dZo = _dz_buffers(dX3, sl, ads)
         if spec.fuse:
             dZs = list(_cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, g, xs, dH2[0], dH2[1], dgv, dga,
-                                        zs=(HZ[0][1], HZ[1][1])))
+                                        zs=(HZ[0][1], HZ[1][1]), outs=dZo))
         else:
-            dZs = [K.act_bwd(dH2[i], HZ[i][1]) for i in range(len(ads))]
+            dZs = [K.act_bwd(dH2[i], HZ[i][1], out=None if dZo is None else dZo[i]) for i in range(len(ads))]
         dM = torch.empty_like(dX3)
         for i, A in enumerate(ads):
-            dZ = dZs[i]
-            _adapter_wgrad(G, A.name, dZ, M[sl[i]], dX3[sl[i]], H2[i])
-            K.gemm_nt(dZ, A.w1t, out=dM[sl[i]], res1=dX3[sl[i]])
-        del HZ, H2, xs, dH2, dZs, M
+            _adapter_wgrad(G, A.name, dZs[i], M[sl[i]], dX3[sl[i]], H2[i])
+        _up_dgrad_pair(dZ_all, dZs, ads, sl, dM, dX3)
+        del HZ, H2, xs, dH2, dZs, M, dZ_all, dZo
         if isinstance(Zm, tuple):
             dY = _mlp_bwd_fused(P, Zm[1], dM, F2)
         else:
@@ -869,17 +904,17 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     X1, mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias = S.pop("s")
     if dH2 is None:
         dH2 = [K.gemm_nt(dX2[sl[i]], A.w2t) for i, A in enumerate(ads)]
+    dZ_all, dZo = _dz_buffers(dX2, sl, ads)
     if spec.fuse:
         dZs = list(_cross_modal_bwd(spec, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, True, g, xs, dH2[0], dH2[1], dgv, dga,
-                                    zs=(HZ[0][1], HZ[1][1])))
+                                    zs=(HZ[0][1], HZ[1][1]), outs=dZo))
     else:
-        dZs = [K.act_bwd(dH2[i], HZ[i][1]) for i in range(len(ads))]
+        dZs = [K.act_bwd(dH2[i], HZ[i][1], out=None if dZo is None else dZo[i]) for i in range(len(ads))]
     dPO = torch.empty_like(dX2)
     for i, A in enumerate(ads):
-        dZ = dZs[i]
-        _adapter_wgrad(G, A.name, dZ, PO[sl[i]], dX2[sl[i]], H2[i])
-        K.gemm_nt(dZ, A.w1t, out=dPO[sl[i]], res1=dX2[sl[i]])
-    del HZ, H2, xs, dH2, dZs, PO
+        _adapter_wgrad(G, A.name, dZs[i], PO[sl[i]], dX2[sl[i]], H2[i])
+    _up_dgrad_pair(dZ_all, dZs, ads, sl, dPO, dX2)
+    del HZ, H2, xs, dH2, dZs, PO, dZ_all, dZo
     dAO = frozen_gemm(dPO, wproj, t=True, fp8=_f8(fp8, "proj", True))
     del dPO
     dQKV = torch.empty_like(QKV)
@@ -907,14 +942,17 @@ def block_backward(S, spec, P, need, prefix, dX3, arena=None, dH_in=None, prev=N
     if spec.t_attn:
         X0, mean, rstd, QKV, AO, lse, PO, hz, tbias, dps = S.pop("t")
         dPO = torch.empty_like(dX1)
+        dZ_all, dZo = _dz_buffers(dX1, sl, tads)
+        dZts = []
         for i, m in enumerate(spec.mods):
             A = tads[i]
             Ht, Zt = hz[i]
             dHt = dHts[i] if dHts is not None else K.gemm_nt(dX1[sl[i]], A.w2t, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
-            dZt = K.act_bwd(dHt, Zt)
+            dZt = K.act_bwd(dHt, Zt, out=None if dZo is None else dZo[i])
             _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=T * N, rs_inner=N)
-            K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
-        del hz, PO
+            dZts.append(dZt)
+        _up_dgrad_pair(dZ_all, dZts, tads, sl, dPO, None)
+        del hz, PO, dZ_all, dZo, dZts
         dAO = frozen_gemm(dPO, wproj, t=True, fp8=_f8(fp8, "proj", True))
         del dPO
         tabs = [G.buf("attn.temporal_position_bias_table" + ("_audio" if m else "")) for m in spec.mods]
