@@ -412,6 +412,14 @@ int stg_act_bwd(const void* dh, const void* dact, void* dz, int64_t numel, void*
 /* out = (a + b + c) * z (bf16): the three gradient paths into an adapter hidden state (own path + the two cross-modal
  * directions, backward of Swin_AVE.py:750-760 / :799-808) joined and taken through the activation derivative in one pass. */
 int stg_add3_mul(const void* a, const void* b, const void* c, const void* z, void* out, int64_t numel, void* stream);
+/* stg_gate_fwd / stg_gate_bwd / stg_add3_mul on TWO equally sized problems in one launch: the two directions of a cross-modal pair
+ * (Swin_AVE.py:750-760, :799-808).  A problem is a few MB there and its launch is latency: 3 x 96 launches per Swin-B step -> 3 x 48. */
+int stg_gate_fwd2(const void* h0, const void* r0, const float* g0, void* out0, const void* h1, const void* r1, const float* g1,
+                  void* out1, int64_t numel, void* stream);
+int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, const void* dout1, const void* r1,
+                  const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream);
+int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
+                  const void* c1, const void* z1, void* out1, int64_t numel, void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

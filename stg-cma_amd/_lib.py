@@ -178,6 +178,9 @@ SIGNATURES = {
     "stg_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_act_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_add3_mul": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_gate_fwd2": (C.c_int, [c_vp] * 8 + [c_i64, c_vp]),
+    "stg_gate_bwd2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
+    "stg_add3_mul2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),

@@ -117,6 +117,83 @@ __global__ void add3_mul_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* 
     }
 }
 
+// ---- the same three kernels on TWO equally sized problems per launch (blockIdx.y): the two directions of a cross-modal pair
+// (Swin_AVE.py:750-760 / :799-808: h_v' = h_v + gate_v r_v and h_a' = h_a + gate_a r_a).  At [62 720, 32] a problem is 4 MB and its
+// launch is latency, not bandwidth: the step carried 3 x 96 of them.
+struct Ew2 {
+    const bf16_t* a[2]; const bf16_t* b[2]; const bf16_t* c[2]; const bf16_t* z[2];
+    const float* g[2]; bf16_t* out[2]; float* dg[2];
+};
+__global__ void gate_fwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+    const int y = blockIdx.y;
+    const bf16_t* h = p.a[y]; const bf16_t* r = p.b[y]; bf16_t* out = p.out[y];
+    const float g = p.g[y][0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(reinterpret_cast<const uint4*>(h)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(r)[i], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += g * b[j];
+        reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        out[i] = f2bf(bf2f(h[i]) + g * bf2f(r[i]));
+    }
+}
+__global__ void gate_bwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+    const int y = blockIdx.y;
+    const bf16_t* dout = p.a[y]; const bf16_t* r = p.b[y]; bf16_t* dr = p.out[y];
+    const float g = p.g[y][0];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(reinterpret_cast<const uint4*>(dout)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(r)[i], b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc += a[j] * b[j]; a[j] *= g; }
+        reinterpret_cast<uint4*>(dr)[i] = pack8(a);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        const float d = bf2f(dout[i]);
+        acc += d * bf2f(r[i]);
+        dr[i] = f2bf(g * d);
+    }
+    acc = wave_sum<64>(acc);
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+        atomicAdd(p.dg[y], t);
+    }
+}
+__global__ void add3_mul2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+    const int y = blockIdx.y;
+    const bf16_t* a = p.a[y]; const bf16_t* b = p.b[y]; const bf16_t* c = p.c[y]; const bf16_t* z = p.z[y]; bf16_t* out = p.out[y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], v[8];
+        unpack8(reinterpret_cast<const uint4*>(a)[i], x);
+        unpack8(reinterpret_cast<const uint4*>(b)[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += v[j];
+        unpack8(reinterpret_cast<const uint4*>(c)[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += v[j];
+        unpack8(reinterpret_cast<const uint4*>(z)[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= v[j];
+        reinterpret_cast<uint4*>(out)[i] = pack8(x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
+        const int64_t i = (n8 << 3) + threadIdx.x;
+        out[i] = f2bf((bf2f(a[i]) + bf2f(b[i]) + bf2f(c[i])) * bf2f(z[i]));
+    }
+}
+
 // ---- dz = dh * act'(z)
 __global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int64_t n8, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -403,6 +480,49 @@ extern "C" int stg_add3_mul(const void* a, const void* b, const void* c, const v
     const int64_t n8 = numel >> 3;
     hipLaunchKernelGGL(add3_mul_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, ST, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c,
                        (const bf16_t*)z, (bf16_t*)out, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+extern "C" int stg_gate_fwd2(const void* h0, const void* r0, const float* g0, void* out0, const void* h1, const void* r1, const float* g1,
+                             void* out1, int64_t numel, void* stream) {
+    STG_CHECK(h0 && r0 && g0 && out0 && h1 && r1 && g1 && out1, -1, "stg_gate_fwd2: null pointer");
+    STG_CHECK(al16(h0) && al16(r0) && al16(out0) && al16(h1) && al16(r1) && al16(out1), -2, "stg_gate_fwd2: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    Ew2 p = {};
+    p.a[0] = (const bf16_t*)h0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)out0;
+    p.a[1] = (const bf16_t*)h1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)out1;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(gate_fwd2_kernel, dim3(grid_for(n8, 256), 2), dim3(256), 0, ST, p, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, const void* dout1, const void* r1,
+                             const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream) {
+    STG_CHECK(dout0 && r0 && g0 && dr0 && dgate0 && dout1 && r1 && g1 && dr1 && dgate1, -1, "stg_gate_bwd2: null pointer");
+    STG_CHECK(al16(dout0) && al16(r0) && al16(dr0) && al16(dout1) && al16(r1) && al16(dr1), -2, "stg_gate_bwd2: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    Ew2 p = {};
+    p.a[0] = (const bf16_t*)dout0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)dr0; p.dg[0] = dgate0;
+    p.a[1] = (const bf16_t*)dout1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)dr1; p.dg[1] = dgate1;
+    const int64_t n8 = numel >> 3;
+    unsigned gb = grid_for(n8, 256);
+    if (gb > 256) gb = 256;      // one memory-side atomic per block and address (see stg_gate_bwd)
+    hipLaunchKernelGGL(gate_bwd2_kernel, dim3(gb, 2), dim3(256), 0, ST, p, n8, numel);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
+                             const void* c1, const void* z1, void* out1, int64_t numel, void* stream) {
+    STG_CHECK(a0 && b0 && c0 && z0 && out0 && a1 && b1 && c1 && z1 && out1, -1, "stg_add3_mul2: null pointer");
+    STG_CHECK(al16(a0) && al16(b0) && al16(c0) && al16(z0) && al16(out0) && al16(a1) && al16(b1) && al16(c1) && al16(z1) && al16(out1), -2,
+              "stg_add3_mul2: pointers must be 16-byte aligned");
+    if (numel <= 0) return 0;
+    Ew2 p = {};
+    p.a[0] = (const bf16_t*)a0; p.b[0] = (const bf16_t*)b0; p.c[0] = (const bf16_t*)c0; p.z[0] = (const bf16_t*)z0; p.out[0] = (bf16_t*)out0;
+    p.a[1] = (const bf16_t*)a1; p.b[1] = (const bf16_t*)b1; p.c[1] = (const bf16_t*)c1; p.z[1] = (const bf16_t*)z1; p.out[1] = (bf16_t*)out1;
+    const int64_t n8 = numel >> 3;
+    hipLaunchKernelGGL(add3_mul2_kernel, dim3(grid_for(n8, 256), 2), dim3(256), 0, ST, p, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -687,6 +687,49 @@ def gate_fwd(h, r, gate):
     return out
 
 
+def gate_fwd2(h0, r0, g0, h1, r1, g1):
+    """gate_fwd on two equally sized problems, one launch: returns (out0, out1)."""
+    for t in (h0, r0, h1, r1):
+        _chk_flat(t, "gate_fwd2 operand")
+    _chk_flat(g0, "gate", F32); _chk_flat(g1, "gate", F32)
+    if not (h0.shape == r0.shape == h1.shape == r1.shape) or g0.numel() != 1 or g1.numel() != 1:
+        raise RuntimeError("gate_fwd2: shape mismatch")
+    o0, o1 = torch.empty_like(h0), torch.empty_like(h1)
+    _lib.check(_lib.lib().stg_gate_fwd2(_p(h0), _p(r0), _p(g0), _p(o0), _p(h1), _p(r1), _p(g1), _p(o1), h0.numel(), _stream()), "stg_gate_fwd2")
+    return o0, o1
+
+
+def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
+    """gate_bwd on two equally sized problems, one launch: returns (dr0, dr1); dgate0 / dgate1 accumulate."""
+    for t in (d0, r0, d1, r1):
+        _chk_flat(t, "gate_bwd2 operand")
+    for t in (g0, g1, dg0, dg1):
+        _chk_flat(t, "gate", F32)
+    if not (d0.shape == r0.shape == d1.shape == r1.shape) or any(t.numel() != 1 for t in (g0, g1, dg0, dg1)):
+        raise RuntimeError("gate_bwd2: shape mismatch")
+    o0, o1 = torch.empty_like(d0), torch.empty_like(d1)
+    _lib.check(_lib.lib().stg_gate_bwd2(_p(d0), _p(r0), _p(g0), _p(o0), _p(dg0), _p(d1), _p(r1), _p(g1), _p(o1), _p(dg1), d0.numel(), _stream()),
+               "stg_gate_bwd2")
+    return o0, o1
+
+
+def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
+    """add3_mul on two equally sized problems, one launch: returns (out0, out1)."""
+    for t in (a0, b0, c0, z0, a1, b1, c1, z1):
+        _chk_flat(t, "add3_mul2 operand")
+        if t.shape != a0.shape:
+            raise RuntimeError("add3_mul2: shape mismatch")
+    if outs is None:
+        outs = (torch.empty_like(a0), torch.empty_like(a1))
+    for t in outs:
+        _chk_flat(t, "out")
+        if t.shape != a0.shape:
+            raise RuntimeError("add3_mul2: shape mismatch")
+    _lib.check(_lib.lib().stg_add3_mul2(_p(a0), _p(b0), _p(c0), _p(z0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1), _p(outs[1]),
+                                        a0.numel(), _stream()), "stg_add3_mul2")
+    return outs[0], outs[1]
+
+
 def gate_bwd(dout, r, gate, dgate):
     _chk_flat(dout, "dout"); _chk_flat(r, "r"); _chk_flat(gate, "gate", F32); _chk_flat(dgate, "dgate", F32)
     if dout.shape != r.shape or gate.numel() != 1 or dgate.numel() != 1:

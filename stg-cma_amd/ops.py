@@ -523,6 +523,31 @@ def _xwin_geom(spec, BT, dev):
     return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
 
 
+PAIR_EW = _os.environ.get("STG_PAIR_EW", "1") != "0"      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
+
+
+def _gate2(hv, rv, gate_v, ha, ra, gate_a):
+    if PAIR_EW and hv.shape == ha.shape:
+        return K.gate_fwd2(hv, rv, gate_v, ha, ra, gate_a)
+    return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a)
+
+
+def _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a):
+    if PAIR_EW and dhv2.shape == dha2.shape:
+        return K.gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
+    return K.gate_bwd(dhv2, rv, gate_v, dgate_v), K.gate_bwd(dha2, ra, gate_a, dgate_a)
+
+
+def _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs):
+    """The three gradient paths into each adapter hidden state joined (and, with zs, multiplied by the saved activation derivative)."""
+    if zs is None:
+        return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
+    if PAIR_EW and dhv2.shape == dha2.shape:
+        return K.add3_mul2(dhv2, dq_v, dkv_v, zs[0], dha2, dq_a, dkv_a, zs[1], outs=outs)
+    return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
+        K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
+
+
 def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=None):
     """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808).
     geoms = (video-queries geometry, audio-queries geometry) when the two token counts differ (ViT)."""
@@ -531,17 +556,16 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         mg = K.MhaGeom(BT, 1, spec.N, hv.shape[1], 1.0)
         rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
         ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
-        return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a), (rv, ra, lse_v, lse_a, mg)
+        return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
         wg = _xwin_geom(spec, BT, hv.device)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
-        return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a), (rv, ra, lse_v, lse_a, wg)
+        return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
     ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
-    hv2 = K.gate_fwd(hv, rv, gate_v)
-    ha2 = K.gate_fwd(ha, ra, gate_a)
+    hv2, ha2 = _gate2(hv, rv, gate_v, ha, ra, gate_a)
     return hv2, ha2, (rv, ra, lse_v, lse_a)
 
 
@@ -555,37 +579,26 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
         if dgate_a is None:
             dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
-        drv = K.gate_bwd(dhv2, rv, gate_v, dgate_v)
-        dra = K.gate_bwd(dha2, ra, gate_a, dgate_a)
+        drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v
         K.winattn_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)      # direction v -> a
-        if zs is not None:
-            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
-                K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
-        return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
+        return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
     if mg is None:
         ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
     if dgate_v is None:
         dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
     if dgate_a is None:
         dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
-    drv = K.gate_bwd(dhv2, rv, gate_v, dgate_v)
-    dra = K.gate_bwd(dha2, ra, gate_a, dgate_a)
+    drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
     if mg is not None:
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
         K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
-        if zs is not None:
-            return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
-                K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
-        return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
+        return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
     dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
     dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
-    if zs is not None:
-        return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
-            K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
-    return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
+    return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
 
 
 def _slices(spec, R):
