@@ -264,6 +264,10 @@ typedef struct {
     float* dbias;
 } stg_attn_bwd_args;
 int stg_attn_bwd(const stg_attn_bwd_args* a, void* stream);
+/* The two directions of one cross-modal pair (Swin_AVE.py:799-808: h_v <- h_a and h_a <- h_v) in one call: where both take the
+ * frame-global kernels with one geometry they share a launch (grid.y = 2), otherwise the call equals two stg_attn_fwd / _bwd. */
+int stg_attn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, void* stream);
+int stg_attn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-window attention: WindowAttention.forward's spatial branch (Swin_AVE.py:256-276) with roll + window_partition /

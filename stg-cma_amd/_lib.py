@@ -155,6 +155,8 @@ SIGNATURES = {
                                        c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
+    "stg_attn_fwd2": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs), c_vp]),
+    "stg_attn_bwd2": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -758,3 +758,36 @@ extern "C" int stg_attn_bwd(const stg_attn_bwd_args* b, void* stream) {
     p.total_items = (int)items;
     return dispatch_d<DkvL>(f->D, p, (hipStream_t)stream);
 }
+
+// Two attention problems of one cross-modal pair (h_v <- h_a and h_a <- h_v, Swin_AVE.py:799-808).  When both take the frame-global
+// kernels of xattn.hip with one geometry they share a launch (grid.y = 2); otherwise this is two calls.
+extern "C" int stg_attn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) {
+    STG_CHECK(f0 != nullptr && f1 != nullptr, -1, "stg_attn_fwd2: null args");
+    if (xattn_on() && f0->P > 0 && stg_xattn_eligible(f0, true) && stg_xattn_eligible(f1, true) && stg_xattn_pairable(f0, f1)) {
+        AttnP p = {};
+        int rc = fill(f0, p, "stg_attn_fwd2");
+        if (rc) return rc;
+        rc = fill(f1, p, "stg_attn_fwd2");
+        if (rc) return rc;
+        STG_CHECK(f0->O && f1->O && f0->ldo % 4 == 0 && f1->ldo % 4 == 0 && ((((uintptr_t)f0->O) | ((uintptr_t)f1->O)) & 7) == 0, -2, "stg_attn_fwd2: bad O");
+        return stg_xattn_fwd2(f0, f1, stream);
+    }
+    const int rc = stg_attn_fwd(f0, stream);
+    return rc ? rc : stg_attn_fwd(f1, stream);
+}
+
+extern "C" int stg_attn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream) {
+    STG_CHECK(b0 != nullptr && b1 != nullptr, -1, "stg_attn_bwd2: null args");
+    const bool x0 = b0->dV == nullptr && b0->dbias == nullptr && stg_xattn_eligible(&b0->f, true);
+    const bool x1 = b1->dV == nullptr && b1->dbias == nullptr && stg_xattn_eligible(&b1->f, true);
+    if (xattn_on() && b0->f.P > 0 && x0 && x1 && stg_xattn_pairable(&b0->f, &b1->f)) {
+        AttnP p = {};
+        int rc = fill(&b0->f, p, "stg_attn_bwd2");
+        if (rc) return rc;
+        rc = fill(&b1->f, p, "stg_attn_bwd2");
+        if (rc) return rc;
+        return stg_xattn_bwd2(b0, b1, stream);
+    }
+    const int rc = stg_attn_bwd(b0, stream);
+    return rc ? rc : stg_attn_bwd(b1, stream);
+}

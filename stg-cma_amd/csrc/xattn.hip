@@ -100,12 +100,15 @@ struct XP {
     int tiles, total;
 };
 
+struct XP2 { XP a[2]; };          // the two directions of a cross-modal pair in one launch (blockIdx.y); a single call fills a[0] only
+
 // per-wave LDS: two [32][D] tiles + 8 bytes of bf16 ones
 template <int D> struct Lds { static constexpr int TILE = 32 * D; static constexpr int PER_WAVE = 2 * TILE + 8; };
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D>
-__global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
+__global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP2 pp) {
+    const XP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int TILE = Lds<D>::TILE;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
@@ -249,7 +252,8 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP a) {
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 template <int D>
-__global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
+__global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP2 pp) {
+    const XP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int TILE = Lds<D>::TILE;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
@@ -364,7 +368,8 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP a) {
 
 // ------------------------------------------------------------------------------------------------ backward: dK + dV (K == V)
 template <int D>
-__global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP a) {
+__global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP2 pp) {
+    const XP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int TILE = Lds<D>::TILE;
     // per wave: Q tile + dO tile (one 32-query tile per trip) + lse2[32] + delta[32]
@@ -495,40 +500,62 @@ bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse) {
            (((uintptr_t)f->Q | (uintptr_t)f->K) & 15) == 0 && ((uintptr_t)f->O & 7) == 0;
 }
 
-int stg_xattn_fwd(const stg_attn_args* f, void* stream) {
-    XP p = make(f);
-    if (p.P == 0) return 0;
-    STG_CHECK(p.lse != nullptr, -1, "stg_attn_fwd (cross-modal path): lse is required");
-    p.tiles = (p.n + 31) / 32;
-    p.total = p.P * p.tiles;
-    const dim3 grid((p.total + 3) / 4), block(256);
-    if (f->D == 16) hipLaunchKernelGGL(xattn_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(xattn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, p);
+static int xattn_fwd_launch(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) {
+    XP2 pp = {};
+    pp.a[0] = make(f0);
+    const int ny = f1 ? 2 : 1;
+    if (f1) pp.a[1] = make(f1);
+    if (pp.a[0].P == 0) return 0;
+    for (int y = 0; y < ny; ++y) {
+        XP& p = pp.a[y];
+        STG_CHECK(p.lse != nullptr, -1, "stg_attn_fwd (cross-modal path): lse is required");
+        p.tiles = (p.n + 31) / 32;
+        p.total = p.P * p.tiles;
+    }
+    const dim3 grid((pp.a[0].total + 3) / 4, ny), block(256);
+    if (f0->D == 16) hipLaunchKernelGGL(xattn_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(xattn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
     return 0;
 }
 
-int stg_xattn_bwd(const stg_attn_bwd_args* b, void* stream) {
-    XP p = make(&b->f);
-    if (p.P == 0) return 0;
-    STG_CHECK(b->dO && b->dQ && b->dK && b->delta && p.lse && p.O, -1, "stg_attn_bwd (cross-modal path): null pointer");
-    STG_CHECK(b->lddo % 8 == 0 && b->lddq % 4 == 0 && b->lddk % 4 == 0 && ((uintptr_t)b->dO & 15) == 0 &&
-              (((uintptr_t)b->dQ | (uintptr_t)b->dK) & 7) == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.O & 15) == 0, -2,
-              "stg_attn_bwd (cross-modal path): misaligned operands");
-    p.dO = (const bf16_t*)b->dO; p.lddo = b->lddo;
-    p.dQ = (bf16_t*)b->dQ; p.lddq = b->lddq;
-    p.dKV = (bf16_t*)b->dK; p.lddk = b->lddk;
-    p.delta = b->delta;
+int stg_xattn_fwd(const stg_attn_args* f, void* stream) { return xattn_fwd_launch(f, nullptr, stream); }
+
+// same geometry (P, n, n_kv, D, scale): the pair shares one grid
+bool stg_xattn_pairable(const stg_attn_args* f0, const stg_attn_args* f1) {
+    return f0->P == f1->P && f0->n == f1->n && f0->n_kv == f1->n_kv && f0->D == f1->D;
+}
+int stg_xattn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) { return xattn_fwd_launch(f0, f1, stream); }
+
+static int xattn_bwd_launch(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream) {
+    XP2 pp = {};
+    const stg_attn_bwd_args* bs[2] = {b0, b1};
+    const int ny = b1 ? 2 : 1;
+    for (int y = 0; y < ny; ++y) {
+        const stg_attn_bwd_args* b = bs[y];
+        XP& p = pp.a[y];
+        p = make(&b->f);
+        if (p.P == 0) return 0;
+        STG_CHECK(b->dO && b->dQ && b->dK && b->delta && p.lse && p.O, -1, "stg_attn_bwd (cross-modal path): null pointer");
+        STG_CHECK(b->lddo % 8 == 0 && b->lddq % 4 == 0 && b->lddk % 4 == 0 && ((uintptr_t)b->dO & 15) == 0 &&
+                  (((uintptr_t)b->dQ | (uintptr_t)b->dK) & 7) == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.O & 15) == 0, -2,
+                  "stg_attn_bwd (cross-modal path): misaligned operands");
+        p.dO = (const bf16_t*)b->dO; p.lddo = b->lddo;
+        p.dQ = (bf16_t*)b->dQ; p.lddq = b->lddq;
+        p.dKV = (bf16_t*)b->dK; p.lddk = b->lddk;
+        p.delta = b->delta;
+    }
     const dim3 block(256);
-    p.tiles = (p.n + 31) / 32;
-    p.total = p.P * p.tiles;
-    if (b->f.D == 16) hipLaunchKernelGGL(xattn_dq_kernel<16>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(xattn_dq_kernel<32>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    for (int y = 0; y < ny; ++y) { pp.a[y].tiles = (pp.a[y].n + 31) / 32; pp.a[y].total = pp.a[y].P * pp.a[y].tiles; }
+    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dq_kernel<16>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(xattn_dq_kernel<32>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
-    p.tiles = (p.n_kv + 31) / 32;
-    p.total = p.P * p.tiles;
-    if (b->f.D == 16) hipLaunchKernelGGL(xattn_dkv_kernel<16>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(xattn_dkv_kernel<32>, dim3((p.total + 3) / 4), block, 0, (hipStream_t)stream, p);
+    for (int y = 0; y < ny; ++y) { pp.a[y].tiles = (pp.a[y].n_kv + 31) / 32; pp.a[y].total = pp.a[y].P * pp.a[y].tiles; }
+    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dkv_kernel<16>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(xattn_dkv_kernel<32>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
     return 0;
 }
+
+int stg_xattn_bwd(const stg_attn_bwd_args* b, void* stream) { return xattn_bwd_launch(b, nullptr, stream); }
+int stg_xattn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream) { return xattn_bwd_launch(b0, b1, stream); }

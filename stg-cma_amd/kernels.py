@@ -1008,6 +1008,48 @@ def attn_fwd(g, Q, K, V, out=None, want_lse=True):
     return out, lse
 
 
+def attn_fwd2(g0, Q0, K0, V0, g1, Q1, K1, V1):
+    """Two attn_fwd problems (the two directions of a cross-modal pair) in one call; the frame-global kernels share a launch.
+    Returns ((O0, lse0), (O1, lse1))."""
+    outs, args = [], []
+    for g, Q, K_, V in ((g0, Q0, K0, V0), (g1, Q1, K1, V1)):
+        dev = Q.device
+        _attn_check_rows(Q, "Q", g, g.n, g.outer, g.map_q, dev)
+        _attn_check_rows(K_, "K", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+        _attn_check_rows(V, "V", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=dev)
+        lse = torch.empty((g.P, g.H, g.n), dtype=F32, device=dev)
+        a = _lib.AttnArgs()
+        _attn_fill(a, g, Q, K_, V, out, lse)
+        outs.append((out, lse)); args.append(a)
+    _lib.check(_lib.lib().stg_attn_fwd2(C.byref(args[0]), C.byref(args[1]), _stream()), "stg_attn_fwd2")
+    return outs[0], outs[1]
+
+
+def attn_bwd2(p0, p1):
+    """Two shared-K/V attn_bwd problems in one call: p = (g, Q, KV, O, lse, dO).  Returns ((dQ0, dKV0), (dQ1, dKV1))."""
+    res, args, keep = [], [], []
+    for g, Q, KV, O, lse, dO in (p0, p1):
+        dev = Q.device
+        for t, name, nt, outer, mp in ((Q, "Q", g.n, g.outer, g.map_q), (KV, "K", g.n_kv, g.outer_kv, g.map_kv),
+                                       (O, "O", g.n, g.outer, g.map_q), (dO, "dO", g.n, g.outer, g.map_q)):
+            _attn_check_rows(t, name, g, nt, outer, mp, dev)
+        if lse.dtype != F32 or lse.numel() != g.P * g.H * g.n:
+            raise RuntimeError("attn_bwd2: bad lse")
+        dQ = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=dev)
+        dK = torch.empty((KV.shape[0], g.H * g.D), dtype=BF16, device=dev)
+        delta = torch.empty((g.P, g.H, g.n), dtype=F32, device=dev)
+        b = _lib.AttnBwdArgs()
+        _attn_fill(b.f, g, Q, KV, KV, O, lse)
+        b.dO, b.lddo = _p(dO), _ld(dO)
+        b.dQ, b.lddq = _p(dQ), _ld(dQ)
+        b.dK, b.lddk = _p(dK), _ld(dK)
+        b.delta = _p(delta)
+        res.append((dQ, dK)); args.append(b); keep.append(delta)
+    _lib.check(_lib.lib().stg_attn_bwd2(C.byref(args[0]), C.byref(args[1]), _stream()), "stg_attn_bwd2")
+    return res[0], res[1]
+
+
 def attn_bwd(g, Q, K, V, O, lse, dO, *, dQ=None, dK=None, dV=None, shared_kv=False, dbias=None):
     """Returns (dQ, dK, dV).  shared_kv: K and V are the same tensor -> dV is None and dK holds dK + dV."""
     dev = Q.device

@@ -563,8 +563,11 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
-    rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
-    ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
+    if PAIR_EW:
+        (rv, lse_v), (ra, lse_a) = K.attn_fwd2(ag_v, hv, ha, ha, ag_a, ha, hv, hv)
+    else:
+        rv, lse_v = K.attn_fwd(ag_v, hv, ha, ha, want_lse=save)
+        ra, lse_a = K.attn_fwd(ag_a, ha, hv, hv, want_lse=save)
     hv2, ha2 = _gate2(hv, rv, gate_v, ha, ra, gate_a)
     return hv2, ha2, (rv, ra, lse_v, lse_a)
 
@@ -596,8 +599,11 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
         K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
         return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
-    dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
-    dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
+    if PAIR_EW:
+        (dq_v, dkv_a), (dq_a, dkv_v) = K.attn_bwd2((ag_v, hv, ha, rv, lse_v, drv), (ag_a, ha, hv, ra, lse_a, dra))
+    else:
+        dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
+        dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a
     return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
 
 
