@@ -18,7 +18,7 @@ extern "C" int stg_version(void) { return STG_VERSION; }
 extern "C" const char* stg_last_error(void) { return g_err; }
 
 // ---- dispatch options (declared in common.h)
-std::atomic<int> stg_opt_gemm_epi{1}, stg_opt_gemm_ktail{2}, stg_opt_gemm_big{1}, stg_opt_gemm_8ph{1}, stg_opt_gemm_8phm{1}, stg_opt_gemm_8phm_walk{0}, stg_opt_gemm_dbg{0}, stg_opt_xattn{1}, stg_opt_winattn_bwd_occ{1}, stg_opt_tattn{1};
+std::atomic<int> stg_opt_gemm_epi{1}, stg_opt_gemm_ktail{2}, stg_opt_gemm_big{1}, stg_opt_gemm_8ph{1}, stg_opt_gemm_8phm{1}, stg_opt_gemm_dbg{0}, stg_opt_xattn{1}, stg_opt_winattn_bwd_occ{1}, stg_opt_tattn{1};
 
 extern "C" int stg_set_option(const char* name, int value) {
     if (name == nullptr) { stg_set_error("stg_set_option: null name"); return -1; }
@@ -27,7 +27,6 @@ extern "C" int stg_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_big")) stg_opt_gemm_big = value;
     else if (!strcmp(name, "gemm_8ph")) stg_opt_gemm_8ph = value;
     else if (!strcmp(name, "gemm_8phm")) stg_opt_gemm_8phm = value;
-    else if (!strcmp(name, "gemm_8phm_walk")) stg_opt_gemm_8phm_walk = value;
     else if (!strcmp(name, "gemm_dbg")) stg_opt_gemm_dbg = value;     // read by the diagnostics build only
     else if (!strcmp(name, "xattn")) stg_opt_xattn = value;
     else if (!strcmp(name, "winattn_bwd_occ")) stg_opt_winattn_bwd_occ = value;

@@ -49,8 +49,7 @@ struct GemmParams {
     const void* res2; int64_t ldr2; int res2_f32;
     int64_t M; int N; int K;
     int nbm, nbn;
-    int ntl;           // multi-tile 8-phase kernel: tiles per workgroup (column walk: consecutive column tiles, divides nbn; row walk: row panels)
-    int walk;          // multi-tile 8-phase kernel: 0 = column walk, 1 = row walk (needs M % 256 == 0)
+    int ntl;           // multi-tile 8-phase kernel: consecutive column tiles per workgroup (divides nbn)
     int64_t split_m; const bf16_t* W2; const float* bias2;           // two row groups (see stgcma.h): rows >= split_m use W2 / bias2
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
@@ -909,29 +908,15 @@ template <int V>
 __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 16 KiB + 32 KiB of epilogue staging
     const int ntl = p.ntl;
-    int bm, bn0, nt;                                     // the group's first tile and its tile count
-    if (p.walk) {
-        // ROW walk (M % 256 == 0): the group keeps its column tile (its W tile stays hot in L2) and walks `ntl` row panels; the nbn groups
-        // of one walk sit on ONE XCD under consecutive dispatch slots, so they run abreast and the XCD's L2 fetches each A panel once
-        // for all of them.  (The column walk re-reads the group's 256 x K A panel per tile while 16 .. 32 other panels stream through the
-        // same 4 MiB L2: PMC 1.75 x the algorithmic bytes on the fc1 / qkv classes, profiles/r03_final_pmc_by_class.json.)
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        bn0 = idx % p.nbn;
-        bm = ((idx / p.nbn) * 8 + xcd) * ntl;
-        nt = p.nbm - bm < ntl ? p.nbm - bm : ntl;
-        if (nt <= 0) return;
-    } else {
-        const int gpr = p.nbn / ntl;                     // tile groups per row panel
-        const int ngrp = p.nbm * gpr;
-        int gid = blockIdx.x;
+    const int gpr = p.nbn / ntl;                         // tile groups per row panel
+    const int ngrp = p.nbm * gpr;
+    int gid = blockIdx.x;
+    {
         const int q = ngrp >> 3, r = ngrp & 7;
         const int xcd = gid & 7, idx = gid >> 3;
         gid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        bm = gid / gpr; bn0 = (gid % gpr) * ntl;
-        nt = ntl;
     }
-    const int64_t dm = p.walk ? GBM : 0;                 // tile t of the group: rows m0 + t dm, columns (bn0 GBN) + t dn
-    const int dn = p.walk ? 0 : GBN;
+    const int bm = gid / gpr, bn0 = (gid % gpr) * ntl;
     const int64_t m0 = (int64_t)bm * GBM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -947,11 +932,12 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
         for (int j = 0; j < 2; ++j) {
             const int q = j * 512 + tid;
             const int row = hf * 128 + (q >> 3), c = (q & 7) ^ ((q >> 3) & 7);
-            const int64_t rm = p.walk ? GBM : p.M - 1 - m0;       // the row walk has no partial panel
+            const int64_t rm = p.M - 1 - m0;
             const int ra = row < rm ? row : (int)rm;
             oa[hf][j] = (uint32_t)(((int64_t)ra * p.lda + c * 8) * 2);
             ow[hf][j] = (uint32_t)(((int64_t)row * p.ldw + c * 8) * 2);
         }
+    const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda);
     const int nk = p.K / BK;
 
     int offA[4][2], offW[2][2];
@@ -966,24 +952,20 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
     float* stg = reinterpret_cast<float*>(smem8 + (wave < 4 ? 5 * SLOT : 8 * SLOT)) + (wave & 3) * 2048;
 
 #pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-        const int64_t mt = m0 + t * dm;
-        const int n0 = bn0 * GBN + t * dn;
-        const bool has_next = t + 1 < nt;
-        const char* baseA = reinterpret_cast<const char*>(p.A + mt * p.lda);
+    for (int t = 0; t < ntl; ++t) {
+        const int n0 = (bn0 + t) * GBN;
         const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
-        const char* baseAn = reinterpret_cast<const char*>(p.A + (mt + (has_next ? dm : 0)) * p.lda);
-        const char* baseWn = reinterpret_cast<const char*>(p.W + (int64_t)(n0 + (has_next ? dn : 0)) * p.ldw);
-        // which: HA0 / HA1 / HW0 / HW1 of k-tile kt; past the end of K: the next tile's k-tile kt - nk (column walk: same A panel, next
-        // W tile; row walk: next A panel, same W tile), or -- behind the group's last tile -- a dummy re-load of the last k-tile (keeps
-        // the counted waits exact)
+        const bool has_next = t + 1 < ntl;
+        const char* baseWn = reinterpret_cast<const char*>(p.W + (int64_t)(n0 + (has_next ? GBN : 0)) * p.ldw);
+        // which: HA0 / HA1 / HW0 / HW1 of k-tile kt; past the end of K: the next tile's k-tile kt - nk (same A panel, next W tile), or --
+        // behind the group's last tile -- a dummy re-load of the last k-tile (keeps the counted waits exact)
         auto issue = [&](int which, int kt) {
             const bool isw = which >= HW0;
             const int hf = which & 1;
             const int par = kt & 1;                      // nk is even: the slot parity continues across the tile boundary
             const char* g = isw ? baseW : baseA;
             if (kt >= nk) {
-                if (has_next) { kt -= nk; g = isw ? baseWn : baseAn; } else kt = nk - 1;
+                if (has_next) { kt -= nk; g = isw ? baseWn : baseA; } else kt = nk - 1;
             }
             bf16_t* dst = smem8 + (par * 4 + which) * SLOT + wave * 512;
             g += (size_t)kt * (BK * 2);
@@ -1065,7 +1047,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
 
         // epilogue of tile t through the wave's 8 KiB staging region (slots 5 / 6 and the extra 32 KiB: nothing in flight writes them)
-        const bool full = mt + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
+        const bool full = m0 + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             AccTile tl;
@@ -1076,8 +1058,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) tl.v[nh * 2 + ni][mi] = acc[mh][nh][ni][mi];
             if (mh) lds_wave_sync();
-            if (full) gemm_epilogue_rows<V, true>(p, tl, mt + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
-            else gemm_epilogue_rows<V, false>(p, tl, mt + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+            if (full) gemm_epilogue_rows<V, true>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+            else gemm_epilogue_rows<V, false>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
         }
         if (has_next) {
             // the next tile's four k-tile-0 half-tiles (and its first two of k-tile 1) were issued before this epilogue's stores:
@@ -1502,7 +1484,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     if (a->res1) STG_CHECK(a->res1_dtype == STG_BF16 || a->res1_dtype == STG_F32, -3, "stg_gemm_nt: bad res1 dtype");
     if (a->res2) STG_CHECK(a->res2_dtype == STG_BF16 || a->res2_dtype == STG_F32, -3, "stg_gemm_nt: bad res2 dtype");
     if (a->M == 0) return 0;
-    GemmParams p{};
+    GemmParams p;
     p.A = (const bf16_t*)a->A; p.lda = a->lda;
     p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == STG_F32);
@@ -1599,7 +1581,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // epilogue stays on the 128 x 128 kernel: 403 vs 473 us)
     // (r2, stage-1 shapes, microbenchmark: 501 760 x 768 x 256 + bias 437 -> 388 us, x 256 x 768 343 -> 297, x 1024 x 256 with GELU +
     // derivative 814 -> 763, x 256 x 256 156 -> 149: the 128 x 128 kernel's main loop is L2-bandwidth-bound there)
-    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8 || (p.epi_variant == EV_DSRC8 && stg_opt_gemm_8phm.load(std::memory_order_relaxed) >= 2));
+    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
@@ -1615,24 +1597,15 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
             for (int c = (int)(gbn < 8 ? gbn : 8); c >= (m8 >= 2 ? 2 : 3); --c)
                 if (gbn % c == 0 && (m8 >= 2 ? c <= m8 : true) && gbm * (gbn / c) >= 2 * 256) { ntl = c; break; }
         }
-        // row walk (option gemm_8phm_walk = tiles per walk, 0 = column walk): see the kernel; legal where no row panel is partial
-        const int wk = stg_opt_gemm_8phm_walk.load(std::memory_order_relaxed);
-        unsigned grid = (unsigned)(gbm * (gbn / (ntl > 1 ? ntl : 1)));
-        p.walk = 0;
-        if (m8 > 0 && wk > 0 && a->M % GBM == 0 && ((gbn >= 3 && a->K <= 512) || m8 >= 2) && gbm >= 2 * wk) {
-            ntl = wk;
-            p.walk = 1;
-            const int64_t walks = (gbm + wk - 1) / wk;
-            grid = (unsigned)(8 * gbn * ((walks + 7) / 8));
-        }
         if (ntl > 1) {
             p.ntl = ntl;
             const int lds = 8 * 128 * BK * 2 + 8 * 4096;
+            const unsigned grid = (unsigned)(gbm * (gbn / ntl));
 #define STG_8PHM(V, slot) case V: STG_CHECK(stg_reserve_lds(gemm_nt_8phm_kernel<V>, lds, lds_8phm_done[slot]), -101, "stg_gemm_nt: cannot reserve 160 KiB of LDS"); \
                               hipLaunchKernelGGL(gemm_nt_8phm_kernel<V>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p); launched = true; break;
             bool launched = false;
             switch (p.epi_variant) {
-                STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2) STG_8PHM(EV_DSRC8, 3)
+                STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2)
                 default: break;
             }
 #undef STG_8PHM
