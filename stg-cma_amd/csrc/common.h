@@ -60,58 +60,64 @@ __device__ __forceinline__ void gelu_fast(float x, float& y, float& dy) {
     dy = fmaf(x * e, 0.3989422804014327f, phi);
     y = x * phi;
 }
-// GELU for bf16 destinations at half the VALU cost: Phi(x) ~ sigmoid(a1 x + a3 x^3 + a5 x^5) (a minimax fit of the logistic form of
-// Page 1977 with one more term: |Phi error| <= 1.9e-5, |x Phi error| <= 5.5e-5 over all x, 1/35 of a bf16 half-ulp at 1; derivative of
-// the fit within 1.4e-4 of GELU').  7 VALU + exp2 + rcp per value (the erfc form above: ~20 + exp2 + rcp), 6 more for the derivative:
-// the fc1 epilogues and the fused MLP kernel are VALU-bound on this function (10^9 values per stage-0 block).  The odd polynomial
-// turns over at |x| = 11.6, so its argument is clamped to [-8, 8] (sigmoid is 1 - 1e-13 / 1e-13 there).
-__device__ __forceinline__ float gelu_sig_core(float x, float& x2, float& xc) {
-    xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-    x2 = xc * xc;
-    float pl = fmaf(x2, 0.000911226f, -0.106178f);          // -log2(e) * (a5 x^2 + a3)
-    pl = fmaf(pl, x2, -2.30172f);                            // ... + a1
-    const float e = __builtin_amdgcn_exp2f(pl * xc);         // exp(-u)
-    return __builtin_amdgcn_rcpf(1.0f + e);                  // sigmoid(u) ~ Phi(x)
-}
-__device__ __forceinline__ float gelu_sig(float x) {
-    float x2, xc;
-    return x * gelu_sig_core(x, x2, xc);
-}
-__device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
-    float x2, xc;
-    const float sg = gelu_sig_core(x, x2, xc);
-    float up = fmaf(x2, -0.0031580704f, 0.2207895358f);      // u'(x) = a1 + 3 a3 x^2 + 5 a5 x^4
-    up = fmaf(up, x2, 1.5954356678f);
-    dy = fmaf(sg * (1.0f - sg), x * up, sg);
-    y = x * sg;
-}
-// The same two functions on PAIRS of values: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 carry two fp32 lanes per issue slot, so the
-// polynomial part costs half (the clamp, exp2 and rcp stay per value): 2 x (13 VALU + 2 transcendentals) -> 14 + 4 for value and
-// derivative.  Same operations in the same order as the scalar forms: bit-identical results.
+// GELU for bf16 destinations WITHOUT transcendentals (round 3; the logistic form it replaces, Phi ~ sigmoid(a1 x + a3 x^3 + a5 x^5),
+// cost 7 VALU + v_exp + v_rcp per value, and the two quarter-rate instructions were 8 of its 15 issue slots):
+//     Phi(x)   ~ 0.5 + xc P(xc^2),   gelu'(x) = Phi(x) + x phi(x) ~ 0.5 + xc Q(xc^2),   xc = clamp(x, -4.5, 4.5)
+// P (9 terms) and Q (8 terms) are weighted minimax fits (Lawson iteration, tools/gelu_fit.py) of the odd parts on [0, 4.5]:
+// |x Phi(x) error| <= 5.2e-5 over all x -- the level of the form it replaces, 1/35 of a bf16 half-ulp at 1 -- and |gelu' error|
+// <= 8.8e-4 (a fifth of the 8-bit derivative code's step; bf16 resolves 3.9e-3 at 1).  Beyond the clamp Phi is 1 - 3.4e-6 / 3.4e-6.
+// All multiply-adds: on PAIRS of values v_pk_mul_f32 / v_pk_fma_f32 carry two fp32 lanes per issue slot, so value + derivative cost
+// 1 (clamp) + 9.5 packed = 10.5 slots per value against 15, the value alone 6.5 against 12.  The fc1 epilogues and the fused MLP
+// kernels are VALU-bound on this function (10^9 values per stage-0 block).  The scalar and the packed forms run the same operations
+// in the same order: bit-identical.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2_t pk_splat(float v) { return (f32x2_t){v, v}; }
-__device__ __forceinline__ f32x2_t gelu_sig_core2(f32x2_t x, f32x2_t& x2, f32x2_t& xc) {
-    xc = (f32x2_t){__builtin_amdgcn_fmed3f(x.x, -8.0f, 8.0f), __builtin_amdgcn_fmed3f(x.y, -8.0f, 8.0f)};
-    x2 = xc * xc;
-    f32x2_t pl = pk_fma(x2, pk_splat(0.000911226f), pk_splat(-0.106178f));
-    pl = pk_fma(pl, x2, pk_splat(-2.30172f));
-    const f32x2_t u = pl * xc;
-    const f32x2_t e = {__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
-    const f32x2_t d = pk_splat(1.0f) + e;
-    return (f32x2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+__device__ __forceinline__ float gp_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f32x2_t gp_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float gp_k(float, float v) { return v; }
+__device__ __forceinline__ f32x2_t gp_k(f32x2_t, float v) { return (f32x2_t){v, v}; }
+__device__ __forceinline__ float gp_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f); }
+__device__ __forceinline__ f32x2_t gp_clamp(f32x2_t x) { return (f32x2_t){__builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f)}; }
+template <typename T>
+__device__ __forceinline__ T gelu_pw_phi(T xc, T s) {         // Phi(x) from the clamped argument and its square
+    T p = gp_fma(s, gp_k(s, 2.759560758e-11f), gp_k(s, -3.063619494e-09f));
+    p = gp_fma(p, s, gp_k(s, 1.496385803e-07f));
+    p = gp_fma(p, s, gp_k(s, -4.260212331e-06f));
+    p = gp_fma(p, s, gp_k(s, 7.918093045e-05f));
+    p = gp_fma(p, s, gp_k(s, -1.022331839e-03f));
+    p = gp_fma(p, s, gp_k(s, 9.528348002e-03f));
+    p = gp_fma(p, s, gp_k(s, -6.588462659e-02f));
+    p = gp_fma(p, s, gp_k(s, 3.986567907e-01f));
+    return gp_fma(xc, p, gp_k(s, 0.5f));
 }
-__device__ __forceinline__ f32x2_t gelu_sig2(f32x2_t x) {
-    f32x2_t x2, xc;
-    return x * gelu_sig_core2(x, x2, xc);
+template <typename T>
+__device__ __forceinline__ T gelu_pw_dphi(T xc, T s) {        // gelu'(x)
+    T q = gp_fma(s, gp_k(s, -7.272945256e-09f), gp_k(s, 6.534896567e-07f));
+    q = gp_fma(q, s, gp_k(s, -2.478124810e-05f));
+    q = gp_fma(q, s, gp_k(s, 5.185177887e-04f));
+    q = gp_fma(q, s, gp_k(s, -6.576145592e-03f));
+    q = gp_fma(q, s, gp_k(s, 5.220721148e-02f));
+    q = gp_fma(q, s, gp_k(s, -2.566600037e-01f));
+    q = gp_fma(q, s, gp_k(s, 7.945217645e-01f));
+    return gp_fma(xc, q, gp_k(s, 0.5f));
 }
-__device__ __forceinline__ void gelu_sig_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
-    f32x2_t x2, xc;
-    const f32x2_t sg = gelu_sig_core2(x, x2, xc);
-    f32x2_t up = pk_fma(x2, pk_splat(-0.0031580704f), pk_splat(0.2207895358f));
-    up = pk_fma(up, x2, pk_splat(1.5954356678f));
-    dy = pk_fma(sg * (pk_splat(1.0f) - sg), x * up, sg);
-    y = x * sg;
+template <typename T>
+__device__ __forceinline__ T gelu_pw(T x) {
+    const T xc = gp_clamp(x);
+    return x * gelu_pw_phi(xc, xc * xc);
+}
+template <typename T>
+__device__ __forceinline__ T gelu_pw_grad(T x) {
+    const T xc = gp_clamp(x);
+    return gelu_pw_dphi(xc, xc * xc);
+}
+template <typename T>
+__device__ __forceinline__ void gelu_pw_both(T x, T& y, T& dy) {
+    const T xc = gp_clamp(x);
+    const T s = xc * xc;
+    dy = gelu_pw_dphi(xc, s);
+    y = x * gelu_pw_phi(xc, s);
 }
 __device__ __forceinline__ void quick_gelu_fast(float x, float& y, float& dy) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.4554669595930157f));   // sigmoid(1.702 x)

@@ -266,11 +266,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmParams& p, const Ac
             }
             if (act == STG_ACT_GELU) {
                 float d[8];
-                if (!G && !c_f32) {                    // bf16 destinations: the cheaper logistic form (common.h)
+                if (!G && !c_f32) {                    // bf16 destinations: the polynomial form (common.h)
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {   // packed fp32 pairs (common.h): bit-identical to gelu_sig_both
+                    for (int j = 0; j < 8; j += 2) {   // packed fp32 pairs
                         f32x2_t y2, d2;
-                        gelu_sig_both2((f32x2_t){t[j], t[j + 1]}, y2, d2);
+                        gelu_pw_both((f32x2_t){t[j], t[j + 1]}, y2, d2);
                         t[j] = y2.x; t[j + 1] = y2.y; d[j] = d2.x; d[j + 1] = d2.y;
                     }
                 } else {
@@ -954,6 +954,10 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
 #pragma unroll 1
     for (int t = 0; t < ntl; ++t) {
         const int n0 = (bn0 + t) * GBN;
+        // the row base is laundered per tile: with a loop-invariant m0 hipcc hoists the epilogue's row addresses out of the tile loop
+        // and keeps them in VGPRs across the main loop (32 .. 70 spilled registers; 5 .. 7 this way)
+        int64_t mt = m0;
+        asm volatile("" : "+s"(mt));
         const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
         const bool has_next = t + 1 < ntl;
         const char* baseWn = reinterpret_cast<const char*>(p.W + (int64_t)(n0 + (has_next ? GBN : 0)) * p.ldw);
@@ -1047,7 +1051,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
 
         // epilogue of tile t through the wave's 8 KiB staging region (slots 5 / 6 and the extra 32 KiB: nothing in flight writes them)
-        const bool full = m0 + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
+        const bool full = mt + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             AccTile tl;
@@ -1058,8 +1062,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) tl.v[nh * 2 + ni][mi] = acc[mh][nh][ni][mi];
             if (mh) lds_wave_sync();
-            if (full) gemm_epilogue_rows<V, true>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
-            else gemm_epilogue_rows<V, false>(p, tl, m0 + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+            if (full) gemm_epilogue_rows<V, true>(p, tl, mt + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
+            else gemm_epilogue_rows<V, false>(p, tl, mt + mh * 128 + wr * 64, n0 + wc * 32, 0, 0, lane, stg, 96);
         }
         if (has_next) {
             // the next tile's four k-tile-0 half-tiles (and its first two of k-tile 1) were issued before this epilogue's stores:

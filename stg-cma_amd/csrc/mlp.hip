@@ -150,10 +150,10 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_kernel(MlpP p) {
                 for (int mt = 0; mt < 2; ++mt) {
                     float x[8];
 #pragma unroll
-                    for (int r = 0; r < 4; r += 2) {     // packed fp32 pairs (common.h): bit-identical to gelu_sig
+                    for (int r = 0; r < 4; r += 2) {     // packed fp32 pairs (common.h)
                         const f32x2_t a2 = {S[2 * q][mt][r] + bv[r], S[2 * q][mt][r + 1] + bv[r + 1]};
                         const f32x2_t b2 = {S[2 * q + 1][mt][r] + bv[4 + r], S[2 * q + 1][mt][r + 1] + bv[4 + r + 1]};
-                        const f32x2_t ya = DIAG == 1 ? a2 : gelu_sig2(a2), yb = DIAG == 1 ? b2 : gelu_sig2(b2);
+                        const f32x2_t ya = DIAG == 1 ? a2 : gelu_pw(a2), yb = DIAG == 1 ? b2 : gelu_pw(b2);
                         x[r] = ya.x; x[r + 1] = ya.y; x[4 + r] = yb.x; x[4 + r + 1] = yb.y;
                     }
                     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -354,12 +354,11 @@ __global__ void __launch_bounds__(512, 2) mlp_bwd_kernel(MlpB p) {
                     for (int mt = 0; mt < MT; ++mt) {
                         float x[8];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float y0, d0, y1, d1;
-                            gelu_sig_both(S[0][mt][r] + bv[r], y0, d0);
-                            gelu_sig_both(S[1][mt][r] + bv[4 + r], y1, d1);
-                            x[r] = G[0][mt][r] * d0;
-                            x[4 + r] = G[1][mt][r] * d1;
+                        for (int r = 0; r < 4; r += 2) {          // packed fp32 pairs: only the derivative is needed here
+                            const f32x2_t d0 = gelu_pw_grad((f32x2_t){S[0][mt][r] + bv[r], S[0][mt][r + 1] + bv[r + 1]});
+                            const f32x2_t d1 = gelu_pw_grad((f32x2_t){S[1][mt][r] + bv[4 + r], S[1][mt][r + 1] + bv[4 + r + 1]});
+                            x[r] = G[0][mt][r] * d0.x; x[r + 1] = G[0][mt][r + 1] * d0.y;
+                            x[4 + r] = G[1][mt][r] * d1.x; x[4 + r + 1] = G[1][mt][r + 1] * d1.y;
                         }
                         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
                         const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
