@@ -17,6 +17,13 @@
  *   - activations are bf16 (uint16 storage) row-major with explicit leading dimensions (in elements);
  *     statistics, biases, trainable-parameter gradients and logits are fp32;
  *   - "rows" are tokens of the fused audio+video tensor X[2, B*T, N, C] (modality 0 = video, 1 = audio).
+ *
+ * Not exported, deliberately: a collective.  The data-parallel exchange of the path -- the average of the trainable gradients,
+ * reference AVE/traintest_adapt_ave29.py:32-35 (nn.DataParallel's gather / reduce) -- is ONE all-reduce of the flat fp32 gradient
+ * arena per step plus one bucket for the task heads (stg-cma_amd/ddp.py), issued through torch.distributed: the process group owns the
+ * RCCL communicator, its bootstrap and its stream ordering against the autograd engine, and a `stg_allreduce_bucket` entry would
+ * have to duplicate all three for a single ncclAllReduce call.  SURVEY.md section 8(b) lists that symbol in its minimum export set;
+ * this library leaves it out on purpose.
  */
 #ifndef STGCMA_H
 #define STGCMA_H
