@@ -333,6 +333,12 @@ __global__ void __launch_bounds__(256, WPS) winattn_bwd_kernel(WinP a) {
 // ds_read_b128 (its 16-lane groups mix four values of R >> 2), for the staging writes and for the transposed reads (the four rows of
 // a block share R >> 2).  P / dS / output tiles [32][32]: 8-byte piece u of row q at u ^ ((q >> 2) & 7).
 // Padded queries carry lse = +1e30 (P = dS = 0), padded keys the table's -1e30; padded rows of the tiles duplicate token n - 1.
+// Score register `reg` of key tile kt holds keys 32 kt + (reg & 3) + 8 (reg >> 2) + 4 hh.  With NKEY > 0 (a compile-time key count: 49 for the 7 x 7
+// windows of every Swin stage) a register whose keys are padding for BOTH half-waves is skipped at compile time: its table entry is -1e30, so its
+// probability is exactly 0 either way (bit-identical results), and 7 of the 32 score registers of a query tile cost no VALU / exp.
+template <int NKEY>
+__device__ __forceinline__ constexpr bool key_reg_live(int kt, int reg) { return NKEY <= 0 || 32 * kt + (reg & 3) + 8 * (reg >> 2) < NKEY; }
+
 __device__ __forceinline__ int sw_off(int row, int chunk) { return row * WD + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
 __device__ __forceinline__ bf16x8_t tr_frag64(const bf16_t* s, int kt, int s2, int hh, int d) {     // tr_frag on a swizzled [64][32] tile
@@ -378,6 +384,7 @@ __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const
     }
 }
 
+template <int NKEY>
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
@@ -477,8 +484,12 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
             for (int reg = 0; reg < 16; ++reg) {
                 const float4 ad = addc[reg >> 2];
                 const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
-                pr[reg] = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + (av - lse_q[qt]));      // padded keys: av = -1e30; padded queries: lse = +1e30
-                ds[reg] = pr[reg] * (dpt[reg] - delta[qt]);
+                if (key_reg_live<NKEY>(kt, reg)) {
+                    pr[reg] = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + (av - lse_q[qt]));  // padded keys: av = -1e30; padded queries: lse = +1e30
+                    ds[reg] = pr[reg] * (dpt[reg] - delta[qt]);
+                } else {
+                    pr[reg] = 0.f; ds[reg] = 0.f;
+                }
             }
             bf16x8_t pp[2], ps[2];
 #pragma unroll
@@ -536,6 +547,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 // ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
 // winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
 // fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
+template <int NKEY>
 __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     constexpr int PER_WAVE = 3 * 64 * WD;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
@@ -601,6 +613,7 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
+                if (!key_reg_live<NKEY>(kt, reg)) continue;
                 const float4 ad = add[qt][kt][reg >> 2];
                 const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
                 x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
@@ -612,6 +625,7 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
+                if (!key_reg_live<NKEY>(kt, reg)) { x[kt][reg] = 0.f; continue; }
                 x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
                 l += x[kt][reg];
             }
@@ -702,7 +716,10 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
-    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) hipLaunchKernelGGL(winattn_fwd1_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
+        if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    }
     else hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
@@ -721,7 +738,8 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (occ <= 1 && p.n == 49) hipLaunchKernelGGL(winattn_bwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
