@@ -73,3 +73,38 @@ def test_every_trainable_element_is_exchanged(stg, gpu, pg):
             assert sync.last_numel == n_train, f"{tag} step {step}: exchanged {sync.last_numel} of {n_train} trainable elements"
         missing = [n for n, p in m.named_parameters() if p.requires_grad and p.grad is None]
         assert not missing, f"{tag}: no gradient for {missing[:5]}"
+
+
+def test_attach_with_a_partly_frozen_task_head_then_unfreeze(stg, gpu, pg):
+    """attach() used to hook every task-head parameter and crashed on a frozen one ('cannot register a hook on a tensor that
+    doesn't require gradient'); a parameter unfrozen after attach() was never synchronised.  Frozen tensors are now recorded without a
+    hook and picked up by rewatch() (run at every arena all-reduce)."""
+    from stgcma import ddp, recipe
+    tag, m, loss_of = [t for t in _models(gpu) if t[0] == "swin_avqa"][0]
+    torch.manual_seed(0)
+    m = m.to(gpu).train()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "D_fc2" in n or "gate_" in n:
+                p.normal_(0.0, 0.05)
+    recipe.apply_freeze(m)
+    head = [(n, p) for n, p in m.named_parameters() if n.startswith("avqatask_") and p.requires_grad]
+    probe = head[: len(head) // 2]                          # a linear-probe style ablation: half of the task head frozen before attach
+    for _, p in probe:
+        p.requires_grad_(False)
+    sync = ddp.attach(m)                                    # must not raise
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    m.zero_grad(set_to_none=True)
+    loss_of(m).backward()
+    torch.cuda.synchronize()
+    assert sync.last_numel == n_train, f"exchanged {sync.last_numel} of {n_train} trainable elements with half the head frozen"
+    assert all(p.grad is None for _, p in probe)
+    for _, p in probe:                                      # unfreeze: hooked at the next backward's arena all-reduce (or by hand)
+        p.requires_grad_(True)
+    sync.rewatch()
+    n_all = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n_all > n_train
+    m.zero_grad(set_to_none=True)
+    loss_of(m).backward()
+    torch.cuda.synchronize()
+    assert sync.last_numel == n_all, f"exchanged {sync.last_numel} of {n_all} trainable elements after the unfreeze"

@@ -66,6 +66,61 @@ def test_fused_adam_state_dict_interchanges_with_torch(stg, gpu):
         assert torch.allclose(x, y, rtol=2e-6, atol=2e-7) and torch.allclose(x, w, rtol=2e-6, atol=2e-7)
 
 
+def test_fused_adam_load_resets_parameters_the_checkpoint_does_not_cover(stg, gpu):
+    """torch.optim.Adam.load_state_dict leaves a parameter that the loaded state does not cover WITHOUT state (it restarts from zero
+    moments and step 0); FusedAdam, whose moments live in flat buffers, must zero them."""
+    from stgcma import recipe
+    a_p, b_p = _params(gpu, 3), _params(gpu, 3)
+    a = torch.optim.Adam([{"params": a_p}], lr=3e-3, betas=(0.95, 0.999))
+    b = recipe.FusedAdam([{"params": b_p}], lr=3e-3, betas=(0.95, 0.999))
+    skip = (2, 5)                                           # these two never see a gradient before the checkpoint is taken
+    _grads(a_p, 0, skip=skip); a.step()
+    ckpt = copy.deepcopy(a.state_dict())
+    assert all(i not in ckpt["state"] for i in skip)
+    for it in range(1, 4):                                  # both optimizers run on (FusedAdam on every tensor), then load the old checkpoint
+        _grads(a_p, it); _grads(b_p, it)
+        a.step(); b.step()
+    with torch.no_grad():
+        for x, y in zip(a_p, b_p):
+            y.copy_(x)
+    a.load_state_dict(copy.deepcopy(ckpt)); b.load_state_dict(copy.deepcopy(ckpt))
+    for it in range(4, 7):
+        _grads(a_p, it); _grads(b_p, it)
+        a.step(); b.step()
+    for i, (x, y) in enumerate(zip(a_p, b_p)):
+        assert torch.allclose(x, y, rtol=2e-6, atol=2e-7), f"tensor {i} ({'not ' if i in skip else ''}covered by the checkpoint)"
+
+
+def test_capture_train_step_bumps_versions_and_rejects_zero_warmup(stg, gpu):
+    """replay() must bump the trainable parameters' version counters (FusedAdam.step's own bump is host code a replay does not run):
+    ops.shadow keys its bf16 weight shadows on the version, so an eager forward after replays would otherwise read stale shadows
+    (ADVICE r2).  warmup < 1 is rejected: lazily built tables / shadows would stay out of the graph's steady state."""
+    from stgcma import recipe
+    ps = _params(gpu, 4)
+    opt = recipe.FusedAdam([{"params": ps}], lr=1e-2, betas=(0.95, 0.999))
+    target = [torch.randn_like(p) for p in ps]
+
+    def step():
+        loss = sum(((p - t) ** 2).sum() for p, t in zip(ps, target))
+        opt.zero_grad(set_to_none=False)
+        loss.backward()
+        opt.step()
+        return loss
+
+    with pytest.raises(ValueError):
+        recipe.capture_train_step(step, warmup=0)
+    replay, static_loss = recipe.capture_train_step(step, warmup=2)
+    v0 = [p._version for p in ps]
+    before = [p.detach().clone() for p in ps]
+    l0 = None
+    for _ in range(3):
+        replay()
+        l0 = float(static_loss.detach()) if l0 is None else l0
+    torch.cuda.synchronize()
+    assert all(p._version > v for p, v in zip(ps, v0)), "replay() left the version counters untouched"
+    assert any(not torch.equal(p.detach(), b) for p, b in zip(ps, before)) and float(static_loss.detach()) < l0
+
+
 def test_fused_adam_in_a_hip_graph(stg, gpu):
     """The whole update replays from a captured graph: step counters and bias corrections live on the device."""
     from stgcma import recipe
