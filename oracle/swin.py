@@ -340,6 +340,11 @@ def swin_backbone(P, a, v, cfg, v_nega=None):
     xv = patch_embed(P, "patch_embed", v.permute(0, 2, 1, 3, 4))
     xa = patch_embed(P, "patch_embed_audio", a.unsqueeze(1))
     xn = patch_embed(P, "patch_embed", v_nega.permute(0, 2, 1, 3, 4)) if v_nega is not None else None
+    if "temporal_embedding" in P:                     # t_relative=False (Swin_AVSModel.py:1800-1806, Swin_AVQAModel_V1.py:1752-1758): v and a only
+        def add_t(x, e):
+            BT, N, C = x.shape
+            return (x.view(BT // T, T, N, C) + e.view(1, T, 1, C)).view(BT, N, C)
+        xv, xa = add_t(xv, P["temporal_embedding"]), add_t(xa, P["temporal_embedding_audio"])
     taps = []
     for s, depth in enumerate(depths):
         H = W = res // (2 ** s)

@@ -382,8 +382,6 @@ class SwinTransformer2D_Adapter_New(nn.Module):
         from ..ops import SwinBackboneFn
         if self.ftmode != 'fusion':
             raise TypeError('ftmode is not expected !!!')
-        if not self.t_relative:
-            raise NotImplementedError("t_relative=False (absolute temporal embedding): built for the AVE model only")
         if not v.is_cuda:
             raise RuntimeError("stg-cma_amd runs on MI355X only: move the model and inputs to the GPU (no CPU fallback)")
         names, tensors = self._flat_tensors()

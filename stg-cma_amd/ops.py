@@ -1224,6 +1224,9 @@ class SwinBackboneFn(torch.autograd.Function):
         for i, x5 in enumerate((v.permute(0, 2, 1, 3, 4), a.unsqueeze(1))):     # 'b t c h w -> b c t h w' (:1793 / :1742)
             patch_embed_into(x5, P[pe[i] + ".proj.weight"], P[pe[i] + ".proj.bias"], P.get(pe[i] + ".norm.weight"),
                              P.get(pe[i] + ".norm.bias"), X[i * Rm:(i + 1) * Rm])
+            te = P.get("temporal_embedding_audio" if i else "temporal_embedding")
+            if te is not None:       # t_relative=False (Swin_AVSModel_Base.py:1800-1806, Swin_AVQAModel_V1.py:1752-1758): v and a, not v_nega
+                K.add_temporal(X[i * Rm:(i + 1) * Rm], f32c(te).reshape(T, -1), B, T, N0)
         Xn = None
         if v_nega is not None:
             Xn = torch.empty((Rm, plan.embed_dim), dtype=RESIDUAL_DTYPE, device=dev)
@@ -1271,6 +1274,7 @@ class SwinBackboneFn(torch.autograd.Function):
         outs += tap_out
         ctx.tape, ctx.final, ctx.P, ctx.need, ctx.names = tape, (X, mean, rstd), P, need, names
         ctx.n_tap, ctx.has_nega = len(tap_out), Xn is not None
+        ctx.geom0 = (B, T, N0)
         ctx.ddp = getattr(plan, "ddp", None)
         ctx.fp8 = plan_fp8
         return tuple(outs)
@@ -1296,10 +1300,11 @@ class SwinBackboneFn(torch.autograd.Function):
         dtaps = list(douts[2 + (1 if ctx.has_nega else 0):])
         tape = ctx.tape
         dH_carry = None
+        need_emb = need.get("temporal_embedding", False) or need.get("temporal_embedding_audio", False)
         while tape:
             kind, spec, pre, Pl, S = tape.pop()
             if kind == "block":
-                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape), need_dx0=bool(tape))
+                dX, g, dH_carry = block_backward(S, spec, Pl, need, pre, dX, arena, dH_carry, _prev_down(tape), need_dx0=bool(tape) or need_emb)
                 for k, val in g.items():
                     grads[pre + k] = val
             else:
@@ -1309,6 +1314,14 @@ class SwinBackboneFn(torch.autograd.Function):
                 if dt is not None:                                       # the tap's gradient joins the video rows
                     dv = dX[:dX.shape[0] // 2]
                     K.add(dv, K.cast_bf16(dt.contiguous()), out=dv)
+        B, T, N0 = ctx.geom0
+        for i, name in enumerate(("temporal_embedding", "temporal_embedding_audio")):     # t_relative=False: as in SwinModelFn.backward
+            if need.get(name, False):
+                Rm = B * T * N0
+                pooled = K.meanpool_fwd(dX[i * Rm:(i + 1) * Rm], B * T, N0, out_dtype=F32)
+                g = arena.view(name, P[name])
+                g.copy_(pooled.view(B, T, -1).sum(0).mul_(float(N0)).view(g.shape))
+                grads[name] = g
         if ctx.ddp is not None:
             ctx.ddp.allreduce_(arena.flat, arena.n_real)
         return (None,) * 8 + tuple(grads.get(n) for n in ctx.names)

@@ -151,7 +151,7 @@ def swin_model_case(S, tag, *, cfg, B, mode, seed, store_all_grads=True, state_f
 
 
 # --------------------------------------------------------------------------------------------------- AVS / AVQA backbones
-BACKBONE_PREFIXES = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.")
+BACKBONE_PREFIXES = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.", "temporal_embedding")
 
 
 def _seed_backbone(m, seed):
@@ -168,19 +168,37 @@ def _seed_backbone(m, seed):
     return shapes, names
 
 
+def _trel(cfg):
+    return {"t_relative": cfg["t_relative"]} if "t_relative" in cfg else {}
+
+
+def _add_temporal(m, xv, xa, B, T):
+    """t_relative=False: the absolute temporal embeddings behind the patch embeddings, on the reference model's own parameters
+    (Swin_AVSModel.py:1800-1806, Swin_AVQAModel_V1.py:1752-1758: '(b t) n c -> (b n) t c', + embedding, back)."""
+    if m.t_relative:
+        return xv, xa
+    from einops import rearrange
+    out = []
+    for x, e in ((xv, m.temporal_embedding), (xa, m.temporal_embedding_audio)):
+        x = rearrange(x, '(b t) n c -> (b n) t c', b=B, t=T) + e
+        out.append(rearrange(x, '(b n) t c -> (b t) n c', b=B, t=T))
+    return out
+
+
 def avs_backbone_case(A, tag, *, cfg, B, seed):
     """Backbone part of SwinTransformer2D_Adapter_AVS.forward[fusion] (AVS/model/Swin_AVSModel.py:1793-1822), run through the
     reference's own modules: patch embeds, BasicLayers returning (x, x_before_downsample), final norm."""
     from einops import rearrange
     m = A.SwinTransformer2D_Adapter_AVS(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
                                         depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
-                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+                                        adapter_mlp_ratio=cfg["adapter_mlp_ratio"], **_trel(cfg)).eval()
     shapes, names = _seed_backbone(m, seed)
     T = cfg["num_frames"]
     a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
     v = GP.seeded_tensor((B, T, 3, 224, 224), seed + 2)
     xv, _, _ = m.patch_embed(rearrange(v, 'b t c h w -> b c t h w'))
     xa, _, _ = m.patch_embed_audio(a.unsqueeze(1))
+    xv, xa = _add_temporal(m, xv, xa, B, T)
     x = (m.pos_drop(xv), m.pos_drop(xa))
     taps = []
     for idx, layer in enumerate(m.layers):
@@ -200,7 +218,7 @@ def avqa_backbone_case(Q, tag, *, cfg, B, seed):
     from einops import rearrange
     m = Q.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"],
                                          depths=cfg["depths"], num_heads=cfg["num_heads"], ftmode="fusion",
-                                         adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+                                         adapter_mlp_ratio=cfg["adapter_mlp_ratio"], **_trel(cfg)).eval()
     shapes, names = _seed_backbone(m, seed)
     T = cfg["num_frames"]
     a = GP.seeded_tensor((B, T, 224, 224), seed + 1, 0.5)
@@ -209,6 +227,7 @@ def avqa_backbone_case(Q, tag, *, cfg, B, seed):
     xv, _, _ = m.patch_embed(rearrange(v, 'b t c h w -> b c t h w'))
     xa, _, _ = m.patch_embed_audio(a.unsqueeze(1))
     xn, _, _ = m.patch_embed(rearrange(vn, 'b t c h w -> b c t h w'))
+    xv, xa = _add_temporal(m, xv, xa, B, T)              # the negative clip gets none (Swin_AVQAModel_V1.py:1752-1758)
     xv, xa, xn = m.pos_drop(xv), m.pos_drop(xa), m.pos_drop(xn)
     for layer in m.layers:
         xv, xa, xn = layer((xv, xa, xn))
@@ -634,6 +653,9 @@ def main(argv):
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
         "avs_tiny_backbone": lambda: avs_backbone_case(ref_avs(), "avs_tiny_backbone", cfg=AVS_TINY, B=1, seed=600),
         "avqa_tiny_backbone": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone", cfg=AVQA_TINY, B=1, seed=610),
+        # t_relative=False on the AVS / AVQA classes (no runner uses it; constructor completeness): B = 2 so that the sum over clips is exercised
+        "avs_tiny_backbone_tabs": lambda: avs_backbone_case(ref_avs(), "avs_tiny_backbone_tabs", cfg=dict(AVS_TINY, t_relative=False, num_frames=2), B=2, seed=650),
+        "avqa_tiny_backbone_tabs": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone_tabs", cfg=dict(AVQA_TINY, t_relative=False), B=2, seed=660),
         "swin_pretrained_ingest": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest", SWIN_TINY, 700, [1, 4, 4]),
         "swin_pretrained_ingest_pd2": lambda: pretrained_ingest_case(S, "swin_pretrained_ingest_pd2", SWIN_TINY, 710, [2, 4, 4]),
         # audio grid 7 x 5 inside the 14 x 14 image grid (centre crop both ways), and 7 x 19 (time axis bilinearly stretched)

@@ -35,7 +35,8 @@ def _dump_report():
 def _build(cls, cfg, shapes, gpu):
     from stgcma import recipe
     m = cls(pretrained=None, num_frames=cfg["num_frames"], embed_dim=cfg["embed_dim"], depths=cfg["depths"],
-            num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"]).eval()
+            num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
+            **({"t_relative": cfg["t_relative"]} if "t_relative" in cfg else {})).eval()
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     sd = m.state_dict()
     for k in sd:
@@ -44,7 +45,7 @@ def _build(cls, cfg, shapes, gpu):
     m.load_state_dict(sd, strict=True)
     m = m.to(gpu)
     names = []
-    backbone = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.")     # the goldens of this file are backbone-only
+    backbone = ("patch_embed.", "patch_embed_audio.", "layers.", "norm.", "temporal_embedding")     # the goldens of this file are backbone-only
     for n, p in m.named_parameters():
         p.requires_grad = recipe.is_trainable(n) and n.startswith(backbone)
         if p.requires_grad:
@@ -82,11 +83,12 @@ def _check_grads(m, names, ref, tag):
     assert off == ref.size
 
 
-def test_avs_backbone_matches_reference(stg, gpu):
+@pytest.mark.parametrize("case", ["avs_tiny_backbone", "avs_tiny_backbone_tabs"])      # _tabs: t_relative=False (absolute temporal embeddings), B = 2
+def test_avs_backbone_matches_reference(stg, gpu, case):
     """a19: taps before every downsample + norm'd last stage + norm(a); gradients arrive through all five outputs."""
     from stgcma.model import Swin_AVSModel
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avs_tiny_backbone")
+    z, cfg, shapes, names = load_case(case)
     m, mine = _build(Swin_AVSModel.SwinTransformer2D_Adapter_AVS, cfg, shapes, gpu)
     assert mine == names
     B, T = cfg["B"], cfg["num_frames"]
@@ -106,11 +108,12 @@ def test_avs_backbone_matches_reference(stg, gpu):
     _check_grads(m, names, z["grads"], "avs")
 
 
-def test_avqa_backbone_matches_reference(stg, gpu):
+@pytest.mark.parametrize("case", ["avqa_tiny_backbone", "avqa_tiny_backbone_tabs"])    # _tabs: t_relative=False, B = 2
+def test_avqa_backbone_matches_reference(stg, gpu, case):
     """a18: the negative clip rides through every block as the plain frozen Swin block (forward-only)."""
     from stgcma.model import Swin_AVQAModel_V1
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avqa_tiny_backbone")
+    z, cfg, shapes, names = load_case(case)
     m, mine = _build(Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA, cfg, shapes, gpu)
     assert mine == names
     B, T = cfg["B"], cfg["num_frames"]

@@ -189,11 +189,12 @@ def test_vit_tiny_model_matches_reference():
 
 
 # ----------------------------------------------------------------------------------------------- AVS / AVQA backbones
-def test_avs_backbone_matches_reference():
+@pytest.mark.parametrize("case", ["avs_tiny_backbone", "avs_tiny_backbone_tabs"])      # _tabs: t_relative=False, B = 2
+def test_avs_backbone_matches_reference(case):
     """multi-scale video taps (before each downsample, last one through norm) + norm(a), and the gradients of
     every trainable backbone tensor for seeded upstream gradients on all five outputs."""
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avs_tiny_backbone")
+    z, cfg, shapes, names = load_case(case)
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     for n in names:
         P[n].requires_grad_(True)
@@ -213,10 +214,11 @@ def test_avs_backbone_matches_reference():
     assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
 
 
-def test_avqa_backbone_matches_reference():
+@pytest.mark.parametrize("case", ["avqa_tiny_backbone", "avqa_tiny_backbone_tabs"])    # _tabs: t_relative=False, B = 2
+def test_avqa_backbone_matches_reference(case):
     """(v, a, v_nega) through every block and downsample; the negative stream is the frozen Swin block."""
     from params import seeded_tensor
-    z, cfg, shapes, names = load_case("avqa_tiny_backbone")
+    z, cfg, shapes, names = load_case(case)
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     for n in names:
         P[n].requires_grad_(True)
