@@ -49,11 +49,15 @@ def feature_fusion_block(P, pre, x0, x1=None):
 
 
 def tpavi(P, pre, x, audio, bn_training=False, bn_stats=None, eps=1e-5):
-    """TPAVIModule.forward (TPAVI.py:81-152), mode 'dot', with audio.  x [B, C, T, H, W], audio [B, T, 128] -> (z, audio_temp).
+    """TPAVIModule.forward (TPAVI.py:81-152), mode 'dot'.  x [B, C, T, H, W], audio [B, T, 128] -> (z, audio_temp); audio None: the
+    visual self-attention form (`audio = x`, TPAVI.py:96-98; audio_temp is then 0).
     bn_training: batch statistics (the caller may read them back through bn_stats = {} to check the running-stat update)."""
     Bn, C, T, H, W = x.shape
-    audio_temp = F.linear(audio, P[pre + ".align_channel.weight"], P[pre + ".align_channel.bias"])        # [B, T, C]
-    au = audio_temp.permute(0, 2, 1)[:, :, :, None, None].expand(Bn, C, T, H, W)
+    if audio is None:
+        audio_temp, au = 0, x
+    else:
+        audio_temp = F.linear(audio, P[pre + ".align_channel.weight"], P[pre + ".align_channel.bias"])    # [B, T, C]
+        au = audio_temp.permute(0, 2, 1)[:, :, :, None, None].expand(Bn, C, T, H, W)
 
     def c1(name, t):
         return F.conv3d(t, P[f"{pre}.{name}.weight"], P[f"{pre}.{name}.bias"])
@@ -88,8 +92,9 @@ def output_conv(P, pre, x):
     return conv(P, pre + ".4", y)
 
 
-def avs_decoder(P, taps, f_a, B, T, tpavi_stages=(0, 1, 2, 3), bn_training=False):
-    """(:1824-1894) taps: 4 video token maps [(B T), N_s, C_s] (last one norm'd), f_a [(B T), N, C]."""
+def avs_decoder(P, taps, f_a, B, T, tpavi_stages=(0, 1, 2, 3), bn_training=False, tpavi_vv=False, tpavi_va=True):
+    """(:1824-1894) taps: 4 video token maps [(B T), N_s, C_s] (last one norm'd), f_a [(B T), N, C].  tpavi_vv / tpavi_va: the two
+    non-local forms of a stage, averaged when both are on (:1873-1886; the SAME block runs both, vv first)."""
     BT = B * T
     audio = F.linear(f_a.mean(dim=1).view(B, T, -1), P["avstask_audio_linear.weight"], P["avstask_audio_linear.bias"])
     fmaps = []
@@ -101,16 +106,22 @@ def avs_decoder(P, taps, f_a, B, T, tpavi_stages=(0, 1, 2, 3), bn_training=False
     for i in tpavi_stages:
         _, C, H, W = fmaps[i].shape
         x5 = fmaps[i].reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4)
-        z, a_t = tpavi(P, f"avstask_tpavi_b{i + 1}", x5, audio, bn_training)
-        fmaps[i] = z.permute(0, 2, 1, 3, 4).reshape(BT, C, H, W)
-        afeas[i] = a_t
+        acc, cnt = 0., 0
+        if tpavi_vv:
+            z, _ = tpavi(P, f"avstask_tpavi_b{i + 1}", x5, None, bn_training)
+            acc, cnt = acc + z, cnt + 1
+        if tpavi_va:
+            z, a_t = tpavi(P, f"avstask_tpavi_b{i + 1}", x5, audio, bn_training)
+            acc, cnt = acc + z, cnt + 1
+            afeas[i] = a_t
+        fmaps[i] = (acc / cnt).permute(0, 2, 1, 3, 4).reshape(BT, C, H, W)
     out, fmaps[3] = feature_fusion_block(P, "avstask_path4", fmaps[3])
     for s in (2, 1, 0):
         out, fmaps[s] = feature_fusion_block(P, f"avstask_path{s + 1}", out, fmaps[s])
     return output_conv(P, "avstask_output_conv", out), fmaps, afeas
 
 
-def avs_forward(P, a, v, cfg, bn_training=False):
+def avs_forward(P, a, v, cfg, bn_training=False, tpavi_vv=False, tpavi_va=True):
     """SwinTransformer2D_Adapter_AVS(_Base).forward[fusion] (:1790-1894): backbone (oracle.swin.swin_backbone) + decoder."""
     out = swin_backbone(P, a, v, cfg)
-    return avs_decoder(P, out["taps"], out["f_a"], v.shape[0], v.shape[1], bn_training=bn_training)
+    return avs_decoder(P, out["taps"], out["f_a"], v.shape[0], v.shape[1], bn_training=bn_training, tpavi_vv=tpavi_vv, tpavi_va=tpavi_va)

@@ -8,8 +8,8 @@ multi-scale video features (before each downsample, the last one through `norm`)
 decoder.  The dense decoder (`avstask_*`: 4 Linear taps, 4 ASPP classifiers, 4 TPAVI blocks, the FeatureFusion path and the output
 convolutions; ctor :1474-1503, forward :1838-1894, AVS/model/TPAVI.py) is here too under the reference's module names, run by
 ..ops_dec on libstgcma_hip.so (channels-last rows, im2col + MFMA GEMM convolutions); `forward(a, v, mode)` returns
-`(pred, feature_map_list, a_fea_list)` like the reference.  Not carried over: tpavi_vv_flag=True (visual self-attention TPAVI,
-unused by the runners).
+`(pred, feature_map_list, a_fea_list)` like the reference, with either or both of the non-local forms of a stage
+(tpavi_va_flag: audio-visual, what the runners use; tpavi_vv_flag: visual self-attention through the same block, :1532-1538).
 """
 import torch
 import torch.nn as nn

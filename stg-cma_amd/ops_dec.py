@@ -202,19 +202,30 @@ def feature_fusion(ffb, x0, x1, geom):
     return BilinearUp2Fn.apply(out, F_, H, Wd, True), r1
 
 
-def tpavi(mod, x, audio, B, T, HW, training):
-    """TPAVIModule.forward (TPAVI.py:81-152), mode 'dot', dimension 3, with audio: x bf16 [(b t hw), C], audio bf16 [(b t), 128]
-    -> (z [(b t hw), C], audio_temp [(b t), C])."""
+def tpavi(mod, x, audio, B, T, HW, training, out_scale=1.0):
+    """TPAVIModule.forward (TPAVI.py:81-152), mode 'dot', dimension 3: x bf16 [(b t hw), C], audio bf16 [(b t), 128]
+    -> (z [(b t hw), C], audio_temp [(b t), C]).  audio None: the visual self-attention form (`audio = x`, TPAVI.py:96-98;
+    tpavi_vv_flag, Swin_AVSModel_Base.py:1532-1538) -> (z, None).  Either way f / N followed by f . g collapses to one 128 x 128
+    matrix per clip (TpaviMixFn): M_b = phi_b^T g_b / n over the clip's n = T HW positions; with audio, phi is constant over a frame
+    and the sum over its positions is HW gbar.  out_scale: a factor on z, folded into the LayerNorm's affine (the caller's average
+    over the vv and va forms, :1885)."""
     if mod.mode != 'dot' or mod.dimension != 3:
         raise NotImplementedError("TPAVI: mode='dot', dimension=3 (what the AVS models build, Swin_AVSModel_Base.py:1495)")
-    a_t = linear(audio, mod.align_channel.weight, mod.align_channel.bias)                      # [(b t), C]
     g_x = _conv1x1_as_linear(x, mod.g)
     theta = _conv1x1_as_linear(x, mod.theta)
-    phi = _conv1x1_as_linear(a_t, mod.phi)                                                     # audio is constant over the frame
-    gbar = MeanFn.apply(g_x, B * T, HW)
-    y = TpaviMixFn.apply(theta, phi, gbar, B, T, HW)
+    if audio is None:
+        a_t = None
+        y = TpaviMixFn.apply(theta, _conv1x1_as_linear(x, mod.phi), g_x, B, T * HW, 1)
+    else:
+        a_t = linear(audio, mod.align_channel.weight, mod.align_channel.bias)                  # [(b t), C]
+        phi = _conv1x1_as_linear(a_t, mod.phi)                                                 # audio is constant over the frame
+        gbar = MeanFn.apply(g_x, B * T, HW)
+        y = TpaviMixFn.apply(theta, phi, gbar, B, T, HW)
     w_y = batchnorm(_conv1x1_as_linear(y, mod.W_z[0]), mod.W_z[1], training)
-    z = LayerNormFn.apply(AddFn.apply(w_y, x), mod.norm_layer.weight, mod.norm_layer.bias)
+    lw, lb = mod.norm_layer.weight, mod.norm_layer.bias
+    if out_scale != 1.0:
+        lw, lb = lw * out_scale, lb * out_scale
+    z = LayerNormFn.apply(AddFn.apply(w_y, x), lw, lb)
     return z, a_t
 
 
@@ -249,12 +260,16 @@ def avs_decoder_forward(m, ms, a_feat, B, T, training):
     if len(m.tpavi_stages) > 0:
         if (not m.tpavi_vv_flag) and (not m.tpavi_va_flag):
             raise Exception('tpavi_vv_flag and tpavi_va_flag cannot be False at the same time if len(tpavi_stages)>0')
-        if m.tpavi_vv_flag:
-            raise NotImplementedError("tpavi_vv_flag=True (visual self-attention TPAVI) is not built; the runners use va only")
+        sc = 1.0 / (int(bool(m.tpavi_vv_flag)) + int(bool(m.tpavi_va_flag)))                    # conv_feat /= tpavi_count (:1885)
         for i in m.tpavi_stages:
-            z, a_t = tpavi(getattr(m, f'avstask_tpavi_b{i + 1}'), feats[i], audio, B, T, geoms[i][1] * geoms[i][2], training)
+            blk, hw, z = getattr(m, f'avstask_tpavi_b{i + 1}'), geoms[i][1] * geoms[i][2], None
+            if m.tpavi_vv_flag:                                                                # the same block, visual self-attention first (:1876-1879)
+                z, _ = tpavi(blk, feats[i], None, B, T, hw, training, out_scale=sc)
+            if m.tpavi_va_flag:
+                z_va, a_t = tpavi(blk, feats[i], audio, B, T, hw, training, out_scale=sc)
+                z = z_va if z is None else AddFn.apply(z, z_va)
+                a_fea_list[i] = a_t.view(B, T, -1)
             feats[i] = z
-            a_fea_list[i] = a_t.view(B, T, -1)
     paths = (m.avstask_path1, m.avstask_path2, m.avstask_path3, m.avstask_path4)
     out, _ = feature_fusion(paths[3], feats[3], None, geoms[3])                                # path4(fm[3])            (:1887)
     # path4 has no second input, so its RCU2's in-place ReLU lands on feature_map_list[3] itself

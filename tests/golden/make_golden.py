@@ -337,6 +337,35 @@ def avs_modules_case(A, tag, seed):
     save(tag, seed=np.array([seed]), **arrs)
 
 
+def avs_tpavi_vv_case(A, tag, seed):
+    """TPAVIModule WITHOUT audio (TPAVI.py:96-98: `audio = x`): the visual self-attention form behind tpavi_vv_flag=True
+    (Swin_AVSModel_Base.py:1532-1538, :1876-1879), mode 'dot', train-mode BatchNorm then eval-mode.  align_channel gets no gradient."""
+    import sys as _s
+    TP = _s.modules["AVS.model.TPAVI"]
+    arrs = {}
+    g = torch.Generator().manual_seed(seed)
+    tp = TP.TPAVIModule(in_channels=32, mode='dot')
+    arrs["tpavi_shapes"] = json.dumps(_seed_all(tp, seed + 3))
+    with torch.no_grad():
+        tp.W_z[1].running_mean.copy_(torch.randn(32, generator=g) * 0.1); tp.W_z[1].running_var.copy_(torch.rand(32, generator=g) + 0.5)
+    xt = torch.randn(2, 32, 3, 5, 5, generator=g)
+    for mode in ("train", "eval"):
+        tp.train(mode == "train")
+        rm0, rv0 = tp.W_z[1].running_mean.clone(), tp.W_z[1].running_var.clone()
+        xr = xt.clone().requires_grad_(True)
+        for p in tp.parameters():
+            p.grad = None
+        z_, at_ = tp(xr)
+        assert at_ == 0
+        gz = torch.randn(z_.shape, generator=g)
+        (z_ * gz).sum().backward()
+        arrs.update({f"tpavi_{mode}_z": z_, f"tpavi_{mode}_gz": gz, f"tpavi_{mode}_dx": xr.grad, f"tpavi_{mode}_rm0": rm0, f"tpavi_{mode}_rv0": rv0,
+                     f"tpavi_{mode}_rm1": tp.W_z[1].running_mean.clone(), f"tpavi_{mode}_rv1": tp.W_z[1].running_var.clone(),
+                     f"tpavi_{mode}_grads": torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in tp.parameters()])})
+    arrs.update(tpavi_x=xt)
+    save(tag, seed=np.array([seed]), **arrs)
+
+
 def avs_full_case(AB, tag, *, cfg, B, seed):
     """The whole SwinTransformer2D_Adapter_AVS_Base.forward[fusion] (AVS/model/Swin_AVSModel_Base.py:1790-1894): backbone + dense
     decoder, train mode without DropPath (BatchNorm on batch statistics), seeded upstream gradients on pred, the returned feature
@@ -671,6 +700,7 @@ def main(argv):
         "swin_l_fusion_refinit": lambda: swin_model_case(S, "swin_l_fusion_refinit", cfg=SWIN_L, B=1, mode="fusion", seed=320,
                                                          store_all_grads=False, state_fn=GP.refinit_state),
         "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
+        "avs_tpavi_vv": lambda: avs_tpavi_vv_case(ref_avs_base(), "avs_tpavi_vv", 860),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
         "avs_full_tiny_evalbn": lambda: avs_full_evalbn_case(ref_avs_base(), "avs_full_tiny_evalbn", cfg=AVS_FULL_TINY, B=1, seed=840),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),

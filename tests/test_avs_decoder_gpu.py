@@ -116,13 +116,36 @@ def test_tpavi_matches_reference_module(stg, gpu, mode):
     _chk(tp.W_z[1].running_mean, z[f"tpavi_{mode}_rm1"], "running_mean"); _chk(tp.W_z[1].running_var, z[f"tpavi_{mode}_rv1"], "running_var")
 
 
-def _build_full(gpu):
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_tpavi_visual_self_attention_matches_reference_module(stg, gpu, mode):
+    """tpavi_vv_flag's form: TPAVIModule without audio (TPAVI.py:96-98), golden `avs_tpavi_vv` from the reference module."""
+    from stgcma import ops_dec as D
+    from stgcma.model import Swin_AVSModel as M
+    z = np.load(os.path.join(GOLD, "avs_tpavi_vv.npz"))
+    tp, keys = _load(M.TPAVIModule(in_channels=32, mode='dot'), z, "tpavi_shapes", 3, gpu)
+    with torch.no_grad():
+        tp.W_z[1].running_mean.copy_(torch.as_tensor(z[f"tpavi_{mode}_rm0"])); tp.W_z[1].running_var.copy_(torch.as_tensor(z[f"tpavi_{mode}_rv0"]))
+    B, C, T, H, W = z["tpavi_x"].shape
+    x = torch.as_tensor(z["tpavi_x"]).permute(0, 2, 3, 4, 1).reshape(-1, C).to(BF16).to(gpu).requires_grad_(True)
+    zz, at = D.tpavi(tp, x, None, B, T, H * W, mode == "train")
+    assert at is None
+    gz = torch.as_tensor(z[f"tpavi_{mode}_gz"]).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    (zz.float() * gz.to(gpu)).sum().backward()
+    _chk(zz.detach().float().cpu().view(B, T, H, W, C).permute(0, 4, 1, 2, 3), z[f"tpavi_{mode}_z"], "z")
+    _chk(x.grad.float().cpu().view(B, T, H, W, C).permute(0, 4, 1, 2, 3), z[f"tpavi_{mode}_dx"], "dx")
+    g = torch.cat([(dict(tp.named_parameters())[k].grad if dict(tp.named_parameters())[k].grad is not None
+                    else torch.zeros_like(dict(tp.named_parameters())[k])).reshape(-1).float().cpu() for k in keys])
+    _chk(g, z[f"tpavi_{mode}_grads"], "param grads", max_rel=5e-2, l2_rel=4e-2)
+    _chk(tp.W_z[1].running_mean, z[f"tpavi_{mode}_rm1"], "running_mean"); _chk(tp.W_z[1].running_var, z[f"tpavi_{mode}_rv1"], "running_var")
+
+
+def _build_full(gpu, vv=False, want_state=False):
     from stgcma import recipe
     from stgcma.model import Swin_AVSModel
     z, cfg, shapes, names = load_case("avs_full_tiny")
     m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                                                     num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
-                                                    drop_path_rate=0.0).train()      # the golden: train-mode BatchNorm, no DropPath
+                                                    drop_path_rate=0.0, tpavi_vv_flag=vv).train()      # the golden: train-mode BatchNorm, no DropPath
     P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
     gg = torch.Generator().manual_seed(cfg["seed"] + 50)
     for k, sh in shapes:                                                  # the running statistics make_golden.py drew after seeding
@@ -145,7 +168,43 @@ def _build_full(gpu):
         if p.requires_grad:
             mine.append(n)
     assert mine == names
+    if want_state:
+        return m, z, cfg, names, P
     return m, z, cfg, names
+
+
+def test_avs_full_model_with_visual_self_attention_matches_oracle(stg, gpu):
+    """tpavi_vv_flag=True AND tpavi_va_flag=True (Swin_AVSModel_Base.py:1873-1886: every TPAVI block runs its visual self-attention form
+    and its audio-visual form, the results are averaged).  No runner uses it, so there is no whole-model golden: the HIP model is
+    compared with the oracle, whose vv form is pinned on the reference module (`avs_tpavi_vv`) and whose decoder is pinned on the
+    reference model (`avs_full_tiny`).  Train-mode BatchNorm without DropPath, like that fixture."""
+    import oracle.avs_decoder as OD
+    from params import seeded_tensor
+    m, z, cfg, names, P = _build_full(gpu, vv=True, want_state=True)
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    with torch.no_grad():
+        ref_pred, ref_maps, ref_af = OD.avs_forward(P, a, v, dict(cfg, num_frames=5), bn_training=True, tpavi_vv=True, tpavi_va=True)
+        base_pred, _, _ = OD.avs_forward(P, a, v, dict(cfg, num_frames=5), bn_training=True)
+    assert float((ref_pred - base_pred).abs().max()) > 1e-3 * float(base_pred.abs().max()), "the vv form changed nothing: fixture does not test it"
+    pred, fmaps, afeas = m(a.to(gpu), v.to(gpu), "fusion")
+    errs = {"pred": _rel(pred, ref_pred.numpy())}
+    for i in range(4):
+        errs[f"fmap{i}"] = _rel(fmaps[i], ref_maps[i].numpy())
+        errs[f"afea{i}"] = _rel(afeas[i], ref_af[i].numpy())
+    with open("gpurun_out/model_parity_report.txt", "a") as f:
+        f.write("avs_full_tiny vv+va (vs oracle) " + " ".join(f"{k}: max/scale={a_:.3e} relL2={b_:.3e}" for k, (a_, b_) in errs.items()) + "\n")
+    for k, (e_max, e_l2) in errs.items():
+        # relative L2 as for the va-only fixture below; the maximum is taken over the WHOLE maps here (16 M elements at stage 0, not that
+        # fixture's every-8th-channel sample), so its bound is wider: measured pred 2.2e-2 / 1.8e-2, maps <= 3.3e-2 / 0.9e-2
+        lim = (3.5e-2, 3e-2) if k == "pred" else (5e-2, 1.5e-2)
+        assert e_max <= lim[0] and e_l2 <= lim[1], f"{k}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
+    pred.float().square().mean().backward()
+    d = dict(m.named_parameters())
+    for n in names:
+        assert d[n].grad is None or torch.isfinite(d[n].grad).all(), n
+    assert d["avstask_tpavi_b1.phi.weight"].grad is not None and float(d["avstask_tpavi_b1.phi.weight"].grad.abs().max()) > 0
 
 
 def test_avs_full_model_matches_reference(stg, gpu):

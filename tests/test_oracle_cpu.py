@@ -421,3 +421,27 @@ def test_avs_full_model_eval_batchnorm_matches_reference():
     assert float(rel.max()) <= 1e-2, f"per-tensor gradient norms: worst {float(rel.max()):.3e}"
     g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
     assert float((g - ref).norm() / ref.norm()) <= 2e-3
+
+
+def test_tpavi_visual_self_attention_matches_reference_module():
+    """TPAVIModule without audio (TPAVI.py:96-98: `audio = x`), the form behind tpavi_vv_flag=True (Swin_AVSModel_Base.py:1532-1538):
+    golden `avs_tpavi_vv` from the reference module, train- and eval-mode BatchNorm."""
+    import oracle.avs_decoder as OD
+    z = np.load(os.path.join(GOLD, "avs_tpavi_vv.npz"))
+    shapes, P0 = _load_mod(z, "tpavi_shapes", 3)
+    for mode in ("train", "eval"):
+        P = {"m." + k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in P0.items()}
+        P["m.W_z.1.running_mean"], P["m.W_z.1.running_var"] = _np(z, f"tpavi_{mode}_rm0"), _np(z, f"tpavi_{mode}_rv0")
+        x = _np(z, "tpavi_x").requires_grad_(True)
+        st = {}
+        zz, at = OD.tpavi(P, "m", x, None, bn_training=(mode == "train"), bn_stats=st)
+        assert isinstance(at, int) and at == 0
+        (zz * _np(z, f"tpavi_{mode}_gz")).sum().backward()
+        _close(zz, z[f"tpavi_{mode}_z"], what=f"tpavi vv {mode} z")
+        _close(x.grad, z[f"tpavi_{mode}_dx"], what=f"tpavi vv {mode} dx")
+        keys = ["m." + k for k, _ in shapes if "running" not in k]
+        g = torch.cat([(P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])).reshape(-1) for k in keys])
+        _close(g, z[f"tpavi_{mode}_grads"], what=f"tpavi vv {mode} grads")
+        if mode == "train":
+            _close(0.9 * _np(z, "tpavi_train_rm0") + 0.1 * st["mean"], z["tpavi_train_rm1"], what="running_mean")
+            _close(0.9 * _np(z, "tpavi_train_rv0") + 0.1 * st["var_unbiased"], z["tpavi_train_rv1"], what="running_var")
