@@ -100,6 +100,13 @@ struct XP {
     int tiles, total;
 };
 
+// Key rows inside a problem (forward, dQ): a wave-uniform 64-bit base + a 32-bit byte offset per lane that ADVANCES by a uniform step per
+// trip (global_load ... v_off, s[base]) instead of a 64-bit (row index) x (leading dimension) product per trip (four v_mul_lo_u32 + two
+// v_mad_u64_u32 in the ISA): forward 955 -> 899 us, dQ 1094 -> 1076 at stage 0.  (The dK / dV kernel did not gain from it -- its d_h = 32
+// form lost 20 % -- and keeps the products.)  Only a tail tile clamps its rows (wave-uniform test); stg_xattn_eligible keeps a problem's
+// key rows inside 2 GiB.
+__device__ __forceinline__ bf16x8_t ld_frag_b(const char* base, uint32_t off) { return *reinterpret_cast<const bf16x8_t*>(base + off); }
+
 struct XP2 { XP a[2]; };          // the two directions of a cross-modal pair in one launch (blockIdx.y); a single call fills a[0] only
 
 // per-wave LDS: two [32][D] tiles + 8 bytes of bf16 ones
@@ -112,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP2 pp) {
     constexpr int KS = D / 16;
     constexpr int TILE = Lds<D>::TILE;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int item = blockIdx.x * 4 + wave;
     if (item >= a.total) return;
@@ -131,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP2 pp) {
     for (int s = 0; s < KS; ++s) qf[s] = ld_frag(a.Q + rowq * a.ldq + 8 * hh + 16 * s);
 
     // this lane's pieces: LDS write slot of its K fragment(s), and its transposed-read base
-    const bf16_t* kvp = a.KV + (int64_t)p * a.outer_kv * a.ldk + 8 * hh;
+    const char* kvb = reinterpret_cast<const char*>(a.KV + (int64_t)p * a.outer_kv * a.ldk);   // wave-uniform
     const int wr_off = r * D + 8 * hh;                           // + 16 s
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
     // D = 16: lanes r >= 16 (A rows 16..31) read ones -> accumulator rows 16.. hold the row sum
@@ -148,15 +155,20 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP2 pp) {
     for (int j = 0; j < 8; ++j) ones_frag[j] = (short)0x3F80;
 
     bf16x8_t kfA[KS], kfB[KS];
-    auto load_pair = [&](int k0) {                              // clamped: every load in bounds, tails masked by value
-        int ka = k0 + r, kb = k0 + 32 + r;
-        ka = ka < a.n_kv ? ka : a.n_kv - 1;
-        kb = kb < a.n_kv ? kb : a.n_kv - 1;
+    uint32_t koff = ((uint32_t)r * (uint32_t)a.ldk + 8 * hh) * 2u;         // this lane's piece of key (next tile) + r
+    const uint32_t khalf = (uint32_t)a.ldk * 64u, klast = ((uint32_t)(a.n_kv - 1) * (uint32_t)a.ldk + 8 * hh) * 2u;
+    auto load_pair = [&](int k0) {                              // tiles are loaded in order: koff tracks k0; every load in bounds, tails masked by value
+        uint32_t oa = koff, ob = koff + khalf;
+        if (k0 + 64 > a.n_kv) {                                 // wave-uniform: only a tail tile clamps
+            oa = k0 + r < a.n_kv ? oa : klast;
+            ob = k0 + 32 + r < a.n_kv ? ob : klast;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kfA[s] = ld_frag(kvp + (int64_t)ka * a.ldk + 16 * s);
-            kfB[s] = ld_frag(kvp + (int64_t)kb * a.ldk + 16 * s);
+            kfA[s] = ld_frag_b(kvb, oa + 32 * s);
+            kfB[s] = ld_frag_b(kvb, ob + 32 * s);
         }
+        koff += 2 * khalf;
     };
     load_pair(0);
 
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP2 pp) {
     constexpr int KS = D / 16;
     constexpr int TILE = Lds<D>::TILE;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * Lds<D>::PER_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int item = blockIdx.x * 4 + wave;
     if (item >= a.total) return;
@@ -283,7 +295,7 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP2 pp) {
     const float lse2 = a.lse[(int64_t)p * a.n + q] * LOG2E;
     if (okq && hh == 0) a.delta[(int64_t)p * a.n + q] = delta;
 
-    const bf16_t* kvp = a.KV + (int64_t)p * a.outer_kv * a.ldk + 8 * hh;
+    const char* kvb = reinterpret_cast<const char*>(a.KV + (int64_t)p * a.outer_kv * a.ldk);   // wave-uniform
     const int wr_off = r * D + 8 * hh;
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
     const int tr_off = (D == 16) ? (4 * hh + gq) * D + 4 * gp : (4 * hh + gq) * D + 16 * c + 4 * gp;   // D = 16: rows 16.. duplicate 0..15 (ignored)
@@ -297,15 +309,20 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP2 pp) {
 
     f32x16_t dq = zero16();
     bf16x8_t kfA[KS], kfB[KS];
+    uint32_t koff = ((uint32_t)r * (uint32_t)a.ldk + 8 * hh) * 2u;         // this lane's piece of key (next tile) + r
+    const uint32_t khalf = (uint32_t)a.ldk * 64u, klast = ((uint32_t)(a.n_kv - 1) * (uint32_t)a.ldk + 8 * hh) * 2u;
     auto load_pair = [&](int k0) {
-        int ka = k0 + r, kb = k0 + 32 + r;
-        ka = ka < a.n_kv ? ka : a.n_kv - 1;
-        kb = kb < a.n_kv ? kb : a.n_kv - 1;
+        uint32_t oa = koff, ob = koff + khalf;
+        if (k0 + 64 > a.n_kv) {                                 // wave-uniform: only a tail tile clamps
+            oa = k0 + r < a.n_kv ? oa : klast;
+            ob = k0 + 32 + r < a.n_kv ? ob : klast;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kfA[s] = ld_frag(kvp + (int64_t)ka * a.ldk + 16 * s);
-            kfB[s] = ld_frag(kvp + (int64_t)kb * a.ldk + 16 * s);
+            kfA[s] = ld_frag_b(kvb, oa + 32 * s);
+            kfB[s] = ld_frag_b(kvb, ob + 32 * s);
         }
+        koff += 2 * khalf;
     };
     load_pair(0);
 
@@ -497,7 +514,8 @@ bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse) {
            f->outer_q >= f->n && f->outer_kv >= f->n_kv && f->P * (int64_t)((f->n + 31) / 32) < (1ll << 30) &&
            f->P * (int64_t)((f->n_kv + 31) / 32) < (1ll << 30) && (!need_lse || f->lse) &&
            f->ldq % 8 == 0 && f->ldk % 8 == 0 && f->ldo % 4 == 0 &&
-           (((uintptr_t)f->Q | (uintptr_t)f->K) & 15) == 0 && ((uintptr_t)f->O & 7) == 0;
+           (((uintptr_t)f->Q | (uintptr_t)f->K) & 15) == 0 && ((uintptr_t)f->O & 7) == 0 &&
+           (int64_t)f->n_kv * f->ldk < (1ll << 30);              // 32-bit byte offsets of the key rows inside a problem
 }
 
 static int xattn_fwd_launch(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) {
