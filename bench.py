@@ -195,8 +195,12 @@ def pmc_traffic(kernel, N, K, epi):
             continue
         c = d.get("classes", {}).get(f"{kernel}|{N}|{K}|{epi}")
         if c is not None:
+            PMC_MFMA[(kernel, N, K, epi)] = c.get("mfma_util_pmc")
             return int(c["hbm_bytes_per_launch"]), f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {c['launches_per_step']} launches of this class per step)"
     return None, None
+
+
+PMC_MFMA = {}        # (kernel, N, K, epilogue) -> rocprof MFMA utilisation of the class's dispatches (tools/ledger.py), filled by pmc_traffic
 
 
 def pmc_step():
@@ -387,11 +391,11 @@ def main():
         gemm_ms = round(sum(c["est_ms_per_step"] for c, _, _ in classes), 2)
         roofs = []
         for c, traffic, traffic_src in classes[:24]:
-            roofs.append(dict(c, traffic=traffic))
+            roofs.append(dict(c, traffic=traffic, mfma_util_pmc=PMC_MFMA.get((c["kernel"], c["N"], c["K"], c["epilogue"]))))
         if classes:
             top, traffic, traffic_src = classes[0]
             roofline = dict(top, traffic=traffic, traffic_unit="bytes/launch, PMC, of THIS class's dispatches (same N, K, epilogue, row count)",
-                            traffic_source=traffic_src)
+                            traffic_source=traffic_src, mfma_util_pmc=PMC_MFMA.get((top["kernel"], top["N"], top["K"], top["epilogue"])))
         else:
             roofline = None
         out = {

@@ -38,17 +38,29 @@ def last_step(rs, key="Kernel_Name"):
     return rs[idx[-2] + 1: idx[-1] + 1]
 
 
-def by_class(tr, fe, wr, seq_path, dst, summary):
+SIMDS, XCDS = 1024, 8          # MI355X: 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE comes summed over the 8 XCDs
+
+
+def mfma_util(mf_cycles, gui_cycles):
+    """rocprof MFMA utilisation of a set of dispatches: matrix-pipe busy cycles (SQ_VALU_MFMA_BUSY_CYCLES, summed over every SIMD of the
+    chip; = 16 x the number of 16x16x32 bf16 MFMAs, MI355X_MICROARCH.md) / (GPU-active cycles per XCD x 1024 SIMDs)."""
+    return round(mf_cycles / max(gui_cycles / XCDS * SIMDS, 1.0), 4)
+
+
+def by_class(tr, fe, wr, seq_path, dst, summary, mf=None, gu=None):
     seq = json.load(open(seq_path))["step"]
-    gd = [(a, b, c) for a, b, c in zip(tr, fe, wr) if short(a["Kernel_Name"]).startswith("gemm_nt")]
+    extra = list(zip(mf, gu)) if mf is not None else [None] * len(tr)
+    gd = [(a, b, c, e) for a, b, c, e in zip(tr, fe, wr, extra) if short(a["Kernel_Name"]).startswith("gemm_nt")]
     if len(gd) != len(seq):
         raise SystemExit(f"{len(gd)} gemm dispatches in the step, {len(seq)} in the sequence file")
     cls = collections.OrderedDict()
-    for (a, b, c), (kern, M, N, K, epi, nbytes) in zip(gd, seq):
+    for (a, b, c, e), (kern, M, N, K, epi, nbytes) in zip(gd, seq):
         if short(a["Kernel_Name"]).split("<")[0] != kern.split("<")[0] or (("<" in kern) and short(a["Kernel_Name"]) != kern):
             raise SystemExit(f"sequence mismatch: trace {short(a['Kernel_Name'])} vs log {kern}")
-        d = cls.setdefault(f"{kern}|{N}|{K}|{epi}", {"n": 0, "ns": 0, "bytes": 0.0, "alg": 0.0, "flops": 0.0, "rows": set()})
+        d = cls.setdefault(f"{kern}|{N}|{K}|{epi}", {"n": 0, "ns": 0, "bytes": 0.0, "alg": 0.0, "flops": 0.0, "rows": set(), "mf": 0.0, "gui": 0.0})
         d["n"] += 1
+        if e is not None:
+            d["mf"] += float(e[0]["Counter_Value"]); d["gui"] += float(e[1]["Counter_Value"])
         d["ns"] += int(a["End_Timestamp"]) - int(a["Start_Timestamp"])
         d["bytes"] += (2 * float(b["Counter_Value"]) + float(c["Counter_Value"])) * 1024
         d["alg"] += nbytes
@@ -60,6 +72,8 @@ def by_class(tr, fe, wr, seq_path, dst, summary):
                   "hbm_bytes_per_launch": round(d["bytes"] / d["n"]), "algorithmic_bytes_per_launch": round(d["alg"] / d["n"]),
                   "traffic_over_algorithmic": round(d["bytes"] / max(d["alg"], 1.0), 3), "tflops": round(d["flops"] / max(d["ns"], 1) / 1e3, 1),
                   "hbm_gbs": round(d["bytes"] / max(d["ns"], 1), 1), "rows": sorted(d["rows"])}
+        if d["gui"] > 0:
+            out[k]["mfma_util_pmc"] = mfma_util(d["mf"], d["gui"])
     out = dict(sorted(out.items(), key=lambda kv: -kv[1]["ms_per_step"]))
     json.dump({"note": "per GEMM class (kernel|N|K|epilogue): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of `bench.py --steps 2 "
                        "--warmup 1`, bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950: FETCH_SIZE tallies 128-B requests as 64 B), "
@@ -72,22 +86,33 @@ def by_class(tr, fe, wr, seq_path, dst, summary):
 
 
 def main(src, dst, seq_path=None):
+    import os
     tr = last_step(rows(src + "_trace.csv.gz"))
     fe = last_step([r for r in rows(src + "_fetch.csv.gz") if r["Counter_Name"] == "FETCH_SIZE"])
     wr = last_step([r for r in rows(src + "_write.csv.gz") if r["Counter_Name"] == "WRITE_SIZE"])
     if not (len(tr) == len(fe) == len(wr)):
         raise SystemExit(f"dispatch counts differ: {len(tr)} {len(fe)} {len(wr)}")
+    mf = gu = None
+    if os.path.exists(src + "_mfma.csv.gz") and os.path.exists(src + "_gui.csv.gz"):
+        mf = last_step([r for r in rows(src + "_mfma.csv.gz") if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"])
+        gu = last_step([r for r in rows(src + "_gui.csv.gz") if r["Counter_Name"] == "GRBM_GUI_ACTIVE"])
+        if not (len(mf) == len(gu) == len(tr)):
+            raise SystemExit(f"dispatch counts differ (MFMA passes): {len(tr)} {len(mf)} {len(gu)}")
     cls = collections.OrderedDict()
     t0, t1 = int(tr[0]["Start_Timestamp"]), int(tr[-1]["End_Timestamp"])
-    for a, b, c in zip(tr, fe, wr):
+    for i, (a, b, c) in enumerate(zip(tr, fe, wr)):
         if not (short(a["Kernel_Name"]) == short(b["Kernel_Name"]) == short(c["Kernel_Name"])):
             raise SystemExit(f"dispatch order differs: {a['Kernel_Name'][:60]} / {b['Kernel_Name'][:60]} / {c['Kernel_Name'][:60]}")
         grid = int(a["Grid_Size_X"]) * int(a["Grid_Size_Y"]) * int(a["Grid_Size_Z"])
         wg = int(a["Workgroup_Size_X"]) * int(a["Workgroup_Size_Y"]) * int(a["Workgroup_Size_Z"])
         k = (short(a["Kernel_Name"]), grid // wg, wg)
         d = cls.setdefault(k, {"n": 0, "ns": 0, "fetch_kb": 0.0, "write_kb": 0.0, "vgpr": int(a["VGPR_Count"]) + int(a["Accum_VGPR_Count"]),
-                               "lds": int(a["LDS_Block_Size"]), "scratch": int(a["Scratch_Size"])})
+                               "lds": int(a["LDS_Block_Size"]), "scratch": int(a["Scratch_Size"]), "mf": 0.0, "gui": 0.0})
         d["n"] += 1
+        if mf is not None:
+            if not (short(mf[i]["Kernel_Name"]) == short(gu[i]["Kernel_Name"]) == short(a["Kernel_Name"])):
+                raise SystemExit(f"dispatch order differs (MFMA passes): {a['Kernel_Name'][:60]}")
+            d["mf"] += float(mf[i]["Counter_Value"]); d["gui"] += float(gu[i]["Counter_Value"])
         d["ns"] += int(a["End_Timestamp"]) - int(a["Start_Timestamp"])
         d["fetch_kb"] += float(b["Counter_Value"])
         d["write_kb"] += float(c["Counter_Value"])
@@ -97,7 +122,8 @@ def main(src, dst, seq_path=None):
         out.append({"kernel": name, "workgroups": wgs, "wg_size": wg, "launches_per_step": d["n"], "us_per_launch": round(d["ns"] / d["n"] / 1e3, 2),
                     "ms_per_step": round(d["ns"] / 1e6, 3), "hbm_mb_per_launch": round(byts / d["n"] / 1e6, 2), "hbm_gb_per_step": round(byts / 1e9, 3),
                     "read_gb_per_step": round(2 * d["fetch_kb"] * 1024 / 1e9, 3), "write_gb_per_step": round(d["write_kb"] * 1024 / 1e9, 3),
-                    "achieved_gbs": round(byts / max(d["ns"], 1), 1), "vgpr": d["vgpr"], "lds": d["lds"], "scratch": d["scratch"]})
+                    "achieved_gbs": round(byts / max(d["ns"], 1), 1), "vgpr": d["vgpr"], "lds": d["lds"], "scratch": d["scratch"],
+                    **({"mfma_util_pmc": mfma_util(d["mf"], d["gui"])} if d["gui"] > 0 else {})})
     out.sort(key=lambda r: -r["ms_per_step"])
     tot_ms = sum(r["ms_per_step"] for r in out)
     tot_gb = sum(r["hbm_gb_per_step"] for r in out)
@@ -106,16 +132,23 @@ def main(src, dst, seq_path=None):
                "hbm_gb_per_step": round(tot_gb, 1), "gemm_ms": round(gemm_ms, 2), "non_gemm_ms": round(tot_ms - gemm_ms, 2),
                "gemm_gb": round(sum(r["hbm_gb_per_step"] for r in out if r["kernel"].startswith("gemm_nt")), 1),
                "bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, rocprofv3 --pmc in separate runs; durations from the counter-free run"}
+    if mf is not None:
+        tmf, tgu = sum(d["mf"] for d in cls.values()), sum(d["gui"] for d in cls.values())
+        gmf = sum(d["mf"] for k, d in cls.items() if k[0].startswith("gemm_nt")); ggu = sum(d["gui"] for k, d in cls.items() if k[0].startswith("gemm_nt"))
+        summary["mfma_util_pmc"] = mfma_util(tmf, tgu)
+        summary["mfma_util_pmc_gemm_kernels"] = mfma_util(gmf, ggu)
+        summary["mfma_util_pmc_what"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), both summed over the step's dispatches, separate "
+                                         "rocprofv3 --pmc runs: the share of SIMD-cycles in which the matrix pipe is busy, at the clock the chip actually runs")
     json.dump({"summary": summary, "classes": out}, open(dst + "_ledger.json", "w"), indent=1)
     with open(dst + "_ledger.md", "w") as f:
         f.write(f"# Step ledger ({src.split('/')[-1]})\n\n{json.dumps(summary)}\n\n")
-        f.write("| kernel | workgroups | x/step | us/launch | ms/step | MB/launch | GB/step | GB/s |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("| kernel | workgroups | x/step | us/launch | ms/step | MB/launch | GB/step | GB/s | MFMA busy |\n|---|---|---|---|---|---|---|---|---|\n")
         for r in out:
             f.write(f"| `{r['kernel']}` | {r['workgroups']} | {r['launches_per_step']} | {r['us_per_launch']} | {r['ms_per_step']} | "
-                    f"{r['hbm_mb_per_launch']} | {r['hbm_gb_per_step']} | {r['achieved_gbs']} |\n")
+                    f"{r['hbm_mb_per_launch']} | {r['hbm_gb_per_step']} | {r['achieved_gbs']} | {r.get('mfma_util_pmc', '')} |\n")
     print(json.dumps(summary))
     if seq_path:
-        by_class(tr, fe, wr, seq_path, dst, summary)
+        by_class(tr, fe, wr, seq_path, dst, summary, mf, gu)
     for r in out[:70]:
         print(f"{r['kernel'][:58]:58s} wg={r['workgroups']:>7d} n={r['launches_per_step']:>3d} us={r['us_per_launch']:>8.1f} ms={r['ms_per_step']:>7.3f} "
               f"MB={r['hbm_mb_per_launch']:>8.1f} GB/s={r['achieved_gbs']:>7.1f} vgpr={r['vgpr']} lds={r['lds']}")

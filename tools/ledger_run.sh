@@ -4,7 +4,10 @@
 #   1. --kernel-trace                 -> gpurun_out/ledger/<tag>_trace.csv.gz   (per dispatch: kernel, grid, workgroup, start / end)
 #   2. --kernel-trace --pmc FETCH_SIZE -> gpurun_out/ledger/<tag>_fetch.csv.gz  (per dispatch counter rows)
 #   3. --kernel-trace --pmc WRITE_SIZE -> gpurun_out/ledger/<tag>_write.csv.gz
-# tools/ledger.py turns them into profiles/<tag>_ledger.{json,md}: class = kernel x grid size, bytes = (2 FETCH + WRITE) KiB.
+#   4. --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -> <tag>_mfma.csv.gz   (matrix-pipe busy cycles, summed over the chip's SIMDs)
+#   5. --kernel-trace --pmc GRBM_GUI_ACTIVE          -> <tag>_gui.csv.gz    (GPU-active cycles, summed over the 8 XCDs)
+# tools/ledger.py turns them into profiles/<tag>_ledger.{json,md}: class = kernel x grid size, bytes = (2 FETCH + WRITE) KiB,
+# MFMA utilisation = MFMA busy cycles / (GPU-active cycles / 8 XCDs x 1024 SIMDs).
 set -u
 tag=${1:-run}; shift || true
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -22,5 +25,11 @@ echo fetch done
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/lg_$tag/w -o run -- python3 $R/bench.py $args > $out/${tag}_write.log 2>&1 || exit 1
 f=$(find /tmp/lg_$tag/w -name '*counter_collection.csv' | head -1); [ -n "$f" ] && gzip -c "$f" > $out/${tag}_write.csv.gz
 echo write done
+for pair in "SQ_VALU_MFMA_BUSY_CYCLES mfma" "GRBM_GUI_ACTIVE gui"; do
+  set -- $pair
+  timeout 600 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d /tmp/lg_$tag/$2 -o run -- python3 $R/bench.py $args > $out/${tag}_$2.log 2>&1 || exit 1
+  f=$(find /tmp/lg_$tag/$2 -name '*counter_collection.csv' | head -1); [ -n "$f" ] && gzip -c "$f" > $out/${tag}_$2.csv.gz
+  echo $2 done
+done
 rm -rf /tmp/lg_$tag
 ls -la $out
