@@ -53,17 +53,6 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* x) {
     const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
     return __builtin_bit_cast(bf16x8_t, w);
 }
-// a * b as ONE v_mul_f32 in program order.  The backward kernels multiply every probability by its dP right behind the exp2 that made it;
-// written as a packed multiply per pair (or left to hipcc's SLP pass) the v_pk_mul_f32 lands directly behind the two v_exp_f32 it depends on
-// and stalls on their latency, 16 times per trip.  `asm volatile` keeps the statements in source order -- four exponentials, then their
-// multiplies -- and keeps them scalar: dQ 1054 -> 850 us, dK / dV 1570 -> 1400 us at stage 0.  Same box, builds interleaved, the WHOLE step went
-// 121.8 -> 115.5 ms (262.8 -> 277.0 clips/s): every other kernel of the step ran ~4 % faster too, i.e. the chip held a higher clock -- measured
-// on two boxes; building with -fno-slp-vectorize (scalar multiplies, compiler-ordered) gives neither effect.
-__device__ __forceinline__ float mul_scalar(float a, float b) {
-    float d;
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
 __device__ __forceinline__ f32x16_t splat16(float v) {
     f32x16_t z;
 #pragma unroll
@@ -366,8 +355,8 @@ __global__ void __launch_bounds__(256, 2) xattn_dq_kernel(XP2 pp) {
             }
             const f32x2_t ea = {__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
             const f32x2_t eb = {__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
-            const f32x2_t ra = {mul_scalar(ea.x, dpA[reg]), mul_scalar(ea.y, dpA[reg + 1])};
-            const f32x2_t rb = {mul_scalar(eb.x, dpB[reg]), mul_scalar(eb.y, dpB[reg + 1])};
+            const f32x2_t ra = ea * (f32x2_t){dpA[reg], dpA[reg + 1]};
+            const f32x2_t rb = eb * (f32x2_t){dpB[reg], dpB[reg + 1]};
             dA[reg] = ra.x; dA[reg + 1] = ra.y; dB[reg] = rb.x; dB[reg + 1] = rb.y;
         }
         lds_sync();
@@ -482,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP2 pp) {
 #pragma unroll
         for (int reg = 0; reg < 16; reg += 2) {                 // exp2 + one packed multiply per pair of scores
             const f32x2_t pv = {__builtin_amdgcn_exp2f(sc[reg]), __builtin_amdgcn_exp2f(sc[reg + 1])};
-            const f32x2_t dv2 = {mul_scalar(pv.x, dp[reg]), mul_scalar(pv.y, dp[reg + 1])};
+            const f32x2_t dv2 = pv * (f32x2_t){dp[reg], dp[reg + 1]};
             pr[reg] = pv.x; pr[reg + 1] = pv.y; ds[reg] = dv2.x; ds[reg + 1] = dv2.y;
         }
 #pragma unroll
