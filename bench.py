@@ -352,6 +352,10 @@ def main():
             json.dump({"steps": args.steps, "launches_per_step": per, "step": seq[-per:] if per else []}, f)
     gp = kernels.gemm_profile_stop()
     final_loss = float(loss.detach())
+    if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
+        # a step that produced NaN / inf is not a measurement (and NaN-filled tensors toggle fewer bits, so the power-limited chip clocks
+        # every kernel HIGHER: such a run looks faster -- DESIGN.md 5.2)
+        raise SystemExit(f"bench.py: non-finite loss {final_loss} after {args.warmup + args.steps} steps -- the run is invalid")
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
