@@ -179,6 +179,25 @@ def cpu_baseline(timeout_s=240):
     return dict(fail, error=(r.stderr or "no output")[-300:])
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` typed without a launcher (no WORLD_SIZE in the environment): start the N ranks as CHILD processes through
+    torch.distributed.run -- the launch line the module docstring gives -- relay their output (rank 0's JSON line) and return their exit
+    code.  This parent imports no torch and makes no HIP call before or after: a child process, never an exec of a GPU-initialised one
+    (what replaces nn.DataParallel's in-process replication, AVE/traintest_adapt_ave29.py:32-35)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 PMC_BY_CLASS = ("r03_pmc_by_class.json",)      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
 
 
@@ -233,10 +252,17 @@ def main():
     ap.add_argument("--gemm-seq", default=None, metavar="PATH",
                     help="write the launch-ordered GEMM class list of ONE step (kernel, M, N, K, epilogue, algorithmic bytes) as JSON: "
                          "tools/ledger.py joins it with a rocprofv3 trace of the same command")
+    ap.add_argument("--microbatch", type=int, default=2,
+                    help="micro-batches per step, each a HIP graph on its own stream, running concurrently (default 2; 1 = one launch chain)")
+    ap.add_argument("--eager", action="store_true", help="time eager single-stream steps only (no HIP graphs, no micro-batch streams): the round-3 form")
+    ap.add_argument("--ddp-one-graph", action="store_true",
+                    help="N > 1: capture the RCCL all-reduce inside the graph too (default: two graphs with the collective eager between them)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -263,16 +289,22 @@ def main():
             raise SystemExit("--fp8 covers the Swin workloads")
         stg_fp8.enable(model)
         workload_desc += "; frozen qkv / proj / fc1 / fc2 / reduction GEMMs (forward + dgrad) on block-scaled e4m3 MFMA"
+    sync = None
     if world > 1:
         ddp.broadcast_parameters(model)
-        ddp.attach(model)
+        sync = ddp.attach(model)
     from stgcma import recipe
     opt = recipe.build_optimizer(model, lr=1e-4, head_lr=0.1, capturable=(world == 1))   # reference recipe: Adam(0.95, 0.999), wd 5e-7, two groups
     loss_fn = torch.nn.CrossEntropyLoss()
     a, v, labels = synth_batch(torch, args.batch, device, rank, args.workload)
 
-    def step():                                                     # traintest_adapt_ave29.py:136-164
-        return recipe.train_step(model, opt, loss_fn, a, v, labels, "fusion")
+    labels2 = labels.reshape(-1, labels.shape[-1])
+
+    def fwd_bwd():                                                  # traintest_adapt_ave29.py:136-163 (recipe.train_step without the optimizer step)
+        loss = loss_fn(model(a, v, "fusion"), labels2)
+        opt.zero_grad()
+        loss.backward()
+        return loss
 
     if args.workload == "avqa":
         g = torch.Generator(device=device).manual_seed(77 + rank)
@@ -283,12 +315,11 @@ def main():
         ans = torch.randint(0, 42, (args.batch,), generator=g, device=device)
         match = torch.tensor([1, 0] * (args.batch * 10), device=device)              # batch_organize: posi / nega interleaved
 
-        def step():                                                 # noqa: F811   traintest_adapt_avqa.py:168-185
+        def fwd_bwd():                                              # noqa: F811   traintest_adapt_avqa.py:168-185
             out_qa, mp, mn = model(aa, vv, vn, qq, "fusion")
             loss = loss_fn(out_qa, ans) + 0.5 * loss_fn(torch.stack((mp, mn), dim=1).reshape(-1, 2), match)
             opt.zero_grad()
             loss.backward()
-            opt.step()
             return loss
 
     if args.workload == "avs":
@@ -298,12 +329,11 @@ def main():
         gt = (torch.rand((args.batch, 1, 224, 224), generator=g, device=device) < 0.3).float()
         bce = torch.nn.BCELoss()
 
-        def step():                                                 # noqa: F811   traintest_adapt_avs.py:158-170, AVS/loss.py:7-26
+        def fwd_bwd():                                              # noqa: F811   traintest_adapt_avs.py:158-170, AVS/loss.py:7-26
             pred, _, _ = model(aa, vv, "fusion")
             loss = bce(torch.sigmoid(pred)[::5], gt)
             opt.zero_grad()
             loss.backward()
-            opt.step()
             return loss
 
     if args.workload in ("avs_backbone", "avqa_backbone"):
@@ -314,7 +344,7 @@ def main():
         vn = torch.randn((args.batch, T, 3, 224, 224), generator=g, device=device) if args.workload == "avqa_backbone" else None
         ups = {}
 
-        def step():                                                 # noqa: F811
+        def fwd_bwd():                                              # noqa: F811
             if vn is None:
                 ms, a_feat = model.forward_features(aa, vv)
                 outs = list(ms) + [a_feat]
@@ -327,30 +357,100 @@ def main():
                 loss = loss + (o * ups[i]).sum()
             opt.zero_grad()
             loss.backward()
-            opt.step()
             return loss
+
+    def step():
+        loss = fwd_bwd()
+        opt.step()
+        return loss
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    MB_OK = ("swin_b", "swin_l", "vit_b")                 # no cross-sample statistic, no task-head gradient bucket: micro-batches are exact
+    nmb = args.microbatch if (args.workload in MB_OK and args.batch % max(args.microbatch, 1) == 0 and not args.fp8) else 1
+    labels3 = labels.view(args.batch, -1, labels.shape[-1])
+
+    def fwd_loss(a_, v_, y_):                                       # one micro-batch: forward + the harness's loss
+        return loss_fn(model(a_, v_, "fusion"), y_.reshape(-1, y_.shape[-1]))
+
+    # ---------------------------------------------------------------------------------------------------------------- pass 1: eager
+    # One stream, one launch per kernel (the round-3 form): the pass the per-class / per-family roofline samples come from (HIP events
+    # around individual launches need eager launches).  At N = 1 it is timed as a whole too (`eager_single_stream`); at N > 1 it is
+    # the warm-up (its first step, which learns the kernel of every call signature, is not sampled).
     kernels.gemm_profile_start(log_sequence=args.gemm_seq is not None)   # learns, during the warm-up, which kernel the C dispatch picks per call signature
-    for _ in range(args.warmup):
+    kernels.family_profile_start()
+    for i in range(args.warmup):
         step()
+        if world > 1 and i == 0:
+            kernels.gemm_profile_reset()
+            kernels.family_profile_reset()
     fence()
-    kernels.gemm_profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
+    prof_steps = max(args.warmup - 1, 1)
+    dt_eager = None
+    if world == 1:
+        kernels.gemm_profile_reset()
+        kernels.family_profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        dt_eager = time.perf_counter() - t0
+        prof_steps = args.steps
     if args.gemm_seq is not None and rank == 0:
         seq = kernels.gemm_profile_sequence()
-        per = len(seq) // max(args.steps, 1)
+        per = len(seq) // max(prof_steps, 1)
         with open(args.gemm_seq, "w") as f:
-            json.dump({"steps": args.steps, "launches_per_step": per, "step": seq[-per:] if per else []}, f)
-    gp = kernels.gemm_profile_stop()
+            json.dump({"steps": prof_steps, "launches_per_step": per, "step": seq[-per:] if per else []}, f)
+    gp, fams = kernels.gemm_profile_stop(), kernels.family_profile_stop()
+
+    # ---------------------------------------------------------------------------------------------------------------- pass 2: the timed steps
+    # The product's step (recipe.capture_train_step_mb): `nmb` micro-batches, each forward + backward a HIP graph on its own stream,
+    # running CONCURRENTLY (two independent launch chains fill each other's ramps and tails: DESIGN.md section 5.3), then a join graph
+    # (gradient sum + Adam).  N > 1: the summed arena is all-reduced eagerly between the join graph and the optimizer graph, so a rank's
+    # host issues ~4 graph launches + 1 collective per step instead of ~1 200 kernel launches.  --microbatch 1: N = 1 keeps the eager
+    # pass as the measurement; N > 1 replays recipe.capture_train_step_ddp's two graphs.  Every rank must take the same path: the ranks
+    # agree on "captured" before the first replay and fall back to eager steps together.
+    replay, static_loss, step_how = None, None, "eager, one stream"
+    want_graph = (nmb > 1 or world > 1) and not args.eager
+    if want_graph:
+        loss = None
+        import gc
+        gc.collect()                  # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream
+        ok, why = 1, ""
+        try:
+            if nmb > 1:
+                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, (a, v, labels3), opt, splits=nmb, sync=sync, warmup=1)
+            else:
+                replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
+        except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)
+            ok, why = 0, repr(e)[:200]
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if not ok:
+            if replay is not None and hasattr(replay, "release"):
+                replay.release()
+            replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
+        else:
+            for _ in range(2):
+                replay()
+        fence()
+    if replay is not None or world > 1:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if replay is not None:
+                replay()
+                loss = static_loss
+            else:
+                loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+    else:
+        dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
     final_loss = float(loss.detach())
     if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
         # a step that produced NaN / inf is not a measurement (and NaN-filled tensors toggle fewer bits, so the power-limited chip clocks
@@ -364,6 +464,7 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         value = clips / dt
+        eager_ms = dt_eager / args.steps * 1e3 if dt_eager is not None else None
         # Roofline per GEMM class (class = kernel the C dispatch chose x N x K x epilogue signature): achieved = algorithmic FLOPs
         # (2 M N K) or algorithmic bytes (every operand / output once) of the class's sampled launches / their HIP-event durations,
         # events on the launch stream inside the timed region (kernels.gemm_profile_start).  Each class is priced against ITS bound:
@@ -387,9 +488,9 @@ def main():
                  "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                  "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
                  "tflops": round(tf, 1), "gbs": round(tbs * 1e3, 0), "flop_per_byte": round(intensity, 1),
-                 "launches_per_step": round(pc["launches"] / max(args.steps, 1), 2), "avg_launch_us": round(avg_us, 2),
+                 "launches_per_step": round(pc["launches"] / prof_steps, 2), "avg_launch_us": round(avg_us, 2),
                  "gflop_per_launch": round(pc["sampled_flops"] / ns / 1e9, 2), "algorithmic_bytes_per_launch": round(pc["sampled_bytes"] / ns),
-                 "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * pc["launches"] / max(args.steps, 1), 3)}
+                 "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * pc["launches"] / prof_steps, 3)}
             classes.append((c, traffic, traffic_src))
         classes.sort(key=lambda t: -t[0]["est_ms_per_step"])
         gemm_ms = round(sum(c["est_ms_per_step"] for c, _, _ in classes), 2)
@@ -402,6 +503,56 @@ def main():
                             traffic_source=traffic_src, mfma_util_pmc=PMC_MFMA.get((top["kernel"], top["N"], top["K"], top["epilogue"])))
         else:
             roofline = None
+        # The other half of the step, the same way (kernels.family_profile_*): per family x shape key the algorithmic bytes (every operand /
+        # output once) and FLOPs of its sampled launches / their HIP-event durations.  Bound: HBM, except the families whose floor is the
+        # matrix pipe or VALU issue (frame-global cross-modal attention, the fused stage-0 MLP, the ViT / generic attention kernels).
+        MFMA_FAMILIES = ("xattn_fwd", "xattn_bwd", "mlp_fused_fwd", "mlp_fused_bwd", "mha_fwd", "mha_bwd")
+        nsteps_prof = prof_steps
+        fam_rows = []
+        for fc in fams:
+            if fc["sampled"] == 0 or fc["sampled_ms"] <= 0:
+                continue
+            ns, sec = fc["sampled"], fc["sampled_ms"] * 1e-3
+            avg_us = fc["sampled_ms"] * 1e3 / ns
+            tf, tbs = fc["sampled_flops"] / sec / 1e12, fc["sampled_bytes"] / sec / 1e12
+            bound = "mfma" if fc["family"] in MFMA_FAMILIES else "hbm"
+            fam_rows.append({"family": fc["family"], "key": fc["key"], "bound": bound,
+                             "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
+                             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
+                             "gbs": round(tbs * 1e3), "tflops": round(tf, 1), "launches_per_step": round(fc["launches"] / nsteps_prof, 2),
+                             "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": round(fc["sampled_bytes"] / ns),
+                             "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * fc["launches"] / nsteps_prof, 3)})
+        fam_rows.sort(key=lambda r: -r["est_ms_per_step"])
+        fam_ms = round(sum(r["est_ms_per_step"] for r in fam_rows), 2)
+        fam_tot = {}
+        for r in fam_rows:
+            t = fam_tot.setdefault(r["family"], {"family": r["family"], "bound": r["bound"], "est_ms_per_step": 0.0, "_b": 0.0, "_f": 0.0})
+            t["est_ms_per_step"] += r["est_ms_per_step"]
+            t["_b"] += r["algorithmic_bytes_per_launch"] * r["launches_per_step"]
+            t["_f"] += r["tflops"] * r["est_ms_per_step"]
+        fam_summary = []
+        for t in sorted(fam_tot.values(), key=lambda t: -t["est_ms_per_step"]):
+            ms = max(t["est_ms_per_step"], 1e-9)
+            gbs, tfl = t["_b"] / ms / 1e6, t["_f"] / ms
+            fam_summary.append({"family": t["family"], "bound": t["bound"], "est_ms_per_step": round(ms, 3), "gbs": round(gbs), "tflops": round(tfl, 1),
+                                "frac": round(tfl / PEAK_BF16_TFLOPS if t["bound"] == "mfma" else gbs / (PEAK_HBM_TBS * 1e3), 4)})
+        # roofline_kernel: the dominant rocprof KERNEL aggregated over its classes, so that this line and profiles/*_kernel_stats.csv name the
+        # same object (the per-class `roofline` above names the largest class)
+        by_kernel = {}
+        for c, _, _ in classes:
+            k = by_kernel.setdefault(c["kernel"], {"kernel": c["kernel"], "ms": 0.0, "gflop": 0.0, "gb": 0.0, "launches": 0.0})
+            k["ms"] += c["est_ms_per_step"]
+            k["gflop"] += c["gflop_per_launch"] * c["launches_per_step"]
+            k["gb"] += c["algorithmic_bytes_per_launch"] * c["launches_per_step"] / 1e9
+            k["launches"] += c["launches_per_step"]
+        roofline_kernel = None
+        if by_kernel:
+            k = max(by_kernel.values(), key=lambda k: k["ms"])
+            tf = k["gflop"] / max(k["ms"], 1e-9)
+            roofline_kernel = {"kernel": k["kernel"], "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / PEAK_BF16_TFLOPS, 4), "est_ms_per_step": round(k["ms"], 3), "launches_per_step": round(k["launches"], 1),
+                               "avg_launch_us": round(k["ms"] * 1e3 / max(k["launches"], 1e-9), 2), "gbs": round(k["gb"] / max(k["ms"], 1e-9) * 1e3),
+                               "what": "all classes routed to this kernel, algorithmic FLOPs / HIP-event time"}
         out = {
             "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
@@ -414,9 +565,23 @@ def main():
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),
             "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),
-            "roofline": roofline, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms,
-            "non_gemm_est_ms_per_step": round(dt / args.steps * 1e3 - gemm_ms, 2), "step_traffic": pmc_step(),
+            "roofline": roofline, "roofline_kernel": roofline_kernel, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms,
+            "non_gemm_est_ms_per_step": round(eager_ms - gemm_ms, 2) if eager_ms else None,
+            "roofline_families": fam_summary, "roofline_family_classes": fam_rows[:40], "family_est_ms_per_step": fam_ms,
+            "step_traffic": pmc_step(),
         }
+        # what the roofline objects were sampled in, and how much of that pass's step they account for
+        out["roofline_pass"] = {
+            "what": ("the eager single-stream pass of this same run (one launch per kernel, HIP events around every 7th / 5th launch of a class): "
+                     + (f"{args.steps} timed steps" if world == 1 else f"the {prof_steps} warm-up step(s) after the first")
+                     + "; the timed `value` steps replay HIP graphs, which carry no events, and run two launch chains concurrently, where a "
+                       "kernel's own duration is not defined"),
+            "ms_per_step": round(eager_ms, 3) if eager_ms else None,
+            "value": round(args.batch * world / (eager_ms * 1e-3), 3) if eager_ms else None, "unit": "clips/s",
+            "accounted_ms_per_step": round(gemm_ms + fam_ms, 2),
+            "accounted_frac": round((gemm_ms + fam_ms) / eager_ms, 4) if eager_ms else None}
+        out["config"]["step"] = step_how
+        out["config"]["options"] = stgcma.options() if hasattr(stgcma, "options") else None
         # the same step replayed from a HIP graph (N = 1, --graph): reported next to the eager number, which stays `value` -- the roofline
         # sampling above needs eager launches (HIP events around individual kernels).  It runs AFTER the headline object is complete and
         # the line is printed in `finally`, so nothing in here can lose the measurement.

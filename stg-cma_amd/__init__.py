@@ -13,3 +13,5 @@ The directory name carries a hyphen, so import it as `import stgcma` (top-level 
 `importlib.import_module("stg-cma_amd")`.
 """
 __version__ = "0.1.0"
+
+from .config import configure, options  # noqa: E402,F401

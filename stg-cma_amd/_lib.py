@@ -239,10 +239,9 @@ def lib():
         raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version {ABI_VERSION}")
     _lib = handle
     # A/B knobs of tools/ (never set in production): forwarded ONCE from the environment to the library's explicit options
-    for env, opt in (("STG_GEMM_EPI", "gemm_epi"), ("STG_GEMM_KTAIL", "gemm_ktail"), ("STG_GEMM_BIG", "gemm_big"),
-                     ("STG_GEMM_8PH", "gemm_8ph"), ("STG_GEMM_8PHM", "gemm_8phm"), ("STG_GEMM_DBG", "gemm_dbg"), ("STG_XATTN", "xattn"), ("STG_WINATTN_BWD_OCC", "winattn_bwd_occ"), ("STG_TATTN_KERNELS", "tattn")):
-        if env in os.environ:
-            check(handle.stg_set_option(opt.encode(), int(os.environ[env])), f"stg_set_option({opt})")
+    from . import config                     # (config.py reads the environment once; configure(lib_<option>=...) lands here too)
+    for opt, val in config.lib_options().items():
+        check(handle.stg_set_option(opt.encode(), int(val)), f"stg_set_option({opt})")
     return _lib
 
 

@@ -46,6 +46,12 @@ class GradSync:
         self._hooked = set()
         self._acc = 0
         self._armed = -1                       # id of the backward pass whose end-of-pass callback is queued
+        # deferred mode (recipe.capture_train_step_ddp): backward only RECORDS what has to be averaged -- the arena, and the packed
+        # bucket of the task heads -- so that forward + backward can live in one HIP graph, the collectives run eagerly between two
+        # graph launches (flush) and the bucket is written back to the .grad tensors inside the second graph (scatter_back)
+        self.defer = False
+        self._pending = []
+        self._bucket = None
 
     # ---------------------------------------------------------------- the collective
     def _average(self, flat):
@@ -62,7 +68,11 @@ class GradSync:
         """Average `flat` in place.  n_real: gradient elements in it when it carries alignment padding."""
         self.calls += 1
         self._acc += flat.numel() if n_real is None else n_real
-        self._average(flat)
+        if self.defer:
+            if not any(f is flat for f in self._pending):
+                self._pending.append(flat)
+        else:
+            self._average(flat)
         if len(self._hooked) != len(self.extra):
             self.rewatch()
         self._arm()
@@ -82,6 +92,11 @@ class GradSync:
         ps = [p for p in self.extra if p.requires_grad]
         if ps:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps])
+            if self.defer:                     # packed inside the capture; averaged by flush(), written back by scatter_back()
+                self._bucket = (flat, ps)
+                self._acc += flat.numel()
+                self.last_numel, self._acc = self._acc, 0
+                return
             self._average(flat)
             off = 0
             for p in ps:
@@ -93,6 +108,27 @@ class GradSync:
                     p.grad.copy_(seg)
             self._acc += flat.numel()
         self.last_numel, self._acc = self._acc, 0
+
+    def flush(self):
+        """Deferred mode: run the collectives the last backward pass recorded (eagerly, on the current stream)."""
+        for f in self._pending:
+            self._average(f)
+        if self._bucket is not None:
+            self._average(self._bucket[0])
+
+    def scatter_back(self):
+        """Deferred mode: copy the averaged task-head bucket back into the parameters' .grad tensors (capturable: copies only)."""
+        if self._bucket is None:
+            return
+        flat, ps = self._bucket
+        off = 0
+        for p in ps:
+            seg = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+            if p.grad is None:
+                p.grad = seg.to(p.dtype).clone()
+            else:
+                p.grad.copy_(seg)
 
     def watch(self, params):
         """Route parameters whose gradients do not pass through the backbone arena into the end-of-backward bucket.  Frozen

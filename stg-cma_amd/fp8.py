@@ -63,4 +63,5 @@ def enabled(model):
 
 
 def env_default():
-    return os.environ.get("STG_FP8", "0") not in ("", "0")
+    from . import config
+    return bool(config.opt("fp8"))

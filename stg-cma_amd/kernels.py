@@ -83,6 +83,73 @@ def _zero_line(device):
     return z
 
 
+# ------------------------------------------------------------------------------------------------ per-family accounting (bench.py roofline_families)
+# The non-GEMM half of the step, accounted like the GEMM classes (gemm_profile_*): a wrapper decorated with @_family(name, cost) reports, per
+# launch, its ALGORITHMIC bytes (every operand / output once, from the shapes the wrapper already checks) and FLOPs; every stride-th launch of
+# a (family, key) class is bracketed by HIP events on the launch stream.  Off (one global test per call) unless bench.py turns it on.
+import functools as _functools
+
+_fam_prof = None
+
+
+def family_profile_start(stride=5):
+    global _fam_prof
+    _fam_prof = {"stride": int(stride), "classes": {}}
+
+
+def family_profile_reset():
+    if _fam_prof is not None:
+        _fam_prof["classes"] = {}
+
+
+def family_profile_stop():
+    """[{family, key, launches, bytes, flops, sampled, sampled_ms, sampled_bytes, sampled_flops}] since the last reset."""
+    global _fam_prof
+    prof, _fam_prof = _fam_prof, None
+    if prof is None:
+        return []
+    torch.cuda.synchronize()
+    out = []
+    for (name, key), pc in prof["classes"].items():
+        rec = pc["rec"]
+        out.append({"family": name, "key": key, "launches": pc["launches"], "bytes": pc["bytes"], "flops": pc["flops"], "sampled": len(rec),
+                    "sampled_ms": sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec), "sampled_bytes": sum(r[2] for r in rec),
+                    "sampled_flops": sum(r[3] for r in rec)})
+    return out
+
+
+def _family(name, cost):
+    """cost(*args, **kwargs) -> (key, algorithmic bytes, FLOPs) of the call (computed from shapes only, before the launch)."""
+    def deco(fn):
+        @_functools.wraps(fn)
+        def wrapped(*a, **kw):
+            prof = _fam_prof
+            if prof is None:
+                return fn(*a, **kw)
+            key, nbytes, flops = cost(*a, **kw)
+            ck = (name, key)
+            pc = prof["classes"].get(ck)
+            if pc is None:
+                pc = prof["classes"][ck] = {"launches": 0, "bytes": 0.0, "flops": 0.0, "rec": []}
+            pc["launches"] += 1
+            pc["bytes"] += nbytes
+            pc["flops"] += flops
+            if pc["launches"] % prof["stride"]:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            pc["rec"].append((e0, e1, nbytes, flops))
+            return r
+        return wrapped
+    return deco
+
+
+def _nb(*ts):
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
+
+
 def conv3x3_gemm_supported(Cin):
     return Cin % 64 == 0 or Cin in (8, 16, 32)
 
@@ -308,9 +375,9 @@ def bmm_tn(A, B, rows):
 
 
 _gemm_prof = None
-import os as _os
-USE_WGRAD_WS = _os.environ.get("STG_WGRAD_WS", "1") != "0"    # 0 = atomic wgrad kernels only (A/B knob)
-USE_WGRAD_MULTI = _os.environ.get("STG_WGRAD_MULTI", "1") != "0"   # 0 = one launch pair per adapter Linear (A/B knob)
+from . import config as _cfg
+USE_WGRAD_WS = _cfg.opt("wgrad_ws")          # 0 = atomic wgrad kernels only (A/B knob)
+USE_WGRAD_MULTI = _cfg.opt("wgrad_multi")    # 0 = one launch pair per adapter Linear (A/B knob)
 
 
 GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GLDS: "gemm_nt_glds_kernel<1, false, false, false>",
@@ -358,6 +425,7 @@ def gemm_profile_stop():
     return out
 
 
+@_family("wgrad", lambda dY, X, dW, db=None, **kw: ((dY.shape[1], X.shape[1]), _nb(dY, X) + 4.0 * dW.numel(), 2.0 * dY.shape[0] * dY.shape[1] * X.shape[1]))
 def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inner=1):
     """dW[N1,N2] += (s * dY).T @ X ; db[N1] += (s * dY).sum(0)   (fp32 accumulate into existing buffers).
     n1: use only the first n1 columns of dY (dY may be zero-padded to a multiple of 8 columns)."""
@@ -422,6 +490,7 @@ def mlp_w2_perm(hidden, device):
     return t
 
 
+@_family("mlp_fused_fwd", lambda Y, W1, b1, W2p, b2, out=None: (Y.shape[1], 2.0 * _nb(Y) + _nb(W1, W2p), 16.0 * Y.shape[0] * Y.shape[1] * Y.shape[1]))
 def mlp_fwd(Y, W1, b1, W2p, b2, out=None):
     """out = fc2(GELU(fc1(Y))) in one kernel (stg_mlp_fwd).  Y [rows, C] bf16, W1 [4C, C] bf16, W2p [C, 4C] bf16 = W2[:, mlp_w2_perm]."""
     rows, C_ = Y.shape
@@ -439,6 +508,7 @@ def mlp_fwd(Y, W1, b1, W2p, b2, out=None):
     return out
 
 
+@_family("mlp_fused_bwd", lambda Y, dM, W1, b1, W2T, out=None: (Y.shape[1], 3.0 * _nb(Y) + _nb(W1, W2T), 24.0 * Y.shape[0] * Y.shape[1] * Y.shape[1]))
 def mlp_bwd(Y, dM, W1, b1, W2T, out=None):
     """dY = ((dM @ W2) * GELU'(Y @ W1.T + b1)) @ W1 in one kernel (stg_mlp_bwd).  W2T [4C, C] bf16 = fc2.weight.T."""
     rows, C_ = Y.shape
@@ -457,6 +527,8 @@ def mlp_bwd(Y, dM, W1, b1, W2T, out=None):
     return out
 
 
+@_family("wgrad", lambda problems: (("multi", len(problems), problems[0][0].shape[1], problems[0][1].shape[1]) if problems else ("multi", 0, 0, 0),
+                                    sum(_nb(q[0], q[1]) + 4.0 * q[2].numel() for q in problems), sum(2.0 * q[0].shape[0] * q[0].shape[1] * q[1].shape[1] for q in problems)))
 def wgrad_tn_multi(problems):
     """Several wgrad_tn calls at once: problems = [(dY, X, dW, db, row_scale, rs_outer, rs_inner)].  Problems that share a launch
     plan of the workspace path (same M, narrow-width class, wide width) go out as ONE pair of launches (stg_wgrad_tn_ws_multi);
@@ -495,6 +567,8 @@ def wgrad_tn_multi(problems):
         wgrad_tn(dY, X, dW, db, row_scale=rs, rs_outer=ro, rs_inner=ri)
 
 
+@_family("ln_fwd", lambda x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None, out_dtype=BF16:
+         (gamma.numel(), _nb(x) + x.numel() * (2.0 if out is None and out_dtype == BF16 else (out.element_size() if out is not None else 4.0)), 0.0))
 def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, out=None, out_dtype=BF16):
     """x: [rows, C] bf16/fp32 -> y bf16 (+ mean, rstd).  gather4=(H, W): PatchMerging gather, x is [F*H*W, C] -> y [F*H*W/4, 4C]."""
     if x.dtype not in (BF16, F32):
@@ -523,6 +597,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, gather4=None, want_stats=True, ou
     return y, mean, rstd
 
 
+@_family("ln_bwd", lambda dy, x, gamma, mean, rstd, *, add_to=None, **kw: (gamma.numel(), _nb(dy, x, add_to) + 2.0 * x.numel(), 0.0))
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, add_to=None, gather4=None, dgamma=None, dbeta=None):
     """Returns dx (bf16, shaped like x).  add_to (shaped like x) is added to the result."""
     _chk2d(x, "x", x.dtype)
@@ -554,6 +629,8 @@ def up_ln_supported(C_, K_):
     return bool(_lib.lib().stg_up_ln_supported(int(C_), int(K_)))
 
 
+@_family("upln_fwd", lambda h, w, bias, res32, gamma, beta, *, res16=None, **kw:
+         ((w.shape[0], h.shape[1]), _nb(h, w, res32, res16) + 6.0 * res32.numel(), 2.0 * h.shape[0] * h.shape[1] * w.shape[0]))
 def up_ln_fwd(h, w, bias, res32, gamma, beta, *, res16=None, row_scale=None, rs_outer=1, rs_inner=1, out=None, eps=1e-5,
               want_stats=True, y_out=None, mean_out=None, rstd_out=None):
     """x = res32 (+ res16) + rs * (h w^T + bias) (fp32) and y = LayerNorm(x) * gamma + beta (bf16) in one pass.
@@ -600,6 +677,8 @@ def ln_bwd_down_supported(C_, J_):
     return bool(_lib.lib().stg_ln_bwd_down_supported(int(C_), int(J_)))
 
 
+@_family("ln_bwd_down", lambda dy, x, gamma, mean, rstd, wt, *, add_to=None, **kw:
+         ((x.shape[1], wt.shape[0]), _nb(dy, x, add_to, wt) + 2.0 * x.numel() + 2.0 * x.shape[0] * wt.shape[0], 2.0 * x.shape[0] * x.shape[1] * wt.shape[0]))
 def ln_bwd_down(dy, x, gamma, mean, rstd, wt, *, add_to=None, row_scale=None, rs_outer=1, rs_inner=1, dx_out=None):
     """dx = LayerNorm backward (+ add_to), bf16, and dh = rs * (dx wt^T), bf16, in one pass.  x [M, C] fp32 (the normalised
     residual row), dy / add_to [M, C] bf16, wt [J, C] bf16 (transposed shadow of D_fc2.weight).  Returns (dx, dh)."""
@@ -630,6 +709,9 @@ def ln_bwd_down(dy, x, gamma, mean, rstd, wt, *, add_to=None, row_scale=None, rs
     return dx, dh
 
 
+@_family("ln_bwd_down", lambda dy, xhat, rstd, wt, *, add_to=None, **kw:
+         ((xhat.shape[1], wt.shape[0]), _nb(dy, xhat, add_to, wt) + 2.0 * xhat.numel() + 2.0 * xhat.shape[0] * wt.shape[0],
+          2.0 * xhat.shape[0] * xhat.shape[1] * wt.shape[0]))
 def ln_bwd_down_xhat(dy, xhat, rstd, wt, *, add_to=None, row_scale=None, rs_outer=1, rs_inner=1, dx_out=None):
     """ln_bwd_down from the NORMALISED row: xhat [M, C] bf16 (what the forward wrote in place of y; gamma / beta live in the frozen
     GEMM weight behind it), rstd [M].  Returns (dx, dh)."""
@@ -658,6 +740,7 @@ def ln_bwd_down_xhat(dy, xhat, rstd, wt, *, add_to=None, row_scale=None, rs_oute
     return dx, dh
 
 
+@_family("ln_bwd", lambda dy, xhat, rstd, add_to=None: (xhat.shape[1], _nb(dy, xhat, add_to) + 2.0 * xhat.numel(), 0.0))
 def layernorm_bwd_xhat(dy, xhat, rstd, add_to=None):
     """LayerNorm backward wrt the input from the NORMALISED row (gamma == 1): dx bf16 = rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add_to)."""
     _chk2d(xhat, "xhat", BF16)
@@ -687,6 +770,7 @@ def gate_fwd(h, r, gate):
     return out
 
 
+@_family("elementwise", lambda h0, *a: ("gate_fwd2", 6.0 * _nb(h0), 0.0))
 def gate_fwd2(h0, r0, g0, h1, r1, g1):
     """gate_fwd on two equally sized problems, one launch: returns (out0, out1)."""
     for t in (h0, r0, h1, r1):
@@ -699,6 +783,7 @@ def gate_fwd2(h0, r0, g0, h1, r1, g1):
     return o0, o1
 
 
+@_family("elementwise", lambda d0, *a: ("gate_bwd2", 6.0 * _nb(d0), 0.0))
 def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
     """gate_bwd on two equally sized problems, one launch: returns (dr0, dr1); dgate0 / dgate1 accumulate."""
     for t in (d0, r0, d1, r1):
@@ -713,6 +798,7 @@ def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
     return o0, o1
 
 
+@_family("elementwise", lambda a0, *a, **kw: ("add3_mul2", 10.0 * _nb(a0), 0.0))
 def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
     """add3_mul on two equally sized problems, one launch: returns (out0, out1)."""
     for t in (a0, b0, c0, z0, a1, b1, c1, z1):
@@ -739,6 +825,7 @@ def gate_bwd(dout, r, gate, dgate):
     return dr
 
 
+@_family("elementwise", lambda a, b, c=None, out=None: ("add", (3.0 if c is None else 4.0) * _nb(a), 0.0))
 def add(a, b, c=None, out=None):
     """out = a + b (+ c), bf16; `out` may alias an input (element-wise)."""
     _chk_flat(a, "a"); _chk_flat(b, "b")
@@ -774,6 +861,7 @@ def add3_mul(a, b, c, z, out=None):
     return out
 
 
+@_family("elementwise", lambda dh, z, out=None: ("act_bwd", 2.0 * _nb(dh) + _nb(z), 0.0))
 def act_bwd(dh, z, out=None):
     """dz = dh * z, z = the activation derivative saved by gemm_nt(want_dact=True)."""
     _chk_flat(dh, "dh"); _chk_flat(z, "z")
@@ -992,6 +1080,14 @@ def _attn_fill(a, g, Q, K, V, O, lse):
         a.mask = _p(g.mask)
 
 
+def _attn_cost(g, nin, nout, nmm):
+    """Generic / frame-global / ViT attention: nin input + nout output tensors of P * n (or n_kv) rows x H * D bf16; nmm n x n_kv x D products."""
+    P, H, n, D = g.P, g.H, g.n, g.D
+    nkv = getattr(g, "n_kv", n)
+    return (H * D, n), 2.0 * P * H * D * (nin * 0.5 * (n + nkv) + nout * n), 2.0 * nmm * P * H * n * nkv * D
+
+
+@_family("attn_fwd", lambda g, *a, **kw: _attn_cost(g, 3, 1, 2))
 def attn_fwd(g, Q, K, V, out=None, want_lse=True):
     """Q/K/V: 2-D bf16 (possibly column-slice views of a fused qkv buffer).  Returns (O, lse)."""
     dev = Q.device
@@ -1008,6 +1104,7 @@ def attn_fwd(g, Q, K, V, out=None, want_lse=True):
     return out, lse
 
 
+@_family("xattn_fwd", lambda g0, Q0, K0, V0, g1, *a: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(g0, 2, 1, 2))))
 def attn_fwd2(g0, Q0, K0, V0, g1, Q1, K1, V1):
     """Two attn_fwd problems (the two directions of a cross-modal pair) in one call; the frame-global kernels share a launch.
     Returns ((O0, lse0), (O1, lse1))."""
@@ -1026,6 +1123,7 @@ def attn_fwd2(g0, Q0, K0, V0, g1, Q1, K1, V1):
     return outs[0], outs[1]
 
 
+@_family("xattn_bwd", lambda p0, p1: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(p0[0], 4, 2, 5))))
 def attn_bwd2(p0, p1):
     """Two shared-K/V attn_bwd problems in one call: p = (g, Q, KV, O, lse, dO).  Returns ((dQ0, dKV0), (dQ1, dKV1))."""
     res, args, keep = [], [], []
@@ -1050,6 +1148,7 @@ def attn_bwd2(p0, p1):
     return res[0], res[1]
 
 
+@_family("attn_bwd", lambda g, *a, **kw: _attn_cost(g, 5, 3, 5))
 def attn_bwd(g, Q, K, V, O, lse, dO, *, dQ=None, dK=None, dV=None, shared_kv=False, dbias=None):
     """Returns (dQ, dK, dV).  shared_kv: K and V are the same tensor -> dV is None and dK holds dK + dV."""
     dev = Q.device
@@ -1149,6 +1248,7 @@ def _win_fill(g, Q, K, V, O, lse):
     return a
 
 
+@_family("winattn_fwd", lambda g, Q, *a, **kw: (g.H * 32, 8.0 * (g.P // g.G) * g.outer * g.H * 32, 4.0 * g.P * g.H * g.n * g.n * 32))
 def winattn_fwd(g, Q, K, V, out=None, want_lse=True):
     """Returns (O bf16 [rows, H*32], lse fp32 [P, H, 64] or None)."""
     if out is None:
@@ -1159,6 +1259,7 @@ def winattn_fwd(g, Q, K, V, out=None, want_lse=True):
     return out, lse
 
 
+@_family("winattn_bwd", lambda g, Q, *a, **kw: (g.H * 32, 16.0 * (g.P // g.G) * g.outer * g.H * 32, 10.0 * g.P * g.H * g.n * g.n * 32))
 def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     """dQ / dK / dV: column slices of one bf16 buffer (same leading dimension), written in place."""
     if lse is None or lse.dtype != F32 or lse.numel() != g.P * g.H * 64:
@@ -1220,6 +1321,7 @@ def _tattn_fill(g, Q, K, V, O):
     return a
 
 
+@_family("tattn_fwd", lambda g, Q, *a, **kw: (g.H * g.D, 8.0 * g.rows * g.H * g.D, 4.0 * g.rows * g.H * g.T * g.D))
 def tattn_fwd(g, Q, K, V, out=None):
     """Returns O bf16 [rows, H*32]; fills g.bm / g.bmT."""
     if out is None:
@@ -1229,6 +1331,7 @@ def tattn_fwd(g, Q, K, V, out=None):
     return out
 
 
+@_family("tattn_bwd", lambda g, Q, *a, **kw: (g.H * g.D, 14.0 * g.rows * g.H * g.D, 10.0 * g.rows * g.H * g.T * g.D))
 def tattn_bwd(g, Q, K, V, dO, *, dQ, dK, dV, dbias=None):
     """dQ / dK / dV: column slices of one bf16 buffer, written in place; dbias fp32 [nm, H, T*T] accumulated (optional).
     g must be the TGeom the forward ran with (its tables are reused)."""
@@ -1279,6 +1382,7 @@ def _mha_fill(g, Q, K, V, O, lse):
     return a
 
 
+@_family("mha_fwd", lambda g, *a, **kw: _attn_cost(g, 3, 1, 2))
 def mha_fwd(g, Q, K, V, out=None):
     """Returns (O bf16 [rows, H*D], lse fp32 [P, H, n] in the log2 domain)."""
     if out is None:
@@ -1289,6 +1393,7 @@ def mha_fwd(g, Q, K, V, out=None):
     return out, lse
 
 
+@_family("mha_bwd", lambda g, *a, **kw: _attn_cost(g, 5, 3, 5))
 def mha_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     """dV=None: K and V are one tensor (cross-modal attention) and dK receives its whole gradient dK + dV."""
     if dV is None and K.data_ptr() != V.data_ptr():

@@ -20,11 +20,12 @@ import torch
 from . import kernels as K
 from .kernels import ACT_GELU, ACT_NONE, BF16, F32
 
-import os as _os
-USE_UPLN = _os.environ.get("STG_UPLN", "1") != "0"     # fused up-projection + residual + LayerNorm (csrc/upln.hip)
+from . import config as _cfg       # every switch below: stgcma.configure(...) / the STG_* environment, read once (config.py)
+USE_UPLN = _cfg.opt("upln")             # fused up-projection + residual + LayerNorm (csrc/upln.hip)
 # the MLP hidden's saved GELU derivative ([rows, 4C], the widest tensor of the step) as one byte per element (STG_U8_LIN) instead of bf16
-MLP_DACT = "u8" if _os.environ.get("STG_MLP_DACT", "u8").lower() == "u8" else True
-RESIDUAL_DTYPE = BF16 if _os.environ.get("STG_RESIDUAL", "fp32").lower() == "bf16" else F32   # fp32 default; bf16 = A/B knob
+MLP_DACT = _cfg.opt("mlp_dact")
+RESIDUAL_DTYPE = _cfg.opt("residual")   # fp32 default; bf16 = A/B knob
+WGRAD_FUSED = _cfg.opt("wgrad_fused")   # adapter D_fc2 weight gradient inside ln_bwd_down (round 4)
 
 # ------------------------------------------------------------------------------------------------ weight shadows
 _shadow_cache = {}   # id(parameter) -> (weakref to it, {transpose: ((data_ptr, version), bf16 tensor)})
@@ -113,7 +114,7 @@ def refresh_shadows(holder, names, P, need):
     ss[1].refresh()
 
 
-USE_XHAT = _os.environ.get("STG_XHAT", "1") != "0"     # 0 = LayerNorm affine applied by the LN kernels, fp32 rows re-read in backward (A/B knob)
+USE_XHAT = _cfg.opt("xhat")     # 0 = LayerNorm affine applied by the LN kernels, fp32 rows re-read in backward (A/B knob)
 _unit_cache = {}
 
 
@@ -211,7 +212,7 @@ def shadow_mlp_w2(p):
 
 # fc1 -> GELU -> fc2 (and its backward, pre-activation recomputed) as ONE kernel where csrc/mlp.hip is built (C = 128: Swin-B stage 0):
 # the [rows, 4C] hidden tensor and its saved derivative never reach HBM
-MLP_FUSED = _os.environ.get("STG_MLP_FUSED", "1") != "0"
+MLP_FUSED = _cfg.opt("mlp_fused")
 
 
 def _f8(sel, site, bwd=False):
@@ -283,9 +284,9 @@ def geom(device, H, W, ws, shift, T):
 
 
 _wintab_cache = {}   # id(bias-table parameter) -> (weakref, tag, (bm, bmT))
-USE_WINATTN = _os.environ.get("STG_WINATTN", "1") != "0"     # 0 = route W-MSA through the generic attention kernels (A/B knob)
-USE_TATTN = _os.environ.get("STG_TATTN", "1") != "0"         # 0 = route temporal attention through the generic kernels
-USE_MHA_X = _os.environ.get("STG_MHA_X", "1") != "0"         # 0 = wide frame-global cross-modal attention through the generic kernels
+USE_WINATTN = _cfg.opt("winattn")     # 0 = route W-MSA through the generic attention kernels (A/B knob)
+USE_TATTN = _cfg.opt("tattn")         # 0 = route temporal attention through the generic kernels
+USE_MHA_X = _cfg.opt("mha_x")         # 0 = wide frame-global cross-modal attention through the generic kernels
 
 
 def win_tables(tab_p, index, mask, n):
@@ -507,7 +508,7 @@ def _xattn_geom(spec, BT, dh, window, g):
     return K.AttnGeom(BT, 1, spec.N, dh, G=1, outer=spec.N, n_kv=spec.N, outer_kv=spec.N, scale=1.0)
 
 
-USE_XWIN = _os.environ.get("STG_XWIN", "1") != "0"     # 0 = window-level cross-modal attention on the generic kernels (A/B knob)
+USE_XWIN = _cfg.opt("xwin")     # 0 = window-level cross-modal attention on the generic kernels (A/B knob)
 _xwin_tabs = {}
 
 
@@ -523,7 +524,7 @@ def _xwin_geom(spec, BT, dev):
     return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
 
 
-PAIR_EW = _os.environ.get("STG_PAIR_EW", "1") != "0"      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
+PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
 
 
 def _gate2(hv, rv, gate_v, ha, ra, gate_a):
@@ -673,7 +674,7 @@ def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
     return dX, dH
 
 
-GEMM_SPLIT = _os.environ.get("STG_GEMM_SPLIT", "1") != "0"     # 0 = one adapter GEMM launch per modality (A/B knob)
+GEMM_SPLIT = _cfg.opt("gemm_split")     # 0 = one adapter GEMM launch per modality (A/B knob)
 
 
 def _pairable(sl, ads):

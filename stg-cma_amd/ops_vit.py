@@ -18,9 +18,9 @@ from .ops import (RESIDUAL_DTYPE, refresh_shadows, GradArena, _Adapter, _adapter
 from . import ops as _ops
 
 _SFX = ("", "_Audio")
-import os as _os
-USE_MHA = _os.environ.get("STG_MHA", "1") != "0"      # 0 = spatial ViT attention through the generic kernels (A/B knob)
-USE_TATTN_VIT = _os.environ.get("STG_TATTN_VIT", "1") != "0"   # 0 = temporal ViT attention through the generic kernels
+from . import config as _cfg
+USE_MHA = _cfg.opt("mha")               # 0 = spatial ViT attention through the generic kernels (A/B knob)
+USE_TATTN_VIT = _cfg.opt("tattn_vit")   # 0 = temporal ViT attention through the generic kernels
 VIT_FROZEN = ("ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.in_proj_weight", "attn.in_proj_bias",
               "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight",
               "mlp.c_proj.bias")

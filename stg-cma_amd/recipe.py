@@ -239,6 +239,192 @@ def capture_train_step(step, warmup=3, params=None):
     return replay, static_loss
 
 
+def capture_train_step_ddp(fwd_bwd, optimizer, sync, warmup=1, collective_in_graph=False):
+    """The N > 1 form of capture_train_step: `fwd_bwd()` = forward + loss + zero_grad + backward (returns the loss), `optimizer` =
+    build_optimizer's FusedAdam, `sync` = ddp.attach(model).  Returns (replay, static_loss, how):
+      how = "two_graphs" (default): graph 1 = forward + backward with the GradSync in deferred mode (the backward records the arena
+            and packs the task-head bucket instead of averaging them), the collectives run EAGERLY between the graph launches
+            (one all-reduce of the flat arena, one of the bucket when the model has task heads), graph 2 = bucket write-back + Adam.
+            Per step the host issues two graph launches and one or two collectives instead of ~1 200 kernel launches.
+      how = "one_graph" (collective_in_graph=True, RCCL only): the all-reduce is captured with the rest.  Not the default: this
+            repository's build boxes have one GPU, so a captured RCCL collective was never executed here.
+    Captures run in thread-local error mode: the process group's watchdog thread polls events while the capture is open.
+    Raises whatever the capture raises; the caller falls back to eager steps in the same process."""
+    import torch
+    if warmup < 1:
+        raise ValueError("capture_train_step_ddp: warmup must be >= 1")
+
+    def eager():
+        loss = fwd_bwd()
+        optimizer.step()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warmup):
+            eager()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    params = [p for grp in optimizer.param_groups for p in grp["params"]]
+    if collective_in_graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            static_loss = eager()
+        graphs, how = (g,), "one_graph"
+
+        def replay():
+            g.replay()
+            torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+    else:
+        sync.defer, sync._pending, sync._bucket = True, [], None
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                static_loss = fwd_bwd()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                sync.scatter_back()
+                optimizer.step()
+        except BaseException:
+            sync.defer, sync._pending, sync._bucket = False, [], None
+            raise
+        graphs, how = (g1, g2), "two_graphs"
+
+        def replay():
+            g1.replay()
+            sync.flush()
+            g2.replay()
+            torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+
+        def release():                       # back to eager steps: the GradSync averages inside backward again
+            sync.defer, sync._pending, sync._bucket = False, [], None
+        replay.release = release
+    replay.graphs = graphs
+    return replay, static_loss, how
+
+
+def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, warmup=1):
+    """One training step as `splits` MICRO-BATCHES that run CONCURRENTLY: each micro-batch's forward + backward is its own HIP graph,
+    replayed on its own stream, then one join graph sums the gradients and runs the optimizer (round 4).
+
+    Why: every launch of the step carries a ramp-up and a tail in which most of the chip idles (~10 us per HBM-bound launch,
+    tools/size_sweep.py, x ~1 200 dependent launches per step on ONE stream).  Two independent launch chains fill each other's gaps:
+    forward + backward of Swin-B at B = 32 measured 123.2 ms as one graph, 132.0 ms as two B = 16 graphs back to back, 116.3 ms as the
+    same two graphs on two streams (tools/two_stream_try.py; four streams of B = 8: 128.6).  Same arithmetic as the full-batch step:
+    the models have no cross-sample statistic (LayerNorm only -- do NOT use this for the AVS decoder's BatchNorm), the loss of
+    micro-batch i is weighted by its share of the batch, and fp32 gradient sums are added once more in fp32.
+
+      fwd_loss(*chunk) -> mean loss over the chunk (forward only; e.g. lambda a, v, y: loss_fn(model(a, v, "fusion"), y.flatten(0, 1)))
+      tensors           static batch tensors, every one with the batch on dimension 0 (copy new batches INTO them between replays)
+      optimizer         build_optimizer's FusedAdam
+      sync              ddp.attach(model) at N > 1: the micro-batch graphs run with the GradSync deferred, the summed arena is
+                        all-reduced eagerly between the join graph and the optimizer graph (models with task-head buckets: not here)
+    Returns (replay, static_loss, how).  replay() must be called on the stream the tensors are produced on (it forks from and joins
+    back into the current stream)."""
+    import torch
+    B = tensors[0].shape[0]
+    S = int(splits)
+    if S < 2 or B % S != 0 or any(t.shape[0] != B for t in tensors):
+        raise ValueError("capture_train_step_mb: the batch (dimension 0 of every tensor) must split evenly into >= 2 micro-batches")
+    if sync is not None and sync.extra:
+        raise RuntimeError("capture_train_step_mb: models with task-head gradient buckets (AVS / AVQA) are not micro-batched")
+    h = B // S
+    chunks = [tuple(t[i * h:(i + 1) * h] for t in tensors) for i in range(S)]
+    params = [p for grp in optimizer.param_groups for p in grp["params"]]
+    w = 1.0 / S
+
+    def fb(chunk, zero=True):
+        loss = fwd_loss(*chunk) * w
+        if zero:
+            for p in params:
+                p.grad = None
+        loss.backward()
+        return loss
+
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(max(int(warmup), 1)):                 # eager steps of the same arithmetic (autograd accumulates the micro-batches)
+            for i, c in enumerate(chunks):
+                fb(c, zero=i == 0)
+            optimizer.step()
+    cur.wait_stream(side)
+    torch.cuda.synchronize()
+    if sync is not None:
+        sync.defer, sync._pending, sync._bucket = True, [], None
+    try:
+        graphs, losses, grads = [], [], []
+        for c in chunks:
+            # a version bump per micro-batch: each graph then casts the trainable weights' bf16 shadows into an arena of ITS OWN pool
+            # (ops.ShadowSet keys on the version) -- shared, one graph would rewrite them while the other reads them
+            torch.autograd.graph.increment_version(params)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                loss = fb(c)
+            graphs.append(g)
+            losses.append(loss)
+            grads.append([p.grad for p in params])
+        live = [k for k in range(len(params)) if all(gr[k] is not None for gr in grads)]
+        if any(gr[k] is not None for gr in grads for k in range(len(params)) if k not in live):
+            raise RuntimeError("capture_train_step_mb: a parameter received a gradient in one micro-batch only")
+        flats = []
+        for gr in grads:                                    # one flat arena per micro-batch (ops.GradArena)?  then the sum is one launch
+            bases = {id(gr[k]._base): gr[k]._base for k in live if gr[k]._base is not None}
+            flats.append(next(iter(bases.values())) if len(bases) == 1 and all(gr[k]._base is not None for k in live) else None)
+        same_layout = all(f is not None and f.shape == flats[0].shape for f in flats) and all(
+            gr[k].storage_offset() == grads[0][k].storage_offset() for gr in grads for k in live)
+        gj = torch.cuda.CUDAGraph()
+        ga = torch.cuda.CUDAGraph() if sync is not None else None
+        with torch.cuda.graph(gj, capture_error_mode="thread_local"):
+            for i in range(1, S):
+                if same_layout:
+                    flats[0].add_(flats[i])
+                else:
+                    torch._foreach_add_([grads[0][k] for k in live], [grads[i][k] for k in live])
+            static_loss = torch.stack(losses).sum()
+            for k, p in enumerate(params):
+                p.grad = grads[0][k]
+            if sync is None:
+                optimizer.step()
+        if sync is not None:
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                optimizer.step()
+    except BaseException:
+        if sync is not None:
+            sync.defer, sync._pending, sync._bucket = False, [], None
+        raise
+    streams = [torch.cuda.Stream() for _ in range(S - 1)]
+    red = flats[0] if same_layout else None
+
+    def replay():
+        c0 = torch.cuda.current_stream()
+        for s, g in zip(streams, graphs[1:]):
+            s.wait_stream(c0)
+            with torch.cuda.stream(s):
+                g.replay()
+        graphs[0].replay()
+        for s in streams:
+            c0.wait_stream(s)
+        gj.replay()
+        if sync is not None:
+            if red is not None:
+                sync._average(red)
+            else:
+                for k in live:
+                    sync._average(grads[0][k])
+            ga.replay()
+        torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+
+    def release():
+        if sync is not None:
+            sync.defer, sync._pending, sync._bucket = False, [], None
+    replay.release = release
+    replay.graphs = tuple(graphs) + (gj,) + ((ga,) if ga is not None else ())
+    return replay, static_loss, f"{S} micro-batch graphs on {S} streams + join" + (" + eager all-reduce + optimizer graph" if sync is not None else "")
+
+
 def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, global_step=0):
     """One iteration of the reference loop (traintest_adapt_ave29.py:136-164): per-group LR from the cosine tables, labels
     'b t c -> (b t) c', forward, loss on float class-probability targets, zero_grad, backward, step.  The reference wraps the
