@@ -14,6 +14,7 @@
 // Block ids are remapped so that the N-tiles sharing one A row-panel run on the same XCD (its L2 holds the panel).
 #include <type_traits>
 #include "common.h"
+#include "gemm_ovl.h"
 #include "../../include/stgcma.h"
 
 // Timing-only ablations exist in the diagnostics build alone (make diag -> libstgcma_hip_diag.so, -DSTG_GEMM_DIAG): the product
@@ -1570,6 +1571,24 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         hipLaunchKernelGGL(gemm_nt_fp8_kernel, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p, e);
         STG_LAUNCH_CHECK();
         return 0;
+    }
+    // overlapped-epilogue kernel (gemm_ovl.hip): short-K shapes whose epilogue is a large share of a tile
+    {
+        const int om = stg_opt_gemm_ovl.load(std::memory_order_relaxed);
+        const int ov = p.epi_variant == EV_PLAIN ? OV_PLAIN : p.epi_variant == EV_GELU8 ? OV_GELU8 : p.epi_variant == EV_DSRC8 ? OV_DSRC8 : -1;
+        const bool legal = (om & 15) && ov >= 0 && !split && !conv && p.batch == 1 && stg_gemm_ovl_supported(ov, a->M, a->N, a->K) &&
+                           (((uintptr_t)a->C | (uintptr_t)a->dact | (uintptr_t)a->dact_src) & 15) == 0;
+        // auto (1) routes NOTHING here: every class of the step measured slower on this kernel than on the shipped routing (fc1 + GELU + byte
+        // derivative 455 vs 397 us, qkv 257 vs 200, N = K = 512 85 vs 75, fc2 dgrad 575 vs 359: DESIGN.md section 5.3); 2 = every legal shape (tools/, tests)
+        const bool want = (om & 15) == 2;
+        if (legal && want) {
+            GemmOvlParams q;
+            q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.C = (bf16_t*)p.C; q.ldc = p.ldc; q.bias = p.bias;
+            q.d8out = (uint8_t*)p.dact; q.ldp = p.ldp; q.d8src = (const uint8_t*)p.dact_src; q.ldd = p.ldd;
+            q.M = p.M; q.N = p.N; q.K = p.K; q.nbm = q.nbn = 0; q.ntl = om >> 4;
+            a->kernel_chosen = STG_GEMM_KERNEL_OVL;
+            return stg_gemm_ovl_launch(ov, q, stream);
+        }
     }
     const int ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed);
     const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);

@@ -544,3 +544,33 @@ def test_mlp_fused_backward(stg, gpu, rows):
     assert float((out.float() - two.float()).norm() / two.float().norm()) <= 4e-3         # the two-GEMM path rounds GELU' and dZ to bf16 too
     assert float((out.float().cpu() - ref).abs().max()) <= 1.5e-2 * max(1.0, scale)
     assert float((out.float().cpu() - ref).norm() / ref.norm()) <= 6e-3
+
+
+def test_gemm_overlapped_epilogue_kernel_is_bit_identical(stg, gpu):
+    """csrc/gemm_ovl.hip (256 x 128 tiles, two accumulator sets, the epilogue of a tile inside the next tile's main loop; opt-in: measured
+    slower than the shipped routing) against the shipped kernels on the three epilogues it serves -- same MFMA / k order and the
+    same epilogue arithmetic, so every output byte must agree (that is also the race screen for its counted waits)."""
+    import stgcma
+    from stgcma import kernels as K
+    from stgcma._lib import ACT_GELU
+    torch.manual_seed(3)
+    M, Kd = 2048, 512
+    A = (torch.randn(M, Kd, device=gpu) * 0.5).to(torch.bfloat16)
+    try:
+        for N in (128, 512, 1536):
+            W = (torch.randn(N, Kd, device=gpu) * 0.05).to(torch.bfloat16)
+            b = torch.randn(N, device=gpu) * 0.1
+            d8 = torch.randint(0, 256, (M, N), device=gpu, dtype=torch.uint8)
+            outs = {}
+            for mode in (0, 2, 16 * 2 + 2):
+                if mode > 2 and (N // 128) % 2:
+                    continue
+                stgcma.configure(lib_gemm_ovl=mode)
+                y, d = K.gemm_nt(A, W, b, act=ACT_GELU, want_dact="u8")
+                outs[mode] = (K.gemm_nt(A, W, b), y, d, K.gemm_nt(A, W, None, dact_src=d8))
+            torch.cuda.synchronize()
+            for mode, o in outs.items():
+                for x, r in zip(o, outs[0]):
+                    assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, r.view(torch.int16) if r.dtype == torch.bfloat16 else r), (N, mode)
+    finally:
+        stgcma.configure(lib_gemm_ovl=1)
