@@ -358,7 +358,7 @@ extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, 
     STG_CHECK(d && n >= 1 && n <= WMAX, -1, "stg_wgrad_tn_ws_multi: 1..%d problems", WMAX);
     STG_CHECK(ws && (((uintptr_t)ws) & 15) == 0, -2, "stg_wgrad_tn_ws_multi: needs a 16-byte aligned workspace");
     WgMulti pm; WrMulti rm;
-    Plan pl0 = {};
+    Plan pl0 = {}, plm = {};
     for (int i = 0; i < n; ++i) {
         const stg_wgrad_desc& q = d[i];
         STG_CHECK(q.dY && q.X && q.dW && q.M > 0 && q.N1 > 0 && q.N2 > 0 && q.lddy >= q.N1 && q.ldx >= q.N2 && q.lddw >= q.N2, -2,
@@ -366,13 +366,28 @@ extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, 
         if (q.row_scale) STG_CHECK(q.rs_outer > 0 && q.rs_inner > 0, -2, "stg_wgrad_tn_ws_multi: bad row_scale params");
         const Plan pl = plan_for(q.M, q.N1, q.N2, q.lddy, q.ldx, q.dY, q.X);
         STG_CHECK(pl.ok, -7, "stg_wgrad_tn_ws_multi: problem %d is not eligible for the workspace path", i);
-        if (i == 0) pl0 = pl;
+        if (i == 0) {
+            pl0 = plm = pl;
+            // The single-problem plan fills the chip on its own (~2 blocks per CU); n problems in one launch need n times fewer row
+            // splits each -- every block leaves a partial tile in the workspace (24 KiB at 32 narrow columns) that the reduce kernel
+            // reads back: with the single-problem split the twelve adapter gradients of a stage-2 block wrote + re-read 2 x 147 MB of
+            // partials beside 818 MB of operands (round 4: PMC 1 109 MB per launch against 866 algorithmic).  Same workspace layout,
+            // fewer slots used (stg_wgrad_ws_floats sizes the caller's buffer for the single-problem plan).
+            const int64_t want = (768 + (int64_t)pl.ncg * n - 1) / ((int64_t)pl.ncg * n);        // ~3 blocks per CU over the whole launch
+            if (n > 1 && want < pl.S) {
+                int64_t S = want < 1 ? 1 : want;
+                int64_t rpb = (q.M + S - 1) / S;
+                rpb = (rpb + WK - 1) / WK * WK;
+                S = (q.M + rpb - 1) / rpb;
+                plm.S = (int)S; plm.rows_per_block = rpb;
+            }
+        }
         STG_CHECK(pl.nt1 == pl0.nt1 && pl.ncg == pl0.ncg && pl.S == pl0.S && pl.rows_per_block == pl0.rows_per_block, -7,
                   "stg_wgrad_tn_ws_multi: problem %d has a different launch plan than problem 0", i);
         for (int j = 0; j < i; ++j) STG_CHECK(d[j].dW != q.dW, -2, "stg_wgrad_tn_ws_multi: problems %d and %d share dW", j, i);
-        fill_problem(pl, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, q.M, q.N1, q.N2, q.row_scale, q.rs_outer, q.rs_inner,
+        fill_problem(plm, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, q.M, q.N1, q.N2, q.row_scale, q.rs_outer, q.rs_inner,
                      ws + (int64_t)i * pl.ws_floats, pm.p[i], rm.p[i]);
     }
     STG_CHECK(ws_floats >= (int64_t)n * pl0.ws_floats, -2, "stg_wgrad_tn_ws_multi: workspace too small");
-    return launch_multi(pl0, pm, rm, n, (hipStream_t)stream);
+    return launch_multi(plm, pm, rm, n, (hipStream_t)stream);
 }
