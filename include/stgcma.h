@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 209
+#define STG_VERSION 210
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -409,6 +409,16 @@ int stg_add_temporal(float* x, const float* emb, int64_t B, int T, int64_t N, in
 int stg_fbank(const float* wave, int64_t n_samples, int64_t wave_stride, int S, int shift, int size, int padded,
               const float* window, const float* melw, int num_mel_bins, float preemphasis, float norm_mean, float norm_std,
               int target_frames, float* out, void* stream);
+/* Video front end (video half): the tensor part of AVE/dataloader.py:346-394 (_aug_frame_train behind the PIL
+ * RandAugment) in one launch -- ToTensor, tensor_normalize (:470-485), random_resized_crop (transforms/video_transforms.py:529-561:
+ * crop box + bilinear resize, align_corners = False), horizontal_flip (:152-186), RandomErasing in 'pixel' mode with one box per clip
+ * (transforms/random_erasing.py:118-152) -- from decoded frames to the models' video input.
+ * frames u8 [B, T, H, W, 3] (host-decoded, RandAugment applied); params int32 [B, 9] = crop top, left, height, width, flip (0 / 1), erase
+ * top, left, height, width in OUTPUT coordinates (height 0: no erase) -- the caller's random draws, the host points of the reference
+ * (Python / NumPy generators); noise fp32 [B, T, 3, S, S], read inside the erase box only (may be NULL when no clip erases);
+ * mean3 / std3 HOST pointers to 3 floats; out fp32 [B, 3, T, S, S] ('b c t h w', what model(a, v, mode) takes). */
+int stg_video_aug(const void* frames, int B, int T, int H, int W, const int32_t* params, const float* noise, const float* mean3,
+                  const float* std3, float* out, int S, void* stream);
 /* bf16 -> fp32 */
 int stg_cast_f32(const void* in, float* out, int64_t numel, void* stream);
 

@@ -174,6 +174,7 @@ SIGNATURES = {
     "stg_add_temporal": (C.c_int, [c_vp, c_vp, c_i64, C.c_int, c_i64, C.c_int, c_vp]),
     "stg_fbank": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, C.c_int, C.c_float, C.c_float, C.c_float,
                             C.c_int, c_vp, c_vp]),
+    "stg_video_aug": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, c_vp]),
     "stg_cast_f32": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "stg_meanpool_fwd": (C.c_int, [c_vp, c_vp, C.c_int, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_meanpool_bwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
@@ -213,7 +214,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 209
+ABI_VERSION = 210
 _lib = None
 
 

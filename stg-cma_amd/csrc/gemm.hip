@@ -1600,8 +1600,9 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
-    // (r2, measured inside the step: K = 512 -> N = 512 projections 101 -> 88 us with bias, 96 -> 91 us plain; the derivative-source
-    // epilogue stays on the 128 x 128 kernel: 403 vs 473 us)
+    // (r2, measured inside the step: K = 512 -> N = 512 projections 101 -> 88 us with bias, 96 -> 91 us plain.  The derivative-source
+    // epilogue of the fc2 dgrad stays on the 128 x 128 kernel: after round 3's epilogue fix the class reads 334-360 us there and the three
+    // routings tried in tools/gemm_route_ab.py are within 1 % of each other, profiles/r03_gemm_route_ab.txt)
     // (r2, stage-1 shapes, microbenchmark: 501 760 x 768 x 256 + bias 437 -> 388 us, x 256 x 768 343 -> 297, x 1024 x 256 with GELU +
     // derivative 814 -> 763, x 256 x 256 156 -> 149: the 128 x 128 kernel's main loop is L2-bandwidth-bound there)
     const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);

@@ -385,7 +385,9 @@ extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, 
         STG_CHECK(pl.nt1 == pl0.nt1 && pl.ncg == pl0.ncg && pl.S == pl0.S && pl.rows_per_block == pl0.rows_per_block, -7,
                   "stg_wgrad_tn_ws_multi: problem %d has a different launch plan than problem 0", i);
         for (int j = 0; j < i; ++j) STG_CHECK(d[j].dW != q.dW, -2, "stg_wgrad_tn_ws_multi: problems %d and %d share dW", j, i);
-        fill_problem(plm, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, q.M, q.N1, q.N2, q.row_scale, q.rs_outer, q.rs_inner,
+        Plan pli = pl;                                    // this problem's own operand orientation, the launch's shared row split
+        pli.S = plm.S; pli.rows_per_block = plm.rows_per_block;
+        fill_problem(pli, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, q.M, q.N1, q.N2, q.row_scale, q.rs_outer, q.rs_inner,
                      ws + (int64_t)i * pl.ws_floats, pm.p[i], rm.p[i]);
     }
     STG_CHECK(ws_floats >= (int64_t)n * pl0.ws_floats, -2, "stg_wgrad_tn_ws_multi: workspace too small");

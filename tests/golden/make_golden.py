@@ -594,6 +594,93 @@ def avqa_ingest_case(Q, tag, seed):
     save(tag, cfg_json=json.dumps(dict(cfg, seed=seed)), missing=missing, unexpected=unexpected, stats_json=json.dumps(stats))
 
 
+def video_aug_case(tag, seeds):
+    """SURVEY f4, video half: the tensor part of the reference's training-time frame pipeline, AVE/dataloader.py:346-394 (_aug_frame_train
+    behind the PIL RandAugment): ToTensor -> tensor_normalize (:470-485) -> spatial_sampling (:396-468: random_resized_crop, scale [0.08, 1],
+    ratio [3/4, 4/3], bilinear to 224 x 224, then horizontal_flip) -> RandomErasing(0.25, 'pixel', cube) (transforms/random_erasing.py).
+    The reference's own functions are called (dataloader.py / video_transforms.py import with empty stand-ins for the ABSENT torchvision / cv2 /
+    torchaudio / h5py modules: none of the functions used here touches them; ToTensor, a torchvision class, is the one restated line).  The
+    random draws they make (crop box, flip, erase box, erase noise) are recorded and stored: the device kernel takes them as arguments."""
+    import random
+    for name in ("cv2", "torchaudio", "h5py"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tv = sys.modules["torchvision"]
+    tvt, tvf = types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.transforms.functional")
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({"torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    DL = load(os.path.join(REF, "AVE/dataloader.py"), "ref_ave_dataloader")
+    VT, RE = DL.video_transforms, DL.random_erasing
+    ds = object.__new__(DL.AudiosetDataset)
+    out = {}
+    for ci, (seed, T, H, W) in enumerate(seeds):
+        g = torch.Generator().manual_seed(seed)
+        # smooth synthetic frames (a random low-resolution field, upsampled) + noise: interpolation weights matter on such data
+        low = torch.rand((T, 3, H // 16 + 1, W // 16 + 1), generator=g)
+        frames = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False).clamp(0, 1)
+        frames = (frames * 235 + torch.rand((T, 3, H, W), generator=g) * 20).round().clamp(0, 255).to(torch.uint8)     # T C H W, what ToPILImage / RandAugment hand on
+        frames_hwc = frames.permute(0, 2, 3, 1).contiguous()
+        buffer = frames.float().div(255)                               # transforms.ToTensor()(img): uint8 HWC -> float CHW in [0, 1]
+        buffer = buffer.permute(0, 2, 3, 1)                            # dataloader.py:359-360
+        buffer = ds.tensor_normalize(buffer, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+        buffer = buffer.permute(3, 0, 1, 2)                            # C T H W (:366)
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        rec = {}
+        crop0, flip0, pix0 = VT._get_param_spatial_crop, VT.horizontal_flip, RE._get_pixels
+
+        def crop_rec(*a, **k):
+            r = crop0(*a, **k)
+            rec["crop"] = r
+            return r
+
+        def flip_rec(prob, images, boxes=None):
+            o, b = flip0(prob, images, boxes)
+            rec["flip"] = int(not torch.equal(o, images))
+            return o, b
+
+        def pix_rec(per_pixel, rand_color, patch_size, dtype=torch.float32, device="cpu"):
+            t = pix0(per_pixel, rand_color, patch_size, dtype=dtype, device=device)
+            rec.setdefault("noise", []).append(t.clone())
+            return t
+        VT._get_param_spatial_crop, VT.horizontal_flip, RE._get_pixels = crop_rec, flip_rec, pix_rec
+        try:
+            buffer = ds.spatial_sampling(buffer, spatial_idx=-1, min_scale=256, max_scale=320, crop_size=224, random_horizontal_flip=True,
+                                         inverse_uniform_sampling=False, aspect_ratio=[0.75, 1.3333], scale=[0.08, 1.0], motion_shift=False)
+            before = buffer.clone()
+            erase = RE.RandomErasing(0.25, mode="pixel", max_count=1, num_splits=1, device="cpu")
+            buffer = buffer.permute(1, 0, 2, 3)                        # T C H W (:389)
+            buffer = erase(buffer)
+            buffer = (buffer if buffer is not None else before.permute(1, 0, 2, 3)).permute(1, 0, 2, 3)
+        finally:
+            VT._get_param_spatial_crop, VT.horizontal_flip, RE._get_pixels = crop0, flip0, pix0
+        # RandomErasing works in place (its __call__ returns None): `before` shares no storage, the erased tensor is the permuted view's base
+        erased = before.permute(1, 0, 2, 3).clone()
+        noise = torch.zeros((T, 3, 224, 224))
+        box = (0, 0, 0, 0)
+        if rec.get("noise"):
+            # redo the erase on a copy to learn the box: the positions where the in-place result differs from `before`
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        final = buffer
+        diff = (final != before).any(dim=0).any(dim=0)                 # [224, 224]
+        if rec.get("noise"):
+            ys, xs = torch.nonzero(diff.any(dim=1)).flatten(), torch.nonzero(diff.any(dim=0)).flatten()
+            eh, ew = rec["noise"][0].shape[1:]
+            top, left = int(ys.min()), int(xs.min())
+            assert int(ys.max()) - top + 1 == eh and int(xs.max()) - left + 1 == ew
+            for t in range(T):
+                noise[t, :, top:top + eh, left:left + ew] = rec["noise"][t]
+            box = (top, left, eh, ew)
+        i, j, h, w = rec["crop"]
+        out[f"frames{ci}"] = frames_hwc.numpy()
+        out[f"params{ci}"] = np.asarray([i, j, h, w, rec["flip"], *box], dtype=np.int32)
+        out[f"noise_box{ci}"] = noise[:, :, box[0]:box[0] + box[2], box[1]:box[1] + box[3]].numpy()
+        out[f"out{ci}"] = final.contiguous().numpy()
+        print(f"   case {ci}: seed {seed} frames {T}x{H}x{W} crop {rec['crop']} flip {rec['flip']} erase box {box}")
+    out["mean"] = np.asarray([0.485, 0.456, 0.406], np.float32)
+    out["std"] = np.asarray([0.229, 0.224, 0.225], np.float32)
+    out["ncases"] = np.asarray([len(seeds)])
+    save(tag, **out)
+
+
 def scheduler_case():
     sch = load(os.path.join(REF, "utilities/scheduler.py"), "ref_sched")
     import contextlib
@@ -704,6 +791,8 @@ def main(argv):
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
         "avs_full_tiny_evalbn": lambda: avs_full_evalbn_case(ref_avs_base(), "avs_full_tiny_evalbn", cfg=AVS_FULL_TINY, B=1, seed=840),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),
+        # (seed, frames, height, width): seeds picked so that the cases cover erase / no erase and flip / no flip
+        "video_aug": lambda: video_aug_case("video_aug", [(2, 2, 240, 320), (4, 2, 360, 270), (3, 1, 240, 320), (5, 2, 180, 320)]),
         "structure": lambda: structure_case(S, Cm),
         "cosine_scheduler": scheduler_case,
     }
