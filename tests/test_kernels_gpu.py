@@ -464,9 +464,9 @@ def test_gemm_u8_saved_derivative(stg, gpu, M, N, K, act):
 
 def test_wgrad_multi_matches_single_calls(stg, gpu):
     """stg_wgrad_tn_ws_multi (the adapter weight gradients of a block in one launch pair) against the same problems issued one by
-    one: the same kernels over FEWER row splits per problem (round 4: n problems in a launch need n times fewer blocks each, and every
-    block's partial tile is workspace traffic), so the fp32 sums are re-associated -- equal to 1e-5 of the largest entry, not bit for bit;
-    incl. the DropPath row scale and both operand orientations; a problem with a different launch plan is carried out on its own."""
+    one: bit-identical (same kernels, same row splits), incl. the DropPath row scale and both operand orientations; a problem with a
+    different launch plan is carried out on its own.  With option wgrad_split = 1 (row splits sized for the whole launch: fewer partial
+    tiles, re-associated fp32 sums) the results agree to 1e-5 of the largest entry."""
     from stgcma import kernels as Kn
     g = torch.Generator().manual_seed(11)
     M, C_, dh = 8192, 256, 32
@@ -490,9 +490,20 @@ def test_wgrad_multi_matches_single_calls(stg, gpu):
     dW1, db1 = dW.clone(), db.clone()
     Kn.wgrad_tn(dY, X, dW1, db1)
     probs.append((dY, X, dW, db, None, 1, 1)); refs.append((dW1, db1))
+    import stgcma
+    saved = [(p[2].clone(), p[3].clone()) for p in probs]
     Kn.wgrad_tn_multi(probs)
     for (dY, X, dW, db, *_), (dW1, db1) in zip(probs, refs):
-        assert float((dW - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max()) and float((db - db1).abs().max()) <= 1e-5 * float(db1.abs().max())
+        assert torch.equal(dW, dW1) and torch.equal(db, db1)
+    try:
+        stgcma.configure(lib_wgrad_split=1)
+        for p, (w0, b0) in zip(probs, saved):
+            p[2].copy_(w0); p[3].copy_(b0)
+        Kn.wgrad_tn_multi(probs)
+        for (dY, X, dW, db, *_), (dW1, db1) in zip(probs, refs):
+            assert float((dW - dW1).abs().max()) <= 1e-5 * float(dW1.abs().max()) and float((db - db1).abs().max()) <= 1e-5 * float(db1.abs().max())
+    finally:
+        stgcma.configure(lib_wgrad_split=0)
 
 
 @pytest.mark.parametrize("rows", [1, 300, 4096, 70000])
