@@ -257,6 +257,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="time eager single-stream steps only (no HIP graphs, no micro-batch streams): the round-3 form")
     ap.add_argument("--ddp-one-graph", action="store_true",
                     help="N > 1: capture the RCCL all-reduce inside the graph too (default: two graphs with the collective eager between them)")
+    ap.add_argument("--residual", choices=("fp32", "bf16"), default="fp32",
+                    help="residual-stream dtype.  fp32 (default) is what the reference's autocast loop keeps; bf16 is a LABELLED SECONDARY "
+                         "measurement (config.residual_dtype says so), never the headline")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -268,6 +271,8 @@ def main():
     import torch.distributed as dist
     import stgcma  # noqa: F401
     from stgcma import ddp, kernels
+    if args.residual == "bf16":
+        stgcma.configure(residual="bf16")
 
     # STG_DDP_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices;
     # RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
@@ -554,14 +559,14 @@ def main():
                                "avg_launch_us": round(k["ms"] * 1e3 / max(k["launches"], 1e-9), 2), "gbs": round(k["gb"] / max(k["ms"], 1e-9) * 1e3),
                                "what": "all classes routed to this kernel, algorithmic FLOPs / HIP-event time"}
         out = {
-            "metric": "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
+            "metric": ("SECONDARY (bf16 residual stream, not the headline dataflow) " if args.residual == "bf16" else "") + "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
                                               "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8-e4m3 (frozen weights + their inputs, E8M0 block scales) / bf16" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": "fp32"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": args.residual},
             "model_tflops": round(value * gflop_per_clip / 1e3, 2),
             "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 4),

@@ -12,6 +12,9 @@ import torch.nn.functional as F
 from golden_util import build_state, load_case
 
 pytestmark = pytest.mark.gpu
+# gradient bounds of the full-model fixtures: 1.5 x measured, per-tensor norm deviation and strided-sample relative L2
+NORM_BOUND = {"avqa_full_tiny": 4.8e-2, "avqa512_full_tiny": 4.1e-2, "avqa_full_d6": 6.4e-2}
+SAMPLE_BOUND = {"avqa_full_tiny": 9.6e-2, "avqa512_full_tiny": 8.2e-2, "avqa_full_d6": 8.5e-2}
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -230,18 +233,20 @@ def test_avqa_full_model_matches_reference(stg, gpu, case, modname):
         if rn > 1e-4 and "gate_" not in n and "temporal_position_bias_table" not in n:
             rel = abs(float(d[n].grad.norm()) - float(rn)) / float(rn)
             worst = max(worst, rel)
-            # 8 % on the V1 model; the 512-d variant routes every gradient through two more bf16 Linears in front of the ReLU match head
-            assert rel <= (1.2e-1 if case == "avqa512_full_tiny" else 8e-2), f"grad norm of {n}: {float(d[n].grad.norm()):.4g} vs {float(rn):.4g}"
+            # 1.5 x the measured worst case per fixture (round 4: 3.2e-2 / 2.7e-2 / 4.2e-2, gpurun_out/model_parity_report.txt)
+            assert rel <= NORM_BOUND[case], f"grad norm of {n}: {float(d[n].grad.norm()):.4g} vs {float(rn):.4g}"
     flat = torch.cat([d[n].grad.reshape(-1).float().cpu() for n in names])[::197]
     ref = torch.as_tensor(z["grads_sample"])
     e_l2 = float((flat - ref).norm() / ref.norm())
-    # The match head is a 4-row ReLU MLP: with ~1 % bf16 noise on the pre-activations ~0.5-1 % of the ReLU gates sit on the
-    # other side of zero than in the fp32 reference, and every flipped gate is a full-size error in dZ: the expected relative L2
-    # deviation of those gradients is sqrt(flipped fraction) = 7-10 % per ReLU layer (measured 7.8 % fc3 -> 11.5 % fc1; each op's
-    # backward is pinned tightly by the unit tests above).  Smooth paths (GELU backbone, tanh / softmax head parts) sit at 1-4 %.
+    # The match head is a ReLU MLP: bf16 noise on its pre-activations puts ~0.1 % of the ReLU gates on the other side of zero than in
+    # the fp32 reference, and every flipped gate is a full-size error in dZ: 8 .. 12 % relative L2 on the weight gradients of those
+    # layers.  SHOWN on the oracle alone (tests/test_oracle_cpu.py::test_avqa_head_gradient_bounds_are_relu_gate_flips: the fp32 head with
+    # bf16-rounded Linears deviates 12.0 / 9.7 / 8.1 % on fc1 / fc2 / fc3, and 0.4 .. 0.6 % once the fp32 run's gate pattern is imposed);
+    # smooth paths (GELU backbone, tanh / softmax head parts) sit at 1-3 %.  The strided sample over ALL trainable tensors measured
+    # 6.4e-2 / 5.4e-2 / 5.6e-2 (round 4); the bound is 1.5 x that.
     with open("gpurun_out/model_parity_report.txt", "a") as f:
         f.write(f"{case} gradients: strided-sample relL2={e_l2:.3e} worst per-tensor norm deviation={worst:.3e}\n")
-    assert e_l2 <= 1.2e-1, f"gradient sample relL2 {e_l2:.3e} (worst per-tensor norm deviation {worst:.3e})"
+    assert e_l2 <= SAMPLE_BOUND[case], f"gradient sample relL2 {e_l2:.3e} (worst per-tensor norm deviation {worst:.3e})"
 
 
 def test_avqa_train_mode_dropouts_and_step(stg, gpu):
