@@ -444,6 +444,26 @@ def main():
             for _ in range(2):
                 replay()
         fence()
+    # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
+    # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
+    # measured on the form that wins there.  Every rank takes the same decision (it is made on all-reduced times).
+    pick = None
+    if replay is not None and world > 1:
+        def timed2(fn):
+            fence()
+            t0_ = time.perf_counter()
+            for _ in range(2):
+                fn()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt) / 2 * 1e3
+        ms_e, ms_r = timed2(step), timed2(replay)
+        pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
+        if ms_r > ms_e:
+            replay.release()
+            replay = None
+            step_how = f"eager, one stream (the replayed form measured {ms_r:.1f} ms per step against {ms_e:.1f} eager on this box)"
     if replay is not None or world > 1:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -454,6 +474,12 @@ def main():
                 loss = step()
         fence()
         dt = time.perf_counter() - t0
+        if world == 1 and dt_eager is not None and dt > dt_eager:
+            # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
+            # reports the faster one as `value` and says so
+            pick = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "replay_ms_per_step": round(dt / args.steps * 1e3, 3)}
+            step_how = f"eager, one stream (the replayed micro-batch form measured {dt / args.steps * 1e3:.1f} ms per step: slower on this box)"
+            dt = dt_eager
     else:
         dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
     final_loss = float(loss.detach())
@@ -586,6 +612,8 @@ def main():
             "accounted_ms_per_step": round(gemm_ms + fam_ms, 2),
             "accounted_frac": round((gemm_ms + fam_ms) / eager_ms, 4) if eager_ms else None}
         out["config"]["step"] = step_how
+        out["config"]["step_forms_measured"] = pick
+        out["config"]["side_streams_overlap"] = getattr(replay, "streams_overlap", None) if replay is not None else None
         out["config"]["options"] = stgcma.options() if hasattr(stgcma, "options") else None
         # the same step replayed from a HIP graph (N = 1, --graph): reported next to the eager number, which stays `value` -- the roofline
         # sampling above needs eager launches (HIP events around individual kernels).  It runs AFTER the headline object is complete and

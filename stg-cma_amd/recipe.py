@@ -304,6 +304,41 @@ def capture_train_step_ddp(fwd_bwd, optimizer, sync, warmup=1, collective_in_gra
     return replay, static_loss, how
 
 
+def _concurrent_streams(n):
+    """n side streams that demonstrably run BESIDE torch's current stream (and beside each other).  HIP multiplexes a process's streams
+    onto a few hardware queues (4 by default): two streams on one queue serialise, and the micro-batch step would then cost MORE than the
+    plain one (two half-batch chains back to back: 132 vs 123 ms).  Which queue a pooled torch stream lands on depends on how many streams
+    the process has touched before, so it is measured: a ~1 ms spin kernel on the current stream and on the candidate must take ~1 ms
+    together, not ~2.  Returns (streams, all_overlap)."""
+    import time
+    import torch
+    cur = torch.cuda.current_stream()
+    ticks = 2_500_000                                    # ~1 ms of torch.cuda._sleep on MI355X (measured 0.42 ms per 1e6)
+
+    def run(ss):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in ss:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(ticks)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run([cur])
+    base = min(run([cur]) for _ in range(2))
+    chosen = []
+    cands = [torch.cuda.Stream() for _ in range(8)] + [torch.cuda.Stream(priority=-1) for _ in range(4)]
+    for c in cands:
+        if len(chosen) == n:
+            break
+        group = [cur] + chosen + [c]
+        if min(run(group) for _ in range(2)) < 1.45 * base:       # all of them in the time of one
+            chosen.append(c)
+    ok = len(chosen) == n
+    while len(chosen) < n:
+        chosen.append(cands[len(chosen)])
+    return chosen, ok
+
+
 def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, warmup=1):
     """One training step as `splits` MICRO-BATCHES that run CONCURRENTLY: each micro-batch's forward + backward is its own HIP graph,
     replayed on its own stream, then one join graph sums the gradients and runs the optimizer (round 4).
@@ -395,7 +430,7 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
         if sync is not None:
             sync.defer, sync._pending, sync._bucket = False, [], None
         raise
-    streams = [torch.cuda.Stream() for _ in range(S - 1)]
+    streams, overlap = _concurrent_streams(S - 1)
     red = flats[0] if same_layout else None
 
     def replay():
@@ -422,7 +457,9 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
             sync.defer, sync._pending, sync._bucket = False, [], None
     replay.release = release
     replay.graphs = tuple(graphs) + (gj,) + ((ga,) if ga is not None else ())
-    return replay, static_loss, f"{S} micro-batch graphs on {S} streams + join" + (" + eager all-reduce + optimizer graph" if sync is not None else "")
+    replay.streams_overlap = overlap
+    return replay, static_loss, (f"{S} micro-batch graphs on {S} streams + join" + (" + eager all-reduce + optimizer graph" if sync is not None else "")
+                                 + ("" if overlap else " (WARNING: no side stream was found to run beside the launch stream)"))
 
 
 def train_step(model, optimizer, loss_fn, a, v, labels, mode, lr_tables=None, global_step=0):
