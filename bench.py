@@ -374,12 +374,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    MB_OK = ("swin_b", "swin_l", "vit_b")                 # no cross-sample statistic, no task-head gradient bucket: micro-batches are exact
+    # micro-batches are exact where no operation looks across the clips of a batch: the AVE models and the AVQA model (LayerNorm, per-clip
+    # attention, mean-reduced losses) -- not the AVS decoder (BatchNorm over the batch).  Under DDP the AVQA task head's gradients travel in
+    # the end-of-backward bucket, which the micro-batch form does not carry: N > 1 then replays capture_train_step_ddp's two graphs.
+    MB_OK = ("swin_b", "swin_l", "vit_b") + (("avqa",) if world == 1 else ())
     nmb = args.microbatch if (args.workload in MB_OK and args.batch % max(args.microbatch, 1) == 0 and not args.fp8) else 1
     labels3 = labels.view(args.batch, -1, labels.shape[-1])
+    mb_tensors = (a, v, labels3)
 
     def fwd_loss(a_, v_, y_):                                       # one micro-batch: forward + the harness's loss
         return loss_fn(model(a_, v_, "fusion"), y_.reshape(-1, y_.shape[-1]))
+
+    if args.workload == "avqa":
+        mb_tensors = (aa, vv, vn, qq, ans, match.view(args.batch, -1))
+
+        def fwd_loss(aa_, vv_, vn_, qq_, ans_, match_):             # noqa: F811   traintest_adapt_avqa.py:168-179 on a chunk of clips
+            out_qa, mp, mn = model(aa_, vv_, vn_, qq_, "fusion")
+            return loss_fn(out_qa, ans_) + 0.5 * loss_fn(torch.stack((mp, mn), dim=1).reshape(-1, 2), match_.reshape(-1))
 
     # ---------------------------------------------------------------------------------------------------------------- pass 1: eager
     # One stream, one launch per kernel (the round-3 form): the pass the per-class / per-family roofline samples come from (HIP events
@@ -427,7 +438,7 @@ def main():
         ok, why = 1, ""
         try:
             if nmb > 1:
-                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, (a, v, labels3), opt, splits=nmb, sync=sync, warmup=1)
+                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
             else:
                 replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
         except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)

@@ -245,3 +245,50 @@ def test_recipe_cosine_scheduler_and_optimizer_groups(stg):
     assert sum(p.numel() for p in g1["params"]) == sum(p.numel() for n, p in m.named_parameters() if n.startswith("mlp_head."))
     assert all(p.requires_grad for g in opt.param_groups for p in g["params"])
     assert not m.layers[0].blocks[0].attn.qkv.weight.requires_grad
+
+
+def test_configure_is_the_one_switchboard():
+    """every Python-side switch goes through stgcma.configure(); the module attributes the hot path reads follow it."""
+    import importlib
+    import pytest
+    import torch
+    import stgcma
+    ops = importlib.import_module("stg-cma_amd.ops")
+    ops_vit = importlib.import_module("stg-cma_amd.ops_vit")
+    o0 = stgcma.options()
+    assert o0["residual"] == "float32" and o0["upln"] is True and o0["fp8"] is False
+    try:
+        stgcma.configure(upln=False, residual="bf16", mlp_dact="bf16")
+        assert ops.USE_UPLN is False and ops.RESIDUAL_DTYPE == torch.bfloat16 and ops_vit.RESIDUAL_DTYPE == torch.bfloat16 and ops.MLP_DACT is True
+        assert stgcma.options()["residual"] == "bfloat16"
+        with pytest.raises(KeyError):
+            stgcma.configure(no_such_switch=1)
+    finally:
+        stgcma.configure(upln=True, residual="fp32", mlp_dact="u8")
+    assert ops.USE_UPLN is True and ops.RESIDUAL_DTYPE == torch.float32 and ops.MLP_DACT == "u8"
+
+
+def test_bench_self_launch_builds_the_documented_command(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE: a CHILD process through torch.distributed.run on 127.0.0.1 with the same arguments; the
+    parent relays its exit code (and has not imported torch)."""
+    import subprocess
+    import sys
+    import pytest
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(4)
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

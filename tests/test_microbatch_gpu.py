@@ -78,9 +78,19 @@ def test_microbatched_step_equals_full_batch_step(stg, gpu):
         if big.any():
             worst = max(worst, float((d1[n].detach() - p0[n])[big].abs().max()))
     assert worst <= 2.5e-4, worst                                   # lr = 1e-3: updates of +-1e-3 agree to a quarter of a step at worst
-    # a second replay keeps training (step counters advance, loss stays finite)
-    replay()
-    torch.cuda.synchronize()
+    # Further replays keep training on FRESH weights: the loss a replay reports must be the loss of the parameters it started from.  (Each
+    # micro-batch graph re-casts the bf16 shadows of the trainable weights into its own arena at its start; a graph that read the other's
+    # arena while that one rewrites it -- or last step's shadows -- would report another loss.)
+    for g in o1.param_groups:
+        g["lr"] = 2e-2                                    # make the weights move visibly between the steps
+    o1._push_hyper()
+    for it in range(3):
+        with torch.no_grad():
+            want = float(fwd_loss(a, v, y))               # eager, full batch, the parameters as they are now
+        replay()
+        torch.cuda.synchronize()
+        got = float(static_loss.detach())
+        assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), (it, got, want)
     assert torch.isfinite(static_loss).all()
 
 
