@@ -107,4 +107,6 @@ def test_bench_launches_its_own_ranks(stg, gpu):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["config"]["global_batch"] == 4
-    assert "micro-batch graphs" in d["config"]["step"] or "graphs" in d["config"]["step"], d["config"]["step"]
+    # which step form the timed region used is decided per run from two timed steps of each (all ranks together): two ranks time-slicing ONE
+    # GPU usually lose on the replayed form, real one-GPU-per-rank runs are expected not to -- either way the line must say what it measured
+    assert "graphs" in d["config"]["step"] or ("eager" in d["config"]["step"] and d["config"]["step_forms_measured"]), d["config"]["step"]
