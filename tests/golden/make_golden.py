@@ -461,10 +461,10 @@ def vit_block_case(Cm, tag, *, d, heads, T, B, nv, na, seed, mode="fusion_adapt"
          stats=torch.stack([ov.sum(), ov.abs().sum(), oa.sum(), oa.abs().sum()]))
 
 
-def vit_model_case(Cm, tag, *, layers, heads, d, B, T, seed, mode="fusion"):
+def vit_model_case(Cm, tag, *, layers, heads, d, B, T, seed, mode="fusion", state_fn=None, store_all_grads=True):
     m = Cm.MM_CLIP_AVE(label_dim=29, layers=layers, num_video_frames=T, embed_dim=d, patch_size=16, heads=heads,
                        pretrained=None, ftmode=mode).eval()
-    shapes = seed_module(m, seed)
+    shapes = seed_module(m, seed, state_fn)
     names = apply_freeze(m)
     a = GP.seeded_tensor((B, T, 102, 128), seed + 1, 0.5)
     v = GP.seeded_tensor((B, 3, T, 224, 224), seed + 2)
@@ -474,9 +474,17 @@ def vit_model_case(Cm, tag, *, layers, heads, d, B, T, seed, mode="fusion"):
     loss.backward()
     n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
     n_head = sum(p.numel() for n, p in m.named_parameters() if n in GP.MLP_HEAD)
-    save(tag, shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(layers=layers, heads=heads, d=d, B=B, T=T, seed=seed,
-         mode=mode)), grad_names_json=json.dumps(names), logits=logits, loss=loss.reshape(1), grads=flat_grads(m, names),
-         n_params=np.array([sum(p.numel() for p in m.parameters()), n_train, n_head]))
+    arrs = dict(shapes_json=json.dumps(shapes), cfg_json=json.dumps(dict(layers=layers, heads=heads, d=d, B=B, T=T, seed=seed, mode=mode)),
+                grad_names_json=json.dumps(names), logits=logits, loss=loss.reshape(1),
+                n_params=np.array([sum(p.numel() for p in m.parameters()), n_train, n_head]))
+    g = flat_grads(m, names)
+    if store_all_grads:
+        arrs["grads"] = g
+    else:                                                  # full depth: per-tensor L2 norms + a strided sample (like the big Swin fixtures)
+        dd = dict(m.named_parameters())
+        arrs["grad_norms"] = torch.stack([dd[n].grad.norm() for n in names])
+        arrs["grads_sample"] = g[::97].clone()
+    save(tag, **arrs)
 
 
 def structure_case(S, Cm):
@@ -697,6 +705,8 @@ SWIN_TINY = dict(label_dim=29, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 
 AVS_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=3, adapter_mlp_ratio=[0.5, 0.5, 0.25, 0.25])
 AVQA_TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], num_frames=2, adapter_mlp_ratio=[0.5, 0.25, 0.125, 0.125])
 AVS_FULL_TINY = dict(embed_dim=128, depths=[2, 2, 2, 2], num_heads=[4, 8, 16, 32], num_frames=5, adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
+# BASELINE config 4's model at FULL depth (AVS/run_adapt_avs.py:146-160: Swin-B, depths [2, 2, 18, 2], adapter ratios [.25, .25, .125, .125], T = 5)
+AVS_FULL_B = dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], num_frames=5, adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125])
 AVQA_FULL_TINY = dict(embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48], num_frames=2, adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
 # BASELINE config 5's model beyond depths [2, 2, 2, 2]: Swin-L widths, the AVQA runner's adapter ratios (AVQA/run_adapt_avqa.py:288-301), six
 # stage-2 blocks (three temporal + three shifted), B = 1, reference-initialised backbone (GP.avqa_deep_state)
@@ -767,6 +777,9 @@ def main(argv):
         "vit_block_cfg1": lambda: vit_block_case(Cm, "vit_block_cfg1", d=768, heads=8, T=10, B=1, nv=196, na=196, seed=400),
         "vit_block_small": lambda: vit_block_case(Cm, "vit_block_small", d=256, heads=4, T=2, B=2, nv=50, na=13, seed=410),
         "vit_tiny_fusion": lambda: vit_model_case(Cm, "vit_tiny_fusion", layers=2, heads=8, d=768, B=1, T=2, seed=500),
+        # BASELINE config 2 at FULL depth (12 layers of ViT-B/16 width, heads = 8 as the runner builds it), reference-initialisation scale, two frames
+        "vit_b12_fusion_refinit": lambda: vit_model_case(Cm, "vit_b12_fusion_refinit", layers=12, heads=8, d=768, B=1, T=2, seed=520,
+                                                         state_fn=GP.refinit_state, store_all_grads=False),
         "avs_tiny_backbone": lambda: avs_backbone_case(ref_avs(), "avs_tiny_backbone", cfg=AVS_TINY, B=1, seed=600),
         "avqa_tiny_backbone": lambda: avqa_backbone_case(ref_avqa(), "avqa_tiny_backbone", cfg=AVQA_TINY, B=1, seed=610),
         # t_relative=False on the AVS / AVQA classes (no runner uses it; constructor completeness): B = 2 so that the sum over clips is exercised
@@ -789,6 +802,7 @@ def main(argv):
         "avs_decoder_modules": lambda: avs_modules_case(ref_avs_base(), "avs_decoder_modules", 800),
         "avs_tpavi_vv": lambda: avs_tpavi_vv_case(ref_avs_base(), "avs_tpavi_vv", 860),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
+        "avs_full_b18": lambda: avs_full_case(ref_avs_base(), "avs_full_b18", cfg=AVS_FULL_B, B=1, seed=830),
         "avs_full_tiny_evalbn": lambda: avs_full_evalbn_case(ref_avs_base(), "avs_full_tiny_evalbn", cfg=AVS_FULL_TINY, B=1, seed=840),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),
         # (seed, frames, height, width): seeds picked so that the cases cover erase / no erase and flip / no flip

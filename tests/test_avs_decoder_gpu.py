@@ -139,10 +139,10 @@ def test_tpavi_visual_self_attention_matches_reference_module(stg, gpu, mode):
     _chk(tp.W_z[1].running_mean, z[f"tpavi_{mode}_rm1"], "running_mean"); _chk(tp.W_z[1].running_var, z[f"tpavi_{mode}_rv1"], "running_var")
 
 
-def _build_full(gpu, vv=False, want_state=False):
+def _build_full(gpu, vv=False, want_state=False, case="avs_full_tiny"):
     from stgcma import recipe
     from stgcma.model import Swin_AVSModel
-    z, cfg, shapes, names = load_case("avs_full_tiny")
+    z, cfg, shapes, names = load_case(case)
     m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=cfg["embed_dim"], depths=cfg["depths"],
                                                     num_heads=cfg["num_heads"], ftmode="fusion", adapter_mlp_ratio=cfg["adapter_mlp_ratio"],
                                                     drop_path_rate=0.0, tpavi_vv_flag=vv).train()      # the golden: train-mode BatchNorm, no DropPath
@@ -205,6 +205,28 @@ def test_avs_full_model_with_visual_self_attention_matches_oracle(stg, gpu):
     for n in names:
         assert d[n].grad is None or torch.isfinite(d[n].grad).all(), n
     assert d["avstask_tpavi_b1.phi.weight"].grad is not None and float(d["avstask_tpavi_b1.phi.weight"].grad.abs().max()) > 0
+
+
+def test_avs_full_depth_model_forward_matches_reference(stg, gpu):
+    """BASELINE config 4's model at FULL depth (Swin-B, depths [2, 2, 18, 2], T = 5): outputs against the fixture the reference's
+    SwinTransformer2D_Adapter_AVS_Base produced (avs_full_b18, B = 1).  24 blocks of seeded unit-gain parameters in front of the decoder:
+    bounds relative to each output's scale, first measured in round 4."""
+    from params import seeded_tensor
+    m, z, cfg, names = _build_full(gpu, case="avs_full_b18")
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5).to(gpu)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2).to(gpu)
+    with torch.no_grad():
+        pred, fmaps, afeas = m(a, v, "fusion")
+    errs = {"pred": _rel(pred, z["pred"])}
+    for i in range(4):
+        errs[f"fmap{i}"] = _rel(fmaps[i][:, ::8], z[f"fmap{i}"])
+        errs[f"afea{i}"] = _rel(afeas[i], z[f"afea{i}"])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/model_parity_report.txt", "a") as f:
+        f.write("avs_full_b18 " + " ".join(f"{k}: max/scale={a_:.3e} relL2={b_:.3e}" for k, (a_, b_) in errs.items()) + "\n")
+    for k, (e_max, e_l2) in errs.items():
+        assert e_max <= 8e-2 and e_l2 <= 5e-2, f"{k}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
 
 
 def test_avs_full_model_matches_reference(stg, gpu):

@@ -188,6 +188,31 @@ def test_vit_tiny_model_matches_reference():
     assert list(z["n_params"][1:]) == [sum(P[n].numel() for n in names), sum(P[n].numel() for n in names if n.startswith("mlp_head"))]
 
 
+def test_vit_b_full_depth_matches_reference():
+    """BASELINE config 2 at FULL depth: 12 layers of ViT-B/16 width (heads = 8, AVE/run_adapt_ave29.py:130-139), reference-initialisation
+    scale, generated by the reference's MM_CLIP_AVE (make_golden.py::vit_model_case, vit_b12_fusion_refinit): logits, loss, per-tensor
+    gradient norms and a strided gradient sample."""
+    from params import seeded_tensor, refinit_state
+    z, cfg, shapes, names = load_case("vit_b12_fusion_refinit")
+    P = build_state(shapes, cfg["seed"], kind="vit", state_fn=refinit_state)
+    for n in names:
+        P[n].requires_grad_(True)
+    B, T = cfg["B"], cfg["T"]
+    a = seeded_tensor((B, T, 102, 128), cfg["seed"] + 1, 0.5)
+    v = seeded_tensor((B, 3, T, 224, 224), cfg["seed"] + 2)
+    logits = OV.vit_forward(P, a, v, cfg, "fusion")
+    tgt = torch.softmax(seeded_tensor((B * T, 29), cfg["seed"] + 3, 2.0), -1)
+    loss = OS.soft_target_cross_entropy(logits, tgt)
+    loss.backward()
+    _close(logits, z["logits"], what="logits")
+    _close(loss.reshape(1), z["loss"], tol=1e-4, what="loss")
+    norms = torch.stack([(P[n].grad if P[n].grad is not None else torch.zeros(())).norm() for n in names])
+    ref_norms = torch.as_tensor(z["grad_norms"])
+    assert float(((norms - ref_norms).abs() / ref_norms.clamp_min(1e-6)).max()) <= 2e-3, "per-tensor gradient norms"
+    g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
+    assert float((g - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
 # ----------------------------------------------------------------------------------------------- AVS / AVQA backbones
 @pytest.mark.parametrize("case", ["avs_tiny_backbone", "avs_tiny_backbone_tabs"])      # _tabs: t_relative=False, B = 2
 def test_avs_backbone_matches_reference(case):
@@ -386,6 +411,32 @@ def test_avs_full_model_matches_reference():
     g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
     assert float((g - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
     assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) >= 0.9999
+
+
+def test_avs_full_depth_model_forward_matches_reference():
+    """BASELINE config 4's model at FULL depth (Swin-B, depths [2, 2, 18, 2], adapter ratios [.25, .25, .125, .125], T = 5; fixture
+    avs_full_b18 from the reference's SwinTransformer2D_Adapter_AVS_Base, B = 1): pred, feature maps, audio features, and the direction of
+    the gradient sample (the whole-model gradient under one-clip batch-statistics BatchNorm is ill-conditioned, see above: norms are not held)."""
+    import oracle.avs_decoder as OD
+    from params import seeded_tensor
+    z, cfg, shapes, names = load_case("avs_full_b18")
+    P = _avs_full_state(z, cfg, shapes)
+    for n in names:
+        P[n].requires_grad_(True)
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    pred, fmaps, afeas = OD.avs_forward(P, a, v, cfg, bn_training=True)
+    _close(pred, z["pred"], what="pred")
+    for i in range(4):
+        _close(fmaps[i][:, ::8], z[f"fmap{i}"], what=f"fmap{i}")
+        _close(afeas[i], z[f"afea{i}"], what=f"afea{i}")
+    loss = (pred * seeded_tensor(pred.shape, seed + 3, 1e-2)).sum()
+    for i, (fm, af) in enumerate(zip(fmaps, afeas)):
+        loss = loss + (fm * seeded_tensor(fm.shape, seed + 10 + i, 1e-2)).sum() + (af * seeded_tensor(af.shape, seed + 20 + i, 1e-1)).sum()
+    loss.backward()
+    g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
+    assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) >= 0.999
 
 
 def _avs_evalbn_state(z, cfg, shapes):
