@@ -225,8 +225,11 @@ def test_avs_full_depth_model_forward_matches_reference(stg, gpu):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/model_parity_report.txt", "a") as f:
         f.write("avs_full_b18 " + " ".join(f"{k}: max/scale={a_:.3e} relL2={b_:.3e}" for k, (a_, b_) in errs.items()) + "\n")
+    # 1.5 x measured (round 4): pred 1.7e-2 / 1.7e-2, maps and audio features <= 1.5e-2 / 1.1e-2; the stage-3 map has one element at 6.8e-2 of
+    # its scale (49 positions behind 24 blocks) with the same relative L2 as the others
     for k, (e_max, e_l2) in errs.items():
-        assert e_max <= 8e-2 and e_l2 <= 5e-2, f"{k}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
+        lim = (2.6e-2, 2.6e-2) if k == "pred" else ((1.05e-1, 1.65e-2) if k == "fmap3" else (2.3e-2, 1.65e-2))
+        assert e_max <= lim[0] and e_l2 <= lim[1], f"{k}: max/scale={e_max:.3e} relL2={e_l2:.3e}"
 
 
 def test_avs_full_model_matches_reference(stg, gpu):

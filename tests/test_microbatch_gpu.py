@@ -100,9 +100,16 @@ def test_bench_launches_its_own_ranks(stg, gpu):
     env = dict(os.environ, STG_DDP_BACKEND="gloo", OMP_NUM_THREADS="4")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                   # the children share this process's GPU: hand the cached blocks of earlier tests back first
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "2"],
                        env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    if r.returncode != 0:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/self_launch_failure.txt", "w") as f:
+            f.write(r.stdout[-4000:] + "\n==== stderr\n" + r.stderr[-12000:])
+    assert r.returncode == 0, [ln for ln in r.stderr.splitlines() if "Error" in ln or "error" in ln][-6:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])

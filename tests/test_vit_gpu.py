@@ -173,7 +173,7 @@ def test_vit_b_full_depth_model_matches_reference(stg, gpu):
     ref = torch.as_tensor(z["grads_sample"])
     e_l2 = float((flat - ref).norm() / ref.norm())
     _report.append(f"vit_b12_refinit gradients: strided-sample relL2={e_l2:.3e} worst per-tensor norm deviation={worst:.3e}")
-    assert worst <= 6e-2 and e_l2 <= 6e-2, (worst, e_l2)          # first measurement pending: set to 1.5 x measured once the report line exists
+    assert worst <= 6.7e-3 and e_l2 <= 9.1e-3, (worst, e_l2)      # 1.5 x measured (4.4e-3 / 6.0e-3; logits 3.6e-3 max-abs, round 4)
 
 
 def test_vit_train_mode_and_no_cpu_fallback(stg, gpu):
