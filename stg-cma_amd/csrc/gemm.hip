@@ -51,6 +51,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int nbm, nbn;
     int ntl;           // multi-tile 8-phase kernel: consecutive column tiles per workgroup (divides nbn)
+    int stag;          // 8-phase kernels: start stagger (option gemm_stagger), 0 = none
     int64_t split_m; const bf16_t* W2; const float* bias2;           // two row groups (see stgcma.h): rows >= split_m use W2 / bias2
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
@@ -66,6 +67,17 @@ __device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) 
 }
 
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
+
+// Start stagger of the one-workgroup-per-CU kernels (option gemm_stagger = 256 * phases + q, phases 0 -> 4): the first round of
+// workgroups (blockIdx < 256, one per CU) starts in `phases` groups q * ~1 us apart, and every later workgroup inherits the phase of
+// the CU it lands on -- so that the epilogue store bursts of the CUs do not all fall into the same few microseconds.
+__device__ __forceinline__ void start_stagger(int stag) {
+    if (stag && blockIdx.x < 256) {
+        const int nph = (stag >> 8) ? (stag >> 8) : 4;
+        const int n = (int)((blockIdx.x >> 3) % nph) * (stag & 255);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+}
 
 struct AccTile { f32x4_t v[4][4]; };   // passed BY VALUE: a by-reference accumulator array ends up mirrored in scratch
 
@@ -731,6 +743,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
 // (late group included): A0 p0 -> p2, W1 p1 -> p3, A1 p2 -> p0', W0 p3 -> p1'.
 __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 128 rows x 64 bf16 = 128 KiB
+    start_stagger(p.stag);
     const int nblk = p.nbm * p.nbn;
     int bid = blockIdx.x;
     {
@@ -908,6 +921,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 template <int V>
 __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 16 KiB + 32 KiB of epilogue staging
+    start_stagger(p.stag);
     const int ntl = p.ntl;
     const int gpr = p.nbn / ntl;                         // tile groups per row panel
     const int ngrp = p.nbm * gpr;
@@ -1489,7 +1503,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     if (a->res1) STG_CHECK(a->res1_dtype == STG_BF16 || a->res1_dtype == STG_F32, -3, "stg_gemm_nt: bad res1 dtype");
     if (a->res2) STG_CHECK(a->res2_dtype == STG_BF16 || a->res2_dtype == STG_F32, -3, "stg_gemm_nt: bad res2 dtype");
     if (a->M == 0) return 0;
-    GemmParams p;
+    GemmParams p; p.stag = 0;
     p.A = (const bf16_t*)a->A; p.lda = a->lda;
     p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == STG_F32);
@@ -1609,6 +1623,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
+        p.stag = stg_opt_gemm_stagger.load(std::memory_order_relaxed);
         // multi-tile form (option gemm_8phm, default on): ntl >= 3 consecutive column tiles per workgroup where the tile is short
         // (K <= 512: turnover + epilogue are a third of it; at K = 768 -- ViT-B, Swin-L stage 2 -- the whole-model A/B is neutral to -0.8 %) and the group count still fills the chip twice.  Measured per class of the
         // step, one process, interleaved (tools/gemm_route_ab.py ... gemm_8phm): qkv 125440 x 1536 x 512 247 -> 217 us (ntl = 3), fc1 with
@@ -1616,10 +1631,19 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         // half as many, twice as long workgroups end on a longer tail, and the next tile's first counted wait also waits for the
         // epilogue's own stores (vmcnt is one in-order counter), which a fresh workgroup does not.
         int ntl = 1;
-        const int m8 = stg_opt_gemm_8phm.load(std::memory_order_relaxed);
+        int m8 = stg_opt_gemm_8phm.load(std::memory_order_relaxed);
+        const bool half_ok = m8 != -1;                     // -1: the round-3 rule alone (A/B knob)
+        if (m8 == -1) m8 = 1;
         if (m8 > 0 && gbn >= 3 && (a->K <= 512 || m8 >= 2)) {
             for (int c = (int)(gbn < 8 ? gbn : 8); c >= (m8 >= 2 ? 2 : 3); --c)
                 if (gbn % c == 0 && (m8 >= 2 ? c <= m8 : true) && gbm * (gbn / c) >= 2 * 256) { ntl = c; break; }
+            // round 4: the default step form runs HALF batches (two micro-batch chains): at 62 720 rows no walk of >= 3 tiles leaves two
+            // workgroups per CU, and the classes fell back to the one-tile kernel.  Second pass: the shortest walk that still gives every
+            // CU a workgroup and a half (qkv: 3 tiles, 490 workgroups; fc1: 4 tiles, 490)
+            if (ntl == 1 && half_ok && m8 == 1) {
+                for (int c = 3; c <= (int)(gbn < 8 ? gbn : 8); ++c)
+                    if (gbn % c == 0 && gbm * (gbn / c) >= 256 + 128) { ntl = c; break; }
+            }
         }
         if (ntl > 1) {
             p.ntl = ntl;

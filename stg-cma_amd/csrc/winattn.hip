@@ -50,6 +50,7 @@ __device__ __forceinline__ f32x16_t zero16() {
     return z;
 }
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8_t pack8(const float* x) {
     const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
     return __builtin_bit_cast(bf16x8_t, w);
@@ -649,6 +650,211 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, pipelined (round 4)
+// winattn_fwd1_kernel is a chain per wave -- 12 LDS-DMAs + 16 table loads, s_waitcnt vmcnt(0), ~2 us of VALU / MFMA, stores, exit -- and
+// with 12 waves per CU the bytes in flight while most waves compute are too few for the HBM (3.8 TB/s measured; its traffic is exactly
+// the algorithmic 4 x rows x C x 2 bytes).  Here a wave is PERSISTENT over `ni` consecutive windows of one (window type, head):
+//   * the additive table (64 VGPRs, 16 KiB per wave, more bytes than the wave's q / k / v) is loaded once per wave, not per window;
+//   * window j + 1's q / k / v tiles are in flight (LDS-DMA into the wave's second buffer) while window j is computed: one counted
+//     wait per window (12 DMA instructions younger than everything the window needs);
+//   * tiles hold NKEY = 49 rows (3136 B, not 64 rows): two buffers x three tiles x eight waves = 147 KiB per CU.  Rows 49 .. 63 of the
+//     padded 64 x 64 problem read row 48 (fragment addresses are clamped): padded keys are -1e30 in the table and padded queries are
+//     never stored, exactly as in winattn_fwd1_kernel, whose results this kernel reproduces bit for bit.
+// Workgroup = four consecutive heads of the same windows (256 contiguous bytes per token row across the four waves).
+template <int NKEY>
+__global__ void __launch_bounds__(256, 2) winattn_fwd2_kernel(WinP a, int nchunk, int ni, int cnt) {
+    static_assert(NKEY > 32 && NKEY <= 64, "two query / key tiles");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_w2[];
+    constexpr int TILE = NKEY * WD;
+    constexpr int BUF = 3 * TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    int bid = blockIdx.x;
+    const int c = bid % nchunk;
+    bid /= nchunk;
+    const int HQ = a.H >> 2;
+    const int hq = bid % HQ, gt = bid / HQ;
+    const int h = hq * 4 + wave;
+    const int j0 = c * ni;
+    const int j1 = j0 + ni < cnt ? j0 + ni : cnt;
+    bf16_t* base = smem_w2 + wave * 2 * BUF;
+
+    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
+    auto issue = [&](int j, bf16_t* buf, int64_t (&trow)[4]) {
+        int pg, g;
+        if (a.Gt == 1) { pg = j / a.G; g = j - pg * a.G; } else { pg = j; g = gt; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
+            const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
+            if (i < 3 || lane < 4 * (NKEY - 48)) {           // the fourth instruction stages rows 48 .. NKEY - 1 only
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(buf + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(buf + TILE + i * 512), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(buf + 2 * TILE + i * 512), 16, 0, 0);
+            }
+        }
+    };
+    int64_t trow[2][4];
+    if (j0 < j1) issue(j0, base, trow[0]);
+
+    float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float* bmq = a.bm + ((int64_t)gt * a.H + h) * 4096 + 4 * (32 * qt + r);       // tiled: see win_table_kernel
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+    }
+    const int r1c = 32 + r < NKEY ? 32 + r : NKEY - 1;      // row of the second tile's fragment, clamped
+
+#pragma unroll 1
+    for (int j = j0; j < j1; j += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int jj = j + par;
+            if (jj >= j1) break;
+            bf16_t* sQ = base + par * BUF;
+            bf16_t* sK = sQ + TILE;
+            bf16_t* sV = sK + TILE;
+            if (jj + 1 < j1) {
+                issue(jj + 1, base + (par ^ 1) * BUF, trow[par ^ 1]);
+                // everything older than the 12 DMAs just issued has landed: window jj's tiles and the previous window's stores.  (Letting those
+                // 4 + 2 stores stay in flight -- vmcnt(18) -- measured 3 .. 5 % SLOWER, profiles/r04_winattn_experiments.txt.)
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_fence();
+
+            bf16x8_t qf[2][2], kf[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qf[0][s] = ld_frag(sQ + sw_off(r, hh + 2 * s));
+                kf[0][s] = ld_frag(sK + sw_off(r, hh + 2 * s));
+                qf[1][s] = ld_frag(sQ + sw_off(r1c, hh + 2 * s));
+                kf[1][s] = ld_frag(sK + sw_off(r1c, hh + 2 * s));
+            }
+            f32x16_t st[2][2];               // [q tile][key tile]: St[key][q]
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    st[qt][kt] = zero16();
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) st[qt][kt] = MFMA32(kf[kt][s], qf[qt][s], st[qt][kt]);
+                }
+            // V^T fragments (rows clamped like the q / k fragments).  Through inline asm: the compiler's waitcnt pass cannot see that a
+            // ds_read_b64_tr_b16 does not alias the LDS-DMA of the NEXT window and would put s_waitcnt vmcnt(0) in front of it
+            s4_t vlo[2][2], vhi[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int gi = r & 15, cc = r >> 4;
+                    int row = 32 * kt + 16 * s2 + 4 * hh + (gi >> 2), row8 = row + 8;
+                    const int u = 4 * cc + (gi & 3);
+                    row = row < NKEY ? row : NKEY - 1;
+                    row8 = row8 < NKEY ? row8 : NKEY - 1;
+                    const uint32_t alo = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(sV + sw_off(row, u >> 1) + ((u & 1) << 2));
+                    const uint32_t ahi = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(sV + sw_off(row8, u >> 1) + ((u & 1) << 2));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[kt][s2]) : "v"(alo));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[kt][s2]) : "v"(ahi));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1])
+                         :: "memory");
+            bf16x8_t vf[2][2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8_t f;
+                    f[0] = vlo[kt][s2][0]; f[1] = vlo[kt][s2][1]; f[2] = vlo[kt][s2][2]; f[3] = vlo[kt][s2][3];
+                    f[4] = vhi[kt][s2][0]; f[5] = vhi[kt][s2][1]; f[6] = vhi[kt][s2][2]; f[7] = vhi[kt][s2][3];
+                    vf[kt][s2] = f;
+                }
+            lds_fence();                     // the Q and K tiles are free: O leaves through them
+            int pg, g;
+            if (a.Gt == 1) { pg = jj / a.G; g = jj - pg * a.G; } else { pg = jj; g = gt; }
+            const int64_t pw = (int64_t)pg * a.G + g;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float x[2][16];
+                float m = NEG_BIG;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (!key_reg_live<NKEY>(kt, reg)) continue;
+                        const float4 ad = add[qt][kt][reg >> 2];
+                        const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
+                        x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
+                        m = fmaxf(m, x[kt][reg]);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (!key_reg_live<NKEY>(kt, reg)) { x[kt][reg] = 0.f; continue; }
+                        x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
+                        l += x[kt][reg];
+                    }
+                l += __shfl_xor(l, 32, 64);
+                f32x16_t o = zero16();
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) o = MFMA32(vf[kt][s2], pack8(x[kt] + 8 * s2), o);
+                bf16_t* T = qt == 0 ? sQ : sK;
+                {                            // put_tile32 through inline asm (an LDS store the waitcnt pass would order behind the next window's DMA)
+                    const float sc = 1.0f / l;
+                    const int swz = (r >> 2) & 7;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint32_t ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + r * 32 + (((2 * g4 + hh) ^ swz) << 2));
+                        const u32x2_t v = {pack_bf2(o[4 * g4] * sc, o[4 * g4 + 1] * sc), pack_bf2(o[4 * g4 + 2] * sc, o[4 * g4 + 3] * sc)};
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(v) : "memory");
+                    }
+                }
+                const int q = 32 * qt + r;
+                if (q < a.n && a.lse && hh == 0) a.lse[(pw * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
+            }
+            lds_fence();
+            {                                // flush_tile32 of both tiles, LDS reads through inline asm (see above)
+                u32x2_t lo[4], hi[4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int jr = 0; jr < 2; ++jr) {
+                        const bf16_t* T = t == 0 ? sQ : sK;
+                        const int tl = (lane >> 2) + 16 * jr, cq = lane & 3, sw = (tl >> 2) & 7;
+                        const uint32_t al = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + tl * 32 + (((2 * cq) ^ sw) << 2));
+                        const uint32_t ah = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(lo[2 * t + jr]) : "v"(al));
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(hi[2 * t + jr]) : "v"(ah));
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                             :: "memory");
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int jr = 0; jr < 2; ++jr) {
+                        const int tl = (lane >> 2) + 16 * jr, cq = lane & 3;
+                        if (32 * t + tl < a.n)
+                            *reinterpret_cast<uint4*>(a.O + trow[par][2 * t + jr] * a.ldo + h * WD + cq * 8) =
+                                make_uint4(lo[2 * t + jr][0], lo[2 * t + jr][1], hi[2 * t + jr][0], hi[2 * t + jr][1]);
+                    }
+            }
+            lds_fence();                     // the staging reads are done before the DMA of window jj + 2 re-fills this buffer
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bias + mask table
 // Additive score term v(q, k) = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to
 // 64 x 64 per (window type g, head h) and stored TILED for the kernels' access pattern -- a lane owns one index x (its
@@ -716,6 +922,23 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
+    // pipelined persistent kernel (option winattn_pipe = target waves / 1024, 0 = off): 7 x 7 windows, heads in fours
+    const int pipe = stg_opt_winattn_pipe.load(std::memory_order_relaxed);
+    if (pipe > 0 && p.n == 49 && p.H % 4 == 0 && stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
+        static std::atomic<uint64_t> lds_done{0};
+        const int cnt = p.P / p.Gt;                        // windows per (window type, head)
+        const int pairs = p.Gt * p.H;
+        int nchunk = (pipe * 1024 + pairs / 2) / pairs;
+        if (nchunk < 1) nchunk = 1;
+        if (nchunk > cnt) nchunk = cnt;
+        const int ni = (cnt + nchunk - 1) / nchunk;
+        nchunk = (cnt + ni - 1) / ni;
+        const int lds = 4 * 2 * 3 * 49 * WD * 2;
+        STG_CHECK(stg_reserve_lds(winattn_fwd2_kernel<49>, lds, lds_done), -101, "stg_winattn_fwd: cannot reserve %d bytes of LDS", lds);
+        hipLaunchKernelGGL(winattn_fwd2_kernel<49>, dim3((unsigned)(p.Gt * (p.H / 4) * nchunk)), dim3(256), lds, (hipStream_t)stream, p, nchunk, ni, cnt);
+        STG_LAUNCH_CHECK();
+        return 0;
+    }
     if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
         if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);

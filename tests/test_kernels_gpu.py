@@ -586,3 +586,23 @@ def test_gemm_overlapped_epilogue_kernel_is_bit_identical(stg, gpu):
                     assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, r.view(torch.int16) if r.dtype == torch.bfloat16 else r), (N, mode)
     finally:
         stgcma.configure(lib_gemm_ovl=1)
+
+
+def test_gemm_start_stagger_changes_nothing_but_timing(stg, gpu):
+    """Option gemm_stagger delays the first round of workgroups of the 8-phase kernels (a measured negative result, profiles/
+    r04_gemm_stagger_ab.txt): outputs are bit-identical."""
+    import stgcma
+    from stgcma import kernels as K
+    from stgcma._lib import ACT_GELU
+    torch.manual_seed(5)
+    A = (torch.randn(8192 + 77, 512, device=gpu) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(1536, 512, device=gpu) * 0.05).to(torch.bfloat16)
+    b = torch.randn(1536, device=gpu) * 0.1
+    ref = K.gemm_nt(A, W, b, act=ACT_GELU, want_dact="u8")
+    try:
+        for m in (3, 514):
+            stgcma.configure(lib_gemm_stagger=m)
+            out = K.gemm_nt(A, W, b, act=ACT_GELU, want_dact="u8")
+            assert torch.equal(out[0].view(torch.int16), ref[0].view(torch.int16)) and torch.equal(out[1], ref[1])
+    finally:
+        stgcma.configure(lib_gemm_stagger=0)

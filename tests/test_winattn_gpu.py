@@ -151,3 +151,30 @@ def test_window_shared_kv_single_head_sums_dk_dv(stg, gpu):
     dq_g, dkv_g, _ = k.attn_bwd(ag, q, kv, kv, O2, lse2, dO, shared_kv=True)
     _close(dQ2.float() / scale, dq_g.float() / scale, tol=1.5e-2, what="dQ vs generic")
     _close(dKV.float() / scale, dkv_g.float() / scale, tol=1.5e-2, what="dK + dV vs generic")
+
+
+@pytest.mark.parametrize("images,heads,Himg,shift", [(37, 12, 14, 3), (5, 4, 28, 0), (64, 16, 14, 3)])
+def test_pipelined_forward_is_bit_identical(stg, gpu, images, heads, Himg, shift):
+    """winattn_fwd2_kernel (option winattn_pipe: persistent waves, next window's tiles in flight, 49-row tiles) against the shipped
+    forward: same O and lse bit for bit, for shifted (one table per window type) and plain blocks and ragged chunk counts."""
+    import stgcma
+    from stgcma import kernels as k, ops
+    import oracle.swin as OS
+    g = torch.Generator().manual_seed(21)
+    ws, n, N, C = 7, 49, Himg * Himg, heads * 32
+    qkv = torch.randn(images * N, 3 * C, generator=g).to(BF16).to(gpu)
+    table = (torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5).to(gpu)
+    index = OS.relative_position_index(ws).reshape(-1).to(gpu)
+    mask = ops.shift_mask(Himg, Himg, ws, shift).to(gpu) if shift > 0 else None
+    bm, bmT = k.winattn_table(table, index, mask, n)
+    wg = k.WinGeom(images, heads, Himg, Himg, ws, shift, 32 ** -0.5, bm, bmT)
+    Q, K_, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    O0, lse0 = k.winattn_fwd(wg, Q, K_, V)
+    try:
+        for pipe in (1, 4, 64):
+            stgcma.configure(lib_winattn_pipe=pipe)
+            O1, lse1 = k.winattn_fwd(wg, Q, K_, V)
+            assert torch.equal(O0.view(torch.int16), O1.view(torch.int16)), f"O differs at winattn_pipe={pipe}"
+            assert torch.equal(lse0[..., :n], lse1[..., :n]), f"lse differs at winattn_pipe={pipe}"
+    finally:
+        stgcma.configure(lib_winattn_pipe=0)
