@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 210
+#define STG_VERSION 211
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -215,6 +215,21 @@ int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, c
                     const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt,
                     const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
                     int64_t M, int C, int J, void* stream);
+
+/* Both modalities in ONE launch (round 4).  The fused [video rows | audio rows] token tensor passes every join twice -- once per modality, each
+ * with its own adapter (Swin_AVE.py:716 T_Adapter / T_Adapter_audio, :780-787 S_Adapter2 / _audio, :810-811 S_Adapter / _audio) -- and the two
+ * launches differ only in (h, w, bias, row_scale) resp. (wt, row_scale, dh).  Rows [0, split_m) take the first set, rows [split_m, M) the second
+ * (h2 / dh2 / row_scale2 are indexed from THEIR row 0); split_m % 16 == 0.  Per row the arithmetic is that of the single launches (bit-identical);
+ * a workgroup serves one row group (it stages one adapter weight).  xhat != 0: x holds bf16 normalised rows (stg_ln_bwd_down_xhat's form). */
+int stg_up_ln_fwd_pair(const void* h, const void* h2, int64_t ldh, const void* w, const void* w2, int64_t ldw, const float* bias,
+                       const float* bias2, int64_t split_m, const float* res32, int64_t ld32, const void* res16, int64_t ld16,
+                       const float* row_scale, const float* row_scale2, int64_t rs_outer, int64_t rs_inner, float* x, int64_t ldx,
+                       const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd, int64_t M,
+                       int C, int K, void* stream);
+int stg_ln_bwd_down_pair(int xhat, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
+                         const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, const void* wt2,
+                         int64_t ldwt, const float* row_scale, const float* row_scale2, int64_t rs_outer, int64_t rs_inner, void* dh,
+                         void* dh2, int64_t lddh, int64_t split_m, int64_t M, int C, int J, void* stream);
 
 /* The two LayerNorm backwards from the NORMALISED row (round 3).  A frozen LayerNorm in front of a frozen Linear (Swin_AVE.py:703 / :718
  * norm1 -> attn.qkv, :790 norm2 -> mlp.fc1) never needs its affine: y W^T + b = x_hat (W gamma)^T + (b + W beta), so the caller folds

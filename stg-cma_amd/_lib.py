@@ -147,6 +147,10 @@ SIGNATURES = {
     "stg_up_ln_supported": (C.c_int, [C.c_int, C.c_int]),
     "stg_up_ln_fwd": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64,
                                 c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_up_ln_fwd_pair": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64,
+                                     c_vp, c_i64, c_vp, c_vp, C.c_float, c_vp, c_i64, c_vp, c_vp, c_i64, C.c_int, C.c_int, c_vp]),
+    "stg_ln_bwd_down_pair": (C.c_int, [C.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                       c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
     "stg_ln_bwd_down_supported": (C.c_int, [C.c_int, C.c_int]),
     "stg_ln_bwd_down": (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                   c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, C.c_int, C.c_int, c_vp]),
@@ -214,7 +218,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 210
+ABI_VERSION = 211
 _lib = None
 
 

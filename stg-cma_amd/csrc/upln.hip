@@ -33,6 +33,9 @@ struct UpLnP {
     bf16_t* y; int64_t ldy;
     float* mean; float* rstd;
     int64_t M; int C; int K;
+    // second row group (pair launches, round 4): rows >= split_m take h2 (indexed from its own row 0) / w2 / bias2 / row_scale2; workgroups
+    // [0, nb1) walk group 1, the rest group 2 (a workgroup stages ONE adapter weight).  nb1 == 0: one group.
+    const bf16_t* h2; const bf16_t* w2; const float* bias2; const float* row_scale2; int64_t split_m; int nb1;
 };
 
 __device__ __forceinline__ void unpack8(const uint4& q, float* v) {
@@ -71,6 +74,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int half = NH == 2 ? (wave & 1) : 0;
+    int bid = blockIdx.x, nbk = gridDim.x;
+    if (p.nb1 > 0) {                                                // pair launch: this workgroup's row group (block-uniform)
+        if (bid >= p.nb1) {
+            const int64_t s0 = p.split_m;
+            p.h = p.h2; p.w = p.w2; p.bias = p.bias2; p.row_scale = p.row_scale2;
+            p.res32 += s0 * p.ld32; p.x += s0 * p.ldx; p.y += s0 * p.ldy;
+            if (R16) p.res16 += s0 * p.ld16;
+            if (p.mean) p.mean += s0;
+            if (p.rstd) p.rstd += s0;
+            p.M -= s0; bid -= p.nb1; nbk -= p.nb1;
+        } else {
+            p.M = p.split_m; nbk = p.nb1;
+        }
+    }
     fill_wfrag<TT, KS>(wfrag, p.w, p.ldw, p.K, tid, NW * 64);
     // bias / gamma / beta live in LDS and are re-read per row group through a laundered offset: as loop invariants the
     // compiler hoists all 3 * C / 64 * 4 values per lane out of the row loop (384 VGPRs at C = 512: spills)
@@ -87,7 +104,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
     const float invC = 1.0f / (float)CC;
     const int64_t ngroups = (p.M + 15) >> 4;
     int par = 0;
-    for (int64_t base = (int64_t)blockIdx.x * GPB; base < ngroups; base += (int64_t)gridDim.x * GPB, par ^= 1) {
+    for (int64_t base = (int64_t)bid * GPB; base < ngroups; base += (int64_t)nbk * GPB, par ^= 1) {
         const int64_t grp = base + wave / NH;                       // may run past the end (NH == 2): clamped rows, no stores
         const int64_t row = grp * 16 + m;
         const bool valid = row < p.M;
@@ -212,12 +229,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
     }
 }
 
+// grid of a (pair) launch: one group -> up to 2048 workgroups; two groups -> up to 1024 each, group 1 first (sets nb1)
+template <typename P>
+int64_t plan_grid(P& p, int GPB) {
+    auto blocks = [&](int64_t rows, int64_t cap) { const int64_t n = ((rows + 15) / 16 + GPB - 1) / GPB; return n > cap ? cap : n; };
+    if (p.split_m <= 0) { p.nb1 = 0; return blocks(p.M, 2048); }
+    p.nb1 = (int)blocks(p.split_m, 1024);
+    return p.nb1 + blocks(p.M - p.split_m, 1024);
+}
+
 template <int NT, int NH, int KS, int NW = 4>
-int launch_upln(const UpLnP& p, hipStream_t st) {
+int launch_upln(const UpLnP& pin, hipStream_t st) {
     constexpr int GPB = NW / NH;
-    const int64_t ngroups = (p.M + 15) / 16;
-    int64_t nblk = (ngroups + GPB - 1) / GPB;
-    if (nblk > 2048) nblk = 2048;
+    UpLnP p = pin;
+    const int64_t nblk = plan_grid(p, GPB);
     const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * NW * 16 * sizeof(float2);
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> d1{0}, d0{0};
@@ -251,6 +276,7 @@ struct LnDownP {
     const float* row_scale; int64_t rs_outer, rs_inner;
     bf16_t* dh; int64_t lddh;
     int64_t M; int C; int J;
+    const bf16_t* wt2; const float* row_scale2; bf16_t* dh2; int64_t split_m; int nb1;      // second row group, as in UpLnP (dh2 indexed from its own row 0)
 };
 
 template <int NT, int NH, int NJ, bool ADD, int NW = 4, bool XH = false>
@@ -260,6 +286,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int half = NH == 2 ? (wave & 1) : 0;
+    int bid = blockIdx.x, nbk = gridDim.x;
+    if (p.nb1 > 0) {                                                // pair launch: this workgroup's row group (block-uniform)
+        if (bid >= p.nb1) {
+            const int64_t s0 = p.split_m;
+            p.wt = p.wt2; p.row_scale = p.row_scale2; p.dh = p.dh2;
+            p.dy += s0 * p.lddy; p.dx += s0 * p.lddx; p.rstd += s0;
+            p.x = XH ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(p.x) + s0 * p.ldx) : p.x + s0 * p.ldx;
+            if (!XH) p.mean += s0;
+            if (ADD) p.add_to += s0 * p.ldadd;
+            p.M -= s0; bid -= p.nb1; nbk -= p.nb1;
+        } else {
+            p.M = p.split_m; nbk = p.nb1;
+        }
+    }
     // Wt [J, C] -> LDS in fragment order: entry (jt * NPT + pg) * 64 + l = lane l's 16 bytes of output tile jt, k-block pg.
     // Output slots are paired like the forward kernel's columns: slot 4g + r of tile 2q + i <-> j = 32q + 8g + 4i + r.
     for (int f = tid; f < NJ * NPT * 64; f += NW * 64) {
@@ -279,7 +319,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
     constexpr int GPB = NW / NH;
     const float invC = 1.0f / (float)CC;
     const int64_t ngroups = (p.M + 15) >> 4;
-    for (int64_t base = (int64_t)blockIdx.x * GPB; base < ngroups; base += (int64_t)gridDim.x * GPB) {
+    for (int64_t base = (int64_t)bid * GPB; base < ngroups; base += (int64_t)nbk * GPB) {
         const int64_t grp = base + wave / NH;
         const int64_t row = grp * 16 + m;
         const bool valid = row < p.M;
@@ -421,11 +461,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
 }
 
 template <int NT, int NH, int NJ, int NW = 4, bool XH = false>
-int launch_lnbd(const LnDownP& p, hipStream_t st) {
+int launch_lnbd(const LnDownP& pin, hipStream_t st) {
     constexpr int GPB = NW / NH;
-    const int64_t ngroups = (p.M + 15) / 16;
-    int64_t nblk = (ngroups + GPB - 1) / GPB;
-    if (nblk > 2048) nblk = 2048;
+    LnDownP p = pin;
+    const int64_t nblk = plan_grid(p, GPB);
     const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + NW * 16 * sizeof(float2) + (size_t)(NW / 2) * NJ * 4 * 64 * 4;
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> d1{0}, d0{0};
@@ -451,19 +490,26 @@ extern "C" int stg_up_ln_supported(int C, int K) {
     return (C == 128 || C == 256 || C == 512 || C == 768) && K >= 8 && K <= 64 && K % 8 == 0;
 }
 
-extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
-                             int64_t ld32, const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer,
-                             int64_t rs_inner, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
-                             int64_t ldy, float* mean, float* rstd, int64_t M, int C, int K, void* stream) {
-    STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "stg_up_ln_fwd: null pointer");
-    STG_CHECK(stg_up_ln_supported(C, K), -2, "stg_up_ln_fwd: unsupported C=%d K=%d (C in {128,256,512,768}, K <= 64, K %% 8 == 0)", C, K);
-    STG_CHECK(M >= 0, -2, "stg_up_ln_fwd: bad M");
-    STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "stg_up_ln_fwd: ldh / ldw must be multiples of 8 and >= K");
-    STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "stg_up_ln_fwd: bad ld32 / ldx / ldy");
-    STG_CHECK(res16 == nullptr || (ld16 % 8 == 0 && ld16 >= C), -2, "stg_up_ln_fwd: bad ld16");
-    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_up_ln_fwd: bad row_scale geometry");
+static int up_ln_impl(const char* who, const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
+                      int64_t ld32, const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer, int64_t rs_inner, float* x,
+                      int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
+                      int64_t M, int C, int K, const void* h2, const void* w2, const float* bias2, const float* row_scale2, int64_t split_m,
+                      void* stream) {
+    STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "%s: null pointer", who);
+    STG_CHECK(stg_up_ln_supported(C, K), -2, "%s: unsupported C=%d K=%d (C in {128,256,512,768}, K <= 64, K %% 8 == 0)", who, C, K);
+    STG_CHECK(M >= 0, -2, "%s: bad M", who);
+    STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "%s: ldh / ldw must be multiples of 8 and >= K", who);
+    STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "%s: bad ld32 / ldx / ldy", who);
+    STG_CHECK(res16 == nullptr || (ld16 % 8 == 0 && ld16 >= C), -2, "%s: bad ld16", who);
+    STG_CHECK((row_scale == nullptr && row_scale2 == nullptr) || (rs_outer > 0 && rs_inner > 0), -2, "%s: bad row_scale geometry", who);
     STG_CHECK(((uintptr_t)h | (uintptr_t)w | (uintptr_t)res32 | (uintptr_t)res16 | (uintptr_t)x | (uintptr_t)y | (uintptr_t)bias |
-               (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, -2, "stg_up_ln_fwd: operands must be 16-byte aligned");
+               (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, -2, "%s: operands must be 16-byte aligned", who);
+    if (split_m > 0) {
+        STG_CHECK(h2 && w2 && bias2, -1, "%s: null pointer in the second row group", who);
+        STG_CHECK(split_m < M && split_m % 16 == 0, -2, "%s: split_m must be a multiple of 16 inside (0, M)", who);
+        STG_CHECK(((uintptr_t)h2 | (uintptr_t)w2 | (uintptr_t)bias2) % 16 == 0, -2, "%s: operands must be 16-byte aligned", who);
+        STG_CHECK((row_scale == nullptr) == (row_scale2 == nullptr), -2, "%s: both row groups or neither carry a row_scale", who);
+    }
     if (M == 0) return 0;
     UpLnP p = {};
     p.h = (const bf16_t*)h; p.ldh = ldh; p.w = (const bf16_t*)w; p.ldw = ldw; p.bias = bias;
@@ -471,6 +517,7 @@ extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t 
     p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner;
     p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps; p.y = (bf16_t*)y; p.ldy = ldy;
     p.mean = mean; p.rstd = rstd; p.M = M; p.C = C; p.K = K;
+    p.h2 = (const bf16_t*)h2; p.w2 = (const bf16_t*)w2; p.bias2 = bias2; p.row_scale2 = row_scale2; p.split_m = split_m > 0 ? split_m : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (C / 16) {
         case 8: return dispatch_ks<8, 1>(p, st);
@@ -480,32 +527,64 @@ extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t 
     }
 }
 
+extern "C" int stg_up_ln_fwd(const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
+                             int64_t ld32, const void* res16, int64_t ld16, const float* row_scale, int64_t rs_outer,
+                             int64_t rs_inner, float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y,
+                             int64_t ldy, float* mean, float* rstd, int64_t M, int C, int K, void* stream) {
+    return up_ln_impl("stg_up_ln_fwd", h, ldh, w, ldw, bias, res32, ld32, res16, ld16, row_scale, rs_outer, rs_inner, x, ldx, gamma, beta, eps, y, ldy,
+                      mean, rstd, M, C, K, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int stg_up_ln_fwd_pair(const void* h, const void* h2, int64_t ldh, const void* w, const void* w2, int64_t ldw, const float* bias,
+                                  const float* bias2, int64_t split_m, const float* res32, int64_t ld32, const void* res16, int64_t ld16,
+                                  const float* row_scale, const float* row_scale2, int64_t rs_outer, int64_t rs_inner, float* x, int64_t ldx,
+                                  const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd, int64_t M,
+                                  int C, int K, void* stream) {
+    STG_CHECK(split_m > 0, -2, "stg_up_ln_fwd_pair: split_m must be positive");
+    return up_ln_impl("stg_up_ln_fwd_pair", h, ldh, w, ldw, bias, res32, ld32, res16, ld16, row_scale, rs_outer, rs_inner, x, ldx, gamma, beta, eps, y,
+                      ldy, mean, rstd, M, C, K, h2, w2, bias2, row_scale2, split_m, stream);
+}
+
 extern "C" int stg_ln_bwd_down_supported(int C, int J) {
     // C = 768 (CLIP ViT-B) is left to stg_layernorm_bwd + stg_gemm_nt: with 24 tiles per wave the kernel sits at the 256-VGPR cap
     // with spills and one 8-wave block per CU, and measured 177 us against 125 us for the pair
     return (C == 128 || C == 256 || C == 512) && (J == 16 || J == 32 || J == 64);
 }
 
-extern "C" int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
-                               const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt,
-                               int64_t ldwt, const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
-                               int64_t M, int C, int J, void* stream) {
-    STG_CHECK(dy && x && gamma && mean && rstd && dx && wt && dh, -1, "stg_ln_bwd_down: null pointer");
-    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "stg_ln_bwd_down: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", C, J);
-    STG_CHECK(M >= 0, -2, "stg_ln_bwd_down: bad M");
-    STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % 4 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "stg_ln_bwd_down: bad lddy / ldx / lddx");
-    STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "stg_ln_bwd_down: bad ldadd");
-    STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "stg_ln_bwd_down: bad ldwt / lddh");
-    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_ln_bwd_down: bad row_scale geometry");
-    STG_CHECK(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)add_to | (uintptr_t)dx | (uintptr_t)wt | (uintptr_t)gamma) % 16 == 0 &&
-              (uintptr_t)dh % 8 == 0 && (J == 16 || (uintptr_t)dh % 16 == 0), -2, "stg_ln_bwd_down: operands must be 16-byte aligned");
+static int ln_bwd_down_impl(const char* who, bool xh, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
+                            const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt,
+                            const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh, int64_t M, int C, int J,
+                            const void* wt2, const float* row_scale2, void* dh2, int64_t split_m, void* stream) {
+    STG_CHECK(dy && x && rstd && dx && wt && dh && (xh || (gamma && mean)), -1, "%s: null pointer", who);
+    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "%s: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", who, C, J);
+    STG_CHECK(M >= 0, -2, "%s: bad M", who);
+    STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % (xh ? 8 : 4) == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "%s: bad lddy / ldx / lddx", who);
+    STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "%s: bad ldadd", who);
+    STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "%s: bad ldwt / lddh", who);
+    STG_CHECK((row_scale == nullptr && row_scale2 == nullptr) || (rs_outer > 0 && rs_inner > 0), -2, "%s: bad row_scale geometry", who);
+    STG_CHECK(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)add_to | (uintptr_t)dx | (uintptr_t)wt | (uintptr_t)(xh ? nullptr : gamma)) % 16 == 0 &&
+              (uintptr_t)dh % 8 == 0 && (J == 16 || (uintptr_t)dh % 16 == 0), -2, "%s: operands must be 16-byte aligned", who);
+    if (split_m > 0) {
+        STG_CHECK(wt2 && dh2, -1, "%s: null pointer in the second row group", who);
+        STG_CHECK(split_m < M && split_m % 16 == 0, -2, "%s: split_m must be a multiple of 16 inside (0, M)", who);
+        STG_CHECK((uintptr_t)wt2 % 16 == 0 && (uintptr_t)dh2 % 8 == 0 && (J == 16 || (uintptr_t)dh2 % 16 == 0), -2, "%s: operands must be 16-byte aligned", who);
+        STG_CHECK((row_scale == nullptr) == (row_scale2 == nullptr), -2, "%s: both row groups or neither carry a row_scale", who);
+    }
     if (M == 0) return 0;
     LnDownP p = {};
-    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
+    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const float*)x; p.ldx = ldx; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
     p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd; p.dx = (bf16_t*)dx; p.lddx = lddx; p.wt = (const bf16_t*)wt; p.ldwt = ldwt;
     p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner; p.dh = (bf16_t*)dh; p.lddh = lddh;
     p.M = M; p.C = C; p.J = J;
+    p.wt2 = (const bf16_t*)wt2; p.row_scale2 = row_scale2; p.dh2 = (bf16_t*)dh2; p.split_m = split_m > 0 ? split_m : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (xh) {
+        switch (C / 16) {
+            case 8: return dispatch_nj<8, 1, true>(p, st);
+            case 16: return dispatch_nj<16, 1, true>(p, st);
+            default: return dispatch_nj<16, 2, true>(p, st);
+        }
+    }
     switch (C / 16) {
         case 8: return dispatch_nj<8, 1>(p, st);
         case 16: return dispatch_nj<16, 1>(p, st);
@@ -513,29 +592,29 @@ extern "C" int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int
     }
 }
 
+extern "C" int stg_ln_bwd_down(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                               const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt,
+                               int64_t ldwt, const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh,
+                               int64_t M, int C, int J, void* stream) {
+    return ln_bwd_down_impl("stg_ln_bwd_down", false, dy, lddy, x, ldx, gamma, mean, rstd, add_to, ldadd, dx, lddx, wt, ldwt, row_scale, rs_outer, rs_inner,
+                            dh, lddh, M, C, J, nullptr, nullptr, nullptr, 0, stream);
+}
+
 // stg_ln_bwd_down from the NORMALISED row (see stg_layernorm_bwd_xhat): xhat [M, C] bf16 in place of the fp32 residual row, gamma == 1.
 extern "C" int stg_ln_bwd_down_xhat(const void* dy, int64_t lddy, const void* xhat, int64_t ldx, const float* rstd, const void* add_to,
                                     int64_t ldadd, void* dx, int64_t lddx, const void* wt, int64_t ldwt, const float* row_scale,
                                     int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh, int64_t M, int C, int J, void* stream) {
-    STG_CHECK(dy && xhat && rstd && dx && wt && dh, -1, "stg_ln_bwd_down_xhat: null pointer");
-    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "stg_ln_bwd_down_xhat: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", C, J);
-    STG_CHECK(M >= 0, -2, "stg_ln_bwd_down_xhat: bad M");
-    STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % 8 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "stg_ln_bwd_down_xhat: bad lddy / ldx / lddx");
-    STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "stg_ln_bwd_down_xhat: bad ldadd");
-    STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "stg_ln_bwd_down_xhat: bad ldwt / lddh");
-    STG_CHECK(row_scale == nullptr || (rs_outer > 0 && rs_inner > 0), -2, "stg_ln_bwd_down_xhat: bad row_scale geometry");
-    STG_CHECK(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)add_to | (uintptr_t)dx | (uintptr_t)wt) % 16 == 0 &&
-              (uintptr_t)dh % 8 == 0 && (J == 16 || (uintptr_t)dh % 16 == 0), -2, "stg_ln_bwd_down_xhat: operands must be 16-byte aligned");
-    if (M == 0) return 0;
-    LnDownP p = {};
-    p.dy = (const bf16_t*)dy; p.lddy = lddy; p.x = (const float*)xhat; p.ldx = ldx; p.rstd = rstd;
-    p.add_to = (const bf16_t*)add_to; p.ldadd = ldadd; p.dx = (bf16_t*)dx; p.lddx = lddx; p.wt = (const bf16_t*)wt; p.ldwt = ldwt;
-    p.row_scale = row_scale; p.rs_outer = rs_outer; p.rs_inner = rs_inner; p.dh = (bf16_t*)dh; p.lddh = lddh;
-    p.M = M; p.C = C; p.J = J;
-    hipStream_t st = (hipStream_t)stream;
-    switch (C / 16) {
-        case 8: return dispatch_nj<8, 1, true>(p, st);
-        case 16: return dispatch_nj<16, 1, true>(p, st);
-        default: return dispatch_nj<16, 2, true>(p, st);
-    }
+    return ln_bwd_down_impl("stg_ln_bwd_down_xhat", true, dy, lddy, xhat, ldx, nullptr, nullptr, rstd, add_to, ldadd, dx, lddx, wt, ldwt, row_scale, rs_outer,
+                            rs_inner, dh, lddh, M, C, J, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Both modalities' adapters in ONE launch (round 4): rows [0, split_m) with (wt, row_scale, dh), rows [split_m, M) with (wt2, row_scale2, dh2).
+// x: fp32 residual rows (xhat == 0; gamma, mean required) or bf16 normalised rows (xhat != 0).  Same arithmetic per row as two launches.
+extern "C" int stg_ln_bwd_down_pair(int xhat, const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
+                                    const float* rstd, const void* add_to, int64_t ldadd, void* dx, int64_t lddx, const void* wt, const void* wt2,
+                                    int64_t ldwt, const float* row_scale, const float* row_scale2, int64_t rs_outer, int64_t rs_inner, void* dh,
+                                    void* dh2, int64_t lddh, int64_t split_m, int64_t M, int C, int J, void* stream) {
+    STG_CHECK(split_m > 0, -2, "stg_ln_bwd_down_pair: split_m must be positive");
+    return ln_bwd_down_impl("stg_ln_bwd_down_pair", xhat != 0, dy, lddy, x, ldx, gamma, mean, rstd, add_to, ldadd, dx, lddx, wt, ldwt, row_scale, rs_outer,
+                            rs_inner, dh, lddh, M, C, J, wt2, row_scale2, dh2, split_m, stream);
 }

@@ -674,6 +674,91 @@ def up_ln_fwd(h, w, bias, res32, gamma, beta, *, res16=None, row_scale=None, rs_
     return x, y, mean, rstd
 
 
+@_family("upln_fwd", lambda h, h2, w, w2, bias, bias2, res32, gamma, beta, *, res16=None, **kw:
+         ((w.shape[0], h.shape[1], "pair"), _nb(h, h2, w, w2, res32, res16) + 6.0 * res32.numel(), 2.0 * res32.shape[0] * h.shape[1] * w.shape[0]))
+def up_ln_fwd_pair(h, h2, w, w2, bias, bias2, res32, gamma, beta, *, res16=None, row_scale=None, row_scale2=None, rs_outer=1, rs_inner=1,
+                   out, y_out, mean_out=None, rstd_out=None, eps=1e-5):
+    """up_ln_fwd for both modalities in ONE launch: rows [0, h.shape[0]) with (h, w, bias, row_scale), the rest with (h2, w2, bias2,
+    row_scale2); res32 / res16 / out / y_out / mean_out / rstd_out span all rows.  Same arithmetic per row as two up_ln_fwd calls."""
+    _chk2d(h, "h", BF16)
+    S, K_ = h.shape
+    _chk2d(h2, "h2", BF16, cols=K_)
+    M = S + h2.shape[0]
+    Cc = w.shape[0]
+    _chk2d(w, "w", BF16, rows=Cc)
+    _chk2d(w2, "w2", BF16, rows=Cc)
+    if w.shape[1] < K_ or w2.shape[1] < K_ or _ld(w) != _ld(w2) or _ld(h) != _ld(h2):
+        raise RuntimeError("up_ln_pair: the two row groups must share K and leading dimensions")
+    if S % 16 or S == 0 or h2.shape[0] == 0:
+        raise RuntimeError("up_ln_pair: the first row group must hold a positive multiple of 16 rows, the second at least one")
+    for name, t in (("bias", bias), ("bias2", bias2), ("gamma", gamma), ("beta", beta)):
+        _chk1d(t, name, F32, Cc)
+    _chk2d(res32, "res32", F32, cols=Cc, rows=M)
+    if res16 is not None:
+        _chk2d(res16, "res16", BF16, cols=Cc, rows=M)
+    _chk2d(out, "x", F32, cols=Cc, rows=M)
+    _chk2d(y_out, "y", BF16, cols=Cc, rows=M)
+    if out.data_ptr() == res32.data_ptr():
+        raise RuntimeError("up_ln_pair: x must not alias res32")
+    if (row_scale is None) != (row_scale2 is None):
+        raise RuntimeError("up_ln_pair: both row groups or neither carry a row_scale")
+    for rs_, rows_ in ((row_scale, S), (row_scale2, M - S)):
+        if rs_ is not None:
+            if rs_.dtype != F32 or not rs_.is_cuda or not rs_.is_contiguous():
+                raise RuntimeError("up_ln_pair: row_scale must be a contiguous fp32 GPU vector")
+            if ((rows_ - 1) // rs_outer) * rs_inner + rs_inner > rs_.numel():
+                raise RuntimeError("up_ln_pair: row_scale too short for (rows, rs_outer, rs_inner)")
+    if mean_out is not None:
+        _chk1d(mean_out, "mean", F32, M)
+        _chk1d(rstd_out, "rstd", F32, M)
+    _lib.check(_lib.lib().stg_up_ln_fwd_pair(_p(h), _p(h2), _ld(h), _p(w), _p(w2), _ld(w), _p(bias), _p(bias2), S, _p(res32), _ld(res32),
+                                             _p(res16), _ld(res16) if res16 is not None else 0, _p(row_scale), _p(row_scale2), int(rs_outer),
+                                             int(rs_inner), _p(out), _ld(out), _p(gamma), _p(beta), float(eps), _p(y_out), _ld(y_out),
+                                             _p(mean_out), _p(rstd_out), M, Cc, K_, _stream()), "stg_up_ln_fwd_pair")
+    return out, y_out, mean_out, rstd_out
+
+
+@_family("ln_bwd_down", lambda dy, x, gamma, mean, rstd, wt, wt2, split, *, add_to=None, **kw:
+         ((x.shape[1], wt.shape[0], "pair"), _nb(dy, x, add_to, wt, wt2) + 2.0 * x.numel() + 2.0 * x.shape[0] * wt.shape[0], 2.0 * x.shape[0] * x.shape[1] * wt.shape[0]))
+def ln_bwd_down_pair(dy, x, gamma, mean, rstd, wt, wt2, split, *, add_to=None, row_scale=None, row_scale2=None, rs_outer=1, rs_inner=1, dx_out=None):
+    """ln_bwd_down (x fp32 + gamma + mean) or ln_bwd_down_xhat (x bf16 normalised rows, gamma = mean = None) for both modalities in ONE
+    launch: rows [0, split) project onto wt, the rest onto wt2.  Returns (dx [M, C], dh [M, J]): dh[:split] / dh[split:] are the two
+    single-launch results."""
+    xh = mean is None
+    _chk2d(x, "x", BF16 if xh else F32)
+    M, Cc = x.shape
+    _chk2d(dy, "dy", BF16, cols=Cc, rows=M)
+    J = wt.shape[0]
+    _chk2d(wt, "wt", BF16, rows=J)
+    _chk2d(wt2, "wt2", BF16, rows=J)
+    if wt.shape[1] < Cc or wt2.shape[1] < Cc or _ld(wt) != _ld(wt2):
+        raise RuntimeError("ln_bwd_down_pair: wt / wt2 must be [J, >= C] with one leading dimension")
+    if split % 16 or not 0 < split < M:
+        raise RuntimeError("ln_bwd_down_pair: split must be a multiple of 16 inside (0, M)")
+    if not xh:
+        _chk1d(gamma, "gamma", F32, Cc)
+        _chk1d(mean, "mean", F32, M)
+    _chk1d(rstd, "rstd", F32, M)
+    if add_to is not None:
+        _chk2d(add_to, "add_to", BF16, cols=Cc, rows=M)
+    if (row_scale is None) != (row_scale2 is None):
+        raise RuntimeError("ln_bwd_down_pair: both row groups or neither carry a row_scale")
+    for rs_, rows_ in ((row_scale, split), (row_scale2, M - split)):
+        if rs_ is not None:
+            if rs_.dtype != F32 or not rs_.is_cuda or not rs_.is_contiguous():
+                raise RuntimeError("ln_bwd_down_pair: row_scale must be a contiguous fp32 GPU vector")
+            if ((rows_ - 1) // rs_outer) * rs_inner + rs_inner > rs_.numel():
+                raise RuntimeError("ln_bwd_down_pair: row_scale too short for (rows, rs_outer, rs_inner)")
+    dx = torch.empty((M, Cc), dtype=BF16, device=x.device) if dx_out is None else dx_out
+    _chk2d(dx, "dx", BF16, cols=Cc, rows=M)
+    dh = torch.empty((M, J), dtype=BF16, device=x.device)
+    _lib.check(_lib.lib().stg_ln_bwd_down_pair(1 if xh else 0, _p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(mean), _p(rstd), _p(add_to),
+                                               _ld(add_to) if add_to is not None else 0, _p(dx), _ld(dx), _p(wt), _p(wt2), _ld(wt),
+                                               _p(row_scale), _p(row_scale2), int(rs_outer), int(rs_inner), _p(dh), _p(dh[split:]), _ld(dh),
+                                               int(split), M, Cc, J, _stream()), "stg_ln_bwd_down_pair")
+    return dx, dh
+
+
 def ln_bwd_down_supported(C_, J_):
     return bool(_lib.lib().stg_ln_bwd_down_supported(int(C_), int(J_)))
 

@@ -652,6 +652,24 @@ def _join(Hh, A, out, rows, res32, res16, ln, **rs):
         K.gemm_nt(Hh, A.w2, A.b2, out=out[rows], res1=res16[rows], res2=res32[rows], **rs)
 
 
+JOIN_PAIR = _cfg.opt("join_pair")       # 1: both modalities' joins / LayerNorm-backward + dgrad in one launch (A/B knob)
+
+
+def _join_all(Hs, ads, out, sl, res32, res16, ln, rss=None, **rsg):
+    """_join for every modality; with two modalities behind a fused LayerNorm (whole-tensor operands, 16-aligned halves) ONE launch."""
+    nm = len(ads)
+    if (JOIN_PAIR and ln is not None and nm == 2 and sl[0].start == 0 and sl[0].stop % 16 == 0 and sl[1].start == sl[0].stop
+            and sl[1].stop == res32.shape[0] and Hs[0].shape[1] == Hs[1].shape[1] and Hs[0].stride(0) == Hs[1].stride(0)
+            and ads[0].w2.stride(0) == ads[1].w2.stride(0) and (rss is None or (rss[0] is None) == (rss[1] is None))):
+        kw = dict(row_scale=rss[0], row_scale2=rss[1], **rsg) if rss is not None and rss[0] is not None else {}
+        K.up_ln_fwd_pair(Hs[0], Hs[1], ads[0].w2, ads[1].w2, ads[0].b2, ads[1].b2, res32, ln.gamma, ln.beta, res16=res16, out=out,
+                         y_out=ln.y, mean_out=ln.mean, rstd_out=ln.rstd, **kw)
+        return
+    for i, A in enumerate(ads):
+        kw = dict(row_scale=rss[i], **rsg) if rss is not None and rss[i] is not None else {}
+        _join(Hs[i], A, out, sl[i], res32, res16, ln, **kw)
+
+
 def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
     """LayerNorm backward over all rows; with w2ts (one transposed D_fc2 shadow per modality) the down-projection of the
     adapter that consumes the result is computed in the same pass.  Returns (dX, [dH per modality] or None).
@@ -663,6 +681,11 @@ def _ln_bwd_join(dY, Xs, gamma, mean, rstd, add_to, sl, w2ts, rss=None, **rsg):
             return K.layernorm_bwd_xhat(dY, Xs, rstd, add_to=add_to), None
         return K.layernorm_bwd(dY, Xs, gamma, mean, rstd, add_to=add_to), None
     dX = torch.empty(dY.shape, dtype=BF16, device=dY.device)
+    if (JOIN_PAIR and len(w2ts) == 2 and sl[0].start == 0 and sl[0].stop % 16 == 0 and sl[1].start == sl[0].stop and sl[1].stop == dY.shape[0]
+            and w2ts[0].shape == w2ts[1].shape and w2ts[0].stride(0) == w2ts[1].stride(0) and (rss is None or (rss[0] is None) == (rss[1] is None))):
+        kw = dict(row_scale=rss[0], row_scale2=rss[1], **rsg) if rss is not None and rss[0] is not None else {}
+        _, dh = K.ln_bwd_down_pair(dY, Xs, None if xh else gamma, mean, rstd, w2ts[0], w2ts[1], sl[0].stop, add_to=add_to, dx_out=dX, **kw)
+        return dX, [dh[sl[0]], dh[sl[1]]]
     dH = []
     for i, w in enumerate(w2ts):
         r = sl[i]
@@ -766,8 +789,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         ads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
         pre = _LnOut(X, n1g, n1b) if _ln_fusable(X, ads) else None          # norm1 of the spatial pass
         hz = _down_pair(PO, sl, ads)
-        for i, A in enumerate(ads):
-            _join(hz[i][0], A, X1, sl[i], X, None, pre, row_scale=dps[i], rs_outer=T * N, rs_inner=N)
+        _join_all([hz_[0] for hz_ in hz], ads, X1, sl, X, None, pre, dps, rs_outer=T * N, rs_inner=N)
         pre = pre.triple() if pre is not None else None
         if save:
             S["t"] = (Yt if xh else X, None if xh else mean, rstd, QKV, AO, lse, PO, hz, tbias, dps)
@@ -798,8 +820,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
         H2 = [hz_[0] for hz_ in HZ]
     X2 = torch.empty_like(X)
     ln2 = _LnOut(X, n2g, n2b) if _ln_fusable(X, ads) else None
-    for i, A in enumerate(ads):
-        _join(H2[i], A, X2, sl[i], X1, PO, ln2)
+    _join_all(H2, ads, X2, sl, X1, PO, ln2)
     if save:
         S["s"] = (Ys if xh else X1, None if xh else mean, rstd, QKV, AO, lse, PO, HZ, H2, xs, sbias)
     del QKV, AO, PO, HZ, H2, Ys
@@ -841,8 +862,7 @@ def block_forward(X, spec, P, training, save, pool=None, pre=None, nxt=None):
             H2 = [Hv2, Ha2]
         else:
             H2 = [hz_[0] for hz_ in HZ]
-        for i, A in enumerate(ads):
-            _join(H2[i], A, X3, sl[i], X2, M, ln3)
+        _join_all(H2, ads, X3, sl, X2, M, ln3)
         if save:
             S["f"] = (Yf if xh else X2, None if xh else mean, rstd, Zm, M, HZ, H2, xs)
     if ln3 is not None:

@@ -606,3 +606,53 @@ def test_gemm_start_stagger_changes_nothing_but_timing(stg, gpu):
             assert torch.equal(out[0].view(torch.int16), ref[0].view(torch.int16)) and torch.equal(out[1], ref[1])
     finally:
         stgcma.configure(lib_gemm_stagger=0)
+
+
+@pytest.mark.parametrize("C,J,S,M2", [(512, 32, 64 * 37, 64 * 37), (128, 16, 16 * 5, 16 * 9 + 3), (256, 64, 4096, 1000)])
+@pytest.mark.parametrize("with_rs", [False, True])
+def test_pair_launches_equal_two_single_launches(stg, gpu, C, J, S, M2, with_rs):
+    """stg_up_ln_fwd_pair / stg_ln_bwd_down_pair (both modalities' adapters in one launch, round 4) against the two single launches they
+    replace: every output bit for bit (x, y, mean, rstd; dx, dh), fp32-residual and x-hat forms, with and without DropPath row scales."""
+    from stgcma import kernels as K
+    torch.manual_seed(C + J + with_rs)
+    M = S + M2
+    bf = lambda *s, sc=1.0: (torch.randn(*s, device=gpu) * sc).to(torch.bfloat16)
+    h = bf(M, J)
+    w1, w2 = bf(C, J, sc=0.1), bf(C, J, sc=0.1)
+    b1, b2 = torch.randn(C, device=gpu) * 0.1, torch.randn(C, device=gpu) * 0.1
+    res32, res16 = torch.randn(M, C, device=gpu), bf(M, C)
+    gamma, beta = torch.rand(C, device=gpu) + 0.5, torch.randn(C, device=gpu) * 0.1
+    inner = 16
+    rs1 = (torch.rand((S + inner - 1) // inner * 1, device=gpu) + 0.5) if with_rs else None
+    rs2 = (torch.rand((M2 + inner - 1) // inner * 1, device=gpu) + 0.5) if with_rs else None
+    rkw = dict(rs_outer=inner, rs_inner=1) if with_rs else {}
+    sl = [slice(0, S), slice(S, M)]
+    for r16 in (res16, None):
+        x0, y0 = torch.empty(M, C, device=gpu), torch.empty(M, C, device=gpu, dtype=torch.bfloat16)
+        m0, r0 = torch.empty(M, device=gpu), torch.empty(M, device=gpu)
+        for i, (w, b, rs) in enumerate(((w1, b1, rs1), (w2, b2, rs2))):
+            K.up_ln_fwd(h[sl[i]], w, b, res32[sl[i]], gamma, beta, res16=None if r16 is None else r16[sl[i]], out=x0[sl[i]], y_out=y0[sl[i]],
+                        mean_out=m0[sl[i]], rstd_out=r0[sl[i]], row_scale=rs, **rkw)
+        x1, y1 = torch.full_like(x0, float("nan")), torch.full_like(y0, float("nan"))
+        m1, r1 = torch.full_like(m0, float("nan")), torch.full_like(r0, float("nan"))
+        K.up_ln_fwd_pair(h[sl[0]], h[sl[1]], w1, w2, b1, b2, res32, gamma, beta, res16=r16, out=x1, y_out=y1, mean_out=m1, rstd_out=r1,
+                         row_scale=rs1, row_scale2=rs2, **rkw)
+        assert torch.equal(x0, x1) and torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    if not K.ln_bwd_down_supported(C, J):
+        return
+    dy = bf(M, C)
+    wt1, wt2 = w1.t().contiguous(), w2.t().contiguous()
+    for xh in (True, False):
+        X = y0 if xh else x0
+        dx0 = torch.empty(M, C, device=gpu, dtype=torch.bfloat16)
+        dh0 = []
+        for i, (wt, rs) in enumerate(((wt1, rs1), (wt2, rs2))):
+            if xh:
+                dh0.append(K.ln_bwd_down_xhat(dy[sl[i]], X[sl[i]], r0[sl[i]], wt, add_to=res16[sl[i]], dx_out=dx0[sl[i]], row_scale=rs, **rkw)[1])
+            else:
+                dh0.append(K.ln_bwd_down(dy[sl[i]], X[sl[i]], gamma, m0[sl[i]], r0[sl[i]], wt, add_to=res16[sl[i]], dx_out=dx0[sl[i]], row_scale=rs, **rkw)[1])
+        dx1 = torch.full_like(dx0, float("nan"))
+        _, dh1 = K.ln_bwd_down_pair(dy, X, None if xh else gamma, None if xh else m0, r0, wt1, wt2, S, add_to=res16, dx_out=dx1,
+                                    row_scale=rs1, row_scale2=rs2, **rkw)
+        assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), f"dx differs (xhat={xh})"
+        assert torch.equal(torch.cat(dh0).view(torch.int16), dh1.view(torch.int16)), f"dh differs (xhat={xh})"
