@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 211
+#define STG_VERSION 212
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -325,6 +325,18 @@ int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
  * AVE/model/Swin_AVE.py:750-760, run with H = 1 and an all-zero bias table) and dK receives dK + dV. */
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
+
+/* The adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760 / the S_Adapter2 site: h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and the same
+ * with the roles swapped), round 4: both directions AND the gates in one launch each way -- per site this replaces 2 x stg_winattn_fwd +
+ * stg_gate_fwd2 resp. stg_gate_bwd2 + 2 x stg_winattn_bwd.  a0 / a1 describe the two directions exactly as stg_winattn_fwd takes them (same
+ * geometry and tables, K == V, O / lse per direction); x0 / x1 [rows, H*32] bf16 receive Q + gate * O.  Backward: dx0 / dx1 are the gradients wrt
+ * x0 / x1; dq / dk per direction are written (dk = dK + dV), dgate0 / dgate1 (fp32 scalars) are ACCUMULATED (one atomicAdd per wave).
+ * Per element the arithmetic of the launches it replaces. */
+int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0, void* x1,
+                          int64_t ldx, void* stream);
+int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, const void* dx0,
+                          const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk, float* dgate0,
+                          float* dgate1, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Temporal attention: WindowAttention.forward's temporal branch (Swin_AVE.py:244-255; block call sites :705-716) with the

@@ -37,7 +37,21 @@ struct WinP {
     const bf16_t* dO; int64_t lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
     int total;
+    // cross-modal pair (XP kernels, round 4): problems [total, 2 total) are the SECOND direction (its own q / k = v / o / lse / gradients);
+    // forward also writes the gated hidden state X = Q + gate * O, backward takes the gradient of X: dO = gate * dX, dgate += <dX, O>
+    const bf16_t* Q2; const bf16_t* K2; const bf16_t* V2; bf16_t* O2; float* lse2;
+    const float* gate[2]; bf16_t* X[2]; int64_t ldx;
+    const bf16_t* dO2; bf16_t* dQ2; bf16_t* dK2; float* dgate[2];
 };
+
+__device__ __forceinline__ void unpack8f(const uint4& q, float* v) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8u(const float* t) {
+    return make_uint4(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]), pack_bf2(t[4], t[5]), pack_bf2(t[6], t[7]));
+}
 
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -385,7 +399,8 @@ __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const
     }
 }
 
-template <int NKEY>
+// XP: the cross-modal pair (see WinP) -- both directions in one launch, the gate's backward folded in (dV == NULL semantics: dK receives dK + dV)
+template <int NKEY, bool XP = false>
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
@@ -393,8 +408,20 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= a.total) return;
+    int item = blockIdx.x * 4 + wave;
+    const bf16_t *Qp = a.Q, *Kp = a.K, *Vp = a.V, *Op = a.O, *dOp = a.dO;
+    const float* lsep = a.lse;
+    bf16_t* dQp = a.dQ;
+    bf16_t* dKp = a.dK;
+    const float* gp = a.gate[0];
+    float* dgp = a.dgate[0];
+    if (XP) {
+        if (item >= 2 * a.total) return;
+        if (item >= a.total) {
+            item -= a.total;
+            Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; dOp = a.dO2; lsep = a.lse2; dQp = a.dQ2; dKp = a.dK2; gp = a.gate[1]; dgp = a.dgate[1];
+        }
+    } else if (item >= a.total) return;
     const int h = item % a.H;
     const int p = item / a.H;
     const int pg = p / a.G, g = p - pg * a.G;
@@ -415,18 +442,18 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     for (int i = 0; i < 4; ++i) {
         trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
         const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(sP + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dO + trow[i] * a.lddo + h * WD + cs * 8),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kp + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qp + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vp + off), (__attribute__((address_space(3))) void*)(sP + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dOp + trow[i] * a.lddo + h * WD + cs * 8),
                                          (__attribute__((address_space(3))) void*)(sD + i * 512), 16, 0, 0);
-        vo[i] = *reinterpret_cast<const uint4*>(a.O + trow[i] * a.ldo + h * WD + cs * 8);
+        vo[i] = *reinterpret_cast<const uint4*>(Op + trow[i] * a.ldo + h * WD + cs * 8);
     }
     float lse_q[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int q = 32 * t + r;
-        lse_q[t] = q < a.n ? a.lse[((int64_t)p * a.H + h) * 64 + q] * 1.4426950408889634f : 1.0e30f;
+        lse_q[t] = q < a.n ? lsep[((int64_t)p * a.H + h) * 64 + q] * 1.4426950408889634f : 1.0e30f;
     }
     const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
     // the additive table of a (key tile, q tile) pair is fetched one pair ahead (L2 hits, but ~1 us each when waited for in place);
@@ -442,9 +469,23 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     lds_fence();
     // delta[q] = sum_d dO[q][d] O[q][d]: the lane's own 16-byte piece of dO (back from LDS) times the same piece of O, summed over the
     // four lanes of the row
+    float gacc = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint4 vd = *reinterpret_cast<const uint4*>(sD + i * 512 + lane * 8);
+        uint4 vd = *reinterpret_cast<const uint4*>(sD + i * 512 + lane * 8);
+        if (XP) {                                          // the tile holds dX: dgate += <dX, O> over the real rows, then dO = gate * dX in place
+            float dd[8], oo[8];
+            unpack8f(vd, dd); unpack8f(vo[i], oo);
+            if ((lane >> 2) + 16 * i < a.n) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) gacc += dd[jj] * oo[jj];
+            }
+            const float gv = gp[0];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) dd[jj] *= gv;
+            vd = pack8u(dd);
+            *reinterpret_cast<uint4*>(sD + i * 512 + lane * 8) = vd;
+        }
         const uint32_t dw[4] = {vd.x, vd.y, vd.z, vd.w}, ow[4] = {vo[i].x, vo[i].y, vo[i].z, vo[i].w};
         float d = 0.f;
 #pragma unroll
@@ -453,6 +494,11 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
         if ((lane & 3) == 0) sDel[(lane >> 2) + 16 * i] = d;
+    }
+    if (XP) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) gacc += __shfl_xor(gacc, o, 64);
+        if (lane == 0) atomicAdd(dgp, gacc);
     }
     lds_fence();
     bf16x8_t vf[2][2];
@@ -519,17 +565,17 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
             for (int g4 = 0; g4 < 4; ++g4) addc[g4] = addn[g4];
         }
         const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * WD, trow[2 * kt + 1] * a.lddqkv + h * WD};
-        if (a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
+        if (XP || a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
 #pragma unroll
             for (int i = 0; i < 16; ++i) dk[i] = fmaf(dk[i], a.scale, dv[i]);
             put_tile32(sP, dk, 1.0f, r, hh);
             lds_fence();
-            flush_tile32(sP, a.dK, ro, kt, a.n, lane);
+            flush_tile32(sP, dKp, ro, kt, a.n, lane);
         } else {
             put_tile32(sP, dk, a.scale, r, hh);
             put_tile32(sS, dv, 1.0f, r, hh);
             lds_fence();
-            flush_tile32(sP, a.dK, ro, kt, a.n, lane);
+            flush_tile32(sP, dKp, ro, kt, a.n, lane);
             flush_tile32(sS, a.dV, ro, kt, a.n, lane);
         }
         lds_fence();
@@ -540,22 +586,31 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     {
         const int64_t r0[2] = {trow[0] * a.lddqkv + h * WD, trow[1] * a.lddqkv + h * WD};
         const int64_t r1[2] = {trow[2] * a.lddqkv + h * WD, trow[3] * a.lddqkv + h * WD};
-        flush_tile32(sP, a.dQ, r0, 0, a.n, lane);
-        flush_tile32(sS, a.dQ, r1, 1, a.n, lane);
+        flush_tile32(sP, dQp, r0, 0, a.n, lane);
+        flush_tile32(sS, dQp, r1, 1, a.n, lane);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
 // winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
 // fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
-template <int NKEY>
+// XP: the cross-modal pair (see WinP) -- both directions in one launch, and X = Q + gate * O written beside O
+template <int NKEY, bool XP = false>
 __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     constexpr int PER_WAVE = 3 * 64 * WD;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= a.total) return;
+    int item = blockIdx.x * 4 + wave;
+    const bf16_t *Qp = a.Q, *Kp = a.K, *Vp = a.V;
+    bf16_t* Op = a.O;
+    bf16_t* Xp = a.X[0];
+    float* lsep = a.lse;
+    const float* gp = a.gate[0];
+    if (XP) {
+        if (item >= 2 * a.total) return;
+        if (item >= a.total) { item -= a.total; Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; lsep = a.lse2; gp = a.gate[1]; Xp = a.X[1]; }
+    } else if (item >= a.total) return;
     const int h = item % a.H;
     const int p = item / a.H;
     const int pg = p / a.G, g = p - pg * a.G;
@@ -569,9 +624,9 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     for (int i = 0; i < 4; ++i) {
         trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
         const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qp + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kp + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vp + off), (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
     }
     const float* bmq[2];
 #pragma unroll
@@ -639,14 +694,36 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         bf16_t* T = qt == 0 ? sQ : sK;
         put_tile32(T, o, 1.0f / l, r, hh);
         const int q = 32 * qt + r;
-        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
+        if (q < a.n && lsep && hh == 0) lsep[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
     }
     lds_fence();
-    {
+    if (XP) {                        // O and the gated hidden state X = Q + gate * O (gate_fwd's arithmetic on the bf16-rounded O)
+        const float gv = gp[0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int jr = 0; jr < 2; ++jr) {
+                const bf16_t* T = t == 0 ? sQ : sK;
+                const int tl = (lane >> 2) + 16 * jr, cq = lane & 3, sw = (tl >> 2) & 7;
+                const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
+                const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
+                if (32 * t + tl < a.n) {
+                    const int64_t ro = trow[2 * t + jr];
+                    const uint4 ov = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    *reinterpret_cast<uint4*>(Op + ro * a.ldo + h * WD + cq * 8) = ov;
+                    float qa[8], ob[8];
+                    unpack8f(*reinterpret_cast<const uint4*>(Qp + ro * a.ld + h * WD + cq * 8), qa);
+                    unpack8f(ov, ob);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) qa[jj] += gv * ob[jj];
+                    *reinterpret_cast<uint4*>(Xp + ro * a.ldx + h * WD + cq * 8) = pack8u(qa);
+                }
+            }
+    } else {
         const int64_t r0[2] = {trow[0] * a.ldo + h * WD, trow[1] * a.ldo + h * WD};
         const int64_t r1[2] = {trow[2] * a.ldo + h * WD, trow[3] * a.ldo + h * WD};
-        flush_tile32(sQ, a.O, r0, 0, a.n, lane);
-        flush_tile32(sK, a.O, r1, 1, a.n, lane);
+        flush_tile32(sQ, Op, r0, 0, a.n, lane);
+        flush_tile32(sK, Op, r1, 1, a.n, lane);
     }
 }
 
@@ -965,6 +1042,63 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     else if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760: h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and the same with the
+// roles swapped), both directions and the gates in one launch each way (round 4).  a0 / a1: the two directions as stg_winattn_fwd would take
+// them (same geometry, K == V); x0 / x1 receive Q + gate * O (bf16, leading dimension ldx).  Per element the arithmetic of stg_winattn_fwd
+// followed by stg_gate_fwd.
+static int xpair_fill(const stg_winattn_args* a0, const stg_winattn_args* a1, WinP& p, const char* who) {
+    STG_CHECK(a0 && a1, -1, "%s: null args", who);
+    int rc = fill(a0, p, who);
+    if (rc) return rc;
+    WinP q = {};
+    rc = fill(a1, q, who);
+    if (rc) return rc;
+    STG_CHECK(a0->K == a0->V && a1->K == a1->V, -2, "%s: the pair kernels serve K == V (dK receives dK + dV)", who);
+    STG_CHECK(a0->P == a1->P && a0->H == a1->H && a0->n == a1->n && a0->ws == a1->ws && a0->shift == a1->shift && a0->Himg == a1->Himg &&
+              a0->Wimg == a1->Wimg && a0->outer == a1->outer && a0->ld == a1->ld && a0->ldo == a1->ldo && a0->bm == a1->bm && a0->bmT == a1->bmT &&
+              a0->Gt == a1->Gt && a0->scale == a1->scale, -2, "%s: the two directions must share geometry, tables and leading dimensions", who);
+    STG_CHECK(a0->O && a1->O && a0->ldo % 8 == 0 && (((uintptr_t)a0->O | (uintptr_t)a1->O) & 15) == 0, -2, "%s: bad O (16-byte stores)", who);
+    p.Q2 = q.Q; p.K2 = q.K; p.V2 = q.V; p.O2 = q.O; p.lse2 = q.lse;
+    return 0;
+}
+
+extern "C" int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0,
+                                     void* x1, int64_t ldx, void* stream) {
+    WinP p = {};
+    int rc = xpair_fill(a0, a1, p, "stg_winattn_xpair_fwd");
+    if (rc) return rc;
+    STG_CHECK(gate0 && gate1 && x0 && x1 && ldx % 8 == 0 && (((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, -2, "stg_winattn_xpair_fwd: bad gate / x operands");
+    if (p.total == 0) return 0;
+    p.gate[0] = gate0; p.gate[1] = gate1; p.X[0] = (bf16_t*)x0; p.X[1] = (bf16_t*)x1; p.ldx = ldx;
+    const unsigned grid = (unsigned)((2 * (int64_t)p.total + 3) / 4);
+    if (p.n == 49) hipLaunchKernelGGL((winattn_fwd1_kernel<49, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winattn_fwd1_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* dx0 / dx1: gradients wrt the gated hidden states x0 / x1.  Writes dQ and dK (+ dV) per direction and ACCUMULATES dgate (one atomicAdd per wave). */
+extern "C" int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1,
+                                     const void* dx0, const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk,
+                                     float* dgate0, float* dgate1, void* stream) {
+    WinP p = {};
+    int rc = xpair_fill(a0, a1, p, "stg_winattn_xpair_bwd");
+    if (rc) return rc;
+    STG_CHECK(a0->lse && a1->lse && gate0 && gate1 && dx0 && dx1 && dq0 && dk0 && dq1 && dk1 && dgate0 && dgate1, -1, "stg_winattn_xpair_bwd: null pointer");
+    STG_CHECK(lddx % 8 == 0 && lddqk % 8 == 0, -2, "stg_winattn_xpair_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)dx0 | (uintptr_t)dx1 | (uintptr_t)dq0 | (uintptr_t)dk0 | (uintptr_t)dq1 | (uintptr_t)dk1) & 15) == 0, -2, "stg_winattn_xpair_bwd: misaligned pointers");
+    if (p.total == 0) return 0;
+    p.gate[0] = gate0; p.gate[1] = gate1; p.dgate[0] = dgate0; p.dgate[1] = dgate1;
+    p.dO = (const bf16_t*)dx0; p.dO2 = (const bf16_t*)dx1; p.lddo = lddx;
+    p.dQ = (bf16_t*)dq0; p.dK = (bf16_t*)dk0; p.dQ2 = (bf16_t*)dq1; p.dK2 = (bf16_t*)dk1; p.dV = nullptr; p.lddqkv = lddqk;
+    const unsigned grid = (unsigned)((2 * (int64_t)p.total + 3) / 4);
+    if (p.n == 49) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winattn_bwd1_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

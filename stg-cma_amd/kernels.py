@@ -1363,6 +1363,52 @@ def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     return dQ, dK, dV
 
 
+def _gate_ok(t, name):
+    if t.dtype != F32 or not t.is_cuda or t.numel() != 1:
+        raise RuntimeError(f"winattn_xpair: {name} must be a one-element fp32 GPU tensor")
+
+
+@_family("winattn_fwd", lambda g, hv, ha, *a, **kw: (("xpair", g.H * 32), 12.0 * (g.P // g.G) * g.outer * g.H * 32, 8.0 * g.P * g.H * g.n * g.n * 32))
+def winattn_xpair_fwd(g, hv, ha, gate_v, gate_a):
+    """The window-level cross-modal pair in ONE launch: r_v = softmax(h_v h_a^T) h_a, r_a = softmax(h_a h_v^T) h_v per window, and the gated
+    hidden states x_v = h_v + gate_v r_v, x_a = h_a + gate_a r_a.  Returns (x_v, x_a, r_v, r_a, lse_v, lse_a)."""
+    _gate_ok(gate_v, "gate_v"); _gate_ok(gate_a, "gate_a")
+    if hv.shape != ha.shape or _ld(hv) != _ld(ha):
+        raise RuntimeError("winattn_xpair: the two hidden-state tensors must share shape and leading dimension")
+    w = g.H * 32
+    rv, ra, xv, xa = (torch.empty((hv.shape[0], w), dtype=BF16, device=hv.device) for _ in range(4))
+    lse_v, lse_a = (torch.empty((g.P, g.H, 64), dtype=F32, device=hv.device) for _ in range(2))
+    a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
+    a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
+    _lib.check(_lib.lib().stg_winattn_xpair_fwd(C.byref(a0), C.byref(a1), _p(gate_v), _p(gate_a), _p(xv), _p(xa), _ld(xv), _stream()),
+               "stg_winattn_xpair_fwd")
+    return xv, xa, rv, ra, lse_v, lse_a
+
+
+@_family("winattn_bwd", lambda g, hv, ha, *a, **kw: (("xpair", g.H * 32), 20.0 * (g.P // g.G) * g.outer * g.H * 32, 20.0 * g.P * g.H * g.n * g.n * 32))
+def winattn_xpair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a, dgate_v, dgate_a):
+    """Backward of winattn_xpair_fwd's attention + gate part: dxv / dxa are the gradients wrt x_v / x_a.  Returns (dq_v, dkv_a, dq_a, dkv_v) --
+    the gradients wrt h_v as queries, h_a as keys / values of direction v, and the same for direction a; dgate_v / dgate_a are accumulated."""
+    for t, name in ((gate_v, "gate_v"), (gate_a, "gate_a"), (dgate_v, "dgate_v"), (dgate_a, "dgate_a")):
+        _gate_ok(t, name)
+    rows = (g.P // g.G) * g.outer
+    for t, name in ((dxv, "dxv"), (dxa, "dxa")):
+        _chk2d(t, name, BF16)
+        if t.shape[1] < g.H * 32 or t.shape[0] < rows:
+            raise RuntimeError(f"winattn_xpair_bwd {name}: needs >= {rows} rows x {g.H * 32} columns")
+    if _ld(dxv) != _ld(dxa):
+        raise RuntimeError("winattn_xpair_bwd: dxv / dxa must share one leading dimension")
+    for l_ in (lse_v, lse_a):
+        if l_ is None or l_.dtype != F32 or l_.numel() != g.P * g.H * 64:
+            raise RuntimeError("winattn_xpair_bwd: bad lse")
+    dq_v, dkv_a, dq_a, dkv_v = (torch.empty((hv.shape[0], g.H * 32), dtype=BF16, device=hv.device) for _ in range(4))
+    a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
+    a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
+    _lib.check(_lib.lib().stg_winattn_xpair_bwd(C.byref(a0), C.byref(a1), _p(gate_v), _p(gate_a), _p(dxv), _p(dxa), _ld(dxv), _p(dq_v), _p(dkv_a),
+                                                _p(dq_a), _p(dkv_v), _ld(dq_v), _p(dgate_v), _p(dgate_a), _stream()), "stg_winattn_xpair_bwd")
+    return dq_v, dkv_a, dq_a, dkv_v
+
+
 class TGeom:
     """One temporal-attention call over the fused qkv buffer: nm modality slabs x B clips x T frames x N tokens, H heads of
     dim 32; row(m, b, t, n) = ((m*B + b)*T + t)*N + n.  bias: fp32 [nm, H, T*T].  The additive tables the kernels read

@@ -524,6 +524,7 @@ def _xwin_geom(spec, BT, dev):
     return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
 
 
+XWIN_PAIR = _cfg.opt("xwin_pair")  # 1: the window-level cross-modal pair (both directions + gates) in one launch each way (A/B knob)
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
 
 
@@ -560,6 +561,9 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
         wg = _xwin_geom(spec, BT, hv.device)
+        if XWIN_PAIR and hv.shape == ha.shape and hv.stride(0) == ha.stride(0):
+            hv2, ha2, rv, ra, lse_v, lse_a = K.winattn_xpair_fwd(wg, hv, ha, gate_v, gate_a)     # both directions + the gates: one launch
+            return hv2, ha2, (rv, ra, lse_v, lse_a, wg)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
@@ -583,6 +587,9 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
         if dgate_a is None:
             dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
+        if XWIN_PAIR and hv.shape == ha.shape and hv.stride(0) == ha.stride(0) and dhv2.stride(0) == dha2.stride(0):
+            dq_v, dkv_a, dq_a, dkv_v = K.winattn_xpair_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, dhv2, dha2, gate_v, gate_a, dgate_v, dgate_a)
+            return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
         drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v

@@ -178,3 +178,41 @@ def test_pipelined_forward_is_bit_identical(stg, gpu, images, heads, Himg, shift
             assert torch.equal(lse0[..., :n], lse1[..., :n]), f"lse differs at winattn_pipe={pipe}"
     finally:
         stgcma.configure(lib_winattn_pipe=0)
+
+
+@pytest.mark.parametrize("images,Himg,shift", [(6, 14, 3), (3, 28, 0), (5, 7, 0)])
+def test_cross_modal_pair_equals_the_launches_it_replaces(stg, gpu, images, Himg, shift):
+    """stg_winattn_xpair_fwd / _bwd (both directions of the window-level cross-modal pair + the gates, one launch each way) against
+    2 x winattn_fwd + gate_fwd2 resp. gate_bwd2 + 2 x winattn_bwd: x, r, lse, dq, dk bit for bit; dgate (atomically accumulated in both
+    forms) to 1e-5 relative."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(31 + images)
+    ws, n, N = 7, 49, Himg * Himg
+    hv = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    ha = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    dxv = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    dxa = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    gate_v = torch.tensor([0.37], device=gpu)
+    gate_a = torch.tensor([-1.21], device=gpu)
+    bm, bmT = k.winattn_table(torch.zeros(((2 * ws - 1) ** 2, 1), device=gpu), torch.zeros(n * n, dtype=torch.int64, device=gpu), None, n)
+    wg = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, bm, bmT)
+    # the launches it replaces
+    rv, lse_v = k.winattn_fwd(wg, hv, ha, ha)
+    ra, lse_a = k.winattn_fwd(wg, ha, hv, hv)
+    xv, xa = k.gate_fwd2(hv, rv, gate_v, ha, ra, gate_a)
+    dg_v, dg_a = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    drv, dra = k.gate_bwd2(dxv, rv, gate_v, dg_v, dxa, ra, gate_a, dg_a)
+    dq_v, dkv_a, dq_a, dkv_v = (torch.full_like(hv, float("nan")) for _ in range(4))
+    k.winattn_bwd(wg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)
+    k.winattn_bwd(wg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)
+    # the pair
+    xv2, xa2, rv2, ra2, lse_v2, lse_a2 = k.winattn_xpair_fwd(wg, hv, ha, gate_v, gate_a)
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert eq(rv, rv2) and eq(ra, ra2), "attention outputs differ"
+    assert torch.equal(lse_v[..., :n], lse_v2[..., :n]) and torch.equal(lse_a[..., :n], lse_a2[..., :n])
+    assert eq(xv, xv2) and eq(xa, xa2), "gated hidden states differ"
+    dg_v2, dg_a2 = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    dq_v2, dkv_a2, dq_a2, dkv_v2 = k.winattn_xpair_bwd(wg, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a, dg_v2, dg_a2)
+    assert eq(dq_v, dq_v2) and eq(dkv_a, dkv_a2) and eq(dq_a, dq_a2) and eq(dkv_v, dkv_v2), "gradients differ"
+    for a, b in ((dg_v, dg_v2), (dg_a, dg_a2)):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(a))), (float(a), float(b))
