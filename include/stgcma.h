@@ -330,13 +330,13 @@ int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, voi
  * with the roles swapped), round 4: both directions AND the gates in one launch each way -- per site this replaces 2 x stg_winattn_fwd +
  * stg_gate_fwd2 resp. stg_gate_bwd2 + 2 x stg_winattn_bwd.  a0 / a1 describe the two directions exactly as stg_winattn_fwd takes them (same
  * geometry and tables, K == V, O / lse per direction); x0 / x1 [rows, H*32] bf16 receive Q + gate * O.  Backward: dx0 / dx1 are the gradients wrt
- * x0 / x1; dq / dk per direction are written (dk = dK + dV), dgate0 / dgate1 (fp32 scalars) are ACCUMULATED (one atomicAdd per wave).
+ * x0 / x1; dq / dk per direction are written (dk = dK + dV); the gates' own gradients <dx, O> are accumulated by stg_add3_mul2_dgate (the join that
+ * reads dx next: one atomic per block there, against one per wave -- 2 560 on one address, 4 x the kernel's time -- here).
  * Per element the arithmetic of the launches it replaces. */
 int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0, void* x1,
                           int64_t ldx, void* stream);
 int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, const void* dx0,
-                          const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk, float* dgate0,
-                          float* dgate1, void* stream);
+                          const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Temporal attention: WindowAttention.forward's temporal branch (Swin_AVE.py:244-255; block call sites :705-716) with the
@@ -469,6 +469,10 @@ int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0,
                   const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream);
 int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                   const void* c1, const void* z1, void* out1, int64_t numel, void* stream);
+/* stg_add3_mul2 where a0 / a1 are the gradients dX of two gated hidden states X = h + gate r: additionally dgate += <a, r> (fp32 scalars, accumulated). */
+int stg_add3_mul2_dgate(const void* a0, const void* b0, const void* c0, const void* z0, const void* r0, float* dgate0, void* out0,
+                        const void* a1, const void* b1, const void* c1, const void* z1, const void* r1, float* dgate1, void* out1,
+                        int64_t numel, void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

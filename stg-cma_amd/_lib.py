@@ -166,7 +166,7 @@ SIGNATURES = {
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_winattn_xpair_fwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_winattn_xpair_bwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
-                                        c_vp, c_vp, c_vp]),
+                                        c_vp]),
     "stg_tattn_fwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp]),
     "stg_tattn_bwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_mha_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -191,6 +191,7 @@ SIGNATURES = {
     "stg_gate_fwd2": (C.c_int, [c_vp] * 8 + [c_i64, c_vp]),
     "stg_gate_bwd2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_add3_mul2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
+    "stg_add3_mul2_dgate": (C.c_int, [c_vp] * 14 + [c_i64, c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),

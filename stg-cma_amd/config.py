@@ -41,7 +41,7 @@ SPEC = {
     "mha_x":       ("STG_MHA_X", _b, True, [("ops", "USE_MHA_X")], "flash kernels for wide frame-global cross-modal attention"),
     "xwin":        ("STG_XWIN", _b, True, [("ops", "USE_XWIN")], "window-level cross-modal attention on the whole-window kernels"),
     "pair_ew":     ("STG_PAIR_EW", _b, True, [("ops", "PAIR_EW")], "both directions of a cross-modal pair per element-wise launch"),
-    "xwin_pair":   ("STG_XWIN_PAIR", _b, True, [("ops", "XWIN_PAIR")], "window-level cross-modal pair: both directions and the gates in one launch each way"),
+    "xwin_pair":   ("STG_XWIN_PAIR", _b, False, [("ops", "XWIN_PAIR")], "window-level cross-modal pair: both directions and the gates in one launch each way (measured neutral eager, slower in the two-chain form)"),
     "join_pair":   ("STG_JOIN_PAIR", _b, True, [("ops", "JOIN_PAIR")], "both modalities' residual joins (+ LayerNorm) and LayerNorm-backward + adapter dgrad in one launch each"),
     "gemm_split":  ("STG_GEMM_SPLIT", _b, True, [("ops", "GEMM_SPLIT")], "video | audio adapter GEMMs as one launch with two row groups"),
     "wgrad_ws":    ("STG_WGRAD_WS", _b, True, [("kernels", "USE_WGRAD_WS")], "workspace (atomic-free) weight-gradient kernels"),

@@ -38,10 +38,10 @@ struct WinP {
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
     int total;
     // cross-modal pair (XP kernels, round 4): problems [total, 2 total) are the SECOND direction (its own q / k = v / o / lse / gradients);
-    // forward also writes the gated hidden state X = Q + gate * O, backward takes the gradient of X: dO = gate * dX, dgate += <dX, O>
+    // forward also writes the gated hidden state X = Q + gate * O, backward takes the gradient of X: dO = gate * dX (dgate = <dX, O>: stg_add3_mul2_dgate)
     const bf16_t* Q2; const bf16_t* K2; const bf16_t* V2; bf16_t* O2; float* lse2;
     const float* gate[2]; bf16_t* X[2]; int64_t ldx;
-    const bf16_t* dO2; bf16_t* dQ2; bf16_t* dK2; float* dgate[2];
+    const bf16_t* dO2; bf16_t* dQ2; bf16_t* dK2;
 };
 
 __device__ __forceinline__ void unpack8f(const uint4& q, float* v) {
@@ -414,12 +414,11 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     bf16_t* dQp = a.dQ;
     bf16_t* dKp = a.dK;
     const float* gp = a.gate[0];
-    float* dgp = a.dgate[0];
     if (XP) {
         if (item >= 2 * a.total) return;
         if (item >= a.total) {
             item -= a.total;
-            Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; dOp = a.dO2; lsep = a.lse2; dQp = a.dQ2; dKp = a.dK2; gp = a.gate[1]; dgp = a.dgate[1];
+            Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; dOp = a.dO2; lsep = a.lse2; dQp = a.dQ2; dKp = a.dK2; gp = a.gate[1];
         }
     } else if (item >= a.total) return;
     const int h = item % a.H;
@@ -469,17 +468,12 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     lds_fence();
     // delta[q] = sum_d dO[q][d] O[q][d]: the lane's own 16-byte piece of dO (back from LDS) times the same piece of O, summed over the
     // four lanes of the row
-    float gacc = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint4 vd = *reinterpret_cast<const uint4*>(sD + i * 512 + lane * 8);
-        if (XP) {                                          // the tile holds dX: dgate += <dX, O> over the real rows, then dO = gate * dX in place
-            float dd[8], oo[8];
-            unpack8f(vd, dd); unpack8f(vo[i], oo);
-            if ((lane >> 2) + 16 * i < a.n) {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) gacc += dd[jj] * oo[jj];
-            }
+        if (XP) {                                          // the tile holds dX: dO = gate * dX in place (dgate = <dX, O> is left to stg_add3_mul2_dgate,
+            float dd[8];                                   // which reads dX anyway: one atomic per WAVE here cost 4 x the kernel, 2 560 on one address)
+            unpack8f(vd, dd);
             const float gv = gp[0];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) dd[jj] *= gv;
@@ -494,11 +488,6 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
         if ((lane & 3) == 0) sDel[(lane >> 2) + 16 * i] = d;
-    }
-    if (XP) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) gacc += __shfl_xor(gacc, o, 64);
-        if (lane == 0) atomicAdd(dgp, gacc);
     }
     lds_fence();
     bf16x8_t vf[2][2];
@@ -1082,18 +1071,19 @@ extern "C" int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winat
     return 0;
 }
 
-/* dx0 / dx1: gradients wrt the gated hidden states x0 / x1.  Writes dQ and dK (+ dV) per direction and ACCUMULATES dgate (one atomicAdd per wave). */
+/* dx0 / dx1: gradients wrt the gated hidden states x0 / x1.  Writes dQ and dK (+ dV) per direction; the gates' own gradients <dx, O> are accumulated by
+ * stg_add3_mul2_dgate, the element-wise join that reads dx next. */
 extern "C" int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1,
                                      const void* dx0, const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk,
-                                     float* dgate0, float* dgate1, void* stream) {
+                                     void* stream) {
     WinP p = {};
     int rc = xpair_fill(a0, a1, p, "stg_winattn_xpair_bwd");
     if (rc) return rc;
-    STG_CHECK(a0->lse && a1->lse && gate0 && gate1 && dx0 && dx1 && dq0 && dk0 && dq1 && dk1 && dgate0 && dgate1, -1, "stg_winattn_xpair_bwd: null pointer");
+    STG_CHECK(a0->lse && a1->lse && gate0 && gate1 && dx0 && dx1 && dq0 && dk0 && dq1 && dk1, -1, "stg_winattn_xpair_bwd: null pointer");
     STG_CHECK(lddx % 8 == 0 && lddqk % 8 == 0, -2, "stg_winattn_xpair_bwd: bad leading dims");
     STG_CHECK((((uintptr_t)dx0 | (uintptr_t)dx1 | (uintptr_t)dq0 | (uintptr_t)dk0 | (uintptr_t)dq1 | (uintptr_t)dk1) & 15) == 0, -2, "stg_winattn_xpair_bwd: misaligned pointers");
     if (p.total == 0) return 0;
-    p.gate[0] = gate0; p.gate[1] = gate1; p.dgate[0] = dgate0; p.dgate[1] = dgate1;
+    p.gate[0] = gate0; p.gate[1] = gate1;
     p.dO = (const bf16_t*)dx0; p.dO2 = (const bf16_t*)dx1; p.lddo = lddx;
     p.dQ = (bf16_t*)dq0; p.dK = (bf16_t*)dk0; p.dQ2 = (bf16_t*)dq1; p.dK2 = (bf16_t*)dk1; p.dV = nullptr; p.lddqkv = lddqk;
     const unsigned grid = (unsigned)((2 * (int64_t)p.total + 3) / 4);

@@ -885,8 +885,9 @@ def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
 
 
 @_family("elementwise", lambda a0, *a, **kw: ("add3_mul2", 10.0 * _nb(a0), 0.0))
-def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
-    """add3_mul on two equally sized problems, one launch: returns (out0, out1)."""
+def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None, gate_dot=None):
+    """add3_mul on two equally sized problems, one launch: returns (out0, out1).  gate_dot = (r0, r1, dgate0, dgate1): a0 / a1 are the
+    gradients of two gated hidden states h + gate r; dgate += <a, r> is accumulated in the same pass (stg_add3_mul2_dgate)."""
     for t in (a0, b0, c0, z0, a1, b1, c1, z1):
         _chk_flat(t, "add3_mul2 operand")
         if t.shape != a0.shape:
@@ -897,6 +898,19 @@ def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
         _chk_flat(t, "out")
         if t.shape != a0.shape:
             raise RuntimeError("add3_mul2: shape mismatch")
+    if gate_dot is not None:
+        r0, r1, dg0, dg1 = gate_dot
+        for t in (r0, r1):
+            _chk_flat(t, "add3_mul2 r")
+            if t.shape != a0.shape:
+                raise RuntimeError("add3_mul2: shape mismatch")
+        for t in (dg0, dg1):
+            _chk_flat(t, "dgate", F32)
+            if t.numel() != 1:
+                raise RuntimeError("add3_mul2: dgate must hold one element")
+        _lib.check(_lib.lib().stg_add3_mul2_dgate(_p(a0), _p(b0), _p(c0), _p(z0), _p(r0), _p(dg0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1),
+                                                  _p(r1), _p(dg1), _p(outs[1]), a0.numel(), _stream()), "stg_add3_mul2_dgate")
+        return outs[0], outs[1]
     _lib.check(_lib.lib().stg_add3_mul2(_p(a0), _p(b0), _p(c0), _p(z0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1), _p(outs[1]),
                                         a0.numel(), _stream()), "stg_add3_mul2")
     return outs[0], outs[1]
@@ -1386,10 +1400,11 @@ def winattn_xpair_fwd(g, hv, ha, gate_v, gate_a):
 
 
 @_family("winattn_bwd", lambda g, hv, ha, *a, **kw: (("xpair", g.H * 32), 20.0 * (g.P // g.G) * g.outer * g.H * 32, 20.0 * g.P * g.H * g.n * g.n * 32))
-def winattn_xpair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a, dgate_v, dgate_a):
+def winattn_xpair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a):
     """Backward of winattn_xpair_fwd's attention + gate part: dxv / dxa are the gradients wrt x_v / x_a.  Returns (dq_v, dkv_a, dq_a, dkv_v) --
-    the gradients wrt h_v as queries, h_a as keys / values of direction v, and the same for direction a; dgate_v / dgate_a are accumulated."""
-    for t, name in ((gate_v, "gate_v"), (gate_a, "gate_a"), (dgate_v, "dgate_v"), (dgate_a, "dgate_a")):
+    the gradients wrt h_v as queries, h_a as keys / values of direction v, and the same for direction a.  The gates' own gradients
+    <dx, r> are left to add3_mul2(..., gate_dot=...), the join that reads dx next."""
+    for t, name in ((gate_v, "gate_v"), (gate_a, "gate_a")):
         _gate_ok(t, name)
     rows = (g.P // g.G) * g.outer
     for t, name in ((dxv, "dxv"), (dxa, "dxa")):
@@ -1405,7 +1420,7 @@ def winattn_xpair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a,
     a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
     a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
     _lib.check(_lib.lib().stg_winattn_xpair_bwd(C.byref(a0), C.byref(a1), _p(gate_v), _p(gate_a), _p(dxv), _p(dxa), _ld(dxv), _p(dq_v), _p(dkv_a),
-                                                _p(dq_a), _p(dkv_v), _ld(dq_v), _p(dgate_v), _p(dgate_a), _stream()), "stg_winattn_xpair_bwd")
+                                                _p(dq_a), _p(dkv_v), _ld(dq_v), _stream()), "stg_winattn_xpair_bwd")
     return dq_v, dkv_a, dq_a, dkv_v
 
 

@@ -587,9 +587,11 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
         if dgate_a is None:
             dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
-        if XWIN_PAIR and hv.shape == ha.shape and hv.stride(0) == ha.stride(0) and dhv2.stride(0) == dha2.stride(0):
-            dq_v, dkv_a, dq_a, dkv_v = K.winattn_xpair_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, dhv2, dha2, gate_v, gate_a, dgate_v, dgate_a)
-            return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
+        if XWIN_PAIR and PAIR_EW and zs is not None and hv.shape == ha.shape and hv.stride(0) == ha.stride(0) and dhv2.shape == dha2.shape \
+                and dhv2.stride(0) == dha2.stride(0):
+            # the attention backward scales dX by the gate itself; the gates' gradients <dX, r> ride on the join that reads dX next
+            dq_v, dkv_a, dq_a, dkv_v = K.winattn_xpair_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, dhv2, dha2, gate_v, gate_a)
+            return K.add3_mul2(dhv2, dq_v, dkv_v, zs[0], dha2, dq_a, dkv_a, zs[1], outs=outs, gate_dot=(rv, ra, dgate_v, dgate_a))
         drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v

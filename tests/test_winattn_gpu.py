@@ -212,7 +212,12 @@ def test_cross_modal_pair_equals_the_launches_it_replaces(stg, gpu, images, Himg
     assert torch.equal(lse_v[..., :n], lse_v2[..., :n]) and torch.equal(lse_a[..., :n], lse_a2[..., :n])
     assert eq(xv, xv2) and eq(xa, xa2), "gated hidden states differ"
     dg_v2, dg_a2 = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
-    dq_v2, dkv_a2, dq_a2, dkv_v2 = k.winattn_xpair_bwd(wg, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a, dg_v2, dg_a2)
+    dq_v2, dkv_a2, dq_a2, dkv_v2 = k.winattn_xpair_bwd(wg, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a)
     assert eq(dq_v, dq_v2) and eq(dkv_a, dkv_a2) and eq(dq_a, dq_a2) and eq(dkv_v, dkv_v2), "gradients differ"
+    # the join that follows: (dX + dq + dk) * z, with / without the gates' gradients riding on it
+    zv, za = torch.rand_like(hv), torch.rand_like(ha)
+    j0 = k.add3_mul2(dxv, dq_v, dkv_v, zv, dxa, dq_a, dkv_a, za)
+    j1 = k.add3_mul2(dxv, dq_v, dkv_v, zv, dxa, dq_a, dkv_a, za, gate_dot=(rv, ra, dg_v2, dg_a2))
+    assert eq(j0[0], j1[0]) and eq(j0[1], j1[1]), "joined gradients differ"
     for a, b in ((dg_v, dg_v2), (dg_a, dg_a2)):
         assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(a))), (float(a), float(b))
