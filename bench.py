@@ -285,8 +285,26 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if os.environ.get("STG_BENCH_POISON_GB"):
+        # robustness rehearsal (tests / tools only): fill that many GB of the caching allocator with NaN patterns and hand them back, so that
+        # every later torch.empty starts as NaN -- a kernel that reads a byte nobody wrote shows up as a non-finite loss
+        n = int(float(os.environ["STG_BENCH_POISON_GB"]) * 2**30 / 4)
+        junk = [torch.full((n // 8,), float("nan"), device=device) for _ in range(8)]
+        torch.cuda.synchronize()
+        del junk
 
     model = build_model(torch, device, args.workload)
+
+    trace_nan = bool(os.environ.get("STG_BENCH_TRACE_NAN"))
+
+    def probe(where):                  # debugging aid (STG_BENCH_TRACE_NAN=1): where do non-finite parameters / gradients first appear?
+        if not trace_nan:
+            return
+        torch.cuda.synchronize()
+        nb_p = sum(1 for p_ in model.parameters() if p_.requires_grad and not bool(torch.isfinite(p_).all()))
+        nb_g = sum(1 for p_ in model.parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all()))
+        print(f"bench.py[rank {rank}] probe {where}: non-finite params {nb_p}, grads {nb_g}", file=sys.stderr, flush=True)
+
     gflop_per_clip, workload_desc = WORKLOADS[args.workload]
     if args.fp8:
         from stgcma import fp8 as stg_fp8
@@ -366,7 +384,11 @@ def main():
 
     def step():
         loss = fwd_bwd()
+        if trace_nan:
+            probe(f"eager step: after backward (loss {float(loss.detach()):.4f})")
         opt.step()
+        if trace_nan:
+            probe("eager step: after optimizer")
         return loss
 
     def fence():
@@ -404,6 +426,7 @@ def main():
             kernels.gemm_profile_reset()
             kernels.family_profile_reset()
     fence()
+    probe("after eager warm-up")
     prof_steps = max(args.warmup - 1, 1)
     dt_eager = None
     if world == 1:
@@ -452,8 +475,10 @@ def main():
                 replay.release()
             replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
         else:
+            probe("after capture")
             for _ in range(2):
                 replay()
+                probe("after a warm replay")
         fence()
     # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
     # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
@@ -469,7 +494,10 @@ def main():
             tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt) / 2 * 1e3
-        ms_e, ms_r = timed2(step), timed2(replay)
+        ms_e = timed2(step)
+        probe("after 2 eager steps (form selection)")
+        ms_r = timed2(replay)
+        probe("after 2 replays (form selection)")
         pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
         if ms_r > ms_e:
             replay.release()
@@ -485,6 +513,7 @@ def main():
                 loss = step()
         fence()
         dt = time.perf_counter() - t0
+        probe("after the timed steps")
         if world == 1 and dt_eager is not None and dt > dt_eager:
             # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
             # reports the faster one as `value` and says so
@@ -495,6 +524,15 @@ def main():
         dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
     final_loss = float(loss.detach())
     if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
+        # say where the non-finite values are before giving up (stderr; the line itself is never printed for an invalid run)
+        try:
+            bad_p = [n for n, p_ in model.named_parameters() if not bool(torch.isfinite(p_).all())]
+            bad_g = [n for n, p_ in model.named_parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
+            print(f"bench.py[rank {rank}]: step form '{step_how}', pick {pick}; non-finite parameters: {len(bad_p)} {bad_p[:4]}; non-finite gradients: "
+                  f"{len(bad_g)} {bad_g[:4]}; inputs finite: {[bool(torch.isfinite(t_.float()).all()) for t_ in mb_tensors] if mb_tensors else None}",
+                  file=sys.stderr, flush=True)
+        except Exception as e_:                                      # noqa: BLE001
+            print(f"bench.py[rank {rank}]: diagnostics failed: {e_!r}", file=sys.stderr, flush=True)
         # a step that produced NaN / inf is not a measurement (and NaN-filled tensors toggle fewer bits, so the power-limited chip clocks
         # every kernel HIGHER: such a run looks faster -- DESIGN.md 5.2)
         raise SystemExit(f"bench.py: non-finite loss {final_loss} after {args.warmup + args.steps} steps -- the run is invalid")

@@ -473,6 +473,9 @@ int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0
 int stg_add3_mul2_dgate(const void* a0, const void* b0, const void* c0, const void* z0, const void* r0, float* dgate0, void* out0,
                         const void* a1, const void* b1, const void* c1, const void* z1, const void* r1, float* dgate1, void* out1,
                         int64_t numel, void* stream);
+/* Test aid: fill the LDS of every CU with NaN bit patterns, so that a kernel reading an LDS byte nobody wrote produces a non-finite result
+ * (stgcma._lib wraps every launch with it under STG_LDS_POISON=1; tests/test_lds_poison_gpu.py). */
+int stg_debug_poison_lds(void* stream);
 /* out = a * mask  (bf16 * fp32 mask), Dropout in mlp_head (Swin_AVE.py:1320) */
 int stg_mul_mask(const void* a, const float* mask, void* out, int64_t numel, void* stream);
 /* bias gather: out[g,h,i,j] = table[index[i*nj+j] , h]  (Swin_AVE.py:246-253,257-261) ; table fp32 [L,H] */

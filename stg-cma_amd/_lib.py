@@ -192,6 +192,7 @@ SIGNATURES = {
     "stg_gate_bwd2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_add3_mul2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_add3_mul2_dgate": (C.c_int, [c_vp] * 14 + [c_i64, c_vp]),
+    "stg_debug_poison_lds": (C.c_int, [c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_bias_scatter": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -230,6 +231,33 @@ class StgLibraryMissing(RuntimeError):
     pass
 
 
+class _PoisonedLds:
+    """Test aid (STG_LDS_POISON=1): every kernel launch through the C ABI is preceded by stg_debug_poison_lds on the same stream, so each kernel
+    starts on LDS full of NaN patterns and a read of an LDS byte it never wrote becomes a non-finite result."""
+
+    launches = 0
+
+    def __init__(self, handle):
+        self._h = handle
+        self._poison = handle.stg_debug_poison_lds
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        sig = SIGNATURES.get(name)
+        if (name in ("stg_debug_poison_lds", "stg_mlp_w2_perm", "stg_conv3x3_wgrad_ws_floats", "stg_wgrad_wide_ws_floats")      # last pointer is not a stream
+                or sig is None or not sig[1] or sig[1][-1] is not c_vp or name.endswith("_supported")):
+            return fn
+        poison = self._poison
+
+        def call(*a):
+            rc = poison(a[-1])                 # the launch functions take the stream last
+            if rc != 0:
+                raise RuntimeError(f"stg_debug_poison_lds failed ({rc})")
+            _PoisonedLds.launches += 1
+            return fn(*a)
+        return call
+
+
 def lib():
     """Load (once) and return the ctypes handle; fail loudly when the HIP extension is absent."""
     global _lib
@@ -246,6 +274,8 @@ def lib():
         fn.argtypes = args
     if handle.stg_version() != ABI_VERSION:
         raise RuntimeError(f"libstgcma_hip.so version {handle.stg_version()} != binding version {ABI_VERSION}")
+    if os.environ.get("STG_LDS_POISON"):
+        handle = _PoisonedLds(handle)
     _lib = handle
     # A/B knobs of tools/ (never set in production): forwarded ONCE from the environment to the library's explicit options
     from . import config                     # (config.py reads the environment once; configure(lib_<option>=...) lands here too)

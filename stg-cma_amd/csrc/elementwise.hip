@@ -585,6 +585,24 @@ extern "C" int stg_add3_mul2_dgate(const void* a0, const void* b0, const void* c
     STG_LAUNCH_CHECK();
     return 0;
 }
+// Test aid (tests/test_lds_poison_gpu.py, STG_LDS_POISON=1): fill the LDS of every CU with NaN bit patterns (0x7FC07FC0: a NaN as fp32 and as two
+// bf16 values).  A kernel that reads an LDS byte nobody wrote -- harmless while the previous tenant of the CU left finite data there, e.g. padded
+// rows whose probabilities are zero: 0 x NaN = NaN -- then shows up as a non-finite result (round 4: that is how a 2-rank rehearsal on one
+// GPU, where the other PROCESS's kernels leave their data in the LDS, produced NaN losses once in ~8 runs).
+__global__ void __launch_bounds__(256) lds_poison_kernel(int words) {
+    extern __shared__ uint32_t lds_all[];
+    volatile uint32_t* s = lds_all;
+    for (int i = threadIdx.x; i < words; i += 256) s[i] = 0x7FC07FC0u;
+    __syncthreads();
+}
+extern "C" int stg_debug_poison_lds(void* stream) {
+    static std::atomic<uint64_t> done{0};
+    const int bytes = 160 * 1024;
+    STG_CHECK(stg_reserve_lds(lds_poison_kernel, bytes, done), -101, "stg_debug_poison_lds: cannot reserve 160 KiB of LDS");
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(1024), dim3(256), bytes, ST, bytes / 4);      // one workgroup owns a CU's whole LDS: 4 rounds over 256 CUs
+    STG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int stg_act_bwd(const void* dh, const void* z, void* dz, int64_t numel, void* stream) {
     STG_CHECK(dh && z && dz, -1, "stg_act_bwd: null pointer");
     STG_CHECK((((uintptr_t)dh | (uintptr_t)z | (uintptr_t)dz) & 15) == 0, -2, "stg_act_bwd: pointers must be 16-byte aligned");
