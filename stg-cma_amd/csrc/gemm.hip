@@ -737,7 +737,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
 //     (A0 after phase 0, W1 after phase 1, A1 after phase 2, W0 after phase 3);
 //   * waves 4-7 run one barrier behind waves 0-3: one group reads fragments / issues DMA while the other runs its MFMA cluster.
 // Schedule of k-tile t (slot parity t & 1), phase p: reads as above; DMA issue p0: A1(t+1)  p1: W0(t+1)  p2: A0(t+2)  p3: W1(t+2);
-// in p3, before its first barrier, s_waitcnt vmcnt(4): everything but the two half-tiles just issued has landed.
+// in p3, before its first barrier, s_waitcnt vmcnt(4): everything but the two half-tiles just issued has landed; in p2 vmcnt(8): A0(t+1),
+// which p3 pre-reads, has landed (round-4 fix).
 // RAW: A1(t+1), W0(t+1) are retired by that wait >= 1 barrier before any wave reads them (phase 0 / 2 of t+1, the late group
 // included); A0(t+2), W1(t+2) by the wait of tile t+1.  WAR: a slot is re-staged >= 3 barrier intervals after its last ds_read
 // (late group included): A0 p0 -> p2, W1 p1 -> p3, A1 p2 -> p0', W0 p3 -> p1'.
@@ -860,7 +861,12 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
                 }
                 if (ph == 0) issue(HA1, kt + 1);
                 if (ph == 1) issue(HW0, kt + 1);
-                if (ph == 2) issue(HA0, kt + 2);
+                // round 4 FIX: phase 3 reads the next tile's A0 (k-step 0) BEFORE its own counted wait, and the rows the other wave group
+                // staged are only covered one barrier after that group's wait -- the read relied on "issued a k-tile ago", which a slow DMA
+                // breaks (1 launch in ~4 000 at 31 360 x 1024 x 4096: one k-tile of rows 32-63 of the partial panel stale).  A0(kt + 1) is the
+                // ninth-youngest DMA instruction here (behind W1(kt+1), A1(kt+1), W0(kt+1), A0(kt+2)): vmcnt(8) retires it one phase early, and
+                // this phase's two barriers carry it to both groups' phase-3 reads.
+                if (ph == 2) { issue(HA0, kt + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
                 if (ph == 3) { issue(HW1, kt + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1045,7 +1051,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
                     }
                     if (ph == 0) issue(HA1, kt + 1);
                     if (ph == 1) issue(HW0, kt + 1);
-                    if (ph == 2) issue(HA0, kt + 2);
+                    if (ph == 2) { issue(HA0, kt + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }      // see gemm_nt_8ph_kernel (round-4 fix)
                     if (ph == 3) { issue(HW1, kt + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
                     __builtin_amdgcn_s_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

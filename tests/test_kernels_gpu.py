@@ -656,3 +656,22 @@ def test_pair_launches_equal_two_single_launches(stg, gpu, C, J, S, M2, with_rs)
                                     row_scale=rs1, row_scale2=rs2, **rkw)
         assert torch.equal(dx0.view(torch.int16), dx1.view(torch.int16)), f"dx differs (xhat={xh})"
         assert torch.equal(torch.cat(dh0).view(torch.int16), dh1.view(torch.int16)), f"dh differs (xhat={xh})"
+
+
+@pytest.mark.parametrize("M,N,Kd", [(31360, 1024, 4096), (7840, 512, 2048)])
+def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd):
+    """Regression test of a race found in round 4: the 8-phase kernel pre-read the next k-tile's A0 fragments one phase BEFORE the counted
+    wait that retires their LDS-DMA (it relied on "issued a k-tile ago"); when a DMA was slow, one k-tile of some rows was computed from the
+    previous contents of the ring slot -- 1 launch in ~4 000 at 31 360 x 1024 x 4096 (the partial last row panel's timing provokes it), a NaN
+    every few hundred training steps at batch 2.  The same launch must give the same bits every time."""
+    from stgcma import kernels as K
+    torch.manual_seed(0)
+    A = (torch.randn(M, Kd, device=gpu) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, Kd, device=gpu) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device=gpu) * 0.1
+    ref = K.gemm_nt(A, W, b).clone()
+    bad = torch.zeros((), device=gpu, dtype=torch.int64)
+    for _ in range(12000 if M > 20000 else 6000):
+        out = K.gemm_nt(A, W, b)
+        bad += (out.view(torch.int16) != ref.view(torch.int16)).any()
+    assert int(bad) == 0, f"{int(bad)} launches differ from the first one"
