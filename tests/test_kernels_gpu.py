@@ -675,3 +675,56 @@ def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd):
         out = K.gemm_nt(A, W, b)
         bad += (out.view(torch.int16) != ref.view(torch.int16)).any()
     assert int(bad) == 0, f"{int(bad)} launches differ from the first one"
+
+
+def test_hot_kernels_are_reproducible(stg, gpu):
+    """The same launch must give the same bits every time (no atomics in these kernels): GEMM classes with partial row panels on every kernel
+    the dispatch uses, the pair joins, window attention backward -- a few hundred launches each with another kernel in between.  A cheap net
+    for the class of bug the 8-phase race was (an operand read that no wait covers)."""
+    from stgcma import kernels as K, ops
+    from stgcma._lib import ACT_GELU
+    import oracle.swin as OS
+    torch.manual_seed(1)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, device=gpu) * sc).to(torch.bfloat16)
+
+    def same(a, b):
+        return bool((a.view(torch.int16) == b.view(torch.int16)).all()) if a.dtype == torch.bfloat16 else torch.equal(a, b)
+
+    def stress(name, fn, reps=400):
+        ref = [t.clone() for t in fn()]
+        junk = torch.randn(2048, 32, device=gpu)
+        bad = torch.zeros((), device=gpu, dtype=torch.int64)
+        for r in range(reps):
+            if r % 3 == 0:
+                junk = junk * 1.0001
+            for t, q in zip(fn(), ref):
+                bad += (t.view(torch.int16) != q.view(torch.int16)).any() if t.dtype == torch.bfloat16 else (t != q).any()
+        assert int(bad) == 0, f"{name}: {int(bad)} of {reps} launches differ from the first"
+
+    M = 7840                                                       # 30 full 256-row panels + 160 rows; 61 full 128-row panels + 32
+    A5, A20 = bf(M, 512, sc=0.5), bf(M, 2048, sc=0.5)
+    for N, Kd, A in ((1536, 512, A5), (512, 512, A5), (512, 2048, A20)):
+        W, b = bf(N, Kd, sc=0.05), torch.randn(N, device=gpu) * 0.1
+        stress(f"gemm {M}x{N}x{Kd}", lambda: (K.gemm_nt(A, W, b),))
+    W1, b1 = bf(2048, 512, sc=0.05), torch.randn(2048, device=gpu) * 0.1
+    stress("gemm fc1 + gelu + d8", lambda: K.gemm_nt(A5, W1, b1, act=ACT_GELU, want_dact="u8"))
+    S = M // 2
+    h, wa, wb = bf(M, 32), bf(512, 32, sc=0.1), bf(512, 32, sc=0.1)
+    ba, bb = torch.randn(512, device=gpu) * 0.1, torch.randn(512, device=gpu) * 0.1
+    res32, res16 = torch.randn(M, 512, device=gpu), bf(M, 512)
+    gamma, beta = torch.rand(512, device=gpu) + 0.5, torch.randn(512, device=gpu) * 0.1
+    x, y = torch.empty(M, 512, device=gpu), torch.empty(M, 512, device=gpu, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=gpu), torch.empty(M, device=gpu)
+    stress("up_ln_fwd_pair", lambda: K.up_ln_fwd_pair(h[:S], h[S:], wa, wb, ba, bb, res32, gamma, beta, res16=res16, out=x, y_out=y, mean_out=mean, rstd_out=rstd))
+    dy, dx = bf(M, 512), torch.empty(M, 512, device=gpu, dtype=torch.bfloat16)
+    stress("ln_bwd_down_pair", lambda: K.ln_bwd_down_pair(dy, y, None, None, rstd, wa.t().contiguous(), wb.t().contiguous(), S, add_to=res16, dx_out=dx))
+    images, heads, Himg, ws = 40, 16, 14, 7
+    n, N_, C = 49, Himg * Himg, heads * 32
+    qkv, dO = bf(images * N_, 3 * C), bf(images * N_, C)
+    bm, bmT = K.winattn_table((torch.randn(169, heads) * 0.5).to(gpu), OS.relative_position_index(ws).reshape(-1).to(gpu), ops.shift_mask(Himg, Himg, ws, 3).to(gpu), n)
+    wg = K.WinGeom(images, heads, Himg, Himg, ws, 3, 32 ** -0.5, bm, bmT)
+    Q, Kk, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    O, lse = K.winattn_fwd(wg, Q, Kk, V)
+    dq = torch.empty_like(qkv)
+    stress("winattn_fwd", lambda: (K.winattn_fwd(wg, Q, Kk, V)[0],))
+    stress("winattn_bwd", lambda: (K.winattn_bwd(wg, Q, Kk, V, O, lse, dO, dQ=dq[:, :C], dK=dq[:, C:2 * C], dV=dq[:, 2 * C:]) and dq,))
