@@ -6,6 +6,7 @@
 #      (eager pass + the graph-replayed micro-batch steps)
 #   3. the five-pass ledger of `bench.py --eager` (trace, FETCH_SIZE, WRITE_SIZE, MFMA busy, GPU active: per dispatch)
 #   4. the other workloads, the default line (with cpu_baseline) last
+# One gpurun call is limited to 20 minutes: in practice the four parts were run as three calls (1; 2 + 3; 4), same order.
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
