@@ -445,104 +445,12 @@ def main():
             json.dump({"steps": prof_steps, "launches_per_step": per, "step": seq[-per:] if per else []}, f)
     gp, fams = kernels.gemm_profile_stop(), kernels.family_profile_stop()
 
-    # ---------------------------------------------------------------------------------------------------------------- pass 2: the timed steps
-    # The product's step (recipe.capture_train_step_mb): `nmb` micro-batches, each forward + backward a HIP graph on its own stream,
-    # running CONCURRENTLY (two independent launch chains fill each other's ramps and tails: DESIGN.md section 5.3), then a join graph
-    # (gradient sum + Adam).  N > 1: the summed arena is all-reduced eagerly between the join graph and the optimizer graph, so a rank's
-    # host issues ~4 graph launches + 1 collective per step instead of ~1 200 kernel launches.  --microbatch 1: N = 1 keeps the eager
-    # pass as the measurement; N > 1 replays recipe.capture_train_step_ddp's two graphs.  Every rank must take the same path: the ranks
-    # agree on "captured" before the first replay and fall back to eager steps together.
-    replay, static_loss, step_how = None, None, "eager, one stream"
-    want_graph = (nmb > 1 or world > 1) and not args.eager
-    if want_graph:
-        loss = None
-        import gc
-        gc.collect()                  # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream
-        ok, why = 1, ""
-        try:
-            if nmb > 1:
-                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
-            else:
-                replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
-        except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)
-            ok, why = 0, repr(e)[:200]
-        if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        if not ok:
-            if replay is not None and hasattr(replay, "release"):
-                replay.release()
-            replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
-        else:
-            probe("after capture")
-            for _ in range(2):
-                replay()
-                probe("after a warm replay")
-        fence()
-    # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
-    # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
-    # measured on the form that wins there.  Every rank takes the same decision (it is made on all-reduced times).
-    pick = None
-    if replay is not None and world > 1:
-        def timed2(fn):
-            fence()
-            t0_ = time.perf_counter()
-            for _ in range(2):
-                fn()
-            fence()
-            tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt) / 2 * 1e3
-        ms_e = timed2(step)
-        probe("after 2 eager steps (form selection)")
-        ms_r = timed2(replay)
-        probe("after 2 replays (form selection)")
-        pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
-        if ms_r > ms_e:
-            replay.release()
-            replay = None
-            step_how = f"eager, one stream (the replayed form measured {ms_r:.1f} ms per step against {ms_e:.1f} eager on this box)"
-    if replay is not None or world > 1:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if replay is not None:
-                replay()
-                loss = static_loss
-            else:
-                loss = step()
-        fence()
-        dt = time.perf_counter() - t0
-        probe("after the timed steps")
-        if world == 1 and dt_eager is not None and dt > dt_eager:
-            # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
-            # reports the faster one as `value` and says so
-            pick = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "replay_ms_per_step": round(dt / args.steps * 1e3, 3)}
-            step_how = f"eager, one stream (the replayed micro-batch form measured {dt / args.steps * 1e3:.1f} ms per step: slower on this box)"
-            dt = dt_eager
-    else:
-        dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
-    final_loss = float(loss.detach())
-    if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
-        # say where the non-finite values are before giving up (stderr; the line itself is never printed for an invalid run)
-        try:
-            bad_p = [n for n, p_ in model.named_parameters() if not bool(torch.isfinite(p_).all())]
-            bad_g = [n for n, p_ in model.named_parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
-            print(f"bench.py[rank {rank}]: step form '{step_how}', pick {pick}; non-finite parameters: {len(bad_p)} {bad_p[:4]}; non-finite gradients: "
-                  f"{len(bad_g)} {bad_g[:4]}; inputs finite: {[bool(torch.isfinite(t_.float()).all()) for t_ in mb_tensors] if mb_tensors else None}",
-                  file=sys.stderr, flush=True)
-        except Exception as e_:                                      # noqa: BLE001
-            print(f"bench.py[rank {rank}]: diagnostics failed: {e_!r}", file=sys.stderr, flush=True)
-        # a step that produced NaN / inf is not a measurement (and NaN-filled tensors toggle fewer bits, so the power-limited chip clocks
-        # every kernel HIGHER: such a run looks faster -- DESIGN.md 5.2)
-        raise SystemExit(f"bench.py: non-finite loss {final_loss} after {args.warmup + args.steps} steps -- the run is invalid")
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
-
-    if rank == 0:
-        clips = args.batch * world * args.steps
+    def emit(dt, n_steps, step_how, pick, overlap, final_loss):
+        """Rank 0: build and print THE JSON line (everything sampled in pass 1 is closed over; the timed-region results are arguments, so the
+        N > 1 watchdog can print a line from the eager measurement when the replayed form never comes back)."""
+        if rank != 0:
+            return
+        clips = args.batch * world * n_steps
         value = clips / dt
         eager_ms = dt_eager / args.steps * 1e3 if dt_eager is not None else None
         # Roofline per GEMM class (class = kernel the C dispatch chose x N x K x epilogue signature): achieved = algorithmic FLOPs
@@ -637,7 +545,7 @@ def main():
             "metric": ("SECONDARY (bf16 residual stream, not the headline dataflow) " if args.residual == "bf16" else "") + "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                                               "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
                                               "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": world, "steps": n_steps, "warmup": args.warmup, "ms_per_step": round(dt / n_steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8-e4m3 (frozen weights + their inputs, E8M0 block scales) / bf16" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
@@ -662,7 +570,7 @@ def main():
             "accounted_frac": round((gemm_ms + fam_ms) / eager_ms, 4) if eager_ms else None}
         out["config"]["step"] = step_how
         out["config"]["step_forms_measured"] = pick
-        out["config"]["side_streams_overlap"] = getattr(replay, "streams_overlap", None) if replay is not None else None
+        out["config"]["side_streams_overlap"] = overlap
         out["config"]["options"] = stgcma.options() if hasattr(stgcma, "options") else None
         # the same step replayed from a HIP graph (N = 1, --graph): reported next to the eager number, which stays `value` -- the roofline
         # sampling above needs eager launches (HIP events around individual kernels).  It runs AFTER the headline object is complete and
@@ -700,6 +608,131 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
         finally:
             print(json.dumps(out), flush=True)
+
+    # ---------------------------------------------------------------------------------------------------------------- pass 2: the timed steps
+    # The product's step (recipe.capture_train_step_mb): `nmb` micro-batches, each forward + backward a HIP graph on its own stream,
+    # running CONCURRENTLY (two independent launch chains fill each other's ramps and tails: DESIGN.md section 5.3), then a join graph
+    # (gradient sum + Adam).  N > 1: the summed arena is all-reduced eagerly between the join graph and the optimizer graph, so a rank's
+    # host issues ~4 graph launches + 1 collective per step instead of ~1 200 kernel launches.  --microbatch 1: N = 1 keeps the eager
+    # pass as the measurement; N > 1 replays recipe.capture_train_step_ddp's two graphs.  Every rank must take the same path: the ranks
+    # agree on "captured" before the first replay and fall back to eager steps together.
+    replay, static_loss, step_how = None, None, "eager, one stream"
+    want_graph = (nmb > 1 or world > 1) and not args.eager
+
+    def timed2(fn):
+        fence()
+        t0_ = time.perf_counter()
+        for _ in range(2):
+            fn()
+        fence()
+        tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt) / 2 * 1e3
+
+    # N > 1: the eager form (with its collectives) is timed over two steps BEFORE anything is captured -- the comparison the form selection
+    # below needs, and what a WATCHDOG falls back on: RCCL has never run under the replayed form on this pool's hardware, and a collective or
+    # a replay that never comes back would otherwise cost the whole line.  If pass 2 has not finished after STG_BENCH_WATCHDOG_S seconds
+    # (default 300), rank 0 prints the line from that eager measurement and every rank leaves.
+    ms_e_pre, watchdog = None, None
+    if want_graph and world > 1:
+        import threading
+        ms_e_pre = timed2(step)
+        probe("after 2 eager steps (form selection)")
+        last_eager_loss = float(step().detach())
+        limit_s = float(os.environ.get("STG_BENCH_WATCHDOG_S", "300"))
+
+        def fire():
+            # the other ranks leave at once (exit code 0); rank 0 prints first.  Its main thread may meanwhile see its peers vanish and raise:
+            # the timer thread is NOT a daemon, so the interpreter waits for it, and os._exit(0) below decides the exit code
+            try:
+                if rank == 0:
+                    emit(ms_e_pre * 2 / 1e3, 2, f"eager, one stream (WATCHDOG: the replayed form did not finish within {limit_s:.0f} s; value = the two eager steps "
+                         "timed before the capture)", {"eager_ms_per_step": round(ms_e_pre, 3), "replay_ms_per_step": None}, None, last_eager_loss)
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(limit_s, fire)
+        watchdog.daemon = False
+        watchdog.start()
+    if want_graph:
+        loss = None
+        import gc
+        gc.collect()                  # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream
+        ok, why = 1, ""
+        try:
+            if nmb > 1:
+                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
+            else:
+                replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
+        except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)
+            ok, why = 0, repr(e)[:200]
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if not ok:
+            if replay is not None and hasattr(replay, "release"):
+                replay.release()
+            replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
+        else:
+            probe("after capture")
+            for _ in range(2):
+                replay()
+                probe("after a warm replay")
+        fence()
+    # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
+    # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
+    # measured on the form that wins there.  Every rank takes the same decision (it is made on all-reduced times).
+    pick = None
+    if replay is not None and world > 1:
+        ms_e = ms_e_pre
+        ms_r = timed2(replay)
+        probe("after 2 replays (form selection)")
+        pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
+        if ms_r > ms_e:
+            replay.release()
+            replay = None
+            step_how = f"eager, one stream (the replayed form measured {ms_r:.1f} ms per step against {ms_e:.1f} eager on this box)"
+    if replay is not None or world > 1:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if replay is not None:
+                replay()
+                loss = static_loss
+            else:
+                loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if watchdog is not None:
+            watchdog.cancel()
+        probe("after the timed steps")
+        if world == 1 and dt_eager is not None and dt > dt_eager:
+            # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
+            # reports the faster one as `value` and says so
+            pick = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "replay_ms_per_step": round(dt / args.steps * 1e3, 3)}
+            step_how = f"eager, one stream (the replayed micro-batch form measured {dt / args.steps * 1e3:.1f} ms per step: slower on this box)"
+            dt = dt_eager
+    else:
+        dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
+    final_loss = float(loss.detach())
+    if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
+        # say where the non-finite values are before giving up (stderr; the line itself is never printed for an invalid run)
+        try:
+            bad_p = [n for n, p_ in model.named_parameters() if not bool(torch.isfinite(p_).all())]
+            bad_g = [n for n, p_ in model.named_parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
+            print(f"bench.py[rank {rank}]: step form '{step_how}', pick {pick}; non-finite parameters: {len(bad_p)} {bad_p[:4]}; non-finite gradients: "
+                  f"{len(bad_g)} {bad_g[:4]}; inputs finite: {[bool(torch.isfinite(t_.float()).all()) for t_ in mb_tensors] if mb_tensors else None}",
+                  file=sys.stderr, flush=True)
+        except Exception as e_:                                      # noqa: BLE001
+            print(f"bench.py[rank {rank}]: diagnostics failed: {e_!r}", file=sys.stderr, flush=True)
+        # a step that produced NaN / inf is not a measurement (and NaN-filled tensors toggle fewer bits, so the power-limited chip clocks
+        # every kernel HIGHER: such a run looks faster -- DESIGN.md 5.2)
+        raise SystemExit(f"bench.py: non-finite loss {final_loss} after {args.warmup + args.steps} steps -- the run is invalid")
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    emit(dt, args.steps, step_how, pick, getattr(replay, "streams_overlap", None) if replay is not None else None, final_loss)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

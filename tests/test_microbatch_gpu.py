@@ -117,3 +117,22 @@ def test_bench_launches_its_own_ranks(stg, gpu):
     # which step form the timed region used is decided per run from two timed steps of each (all ranks together): two ranks time-slicing ONE
     # GPU usually lose on the replayed form, real one-GPU-per-rank runs are expected not to -- either way the line must say what it measured
     assert "graphs" in d["config"]["step"] or ("eager" in d["config"]["step"] and d["config"]["step_forms_measured"]), d["config"]["step"]
+
+
+def test_bench_watchdog_prints_the_eager_line_when_the_replayed_form_never_returns(stg, gpu):
+    """N > 1 safety net: RCCL has never run under the replayed step form on this pool's hardware, so bench.py times the eager form before it
+    captures anything and arms a watchdog around pass 2; when that fires (here: forced after 1 s) rank 0 prints ONE complete line from the
+    eager measurement, says so in config.step, and every rank exits with code 0."""
+    env = dict(os.environ, STG_DDP_BACKEND="gloo", OMP_NUM_THREADS="4", STG_BENCH_WATCHDOG_S="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "WATCHDOG" in d["config"]["step"] and d["roofline"] is not None
