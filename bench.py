@@ -12,13 +12,17 @@ the 5.6 M trainable parameters, one RCCL all-reduce of the flat gradient arena (
 hyper-parameters (:68).  Rank 0 prints ONE JSON line; `value` is the whole-job clips/s (all ranks), timed between
 barrier + synchronize on both sides and taking the max over ranks.
 
-Extra objects in the line:
-  roofline      the GEMM class (kernel x N x K x epilogue) with the largest share of the step, priced against ITS bound: MFMA (2.5
-                PFLOP/s dense bf16) when its arithmetic intensity exceeds 312 FLOP/B, HBM (8 TB/s) otherwise; achieved = algorithmic
-                FLOPs (2*M*N*K, no padding) or algorithmic bytes (every operand / output once) / HIP-event time of the class's sampled
-                launches inside the timed region.  roofline_classes = the classes that carry the GEMM time, each with its own bound.
-  cpu_baseline  the oracle (oracle/swin.py, fp32 PyTorch-CPU restatement, "port") timed on this box's host cores on a bounded
-                sample (B=1 clip, fwd+bwd), rank 0 at N=1 only.
+The line is <= 6144 bytes (LINE_MAX).  Extra objects in it:
+  roofline        the dominant rocprof KERNEL of the step aggregated over its (N, K, epilogue) classes: achieved = algorithmic FLOPs (2*M*N*K,
+                  no padding) / HIP-event time of its sampled launches on the launch stream, inside this run; peak 2.5 PFLOP/s dense bf16;
+                  traffic = PMC HBM bytes per launch (committed rocprofv3 --pmc passes of this same command).
+  roofline_class  the largest single class, priced against ITS bound (MFMA above 312 FLOP/B, HBM 8 TB/s below).
+  roofline_families  one row per non-GEMM kernel family (algorithmic bytes / HIP-event time).
+  roofline_pass   the eager pass those samples come from, and how much of its step they account for.
+  cpu_baseline    the oracle (oracle/swin.py, fp32 PyTorch-CPU restatement, "port") timed on this box's host cores on a bounded
+                  sample (B=1 clip, fwd+bwd), rank 0 at N=1 only.
+The per-class / per-family tables go to gpurun_out/bench_detail.json (`detail` names it) and to a 'BENCH_DETAIL ...' stdout line BEFORE the
+JSON line; nothing follows the JSON line on stdout.
 """
 import argparse
 import json
@@ -233,6 +237,177 @@ def pmc_step():
     return None
 
 
+LINE_MAX = 6144        # bytes of the final stdout line: the driver keeps an 8 KB tail and parses its last line (BENCH_r04 lost a 28 KB one)
+MFMA_FAMILIES = ("xattn_fwd", "xattn_bwd", "mlp_fused_fwd", "mlp_fused_bwd", "mha_fwd", "mha_bwd")
+METRIC_NAMES = {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
+                "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
+                "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}
+
+
+def build_report(gp, fams, ctx):
+    """(line, detail) from the pass-1 samples.  `gp` = kernels.gemm_profile_stop() rows (one per GEMM class = kernel the C dispatch chose x
+    N x K x epilogue), `fams` = kernels.family_profile_stop() rows (one per non-GEMM family x shape key), `ctx` = the run's scalars.  Pure
+    host arithmetic (tests/test_bench_line_cpu.py feeds it synthetic profiles).
+
+    line["roofline"]        the dominant rocprof KERNEL aggregated over its classes (the object profiles/*_kernel_stats.csv names): achieved
+                            = algorithmic FLOPs (2 M N K, no padding) / HIP-event time of its sampled launches; traffic = PMC bytes per launch
+                            averaged over its classes' dispatches (committed rocprofv3 --pmc passes of this same command).
+    line["roofline_class"]  its / the step's largest single class, priced against ITS bound (MFMA above 312 FLOP/B, else HBM).
+    line["roofline_families"]  one row per non-GEMM family.  Per-class and per-family-key tables -> detail."""
+    batch, world, n_steps, prof_steps = ctx["batch"], ctx["world"], ctx["n_steps"], max(ctx["prof_steps"], 1)
+    value = batch * world * n_steps / ctx["dt"]
+    eager_ms = ctx["dt_eager"] / ctx["steps_arg"] * 1e3 if ctx.get("dt_eager") is not None else None
+    RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_TBS * 1e12)
+    classes = []
+    for pc in gp:
+        if pc["sampled"] == 0 or pc["sampled_ms"] <= 0:
+            continue
+        ns = pc["sampled"]
+        avg_us = pc["sampled_ms"] * 1e3 / ns
+        sec = pc["sampled_ms"] * 1e-3
+        intensity = pc["sampled_flops"] / max(pc["sampled_bytes"], 1.0)
+        tf, tbs = pc["sampled_flops"] / sec / 1e12, pc["sampled_bytes"] / sec / 1e12
+        bound = "mfma" if intensity > RIDGE else "hbm"
+        traffic, traffic_src = pmc_traffic(pc["kernel"], pc["N"], pc["K"], pc["epi"])
+        classes.append({"bound": bound, "kernel": pc["kernel"], "N": pc["N"], "K": pc["K"], "epilogue": pc["epi"],
+                        "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
+                        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                        "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
+                        "tflops": round(tf, 1), "gbs": round(tbs * 1e3, 0), "flop_per_byte": round(intensity, 1),
+                        "launches_per_step": round(pc["launches"] / prof_steps, 2), "avg_launch_us": round(avg_us, 2),
+                        "gflop_per_launch": round(pc["sampled_flops"] / ns / 1e9, 2), "algorithmic_bytes_per_launch": round(pc["sampled_bytes"] / ns),
+                        "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * pc["launches"] / prof_steps, 3),
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "mfma_util_pmc": PMC_MFMA.get((pc["kernel"], pc["N"], pc["K"], pc["epi"]))})
+    classes.sort(key=lambda c: -c["est_ms_per_step"])
+    gemm_ms = round(sum(c["est_ms_per_step"] for c in classes), 2)
+    # the other half of the step, the same way: bound HBM except the families whose floor is the matrix pipe / VALU issue
+    fam_rows = []
+    for fc in fams:
+        if fc["sampled"] == 0 or fc["sampled_ms"] <= 0:
+            continue
+        ns, sec = fc["sampled"], fc["sampled_ms"] * 1e-3
+        avg_us = fc["sampled_ms"] * 1e3 / ns
+        tf, tbs = fc["sampled_flops"] / sec / 1e12, fc["sampled_bytes"] / sec / 1e12
+        bound = "mfma" if fc["family"] in MFMA_FAMILIES else "hbm"
+        fam_rows.append({"family": fc["family"], "key": fc["key"], "bound": bound,
+                         "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
+                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
+                         "gbs": round(tbs * 1e3), "tflops": round(tf, 1), "launches_per_step": round(fc["launches"] / prof_steps, 2),
+                         "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": round(fc["sampled_bytes"] / ns),
+                         "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * fc["launches"] / prof_steps, 3)})
+    fam_rows.sort(key=lambda r: -r["est_ms_per_step"])
+    fam_ms = round(sum(r["est_ms_per_step"] for r in fam_rows), 2)
+    fam_tot = {}
+    for r in fam_rows:
+        t = fam_tot.setdefault(r["family"], {"family": r["family"], "bound": r["bound"], "ms": 0.0, "_b": 0.0, "_f": 0.0})
+        t["ms"] += r["est_ms_per_step"]
+        t["_b"] += r["algorithmic_bytes_per_launch"] * r["launches_per_step"]
+        t["_f"] += r["tflops"] * r["est_ms_per_step"]
+    fam_summary = []
+    for t in sorted(fam_tot.values(), key=lambda t: -t["ms"]):
+        ms = max(t["ms"], 1e-9)
+        gbs, tfl = t["_b"] / ms / 1e6, t["_f"] / ms
+        fam_summary.append({"family": t["family"], "bound": t["bound"], "ms": round(ms, 2), "gbs": round(gbs), "tflops": round(tfl, 1),
+                            "frac": round(tfl / PEAK_BF16_TFLOPS if t["bound"] == "mfma" else gbs / (PEAK_HBM_TBS * 1e3), 3)})
+    # the dominant kernel, aggregated over its classes
+    by_kernel = {}
+    for c in classes:
+        k = by_kernel.setdefault(c["kernel"], {"kernel": c["kernel"], "ms": 0.0, "gflop": 0.0, "gb": 0.0, "launches": 0.0, "pmc_b": 0.0, "pmc_l": 0.0, "src": None})
+        k["ms"] += c["est_ms_per_step"]
+        k["gflop"] += c["gflop_per_launch"] * c["launches_per_step"]
+        k["gb"] += c["algorithmic_bytes_per_launch"] * c["launches_per_step"] / 1e9
+        k["launches"] += c["launches_per_step"]
+        if c["traffic"] is not None:
+            k["pmc_b"] += c["traffic"] * c["launches_per_step"]
+            k["pmc_l"] += c["launches_per_step"]
+            k["src"] = (c["traffic_source"] or "").split(" ")[0]
+    roofline, roofline_class = None, None
+    if by_kernel:
+        k = max(by_kernel.values(), key=lambda k: k["ms"])
+        ms, nl = max(k["ms"], 1e-9), max(k["launches"], 1e-9)
+        tf, gbs = k["gflop"] / ms, k["gb"] / ms * 1e3
+        bound = "mfma" if k["gflop"] / max(k["gb"], 1e-9) > RIDGE else "hbm"
+        roofline = {"kernel": k["kernel"], "bound": bound, "achieved": round(tf if bound == "mfma" else gbs, 1),
+                    "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                    "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / (PEAK_HBM_TBS * 1e3), 4),
+                    "traffic": round(k["pmc_b"] / k["pmc_l"]) if k["pmc_l"] else None,
+                    "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE KiB, rocprofv3 --pmc), mean over this kernel's dispatches",
+                    "traffic_source": k["src"], "algorithmic_bytes_per_launch": round(k["gb"] * 1e9 / nl),
+                    "gflop_per_launch": round(k["gflop"] / nl, 2), "avg_launch_us": round(ms * 1e3 / nl, 2), "launches_per_step": round(nl, 1),
+                    "est_ms_per_step": round(ms, 3), "tflops": round(tf, 1), "gbs": round(gbs),
+                    "what": "dominant kernel of the step, all its (N, K, epilogue) classes: algorithmic FLOPs / HIP-event time in this run"}
+        top = classes[0]
+        roofline_class = {kk: top[kk] for kk in ("kernel", "N", "K", "epilogue", "bound", "achieved", "peak", "unit", "frac", "tflops", "gbs", "avg_launch_us",
+                                                 "launches_per_step", "algorithmic_bytes_per_launch", "traffic", "mfma_util_pmc", "est_ms_per_step")}
+    st = pmc_step()
+    if st is not None:
+        st = {kk: st[kk] for kk in ("hbm_gb_per_step", "step_kernel_ms", "launches", "gemm_ms", "non_gemm_ms", "gemm_gb", "mfma_util_pmc",
+                                    "mfma_util_pmc_gemm_kernels", "source") if kk in st}
+    line = {
+        "metric": ("SECONDARY (bf16 residual stream, not the headline dataflow) " if ctx["residual"] == "bf16" else "") + "clips/sec fwd+bwd, " + METRIC_NAMES[ctx["workload"]],
+        "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": n_steps, "warmup": ctx["warmup"],
+        "ms_per_step": round(ctx["dt"] / n_steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8-e4m3 (frozen weights + their inputs, E8M0 block scales) / bf16" if ctx["fp8"] else "bf16", "data": "synthetic",
+        "config": {"workload": ctx["workload_desc"], "clips_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                   "residual_dtype": ctx["residual"], "step": ctx["step_how"], "step_forms_measured": ctx["pick"],
+                   "side_streams_overlap": ctx["overlap"]},
+        "model_tflops": round(value * ctx["gflop_per_clip"] / 1e3, 2),
+        "mfma_frac_whole_step": round(value * ctx["gflop_per_clip"] / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+        "final_loss": round(ctx["final_loss"], 4),
+        "roofline": roofline, "roofline_class": roofline_class,
+        "gemm_est_ms_per_step": gemm_ms, "non_gemm_est_ms_per_step": round(eager_ms - gemm_ms, 2) if eager_ms else None,
+        "roofline_families": fam_summary, "family_est_ms_per_step": fam_ms, "step_traffic": st,
+        "roofline_pass": {
+            "what": "eager single-stream pass of this run (HIP events around sampled launches): "
+                    + (f"{ctx['steps_arg']} timed steps" if world == 1 else f"{prof_steps} warm-up step(s)")
+                    + "; `value` steps replay HIP graphs (no events inside)",
+            "ms_per_step": round(eager_ms, 3) if eager_ms else None,
+            "value": round(batch * world / (eager_ms * 1e-3), 3) if eager_ms else None, "unit": "clips/s",
+            "accounted_ms_per_step": round(gemm_ms + fam_ms, 2),
+            "accounted_frac": round((gemm_ms + fam_ms) / eager_ms, 4) if eager_ms else None},
+    }
+    detail = {"roofline_classes": classes, "roofline_family_classes": fam_rows, "options": ctx.get("options"),
+              "headline": {kk: line[kk] for kk in ("metric", "value", "unit", "n_gpus", "ms_per_step", "config")}}
+    return line, detail
+
+
+def write_detail(detail):
+    """Per-class / per-family tables -> gpurun_out/bench_detail.json (merged back by gpurun) and one 'BENCH_DETAIL ' stdout line that does
+    not start with '{', printed BEFORE the JSON line.  Returns the path (or None when the directory is not writable)."""
+    print("BENCH_DETAIL " + json.dumps(detail), flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_detail.json")
+        with open(path, "w") as f:
+            json.dump(detail, f)
+        return "gpurun_out/bench_detail.json"
+    except OSError:
+        return None
+
+
+def finalize_line(line):
+    """json.dumps(line) within LINE_MAX bytes: drop the least important objects, in order, until it fits (never value / roofline / cpu_baseline)."""
+    s = json.dumps(line)
+    for victim in ("step_traffic", "roofline_class", "roofline_families", "roofline_pass"):
+        if len(s) <= LINE_MAX:
+            break
+        if victim == "roofline_families" and line.get(victim):
+            line[victim] = line[victim][:8]                 # the largest eight first, then drop entirely
+            s = json.dumps(line)
+            if len(s) <= LINE_MAX:
+                break
+        line[victim] = None
+        s = json.dumps(line)
+    if len(s) > LINE_MAX:
+        line["config"]["workload"] = line["config"]["workload"][:120]
+        line["config"]["step"] = str(line["config"]["step"])[:120]
+        s = json.dumps(line)
+    assert len(s) <= LINE_MAX, len(s)
+    return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,7 +603,7 @@ def main():
     fence()
     probe("after eager warm-up")
     prof_steps = max(args.warmup - 1, 1)
-    dt_eager = None
+    dt_eager, loss = None, None
     if world == 1:
         kernels.gemm_profile_reset()
         kernels.family_profile_reset()
@@ -447,167 +622,22 @@ def main():
 
     def emit(dt, n_steps, step_how, pick, overlap, final_loss):
         """Rank 0: build and print THE JSON line (everything sampled in pass 1 is closed over; the timed-region results are arguments, so the
-        N > 1 watchdog can print a line from the eager measurement when the replayed form never comes back)."""
+        N > 1 watchdog can print a line from the eager measurement when the replayed form never comes back).  The line is <= LINE_MAX bytes;
+        the per-class / per-family tables go to gpurun_out/bench_detail.json (named in the line) and to a stdout line that starts with
+        'BENCH_DETAIL ' BEFORE the JSON line.  Nothing follows the JSON line on stdout."""
         if rank != 0:
             return
-        clips = args.batch * world * n_steps
-        value = clips / dt
-        eager_ms = dt_eager / args.steps * 1e3 if dt_eager is not None else None
-        # Roofline per GEMM class (class = kernel the C dispatch chose x N x K x epilogue signature): achieved = algorithmic FLOPs
-        # (2 M N K) or algorithmic bytes (every operand / output once) of the class's sampled launches / their HIP-event durations,
-        # events on the launch stream inside the timed region (kernels.gemm_profile_start).  Each class is priced against ITS bound:
-        # MFMA when its arithmetic intensity exceeds the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), HBM otherwise -- one averaged
-        # number over shapes from 9 us to 1.4 ms hid which shapes are bad (VERDICT r1).  `roofline` = the class with the largest
-        # share of the step; `roofline_classes` = the classes that carry the GEMM time, largest first.
-        RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_TBS * 1e12)
-        classes = []
-        for pc in gp:
-            if pc["sampled"] == 0 or pc["sampled_ms"] <= 0:
-                continue
-            ns = pc["sampled"]
-            avg_us = pc["sampled_ms"] * 1e3 / ns
-            sec = pc["sampled_ms"] * 1e-3
-            intensity = pc["sampled_flops"] / max(pc["sampled_bytes"], 1.0)
-            tf, tbs = pc["sampled_flops"] / sec / 1e12, pc["sampled_bytes"] / sec / 1e12
-            bound = "mfma" if intensity > RIDGE else "hbm"
-            traffic, traffic_src = pmc_traffic(pc["kernel"], pc["N"], pc["K"], pc["epi"])
-            c = {"bound": bound, "kernel": pc["kernel"], "N": pc["N"], "K": pc["K"], "epilogue": pc["epi"],
-                 "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
-                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                 "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
-                 "tflops": round(tf, 1), "gbs": round(tbs * 1e3, 0), "flop_per_byte": round(intensity, 1),
-                 "launches_per_step": round(pc["launches"] / prof_steps, 2), "avg_launch_us": round(avg_us, 2),
-                 "gflop_per_launch": round(pc["sampled_flops"] / ns / 1e9, 2), "algorithmic_bytes_per_launch": round(pc["sampled_bytes"] / ns),
-                 "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * pc["launches"] / prof_steps, 3)}
-            classes.append((c, traffic, traffic_src))
-        classes.sort(key=lambda t: -t[0]["est_ms_per_step"])
-        gemm_ms = round(sum(c["est_ms_per_step"] for c, _, _ in classes), 2)
-        roofs = []
-        for c, traffic, traffic_src in classes[:24]:
-            roofs.append(dict(c, traffic=traffic, mfma_util_pmc=PMC_MFMA.get((c["kernel"], c["N"], c["K"], c["epilogue"]))))
-        if classes:
-            top, traffic, traffic_src = classes[0]
-            roofline = dict(top, traffic=traffic, traffic_unit="bytes/launch, PMC, of THIS class's dispatches (same N, K, epilogue, row count)",
-                            traffic_source=traffic_src, mfma_util_pmc=PMC_MFMA.get((top["kernel"], top["N"], top["K"], top["epilogue"])))
-        else:
-            roofline = None
-        # The other half of the step, the same way (kernels.family_profile_*): per family x shape key the algorithmic bytes (every operand /
-        # output once) and FLOPs of its sampled launches / their HIP-event durations.  Bound: HBM, except the families whose floor is the
-        # matrix pipe or VALU issue (frame-global cross-modal attention, the fused stage-0 MLP, the ViT / generic attention kernels).
-        MFMA_FAMILIES = ("xattn_fwd", "xattn_bwd", "mlp_fused_fwd", "mlp_fused_bwd", "mha_fwd", "mha_bwd")
-        nsteps_prof = prof_steps
-        fam_rows = []
-        for fc in fams:
-            if fc["sampled"] == 0 or fc["sampled_ms"] <= 0:
-                continue
-            ns, sec = fc["sampled"], fc["sampled_ms"] * 1e-3
-            avg_us = fc["sampled_ms"] * 1e3 / ns
-            tf, tbs = fc["sampled_flops"] / sec / 1e12, fc["sampled_bytes"] / sec / 1e12
-            bound = "mfma" if fc["family"] in MFMA_FAMILIES else "hbm"
-            fam_rows.append({"family": fc["family"], "key": fc["key"], "bound": bound,
-                             "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_TBS * 1e3,
-                             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(tf / PEAK_BF16_TFLOPS if bound == "mfma" else tbs / PEAK_HBM_TBS, 4),
-                             "gbs": round(tbs * 1e3), "tflops": round(tf, 1), "launches_per_step": round(fc["launches"] / nsteps_prof, 2),
-                             "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": round(fc["sampled_bytes"] / ns),
-                             "sampled_launches": ns, "est_ms_per_step": round(avg_us * 1e-3 * fc["launches"] / nsteps_prof, 3)})
-        fam_rows.sort(key=lambda r: -r["est_ms_per_step"])
-        fam_ms = round(sum(r["est_ms_per_step"] for r in fam_rows), 2)
-        fam_tot = {}
-        for r in fam_rows:
-            t = fam_tot.setdefault(r["family"], {"family": r["family"], "bound": r["bound"], "est_ms_per_step": 0.0, "_b": 0.0, "_f": 0.0})
-            t["est_ms_per_step"] += r["est_ms_per_step"]
-            t["_b"] += r["algorithmic_bytes_per_launch"] * r["launches_per_step"]
-            t["_f"] += r["tflops"] * r["est_ms_per_step"]
-        fam_summary = []
-        for t in sorted(fam_tot.values(), key=lambda t: -t["est_ms_per_step"]):
-            ms = max(t["est_ms_per_step"], 1e-9)
-            gbs, tfl = t["_b"] / ms / 1e6, t["_f"] / ms
-            fam_summary.append({"family": t["family"], "bound": t["bound"], "est_ms_per_step": round(ms, 3), "gbs": round(gbs), "tflops": round(tfl, 1),
-                                "frac": round(tfl / PEAK_BF16_TFLOPS if t["bound"] == "mfma" else gbs / (PEAK_HBM_TBS * 1e3), 4)})
-        # roofline_kernel: the dominant rocprof KERNEL aggregated over its classes, so that this line and profiles/*_kernel_stats.csv name the
-        # same object (the per-class `roofline` above names the largest class)
-        by_kernel = {}
-        for c, _, _ in classes:
-            k = by_kernel.setdefault(c["kernel"], {"kernel": c["kernel"], "ms": 0.0, "gflop": 0.0, "gb": 0.0, "launches": 0.0})
-            k["ms"] += c["est_ms_per_step"]
-            k["gflop"] += c["gflop_per_launch"] * c["launches_per_step"]
-            k["gb"] += c["algorithmic_bytes_per_launch"] * c["launches_per_step"] / 1e9
-            k["launches"] += c["launches_per_step"]
-        roofline_kernel = None
-        if by_kernel:
-            k = max(by_kernel.values(), key=lambda k: k["ms"])
-            tf = k["gflop"] / max(k["ms"], 1e-9)
-            roofline_kernel = {"kernel": k["kernel"], "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_BF16_TFLOPS, 4), "est_ms_per_step": round(k["ms"], 3), "launches_per_step": round(k["launches"], 1),
-                               "avg_launch_us": round(k["ms"] * 1e3 / max(k["launches"], 1e-9), 2), "gbs": round(k["gb"] / max(k["ms"], 1e-9) * 1e3),
-                               "what": "all classes routed to this kernel, algorithmic FLOPs / HIP-event time"}
-        out = {
-            "metric": ("SECONDARY (bf16 residual stream, not the headline dataflow) " if args.residual == "bf16" else "") + "clips/sec fwd+bwd, " + {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
-                                              "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
-                                              "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}[args.workload], "value": round(value, 3), "unit": "clips/s",
-            "n_gpus": world, "steps": n_steps, "warmup": args.warmup, "ms_per_step": round(dt / n_steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8-e4m3 (frozen weights + their inputs, E8M0 block scales) / bf16" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": workload_desc, "clips_per_gpu": args.batch,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "residual_dtype": args.residual},
-            "model_tflops": round(value * gflop_per_clip / 1e3, 2),
-            "mfma_frac_whole_step": round(value * gflop_per_clip / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-            "final_loss": round(final_loss, 4),
-            "roofline": roofline, "roofline_kernel": roofline_kernel, "roofline_classes": roofs, "gemm_est_ms_per_step": gemm_ms,
-            "non_gemm_est_ms_per_step": round(eager_ms - gemm_ms, 2) if eager_ms else None,
-            "roofline_families": fam_summary, "roofline_family_classes": fam_rows[:40], "family_est_ms_per_step": fam_ms,
-            "step_traffic": pmc_step(),
-        }
-        # what the roofline objects were sampled in, and how much of that pass's step they account for
-        out["roofline_pass"] = {
-            "what": ("the eager single-stream pass of this same run (one launch per kernel, HIP events around every 7th / 5th launch of a class): "
-                     + (f"{args.steps} timed steps" if world == 1 else f"the {prof_steps} warm-up step(s) after the first")
-                     + "; the timed `value` steps replay HIP graphs, which carry no events, and run two launch chains concurrently, where a "
-                       "kernel's own duration is not defined"),
-            "ms_per_step": round(eager_ms, 3) if eager_ms else None,
-            "value": round(args.batch * world / (eager_ms * 1e-3), 3) if eager_ms else None, "unit": "clips/s",
-            "accounted_ms_per_step": round(gemm_ms + fam_ms, 2),
-            "accounted_frac": round((gemm_ms + fam_ms) / eager_ms, 4) if eager_ms else None}
-        out["config"]["step"] = step_how
-        out["config"]["step_forms_measured"] = pick
-        out["config"]["side_streams_overlap"] = overlap
-        out["config"]["options"] = stgcma.options() if hasattr(stgcma, "options") else None
-        # the same step replayed from a HIP graph (N = 1, --graph): reported next to the eager number, which stays `value` -- the roofline
-        # sampling above needs eager launches (HIP events around individual kernels).  It runs AFTER the headline object is complete and
-        # the line is printed in `finally`, so nothing in here can lose the measurement (ADVICE r2).
+        ctx = {"batch": args.batch, "world": world, "n_steps": n_steps, "warmup": args.warmup, "steps_arg": args.steps, "dt": dt,
+               "dt_eager": dt_eager, "prof_steps": prof_steps, "workload": args.workload, "workload_desc": workload_desc,
+               "gflop_per_clip": gflop_per_clip, "fp8": args.fp8, "residual": args.residual, "step_how": step_how, "pick": pick,
+               "overlap": overlap, "final_loss": final_loss, "options": stgcma.options() if hasattr(stgcma, "options") else None}
+        line, detail = build_report(gp, fams, ctx)
         try:
-            if world == 1 and args.graph:
-                import gc
-                loss = None                   # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream:
-                gc.collect()                  # kept alive, they drag that stream into the capture and invalidate it
-                try:
-                    replay, static_loss = recipe.capture_train_step(step, warmup=1)
-                    for _ in range(2):
-                        replay()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    replay()                  # ONE replay from an idle stream: the host cost of launching a step
-                    host_one = time.perf_counter() - t1
-                    torch.cuda.synchronize()
-                    tg = time.perf_counter()
-                    for _ in range(args.steps):
-                        replay()
-                    th = time.perf_counter() - tg
-                    torch.cuda.synchronize()
-                    tg = time.perf_counter() - tg
-                    out["graph_replay"] = {
-                        "value": round(args.batch * args.steps / tg, 3), "unit": "clips/s", "ms_per_step": round(tg / args.steps * 1e3, 3),
-                        "host_ms_one_replay": round(host_one * 1e3, 3), "host_ms_per_step_back_to_back": round(th / args.steps * 1e3, 3),
-                        "final_loss": round(float(static_loss.detach()), 4),
-                        "what": "the identical step (forward + loss + backward + Adam) captured once with torch.cuda.graph and replayed; "
-                                "host_ms_one_replay = launching one replay on an idle stream; back to back the host blocks on the launch "
-                                "queue once a few replays are in flight, so that figure tends to the GPU time per step"}
-                except Exception as e:                               # a capture failure must not take the headline number with it
-                    out["graph_replay"] = {"error": repr(e)[:200]}
             if world == 1 and not args.no_cpu_baseline and args.workload == "swin_b":
-                out["cpu_baseline"] = cpu_baseline()
+                line["cpu_baseline"] = cpu_baseline()
         finally:
-            print(json.dumps(out), flush=True)
+            line["detail"] = write_detail(detail)
+            print(finalize_line(line), flush=True)
 
     # ---------------------------------------------------------------------------------------------------------------- pass 2: the timed steps
     # The product's step (recipe.capture_train_step_mb): `nmb` micro-batches, each forward + backward a HIP graph on its own stream,
@@ -642,77 +672,86 @@ def main():
         limit_s = float(os.environ.get("STG_BENCH_WATCHDOG_S", "300"))
 
         def fire():
-            # the other ranks leave at once (exit code 0); rank 0 prints first.  Its main thread may meanwhile see its peers vanish and raise:
-            # the timer thread is NOT a daemon, so the interpreter waits for it, and os._exit(0) below decides the exit code
+            # a hang is a FAILURE: rank 0 still prints the line from the eager measurement (so the number is not lost), then every rank
+            # leaves with exit code 3.  The timer thread is NOT a daemon, so the interpreter waits for it and os._exit decides the code
             try:
-                if rank == 0:
+                if rank == 0 and last_eager_loss == last_eager_loss and abs(last_eager_loss) != float("inf"):
                     emit(ms_e_pre * 2 / 1e3, 2, f"eager, one stream (WATCHDOG: the replayed form did not finish within {limit_s:.0f} s; value = the two eager steps "
                          "timed before the capture)", {"eager_ms_per_step": round(ms_e_pre, 3), "replay_ms_per_step": None}, None, last_eager_loss)
+                else:
+                    time.sleep(5.0)           # the launcher tears every rank down when the first one fails: let rank 0 print first
             finally:
-                os._exit(0)
+                os._exit(3)
         watchdog = threading.Timer(limit_s, fire)
         watchdog.daemon = False
         watchdog.start()
-    if want_graph:
-        loss = None
-        import gc
-        gc.collect()                  # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream
-        ok, why = 1, ""
-        try:
-            if nmb > 1:
-                replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
+    # the eager pass's last loss, DETACHED (its autograd graph must not survive into the capture): reported whenever the timed region falls back to dt_eager
+    eager_loss = loss.detach().clone() if loss is not None else None
+    try:
+        if want_graph:
+            loss = None
+            import gc
+            gc.collect()                  # the last eager step's autograd graph holds AccumulateGrad nodes bound to the default stream
+            ok, why = 1, ""
+            try:
+                if os.environ.get("STG_BENCH_FAIL_CAPTURE"):                 # tests only: rehearse the capture-failure fallback
+                    raise RuntimeError("capture failure forced by STG_BENCH_FAIL_CAPTURE")
+                if nmb > 1:
+                    replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
+                else:
+                    replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
+            except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)
+                ok, why = 0, repr(e)[:200]
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag)
+            if not ok:
+                if replay is not None and hasattr(replay, "release"):
+                    replay.release()
+                replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
             else:
-                replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
-        except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)
-            ok, why = 0, repr(e)[:200]
-        if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        if not ok:
-            if replay is not None and hasattr(replay, "release"):
-                replay.release()
-            replay, step_how = None, f"eager, one stream (graph capture failed{': ' + why if why else ' on another rank'})"
+                probe("after capture")
+                for _ in range(2):
+                    replay()
+                    probe("after a warm replay")
+            fence()
+        # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
+        # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
+        # measured on the form that wins there.  Every rank takes the same decision (it is made on all-reduced times).
+        pick = None
+        if replay is not None and world > 1:
+            ms_e = ms_e_pre
+            ms_r = timed2(replay)
+            probe("after 2 replays (form selection)")
+            pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
+            if ms_r > ms_e:
+                if hasattr(replay, "release"):
+                    replay.release()
+                replay = None
+                step_how = f"eager, one stream (the replayed form measured {ms_r:.1f} ms per step against {ms_e:.1f} eager on this box)"
+        if replay is not None or world > 1:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if replay is not None:
+                    replay()
+                    loss = static_loss
+                else:
+                    loss = step()
+            fence()
+            dt = time.perf_counter() - t0
+            probe("after the timed steps")
+            if world == 1 and dt_eager is not None and dt > dt_eager:
+                # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
+                # reports the faster one as `value` and says so
+                pick = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "replay_ms_per_step": round(dt / args.steps * 1e3, 3)}
+                step_how = f"eager, one stream (the replayed micro-batch form measured {dt / args.steps * 1e3:.1f} ms per step: slower on this box)"
+                dt, loss = dt_eager, eager_loss
         else:
-            probe("after capture")
-            for _ in range(2):
-                replay()
-                probe("after a warm replay")
-        fence()
-    # N > 1 has no timed eager pass to compare with: time two steps of each form (max over ranks) and keep the faster for the timed region,
-    # so that a box on which the replayed form loses (streams sharing a hardware queue, a collective that serialises behind a graph) is
-    # measured on the form that wins there.  Every rank takes the same decision (it is made on all-reduced times).
-    pick = None
-    if replay is not None and world > 1:
-        ms_e = ms_e_pre
-        ms_r = timed2(replay)
-        probe("after 2 replays (form selection)")
-        pick = {"eager_ms_per_step": round(ms_e, 3), "replay_ms_per_step": round(ms_r, 3)}
-        if ms_r > ms_e:
-            replay.release()
-            replay = None
-            step_how = f"eager, one stream (the replayed form measured {ms_r:.1f} ms per step against {ms_e:.1f} eager on this box)"
-    if replay is not None or world > 1:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if replay is not None:
-                replay()
-                loss = static_loss
-            else:
-                loss = step()
-        fence()
-        dt = time.perf_counter() - t0
+            dt, loss = dt_eager, eager_loss                              # N = 1 without graphs (or capture failed): the eager pass IS the measurement
+    finally:                                     # an exception in pass 2 must surface at once with its own exit code, not after the watchdog's limit
         if watchdog is not None:
             watchdog.cancel()
-        probe("after the timed steps")
-        if world == 1 and dt_eager is not None and dt > dt_eager:
-            # the replayed micro-batch form lost to the eager pass on this box (both are K timed steps of the same workload): the line
-            # reports the faster one as `value` and says so
-            pick = {"eager_ms_per_step": round(dt_eager / args.steps * 1e3, 3), "replay_ms_per_step": round(dt / args.steps * 1e3, 3)}
-            step_how = f"eager, one stream (the replayed micro-batch form measured {dt / args.steps * 1e3:.1f} ms per step: slower on this box)"
-            dt = dt_eager
-    else:
-        dt = dt_eager                                                # N = 1 without graphs: the eager pass IS the measurement
     final_loss = float(loss.detach())
     if final_loss != final_loss or final_loss in (float("inf"), float("-inf")):
         # say where the non-finite values are before giving up (stderr; the line itself is never printed for an invalid run)

@@ -122,7 +122,7 @@ def test_bench_launches_its_own_ranks(stg, gpu):
 def test_bench_watchdog_prints_the_eager_line_when_the_replayed_form_never_returns(stg, gpu):
     """N > 1 safety net: RCCL has never run under the replayed step form on this pool's hardware, so bench.py times the eager form before it
     captures anything and arms a watchdog around pass 2; when that fires (here: forced after 1 s) rank 0 prints ONE complete line from the
-    eager measurement, says so in config.step, and every rank exits with code 0."""
+    eager measurement, says so in config.step, and every rank exits with code 3: a hang is a failure, the line keeps the number."""
     env = dict(os.environ, STG_DDP_BACKEND="gloo", OMP_NUM_THREADS="4", STG_BENCH_WATCHDOG_S="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -131,8 +131,27 @@ def test_bench_watchdog_prints_the_eager_line_when_the_replayed_form_never_retur
     torch.cuda.empty_cache()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "2", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode != 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) <= 6144 and r.stdout.rstrip().splitlines()[-1] == lines[0]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "WATCHDOG" in d["config"]["step"] and d["roofline"] is not None
+
+
+def test_bench_n1_capture_failure_falls_back_to_the_eager_measurement(stg, gpu):
+    """N = 1: when the micro-batch capture raises, the complete eager measurement is the line (it used to die on a None loss)."""
+    env = dict(os.environ, STG_BENCH_FAIL_CAPTURE="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--batch", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.rstrip().splitlines()[-1]
+    assert len(last) <= 6144
+    d = json.loads(last)
+    assert "capture failed" in d["config"]["step"] and d["value"] > 0 and d["final_loss"] == d["final_loss"]
+    assert d["roofline"]["frac"] > 0 and d["detail"]
