@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 212
+#define STG_VERSION 213
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -109,8 +109,7 @@ typedef struct {
     int64_t split_m; const void* W2; const float* bias2;
 } stg_gemm_args;
 enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
-       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8,
-       STG_GEMM_KERNEL_OVL = 9 /* 256 x 128 tiles, two accumulator sets, the epilogue inside the next tile's main loop (csrc/gemm_ovl.hip) */ };
+       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8 };
 int stg_gemm_nt(stg_gemm_args* args, void* stream);
 
 /* Block-scaled e4m3 quantisation of a bf16 matrix (the producer side of ab_dtype == STG_FP8_MX): for every row r and 32-wide
@@ -326,18 +325,6 @@ int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
 
-/* The adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760 / the S_Adapter2 site: h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and the same
- * with the roles swapped), round 4: both directions AND the gates in one launch each way -- per site this replaces 2 x stg_winattn_fwd +
- * stg_gate_fwd2 resp. stg_gate_bwd2 + 2 x stg_winattn_bwd.  a0 / a1 describe the two directions exactly as stg_winattn_fwd takes them (same
- * geometry and tables, K == V, O / lse per direction); x0 / x1 [rows, H*32] bf16 receive Q + gate * O.  Backward: dx0 / dx1 are the gradients wrt
- * x0 / x1; dq / dk per direction are written (dk = dK + dV); the gates' own gradients <dx, O> are accumulated by stg_add3_mul2_dgate (the join that
- * reads dx next: one atomic per block there, against one per wave -- 2 560 on one address, 4 x the kernel's time -- here).
- * Per element the arithmetic of the launches it replaces. */
-int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0, void* x1,
-                          int64_t ldx, void* stream);
-int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, const void* dx0,
-                          const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk, void* stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Temporal attention: WindowAttention.forward's temporal branch (Swin_AVE.py:244-255; block call sites :705-716) with the
  * '(b t) n c -> (b n) t c' rearranges as addressing.  The fused token tensor holds nm modality slabs of B clips x T frames x
@@ -469,10 +456,6 @@ int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0,
                   const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream);
 int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                   const void* c1, const void* z1, void* out1, int64_t numel, void* stream);
-/* stg_add3_mul2 where a0 / a1 are the gradients dX of two gated hidden states X = h + gate r: additionally dgate += <a, r> (fp32 scalars, accumulated). */
-int stg_add3_mul2_dgate(const void* a0, const void* b0, const void* c0, const void* z0, const void* r0, float* dgate0, void* out0,
-                        const void* a1, const void* b1, const void* c1, const void* z1, const void* r1, float* dgate1, void* out1,
-                        int64_t numel, void* stream);
 /* Test aid: fill the LDS of every CU with NaN bit patterns, so that a kernel reading an LDS byte nobody wrote produces a non-finite result
  * (stgcma._lib wraps every launch with it under STG_LDS_POISON=1; tests/test_lds_poison_gpu.py). */
 int stg_debug_poison_lds(void* stream);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so
 
 STG_F32, STG_BF16, STG_FP8_MX, STG_U8_LIN = 0, 1, 2, 3
 (GEMM_KERNEL_REG, GEMM_KERNEL_GLDS, GEMM_KERNEL_BIG, GEMM_KERNEL_8PH, GEMM_KERNEL_GLDS_CONV, GEMM_KERNEL_GLDS_BATCH, GEMM_KERNEL_GLDS_KTAIL,
- GEMM_KERNEL_FP8, GEMM_KERNEL_8PHM, GEMM_KERNEL_OVL) = range(10)
+ GEMM_KERNEL_FP8, GEMM_KERNEL_8PHM) = range(9)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 
 c_i64 = C.c_int64
@@ -164,9 +164,6 @@ SIGNATURES = {
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "stg_winattn_xpair_fwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "stg_winattn_xpair_bwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
-                                        c_vp]),
     "stg_tattn_fwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp]),
     "stg_tattn_bwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_mha_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -191,7 +188,6 @@ SIGNATURES = {
     "stg_gate_fwd2": (C.c_int, [c_vp] * 8 + [c_i64, c_vp]),
     "stg_gate_bwd2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_add3_mul2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
-    "stg_add3_mul2_dgate": (C.c_int, [c_vp] * 14 + [c_i64, c_vp]),
     "stg_debug_poison_lds": (C.c_int, [c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -223,7 +219,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 212
+ABI_VERSION = 213
 _lib = None
 
 

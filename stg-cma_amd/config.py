@@ -41,12 +41,10 @@ SPEC = {
     "mha_x":       ("STG_MHA_X", _b, True, [("ops", "USE_MHA_X")], "flash kernels for wide frame-global cross-modal attention"),
     "xwin":        ("STG_XWIN", _b, True, [("ops", "USE_XWIN")], "window-level cross-modal attention on the whole-window kernels"),
     "pair_ew":     ("STG_PAIR_EW", _b, True, [("ops", "PAIR_EW")], "both directions of a cross-modal pair per element-wise launch"),
-    "xwin_pair":   ("STG_XWIN_PAIR", _b, False, [("ops", "XWIN_PAIR")], "window-level cross-modal pair: both directions and the gates in one launch each way (measured neutral eager, slower in the two-chain form)"),
     "join_pair":   ("STG_JOIN_PAIR", _b, True, [("ops", "JOIN_PAIR")], "both modalities' residual joins (+ LayerNorm) and LayerNorm-backward + adapter dgrad in one launch each"),
     "gemm_split":  ("STG_GEMM_SPLIT", _b, True, [("ops", "GEMM_SPLIT")], "video | audio adapter GEMMs as one launch with two row groups"),
     "wgrad_ws":    ("STG_WGRAD_WS", _b, True, [("kernels", "USE_WGRAD_WS")], "workspace (atomic-free) weight-gradient kernels"),
     "wgrad_multi": ("STG_WGRAD_MULTI", _b, True, [("kernels", "USE_WGRAD_MULTI")], "adapter weight gradients of a block in one launch pair"),
-    "wgrad_fused": ("STG_WGRAD_FUSED", _b, True, [("ops", "WGRAD_FUSED")], "adapter D_fc2 weight gradient inside the LayerNorm-backward kernel (round 4)"),
     "mha":         ("STG_MHA", _b, True, [("ops_vit", "USE_MHA")], "ViT spatial attention on the flash kernels"),
     "tattn_vit":   ("STG_TATTN_VIT", _b, True, [("ops_vit", "USE_TATTN_VIT")], "ViT temporal attention on the packed kernels"),
     "fp8":         ("STG_FP8", _b, False, [], "frozen backbone Linears on block-scaled e4m3 (opt-in; misses the 1e-2 logit bound, DESIGN section 8)"),
@@ -54,7 +52,7 @@ SPEC = {
 # options of the C library (stg_set_option): environment variable -> option name
 LIB_SPEC = {"STG_GEMM_EPI": "gemm_epi", "STG_GEMM_KTAIL": "gemm_ktail", "STG_GEMM_BIG": "gemm_big", "STG_GEMM_8PH": "gemm_8ph",
             "STG_GEMM_8PHM": "gemm_8phm", "STG_GEMM_DBG": "gemm_dbg", "STG_XATTN": "xattn", "STG_WINATTN_BWD_OCC": "winattn_bwd_occ",
-            "STG_TATTN_KERNELS": "tattn", "STG_GEMM_OVL": "gemm_ovl", "STG_WGRAD_SPLIT": "wgrad_split", "STG_MLP_STAGGER": "mlp_stagger", "STG_GEMM_STAGGER": "gemm_stagger", "STG_WINATTN_PIPE": "winattn_pipe"}
+            "STG_TATTN_KERNELS": "tattn"}
 
 _values = {k: v[2] for k, v in SPEC.items()}
 _lib_values = {}

@@ -184,11 +184,6 @@ extern std::atomic<int> stg_opt_gemm_dbg;     // diagnostics build only (-DSTG_G
 extern std::atomic<int> stg_opt_winattn_bwd_occ;   // window attention: 1 (default) the coalesced round-2 kernels (winattn_fwd1 / winattn_bwd1); 2 / 3: the round-1
                                                    // kernels, backward held to 2 / 3 waves per SIMD
 extern std::atomic<int> stg_opt_tattn;        // temporal attention (head dim 32): 1 the coalesced round-2 kernels, 0 the round-1 kernels
-extern std::atomic<int> stg_opt_gemm_ovl;     // overlapped-epilogue kernel (gemm_ovl.hip): 0 off, 1 auto (default), 2 every legal shape; 16 * ntl + mode: fixed walk length (tools/)
-extern std::atomic<int> stg_opt_wgrad_split;  // multi-problem wgrad launches: 0 (default) the single-problem row split per problem, 1 row splits sized for the whole launch (A/B: -36 % workspace traffic, same time)
-extern std::atomic<int> stg_opt_winattn_pipe; // window attention forward: 0 = one window per wave (winattn_fwd1), n > 0 = persistent pipelined waves, ~n * 1024 of them (winattn_fwd2)
-extern std::atomic<int> stg_opt_gemm_stagger; // 8-phase GEMM kernels: start stagger of the first round of workgroups, 256 * phases + q (gemm.hip start_stagger); 0 = none
-extern std::atomic<int> stg_opt_mlp_stagger;  // fused MLP (C = 128): 1 = waves 4-7 one half-chunk behind waves 0-3 (mlp_fwd_stag_kernel)
 extern std::atomic<int> stg_opt_xattn;        // 0: frame-global cross-modal attention on the generic attention kernels
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: `done` (one static per kernel instantiation) remembers the

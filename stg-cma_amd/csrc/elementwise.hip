@@ -194,48 +194,6 @@ __global__ void add3_mul2_kernel(Ew2 p, int64_t n8, int64_t numel) {
     }
 }
 
-// add3_mul2 + the gate gradients of a cross-modal pair: a is dX (the gradient of the gated hidden state X = h + gate r), so beside
-// out = (a + b + c) z the kernel accumulates dgate += <a, r> -- what gate_bwd2 computed in its own pass over the same dX (round 4: the
-// attention backward scales dX by the gate itself, stg_winattn_xpair_bwd).  One memory-side atomic per block and address: <= 256 blocks.
-__global__ void add3_mul2_dg_kernel(Ew2 p, const bf16_t* r0, const bf16_t* r1, int64_t n8, int64_t numel) {
-    const int y = blockIdx.y;
-    const bf16_t* a = p.a[y]; const bf16_t* b = p.b[y]; const bf16_t* c = p.c[y]; const bf16_t* z = p.z[y]; bf16_t* out = p.out[y];
-    const bf16_t* r = y ? r1 : r0;
-    float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        float x[8], v[8];
-        unpack8(reinterpret_cast<const uint4*>(a)[i], x);
-        unpack8(reinterpret_cast<const uint4*>(r)[i], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += x[j] * v[j];
-        unpack8(reinterpret_cast<const uint4*>(b)[i], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] += v[j];
-        unpack8(reinterpret_cast<const uint4*>(c)[i], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] += v[j];
-        unpack8(reinterpret_cast<const uint4*>(z)[i], v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] *= v[j];
-        reinterpret_cast<uint4*>(out)[i] = pack8(x);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
-        const int64_t i = (n8 << 3) + threadIdx.x;
-        acc += bf2f(a[i]) * bf2f(r[i]);
-        out[i] = f2bf((bf2f(a[i]) + bf2f(b[i]) + bf2f(c[i])) * bf2f(z[i]));
-    }
-    acc = wave_sum<64>(acc);
-    __shared__ float part[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) part[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
-        atomicAdd(p.dg[y], t);
-    }
-}
-
 // ---- dz = dh * act'(z)
 __global__ void act_bwd_kernel(const bf16_t* dh, const bf16_t* z, bf16_t* dz, int64_t n8, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -565,23 +523,6 @@ extern "C" int stg_add3_mul2(const void* a0, const void* b0, const void* c0, con
     p.a[1] = (const bf16_t*)a1; p.b[1] = (const bf16_t*)b1; p.c[1] = (const bf16_t*)c1; p.z[1] = (const bf16_t*)z1; p.out[1] = (bf16_t*)out1;
     const int64_t n8 = numel >> 3;
     hipLaunchKernelGGL(add3_mul2_kernel, dim3(grid_for(n8, 256), 2), dim3(256), 0, ST, p, n8, numel);
-    STG_LAUNCH_CHECK();
-    return 0;
-}
-extern "C" int stg_add3_mul2_dgate(const void* a0, const void* b0, const void* c0, const void* z0, const void* r0, float* dgate0, void* out0,
-                                   const void* a1, const void* b1, const void* c1, const void* z1, const void* r1, float* dgate1, void* out1,
-                                   int64_t numel, void* stream) {
-    STG_CHECK(a0 && b0 && c0 && z0 && r0 && dgate0 && out0 && a1 && b1 && c1 && z1 && r1 && dgate1 && out1, -1, "stg_add3_mul2_dgate: null pointer");
-    STG_CHECK(al16(a0) && al16(b0) && al16(c0) && al16(z0) && al16(r0) && al16(out0) && al16(a1) && al16(b1) && al16(c1) && al16(z1) && al16(r1) && al16(out1),
-              -2, "stg_add3_mul2_dgate: pointers must be 16-byte aligned");
-    if (numel <= 0) return 0;
-    Ew2 p = {};
-    p.a[0] = (const bf16_t*)a0; p.b[0] = (const bf16_t*)b0; p.c[0] = (const bf16_t*)c0; p.z[0] = (const bf16_t*)z0; p.out[0] = (bf16_t*)out0; p.dg[0] = dgate0;
-    p.a[1] = (const bf16_t*)a1; p.b[1] = (const bf16_t*)b1; p.c[1] = (const bf16_t*)c1; p.z[1] = (const bf16_t*)z1; p.out[1] = (bf16_t*)out1; p.dg[1] = dgate1;
-    const int64_t n8 = numel >> 3;
-    unsigned gb = grid_for(n8, 256);
-    if (gb > 256) gb = 256;      // one memory-side atomic per block and address
-    hipLaunchKernelGGL(add3_mul2_dg_kernel, dim3(gb, 2), dim3(256), 0, ST, p, (const bf16_t*)r0, (const bf16_t*)r1, n8, numel);
     STG_LAUNCH_CHECK();
     return 0;
 }

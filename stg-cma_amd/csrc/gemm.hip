@@ -14,7 +14,6 @@
 // Block ids are remapped so that the N-tiles sharing one A row-panel run on the same XCD (its L2 holds the panel).
 #include <type_traits>
 #include "common.h"
-#include "gemm_ovl.h"
 #include "../../include/stgcma.h"
 
 // Timing-only ablations exist in the diagnostics build alone (make diag -> libstgcma_hip_diag.so, -DSTG_GEMM_DIAG): the product
@@ -51,7 +50,6 @@ struct GemmParams {
     int64_t M; int N; int K;
     int nbm, nbn;
     int ntl;           // multi-tile 8-phase kernel: consecutive column tiles per workgroup (divides nbn)
-    int stag;          // 8-phase kernels: start stagger (option gemm_stagger), 0 = none
     int64_t split_m; const bf16_t* W2; const float* bias2;           // two row groups (see stgcma.h): rows >= split_m use W2 / bias2
     int vec_ok;
     int epi_variant;   // EV_* (row-layout epilogue), or -1: element-wise fallback
@@ -67,17 +65,6 @@ __device__ __forceinline__ float ld_res1(const void* res, int f32, int64_t off) 
 }
 
 __device__ __forceinline__ int swz(int row, int c) { return (c ^ (row & 7)); }
-
-// Start stagger of the one-workgroup-per-CU kernels (option gemm_stagger = 256 * phases + q, phases 0 -> 4): the first round of
-// workgroups (blockIdx < 256, one per CU) starts in `phases` groups q * ~1 us apart, and every later workgroup inherits the phase of
-// the CU it lands on -- so that the epilogue store bursts of the CUs do not all fall into the same few microseconds.
-__device__ __forceinline__ void start_stagger(int stag) {
-    if (stag && blockIdx.x < 256) {
-        const int nph = (stag >> 8) ? (stag >> 8) : 4;
-        const int n = (int)((blockIdx.x >> 3) % nph) * (stag & 255);
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-}
 
 struct AccTile { f32x4_t v[4][4]; };   // passed BY VALUE: a by-reference accumulator array ends up mirrored in scratch
 
@@ -744,7 +731,6 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
 // (late group included): A0 p0 -> p2, W1 p1 -> p3, A1 p2 -> p0', W0 p3 -> p1'.
 __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 128 rows x 64 bf16 = 128 KiB
-    start_stagger(p.stag);
     const int nblk = p.nbm * p.nbn;
     int bid = blockIdx.x;
     {
@@ -927,7 +913,6 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 template <int V>
 __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 16 KiB + 32 KiB of epilogue staging
-    start_stagger(p.stag);
     const int ntl = p.ntl;
     const int gpr = p.nbn / ntl;                         // tile groups per row panel
     const int ngrp = p.nbm * gpr;
@@ -1509,7 +1494,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     if (a->res1) STG_CHECK(a->res1_dtype == STG_BF16 || a->res1_dtype == STG_F32, -3, "stg_gemm_nt: bad res1 dtype");
     if (a->res2) STG_CHECK(a->res2_dtype == STG_BF16 || a->res2_dtype == STG_F32, -3, "stg_gemm_nt: bad res2 dtype");
     if (a->M == 0) return 0;
-    GemmParams p; p.stag = 0;
+    GemmParams p;
     p.A = (const bf16_t*)a->A; p.lda = a->lda;
     p.W = (const bf16_t*)a->W; p.ldw = a->ldw;
     p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == STG_F32);
@@ -1592,24 +1577,6 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         STG_LAUNCH_CHECK();
         return 0;
     }
-    // overlapped-epilogue kernel (gemm_ovl.hip): short-K shapes whose epilogue is a large share of a tile
-    {
-        const int om = stg_opt_gemm_ovl.load(std::memory_order_relaxed);
-        const int ov = p.epi_variant == EV_PLAIN ? OV_PLAIN : p.epi_variant == EV_GELU8 ? OV_GELU8 : p.epi_variant == EV_DSRC8 ? OV_DSRC8 : -1;
-        const bool legal = (om & 15) && ov >= 0 && !split && !conv && p.batch == 1 && stg_gemm_ovl_supported(ov, a->M, a->N, a->K) &&
-                           (((uintptr_t)a->C | (uintptr_t)a->dact | (uintptr_t)a->dact_src) & 15) == 0;
-        // auto (1) routes NOTHING here: every class of the step measured slower on this kernel than on the shipped routing (fc1 + GELU + byte
-        // derivative 455 vs 397 us, qkv 257 vs 200, N = K = 512 85 vs 75, fc2 dgrad 575 vs 359: DESIGN.md section 5.3); 2 = every legal shape (tools/, tests)
-        const bool want = (om & 15) == 2;
-        if (legal && want) {
-            GemmOvlParams q;
-            q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.C = (bf16_t*)p.C; q.ldc = p.ldc; q.bias = p.bias;
-            q.d8out = (uint8_t*)p.dact; q.ldp = p.ldp; q.d8src = (const uint8_t*)p.dact_src; q.ldd = p.ldd;
-            q.M = p.M; q.N = p.N; q.K = p.K; q.nbm = q.nbn = 0; q.ntl = om >> 4;
-            a->kernel_chosen = STG_GEMM_KERNEL_OVL;
-            return stg_gemm_ovl_launch(ov, q, stream);
-        }
-    }
     const int ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed);
     const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
     const bool big_ok = !split && !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
@@ -1629,7 +1596,6 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
-        p.stag = stg_opt_gemm_stagger.load(std::memory_order_relaxed);
         // multi-tile form (option gemm_8phm, default on): ntl >= 3 consecutive column tiles per workgroup where the tile is short
         // (K <= 512: turnover + epilogue are a third of it; at K = 768 -- ViT-B, Swin-L stage 2 -- the whole-model A/B is neutral to -0.8 %) and the group count still fills the chip twice.  Measured per class of the
         // step, one process, interleaved (tools/gemm_route_ab.py ... gemm_8phm): qkv 125440 x 1536 x 512 247 -> 217 us (ntl = 3), fc1 with

@@ -214,215 +214,6 @@ __global__ void __launch_bounds__(512, 2) mlp_fwd_kernel(MlpP p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, staggered (round 4)
-// The kernel above runs its three phases per chunk -- first product (MFMA), GELU (VALU), second product (MFMA) -- in BOTH waves of a SIMD
-// between the same barriers, so the SIMD alternates between all-matrix and all-vector stretches and the chunk costs their SUM (ablations,
-// identity instead of GELU -400 us of 827).  Here a chunk is cut into two INTERVALS with a raw barrier behind each,
-//     interval 1: first product, GELU of the chunk's first half        interval 2: GELU of the second half, second product
-// and waves 4-7 run ONE INTERVAL behind waves 0-3: whenever one group starts an interval with MFMAs the other starts it with VALU work
-// (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  The weight ring follows the intervals: at the start of global interval t every
-// wave issues its four DMA pieces of W1 (t even) / W2 (t odd) of chunk t / 2 + 1 into the other buffer -- W1 of that buffer was last read
-// in interval t - 1 (late group), W2 in interval t - 1 likewise one step later -- and before every barrier `s_waitcnt vmcnt(4)`: all but the
-// pieces just issued have landed, i.e. everything the NEXT interval of either group reads (issued at least two intervals ago).
-template <int C>
-__global__ void __launch_bounds__(512, 2) mlp_fwd_stag_kernel(MlpP p) {
-    static_assert(C == 128, "one LDS row = one 256-byte weight row");
-    constexpr int NCH = 4 * C / HC;
-    constexpr int KS1 = C / 32;
-    constexpr int CT = C / 16;
-    constexpr int WBYTES = HC * C * 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* stage_out = smem + 4 * WBYTES;
-    float* sb1 = reinterpret_cast<float*>(stage_out + MLP_WAVES * 2048);
-    float* sb2 = sb1 + 4 * C;
-    for (int i = threadIdx.x; i < 4 * C; i += 512) sb1[i] = p.b1[i];
-    if (threadIdx.x < C) sb2[threadIdx.x] = p.b2[threadIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, g = lane >> 4;
-    const bool late = wave >= 4;
-
-    uint32_t off1[4], off2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = (wave * 4 + j) * 64 + lane;
-        const int row = q >> 4, sc = (q & 15) ^ (row & 15);
-        off1[j] = (uint32_t)((row * C + sc * 8) * 2);
-        off2[j] = (uint32_t)((row * (4 * C) + sc * 8) * 2);
-    }
-    int64_t tile = blockIdx.x;
-    if (tile >= p.ntiles) return;
-    const int my_tiles = (int)((p.ntiles - 1 - tile) / gridDim.x) + 1;
-    const int total_chunks = my_tiles * NCH;
-    // which = 0: the W1 pieces, 1: the W2 pieces of this workgroup's chunk number j (counted over its tiles) -> buffer j & 1
-    auto issue_half = [&](int which, int j) {
-        if (j >= total_chunks) return;
-        const int ch = j % NCH;
-        uint8_t* d = smem + (j & 1) * 2 * WBYTES + which * WBYTES;
-        const char* s_ = which ? reinterpret_cast<const char*>(p.W2p) + (size_t)ch * HC * 2 : reinterpret_cast<const char*>(p.W1) + (size_t)ch * HC * C * 2;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (which ? off2[jj] : off1[jj])),
-                                             (__attribute__((address_space(3))) void*)(d + (wave * 4 + jj) * 1024), 16, 0, 0);
-    };
-    auto frag = [&](const uint8_t* base, int t, int kc) {
-        const int row = t * 16 + li;
-        return ld16(base + row * 256 + ((kc ^ (row & 15)) << 4));
-    };
-    auto load_y = [&](int64_t tl, bf16x8_t (&yf)[2][KS1]) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            int64_t m = tl * MLP_ROWS + wave * 32 + mt * 16 + li;
-            m = m < p.rows ? m : p.rows - 1;
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) yf[mt][ks] = ld16(p.Y + m * p.ldy + ks * 32 + g * 8);
-        }
-    };
-    auto interval_end = [&]() {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    bf16x8_t yf[2][KS1];
-    load_y(tile, yf);
-    issue_half(0, 0);
-    issue_half(1, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                      // chunk 0 and the biases are in LDS
-    int t = 0;                                            // global interval: W1 / W2 of chunk t / 2 + 1 is issued at its start
-    if (late) {                                           // the late group idles through interval 0 (its DMA share still goes out)
-        issue_half(0, 1);
-        interval_end();
-        t = 1;
-    }
-    int gch = 0;
-    f32x4_t O[CT][2];
-    bool have_out = false;
-    int64_t out_tile = 0;
-    auto epilogue = [&](int64_t tl) {
-        uint8_t* st = stage_out + wave * 2048;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                if ((li >> 3) == ps) {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        const float4 b = *reinterpret_cast<const float4*>(sb2 + ct * 16 + 4 * g);
-                        const uint2 v = make_uint2(pack_bf2(O[ct][mt][0] + b.x, O[ct][mt][1] + b.y), pack_bf2(O[ct][mt][2] + b.z, O[ct][mt][3] + b.w));
-                        const int cc = (ct * 2 + (g >> 1)) ^ (li & 7);
-                        *reinterpret_cast<uint2*>(st + (li & 7) * 256 + cc * 16 + (g & 1) * 8) = v;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int row = it * 4 + g;
-                    const uint4 v = *reinterpret_cast<const uint4*>(st + row * 256 + ((li ^ row) << 4));
-                    const int64_t m = tl * MLP_ROWS + wave * 32 + mt * 16 + ps * 8 + row;
-                    if (m < p.rows) *reinterpret_cast<uint4*>(p.Out + m * p.ldo + li * 8) = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-            }
-        }
-    };
-    for (; tile < p.ntiles; tile += gridDim.x) {
-        // the previous tile's output leaves at the START of this tile's first interval: its stores are then OLDER than the interval's DMA
-        // pieces, so the counted wait at the interval's end does not wait for those pieces (vmcnt counts in issue order)
-        if (have_out) epilogue(out_tile);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) { O[ct][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; O[ct][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-        const int64_t tnext = tile + gridDim.x;
-#pragma unroll 1
-        for (int ch = 0; ch < NCH; ++ch, ++gch) {
-            const uint8_t* w1 = smem + (gch & 1) * 2 * WBYTES;
-            const uint8_t* w2 = w1 + WBYTES;
-            // ------------------------------------------------ interval 1: first product, GELU of h tiles 0-3
-            issue_half(t & 1, (t >> 1) + 1);
-            f32x4_t S[HC / 16][2];
-            bf16x8_t af[2][KS1];
-#pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) af[0][ks] = frag(w1, 0, ks * 4 + g);
-#pragma unroll
-            for (int ht = 0; ht < HC / 16; ++ht) {
-                if (ht + 1 < HC / 16) {
-#pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks) af[(ht + 1) & 1][ks] = frag(w1, ht + 1, ks * 4 + g);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                S[ht][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; S[ht][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) {
-                    S[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ht & 1][ks], yf[0][ks], S[ht][0], 0, 0, 0);
-                    S[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ht & 1][ks], yf[1][ks], S[ht][1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (ch == NCH - 1 && tnext < p.ntiles) load_y(tnext, yf);
-            bf16x8_t hb[HC / 32][2];
-            auto gelu_q = [&](int q) {
-                const float4 ba = *reinterpret_cast<const float4*>(sb1 + ch * HC + 32 * q + 4 * g);
-                const float4 bb = *reinterpret_cast<const float4*>(sb1 + ch * HC + 32 * q + 16 + 4 * g);
-                const float bv[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    float x[8];
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const f32x2_t a2 = {S[2 * q][mt][r] + bv[r], S[2 * q][mt][r + 1] + bv[r + 1]};
-                        const f32x2_t b2 = {S[2 * q + 1][mt][r] + bv[4 + r], S[2 * q + 1][mt][r + 1] + bv[4 + r + 1]};
-                        const f32x2_t ya = gelu_pw(a2), yb = gelu_pw(b2);
-                        x[r] = ya.x; x[r + 1] = ya.y; x[4 + r] = yb.x; x[4 + r + 1] = yb.y;
-                    }
-                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-                    const u32x4_t w = {pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
-                    hb[q][mt] = __builtin_bit_cast(bf16x8_t, w);
-                }
-            };
-            gelu_q(0);
-            gelu_q(1);
-            interval_end();
-            ++t;
-            // ------------------------------------------------ interval 2: GELU of h tiles 4-7, second product
-            issue_half(t & 1, (t >> 1) + 1);
-            gelu_q(2);
-            gelu_q(3);
-            bf16x8_t wf[2][HC / 32];
-#pragma unroll
-            for (int q = 0; q < HC / 32; ++q) wf[0][q] = frag(w2, 0, q * 4 + g);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (ct + 1 < CT) {
-#pragma unroll
-                    for (int q = 0; q < HC / 32; ++q) wf[(ct + 1) & 1][q] = frag(w2, ct + 1, q * 4 + g);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < HC / 32; ++q) {
-                    O[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct & 1][q], hb[q][0], O[ct][0], 0, 0, 0);
-                    O[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct & 1][q], hb[q][1], O[ct][1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            interval_end();
-            ++t;
-        }
-        have_out = true;
-        out_tile = tile;
-    }
-    if (!late) {                                          // pairs with the late group's last barrier
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    if (have_out) epilogue(out_tile);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // ------------------------------------------------------------------------------------------------ backward
 // dy = ((dm . W2) * GELU'(y . W1^T + b1)) . W1 in one kernel, the pre-activation RECOMPUTED from y (nothing of the hidden tensor was
 // saved): per 128-wide hidden chunk
@@ -667,13 +458,6 @@ extern "C" int stg_mlp_fwd(const void* Y, int64_t ldy, const void* W1, const flo
 #undef STG_MLP_DIAG
     }
 #endif
-    if (stg_opt_mlp_stagger.load(std::memory_order_relaxed)) {
-        static std::atomic<uint64_t> sd{0};
-        STG_CHECK(stg_reserve_lds(mlp_fwd_stag_kernel<128>, lds, sd), -101, "stg_mlp_fwd: cannot reserve %d bytes of LDS", lds);
-        hipLaunchKernelGGL(mlp_fwd_stag_kernel<128>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
-        STG_LAUNCH_CHECK();
-        return 0;
-    }
     hipLaunchKernelGGL(mlp_fwd_kernel<128>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;

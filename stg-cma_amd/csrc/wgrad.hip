@@ -368,20 +368,6 @@ extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, 
         STG_CHECK(pl.ok, -7, "stg_wgrad_tn_ws_multi: problem %d is not eligible for the workspace path", i);
         if (i == 0) {
             pl0 = plm = pl;
-            // Option wgrad_split = 1 (round 4 A/B, off by default): the single-problem plan fills the chip on its own (~2 blocks per CU), so n
-            // problems in one launch could take n times fewer row splits each -- every block leaves a partial tile in the workspace (24 KiB at
-            // 32 narrow columns) that the reduce kernel reads back: the twelve adapter gradients of a stage-2 block write + re-read 2 x 147 MB of
-            // partials beside 818 MB of operands.  MEASURED same-box (bench.py, two rounds each): the family 5.98 -> 6.28 ms per step in
-            // isolation, the step 114.8 -> 114.7 ms: the kernel is not bound by those bytes (fewer, longer blocks lose what the traffic
-            // returns).  Same workspace layout, fewer slots used; the default keeps the single-problem split (bit-identical to single calls).
-            const int64_t want = (768 + (int64_t)pl.ncg * n - 1) / ((int64_t)pl.ncg * n);        // ~3 blocks per CU over the whole launch
-            if (n > 1 && want < pl.S && stg_opt_wgrad_split.load(std::memory_order_relaxed)) {
-                int64_t S = want < 1 ? 1 : want;
-                int64_t rpb = (q.M + S - 1) / S;
-                rpb = (rpb + WK - 1) / WK * WK;
-                S = (q.M + rpb - 1) / rpb;
-                plm.S = (int)S; plm.rows_per_block = rpb;
-            }
         }
         STG_CHECK(pl.nt1 == pl0.nt1 && pl.ncg == pl0.ncg && pl.S == pl0.S && pl.rows_per_block == pl0.rows_per_block, -7,
                   "stg_wgrad_tn_ws_multi: problem %d has a different launch plan than problem 0", i);

@@ -37,11 +37,6 @@ struct WinP {
     const bf16_t* dO; int64_t lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
     int total;
-    // cross-modal pair (XP kernels, round 4): problems [total, 2 total) are the SECOND direction (its own q / k = v / o / lse / gradients);
-    // forward also writes the gated hidden state X = Q + gate * O, backward takes the gradient of X: dO = gate * dX (dgate = <dX, O>: stg_add3_mul2_dgate)
-    const bf16_t* Q2; const bf16_t* K2; const bf16_t* V2; bf16_t* O2; float* lse2;
-    const float* gate[2]; bf16_t* X[2]; int64_t ldx;
-    const bf16_t* dO2; bf16_t* dQ2; bf16_t* dK2;
 };
 
 __device__ __forceinline__ void unpack8f(const uint4& q, float* v) {
@@ -399,8 +394,7 @@ __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const
     }
 }
 
-// XP: the cross-modal pair (see WinP) -- both directions in one launch, the gate's backward folded in (dV == NULL semantics: dK receives dK + dV)
-template <int NKEY, bool XP = false>
+template <int NKEY>
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
@@ -413,14 +407,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     const float* lsep = a.lse;
     bf16_t* dQp = a.dQ;
     bf16_t* dKp = a.dK;
-    const float* gp = a.gate[0];
-    if (XP) {
-        if (item >= 2 * a.total) return;
-        if (item >= a.total) {
-            item -= a.total;
-            Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; dOp = a.dO2; lsep = a.lse2; dQp = a.dQ2; dKp = a.dK2; gp = a.gate[1];
-        }
-    } else if (item >= a.total) return;
+    if (item >= a.total) return;
     const int h = item % a.H;
     const int p = item / a.H;
     const int pg = p / a.G, g = p - pg * a.G;
@@ -471,15 +458,6 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint4 vd = *reinterpret_cast<const uint4*>(sD + i * 512 + lane * 8);
-        if (XP) {                                          // the tile holds dX: dO = gate * dX in place (dgate = <dX, O> is left to stg_add3_mul2_dgate,
-            float dd[8];                                   // which reads dX anyway: one atomic per WAVE here cost 4 x the kernel, 2 560 on one address)
-            unpack8f(vd, dd);
-            const float gv = gp[0];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) dd[jj] *= gv;
-            vd = pack8u(dd);
-            *reinterpret_cast<uint4*>(sD + i * 512 + lane * 8) = vd;
-        }
         const uint32_t dw[4] = {vd.x, vd.y, vd.z, vd.w}, ow[4] = {vo[i].x, vo[i].y, vo[i].z, vo[i].w};
         float d = 0.f;
 #pragma unroll
@@ -554,7 +532,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
             for (int g4 = 0; g4 < 4; ++g4) addc[g4] = addn[g4];
         }
         const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * WD, trow[2 * kt + 1] * a.lddqkv + h * WD};
-        if (XP || a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
+        if (a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
 #pragma unroll
             for (int i = 0; i < 16; ++i) dk[i] = fmaf(dk[i], a.scale, dv[i]);
             put_tile32(sP, dk, 1.0f, r, hh);
@@ -583,8 +561,7 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 // ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
 // winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
 // fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
-// XP: the cross-modal pair (see WinP) -- both directions in one launch, and X = Q + gate * O written beside O
-template <int NKEY, bool XP = false>
+template <int NKEY>
 __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     constexpr int PER_WAVE = 3 * 64 * WD;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
@@ -593,13 +570,8 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     int item = blockIdx.x * 4 + wave;
     const bf16_t *Qp = a.Q, *Kp = a.K, *Vp = a.V;
     bf16_t* Op = a.O;
-    bf16_t* Xp = a.X[0];
     float* lsep = a.lse;
-    const float* gp = a.gate[0];
-    if (XP) {
-        if (item >= 2 * a.total) return;
-        if (item >= a.total) { item -= a.total; Qp = a.Q2; Kp = a.K2; Vp = a.V2; Op = a.O2; lsep = a.lse2; gp = a.gate[1]; Xp = a.X[1]; }
-    } else if (item >= a.total) return;
+    if (item >= a.total) return;
     const int h = item % a.H;
     const int p = item / a.H;
     const int pg = p / a.G, g = p - pg * a.G;
@@ -686,239 +658,10 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         if (q < a.n && lsep && hh == 0) lsep[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
     }
     lds_fence();
-    if (XP) {                        // O and the gated hidden state X = Q + gate * O (gate_fwd's arithmetic on the bf16-rounded O)
-        const float gv = gp[0];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int jr = 0; jr < 2; ++jr) {
-                const bf16_t* T = t == 0 ? sQ : sK;
-                const int tl = (lane >> 2) + 16 * jr, cq = lane & 3, sw = (tl >> 2) & 7;
-                const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
-                const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
-                if (32 * t + tl < a.n) {
-                    const int64_t ro = trow[2 * t + jr];
-                    const uint4 ov = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    *reinterpret_cast<uint4*>(Op + ro * a.ldo + h * WD + cq * 8) = ov;
-                    float qa[8], ob[8];
-                    unpack8f(*reinterpret_cast<const uint4*>(Qp + ro * a.ld + h * WD + cq * 8), qa);
-                    unpack8f(ov, ob);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) qa[jj] += gv * ob[jj];
-                    *reinterpret_cast<uint4*>(Xp + ro * a.ldx + h * WD + cq * 8) = pack8u(qa);
-                }
-            }
-    } else {
-        const int64_t r0[2] = {trow[0] * a.ldo + h * WD, trow[1] * a.ldo + h * WD};
-        const int64_t r1[2] = {trow[2] * a.ldo + h * WD, trow[3] * a.ldo + h * WD};
-        flush_tile32(sQ, Op, r0, 0, a.n, lane);
-        flush_tile32(sK, Op, r1, 1, a.n, lane);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ forward, pipelined (round 4)
-// winattn_fwd1_kernel is a chain per wave -- 12 LDS-DMAs + 16 table loads, s_waitcnt vmcnt(0), ~2 us of VALU / MFMA, stores, exit -- and
-// with 12 waves per CU the bytes in flight while most waves compute are too few for the HBM (3.8 TB/s measured; its traffic is exactly
-// the algorithmic 4 x rows x C x 2 bytes).  Here a wave is PERSISTENT over `ni` consecutive windows of one (window type, head):
-//   * the additive table (64 VGPRs, 16 KiB per wave, more bytes than the wave's q / k / v) is loaded once per wave, not per window;
-//   * window j + 1's q / k / v tiles are in flight (LDS-DMA into the wave's second buffer) while window j is computed: one counted
-//     wait per window (12 DMA instructions younger than everything the window needs);
-//   * tiles hold NKEY = 49 rows (3136 B, not 64 rows): two buffers x three tiles x eight waves = 147 KiB per CU.  Rows 49 .. 63 of the
-//     padded 64 x 64 problem read row 48 (fragment addresses are clamped): padded keys are -1e30 in the table and padded queries are
-//     never stored, exactly as in winattn_fwd1_kernel, whose results this kernel reproduces bit for bit.
-// Workgroup = four consecutive heads of the same windows (256 contiguous bytes per token row across the four waves).
-template <int NKEY>
-__global__ void __launch_bounds__(256, 2) winattn_fwd2_kernel(WinP a, int nchunk, int ni, int cnt) {
-    static_assert(NKEY > 32 && NKEY <= 64, "two query / key tiles");
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem_w2[];
-    constexpr int TILE = NKEY * WD;
-    constexpr int BUF = 3 * TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    int bid = blockIdx.x;
-    const int c = bid % nchunk;
-    bid /= nchunk;
-    const int HQ = a.H >> 2;
-    const int hq = bid % HQ, gt = bid / HQ;
-    const int h = hq * 4 + wave;
-    const int j0 = c * ni;
-    const int j1 = j0 + ni < cnt ? j0 + ni : cnt;
-    bf16_t* base = smem_w2 + wave * 2 * BUF;
-
-    const int cs = (lane & 3) ^ ((lane >> 4) & 3);
-    auto issue = [&](int j, bf16_t* buf, int64_t (&trow)[4]) {
-        int pg, g;
-        if (a.Gt == 1) { pg = j / a.G; g = j - pg * a.G; } else { pg = j; g = gt; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
-            const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
-            if (i < 3 || lane < 4 * (NKEY - 48)) {           // the fourth instruction stages rows 48 .. NKEY - 1 only
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.Q + off), (__attribute__((address_space(3))) void*)(buf + i * 512), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.K + off), (__attribute__((address_space(3))) void*)(buf + TILE + i * 512), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.V + off), (__attribute__((address_space(3))) void*)(buf + 2 * TILE + i * 512), 16, 0, 0);
-            }
-        }
-    };
-    int64_t trow[2][4];
-    if (j0 < j1) issue(j0, base, trow[0]);
-
-    float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const float* bmq = a.bm + ((int64_t)gt * a.H + h) * 4096 + 4 * (32 * qt + r);       // tiled: see win_table_kernel
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
-    }
-    const int r1c = 32 + r < NKEY ? 32 + r : NKEY - 1;      // row of the second tile's fragment, clamped
-
-#pragma unroll 1
-    for (int j = j0; j < j1; j += 2) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int jj = j + par;
-            if (jj >= j1) break;
-            bf16_t* sQ = base + par * BUF;
-            bf16_t* sK = sQ + TILE;
-            bf16_t* sV = sK + TILE;
-            if (jj + 1 < j1) {
-                issue(jj + 1, base + (par ^ 1) * BUF, trow[par ^ 1]);
-                // everything older than the 12 DMAs just issued has landed: window jj's tiles and the previous window's stores.  (Letting those
-                // 4 + 2 stores stay in flight -- vmcnt(18) -- measured 3 .. 5 % SLOWER, profiles/r04_winattn_experiments.txt.)
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            lds_fence();
-
-            bf16x8_t qf[2][2], kf[2][2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qf[0][s] = ld_frag(sQ + sw_off(r, hh + 2 * s));
-                kf[0][s] = ld_frag(sK + sw_off(r, hh + 2 * s));
-                qf[1][s] = ld_frag(sQ + sw_off(r1c, hh + 2 * s));
-                kf[1][s] = ld_frag(sK + sw_off(r1c, hh + 2 * s));
-            }
-            f32x16_t st[2][2];               // [q tile][key tile]: St[key][q]
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    st[qt][kt] = zero16();
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) st[qt][kt] = MFMA32(kf[kt][s], qf[qt][s], st[qt][kt]);
-                }
-            // V^T fragments (rows clamped like the q / k fragments).  Through inline asm: the compiler's waitcnt pass cannot see that a
-            // ds_read_b64_tr_b16 does not alias the LDS-DMA of the NEXT window and would put s_waitcnt vmcnt(0) in front of it
-            s4_t vlo[2][2], vhi[2][2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int gi = r & 15, cc = r >> 4;
-                    int row = 32 * kt + 16 * s2 + 4 * hh + (gi >> 2), row8 = row + 8;
-                    const int u = 4 * cc + (gi & 3);
-                    row = row < NKEY ? row : NKEY - 1;
-                    row8 = row8 < NKEY ? row8 : NKEY - 1;
-                    const uint32_t alo = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(sV + sw_off(row, u >> 1) + ((u & 1) << 2));
-                    const uint32_t ahi = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(sV + sw_off(row8, u >> 1) + ((u & 1) << 2));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[kt][s2]) : "v"(alo));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[kt][s2]) : "v"(ahi));
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[1][0]), "+v"(vhi[1][1])
-                         :: "memory");
-            bf16x8_t vf[2][2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8_t f;
-                    f[0] = vlo[kt][s2][0]; f[1] = vlo[kt][s2][1]; f[2] = vlo[kt][s2][2]; f[3] = vlo[kt][s2][3];
-                    f[4] = vhi[kt][s2][0]; f[5] = vhi[kt][s2][1]; f[6] = vhi[kt][s2][2]; f[7] = vhi[kt][s2][3];
-                    vf[kt][s2] = f;
-                }
-            lds_fence();                     // the Q and K tiles are free: O leaves through them
-            int pg, g;
-            if (a.Gt == 1) { pg = jj / a.G; g = jj - pg * a.G; } else { pg = jj; g = gt; }
-            const int64_t pw = (int64_t)pg * a.G + g;
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                float x[2][16];
-                float m = NEG_BIG;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (!key_reg_live<NKEY>(kt, reg)) continue;
-                        const float4 ad = add[qt][kt][reg >> 2];
-                        const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
-                        x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
-                        m = fmaxf(m, x[kt][reg]);
-                    }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                float l = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (!key_reg_live<NKEY>(kt, reg)) { x[kt][reg] = 0.f; continue; }
-                        x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
-                        l += x[kt][reg];
-                    }
-                l += __shfl_xor(l, 32, 64);
-                f32x16_t o = zero16();
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) o = MFMA32(vf[kt][s2], pack8(x[kt] + 8 * s2), o);
-                bf16_t* T = qt == 0 ? sQ : sK;
-                {                            // put_tile32 through inline asm (an LDS store the waitcnt pass would order behind the next window's DMA)
-                    const float sc = 1.0f / l;
-                    const int swz = (r >> 2) & 7;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const uint32_t ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + r * 32 + (((2 * g4 + hh) ^ swz) << 2));
-                        const u32x2_t v = {pack_bf2(o[4 * g4] * sc, o[4 * g4 + 1] * sc), pack_bf2(o[4 * g4 + 2] * sc, o[4 * g4 + 3] * sc)};
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(v) : "memory");
-                    }
-                }
-                const int q = 32 * qt + r;
-                if (q < a.n && a.lse && hh == 0) a.lse[(pw * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
-            }
-            lds_fence();
-            {                                // flush_tile32 of both tiles, LDS reads through inline asm (see above)
-                u32x2_t lo[4], hi[4];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int jr = 0; jr < 2; ++jr) {
-                        const bf16_t* T = t == 0 ? sQ : sK;
-                        const int tl = (lane >> 2) + 16 * jr, cq = lane & 3, sw = (tl >> 2) & 7;
-                        const uint32_t al = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + tl * 32 + (((2 * cq) ^ sw) << 2));
-                        const uint32_t ah = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
-                        asm volatile("ds_read_b64 %0, %1" : "=v"(lo[2 * t + jr]) : "v"(al));
-                        asm volatile("ds_read_b64 %0, %1" : "=v"(hi[2 * t + jr]) : "v"(ah));
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
-                             :: "memory");
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int jr = 0; jr < 2; ++jr) {
-                        const int tl = (lane >> 2) + 16 * jr, cq = lane & 3;
-                        if (32 * t + tl < a.n)
-                            *reinterpret_cast<uint4*>(a.O + trow[par][2 * t + jr] * a.ldo + h * WD + cq * 8) =
-                                make_uint4(lo[2 * t + jr][0], lo[2 * t + jr][1], hi[2 * t + jr][0], hi[2 * t + jr][1]);
-                    }
-            }
-            lds_fence();                     // the staging reads are done before the DMA of window jj + 2 re-fills this buffer
-        }
-    }
+    const int64_t r0[2] = {trow[0] * a.ldo + h * WD, trow[1] * a.ldo + h * WD};
+    const int64_t r1[2] = {trow[2] * a.ldo + h * WD, trow[3] * a.ldo + h * WD};
+    flush_tile32(sQ, Op, r0, 0, a.n, lane);
+    flush_tile32(sK, Op, r1, 1, a.n, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ bias + mask table
@@ -988,23 +731,6 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
-    // pipelined persistent kernel (option winattn_pipe = target waves / 1024, 0 = off): 7 x 7 windows, heads in fours
-    const int pipe = stg_opt_winattn_pipe.load(std::memory_order_relaxed);
-    if (pipe > 0 && p.n == 49 && p.H % 4 == 0 && stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
-        static std::atomic<uint64_t> lds_done{0};
-        const int cnt = p.P / p.Gt;                        // windows per (window type, head)
-        const int pairs = p.Gt * p.H;
-        int nchunk = (pipe * 1024 + pairs / 2) / pairs;
-        if (nchunk < 1) nchunk = 1;
-        if (nchunk > cnt) nchunk = cnt;
-        const int ni = (cnt + nchunk - 1) / nchunk;
-        nchunk = (cnt + ni - 1) / ni;
-        const int lds = 4 * 2 * 3 * 49 * WD * 2;
-        STG_CHECK(stg_reserve_lds(winattn_fwd2_kernel<49>, lds, lds_done), -101, "stg_winattn_fwd: cannot reserve %d bytes of LDS", lds);
-        hipLaunchKernelGGL(winattn_fwd2_kernel<49>, dim3((unsigned)(p.Gt * (p.H / 4) * nchunk)), dim3(256), lds, (hipStream_t)stream, p, nchunk, ni, cnt);
-        STG_LAUNCH_CHECK();
-        return 0;
-    }
     if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
         if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
@@ -1031,64 +757,6 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     else if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    STG_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760: h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and the same with the
-// roles swapped), both directions and the gates in one launch each way (round 4).  a0 / a1: the two directions as stg_winattn_fwd would take
-// them (same geometry, K == V); x0 / x1 receive Q + gate * O (bf16, leading dimension ldx).  Per element the arithmetic of stg_winattn_fwd
-// followed by stg_gate_fwd.
-static int xpair_fill(const stg_winattn_args* a0, const stg_winattn_args* a1, WinP& p, const char* who) {
-    STG_CHECK(a0 && a1, -1, "%s: null args", who);
-    int rc = fill(a0, p, who);
-    if (rc) return rc;
-    WinP q = {};
-    rc = fill(a1, q, who);
-    if (rc) return rc;
-    STG_CHECK(a0->K == a0->V && a1->K == a1->V, -2, "%s: the pair kernels serve K == V (dK receives dK + dV)", who);
-    STG_CHECK(a0->P == a1->P && a0->H == a1->H && a0->n == a1->n && a0->ws == a1->ws && a0->shift == a1->shift && a0->Himg == a1->Himg &&
-              a0->Wimg == a1->Wimg && a0->outer == a1->outer && a0->ld == a1->ld && a0->ldo == a1->ldo && a0->bm == a1->bm && a0->bmT == a1->bmT &&
-              a0->Gt == a1->Gt && a0->scale == a1->scale, -2, "%s: the two directions must share geometry, tables and leading dimensions", who);
-    STG_CHECK(a0->O && a1->O && a0->ldo % 8 == 0 && (((uintptr_t)a0->O | (uintptr_t)a1->O) & 15) == 0, -2, "%s: bad O (16-byte stores)", who);
-    p.Q2 = q.Q; p.K2 = q.K; p.V2 = q.V; p.O2 = q.O; p.lse2 = q.lse;
-    return 0;
-}
-
-extern "C" int stg_winattn_xpair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0,
-                                     void* x1, int64_t ldx, void* stream) {
-    WinP p = {};
-    int rc = xpair_fill(a0, a1, p, "stg_winattn_xpair_fwd");
-    if (rc) return rc;
-    STG_CHECK(gate0 && gate1 && x0 && x1 && ldx % 8 == 0 && (((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, -2, "stg_winattn_xpair_fwd: bad gate / x operands");
-    if (p.total == 0) return 0;
-    p.gate[0] = gate0; p.gate[1] = gate1; p.X[0] = (bf16_t*)x0; p.X[1] = (bf16_t*)x1; p.ldx = ldx;
-    const unsigned grid = (unsigned)((2 * (int64_t)p.total + 3) / 4);
-    if (p.n == 49) hipLaunchKernelGGL((winattn_fwd1_kernel<49, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((winattn_fwd1_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    STG_LAUNCH_CHECK();
-    return 0;
-}
-
-/* dx0 / dx1: gradients wrt the gated hidden states x0 / x1.  Writes dQ and dK (+ dV) per direction; the gates' own gradients <dx, O> are accumulated by
- * stg_add3_mul2_dgate, the element-wise join that reads dx next. */
-extern "C" int stg_winattn_xpair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1,
-                                     const void* dx0, const void* dx1, int64_t lddx, void* dq0, void* dk0, void* dq1, void* dk1, int64_t lddqk,
-                                     void* stream) {
-    WinP p = {};
-    int rc = xpair_fill(a0, a1, p, "stg_winattn_xpair_bwd");
-    if (rc) return rc;
-    STG_CHECK(a0->lse && a1->lse && gate0 && gate1 && dx0 && dx1 && dq0 && dk0 && dq1 && dk1, -1, "stg_winattn_xpair_bwd: null pointer");
-    STG_CHECK(lddx % 8 == 0 && lddqk % 8 == 0, -2, "stg_winattn_xpair_bwd: bad leading dims");
-    STG_CHECK((((uintptr_t)dx0 | (uintptr_t)dx1 | (uintptr_t)dq0 | (uintptr_t)dk0 | (uintptr_t)dq1 | (uintptr_t)dk1) & 15) == 0, -2, "stg_winattn_xpair_bwd: misaligned pointers");
-    if (p.total == 0) return 0;
-    p.gate[0] = gate0; p.gate[1] = gate1;
-    p.dO = (const bf16_t*)dx0; p.dO2 = (const bf16_t*)dx1; p.lddo = lddx;
-    p.dQ = (bf16_t*)dq0; p.dK = (bf16_t*)dk0; p.dQ2 = (bf16_t*)dq1; p.dK2 = (bf16_t*)dk1; p.dV = nullptr; p.lddqkv = lddqk;
-    const unsigned grid = (unsigned)((2 * (int64_t)p.total + 3) / 4);
-    if (p.n == 49) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((winattn_bwd1_kernel<0, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -312,6 +312,8 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             prof["kid"][sig] = int(a.kernel_chosen)
         return (out, pre) if want_dact else out
     _lib.check(_lib.lib().stg_gemm_nt(C.byref(a), _stream()), "stg_gemm_nt")
+    global LAST_GEMM_KERNEL
+    LAST_GEMM_KERNEL = GEMM_KERNEL_NAMES.get(int(a.kernel_chosen), str(int(a.kernel_chosen)))     # which kernel the C dispatch chose (tests)
     return (out, pre) if want_dact else out
 
 
@@ -380,12 +382,12 @@ USE_WGRAD_WS = _cfg.opt("wgrad_ws")          # 0 = atomic wgrad kernels only (A/
 USE_WGRAD_MULTI = _cfg.opt("wgrad_multi")    # 0 = one launch pair per adapter Linear (A/B knob)
 
 
+LAST_GEMM_KERNEL = None
 GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GLDS: "gemm_nt_glds_kernel<1, false, false, false>",
                      _lib.GEMM_KERNEL_BIG: "gemm_nt_big_kernel", _lib.GEMM_KERNEL_8PH: "gemm_nt_8ph_kernel", _lib.GEMM_KERNEL_8PHM: "gemm_nt_8phm_kernel",
                      _lib.GEMM_KERNEL_GLDS_CONV: "gemm_nt_glds_kernel<1, true, false, false>",
                      _lib.GEMM_KERNEL_GLDS_BATCH: "gemm_nt_glds_kernel<1, false, true, false>",
-                     _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel",
-                     _lib.GEMM_KERNEL_OVL: "gemm_nt_ovl_kernel"}
+                     _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel"}
 
 
 def gemm_profile_start(stride=7, log_sequence=False):
@@ -885,9 +887,8 @@ def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
 
 
 @_family("elementwise", lambda a0, *a, **kw: ("add3_mul2", 10.0 * _nb(a0), 0.0))
-def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None, gate_dot=None):
-    """add3_mul on two equally sized problems, one launch: returns (out0, out1).  gate_dot = (r0, r1, dgate0, dgate1): a0 / a1 are the
-    gradients of two gated hidden states h + gate r; dgate += <a, r> is accumulated in the same pass (stg_add3_mul2_dgate)."""
+def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
+    """add3_mul on two equally sized problems, one launch: returns (out0, out1)."""
     for t in (a0, b0, c0, z0, a1, b1, c1, z1):
         _chk_flat(t, "add3_mul2 operand")
         if t.shape != a0.shape:
@@ -898,19 +899,6 @@ def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None, gate_dot=None):
         _chk_flat(t, "out")
         if t.shape != a0.shape:
             raise RuntimeError("add3_mul2: shape mismatch")
-    if gate_dot is not None:
-        r0, r1, dg0, dg1 = gate_dot
-        for t in (r0, r1):
-            _chk_flat(t, "add3_mul2 r")
-            if t.shape != a0.shape:
-                raise RuntimeError("add3_mul2: shape mismatch")
-        for t in (dg0, dg1):
-            _chk_flat(t, "dgate", F32)
-            if t.numel() != 1:
-                raise RuntimeError("add3_mul2: dgate must hold one element")
-        _lib.check(_lib.lib().stg_add3_mul2_dgate(_p(a0), _p(b0), _p(c0), _p(z0), _p(r0), _p(dg0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1),
-                                                  _p(r1), _p(dg1), _p(outs[1]), a0.numel(), _stream()), "stg_add3_mul2_dgate")
-        return outs[0], outs[1]
     _lib.check(_lib.lib().stg_add3_mul2(_p(a0), _p(b0), _p(c0), _p(z0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1), _p(outs[1]),
                                         a0.numel(), _stream()), "stg_add3_mul2")
     return outs[0], outs[1]
@@ -1375,53 +1363,6 @@ def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     _lib.check(_lib.lib().stg_winattn_bwd(C.byref(a), _p(dO), _ld(dO), _p(dQ), _p(dK), _p(dV), _ld(dQ), _stream()),
                "stg_winattn_bwd")
     return dQ, dK, dV
-
-
-def _gate_ok(t, name):
-    if t.dtype != F32 or not t.is_cuda or t.numel() != 1:
-        raise RuntimeError(f"winattn_xpair: {name} must be a one-element fp32 GPU tensor")
-
-
-@_family("winattn_fwd", lambda g, hv, ha, *a, **kw: (("xpair", g.H * 32), 12.0 * (g.P // g.G) * g.outer * g.H * 32, 8.0 * g.P * g.H * g.n * g.n * 32))
-def winattn_xpair_fwd(g, hv, ha, gate_v, gate_a):
-    """The window-level cross-modal pair in ONE launch: r_v = softmax(h_v h_a^T) h_a, r_a = softmax(h_a h_v^T) h_v per window, and the gated
-    hidden states x_v = h_v + gate_v r_v, x_a = h_a + gate_a r_a.  Returns (x_v, x_a, r_v, r_a, lse_v, lse_a)."""
-    _gate_ok(gate_v, "gate_v"); _gate_ok(gate_a, "gate_a")
-    if hv.shape != ha.shape or _ld(hv) != _ld(ha):
-        raise RuntimeError("winattn_xpair: the two hidden-state tensors must share shape and leading dimension")
-    w = g.H * 32
-    rv, ra, xv, xa = (torch.empty((hv.shape[0], w), dtype=BF16, device=hv.device) for _ in range(4))
-    lse_v, lse_a = (torch.empty((g.P, g.H, 64), dtype=F32, device=hv.device) for _ in range(2))
-    a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
-    a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
-    _lib.check(_lib.lib().stg_winattn_xpair_fwd(C.byref(a0), C.byref(a1), _p(gate_v), _p(gate_a), _p(xv), _p(xa), _ld(xv), _stream()),
-               "stg_winattn_xpair_fwd")
-    return xv, xa, rv, ra, lse_v, lse_a
-
-
-@_family("winattn_bwd", lambda g, hv, ha, *a, **kw: (("xpair", g.H * 32), 20.0 * (g.P // g.G) * g.outer * g.H * 32, 20.0 * g.P * g.H * g.n * g.n * 32))
-def winattn_xpair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a):
-    """Backward of winattn_xpair_fwd's attention + gate part: dxv / dxa are the gradients wrt x_v / x_a.  Returns (dq_v, dkv_a, dq_a, dkv_v) --
-    the gradients wrt h_v as queries, h_a as keys / values of direction v, and the same for direction a.  The gates' own gradients
-    <dx, r> are left to add3_mul2(..., gate_dot=...), the join that reads dx next."""
-    for t, name in ((gate_v, "gate_v"), (gate_a, "gate_a")):
-        _gate_ok(t, name)
-    rows = (g.P // g.G) * g.outer
-    for t, name in ((dxv, "dxv"), (dxa, "dxa")):
-        _chk2d(t, name, BF16)
-        if t.shape[1] < g.H * 32 or t.shape[0] < rows:
-            raise RuntimeError(f"winattn_xpair_bwd {name}: needs >= {rows} rows x {g.H * 32} columns")
-    if _ld(dxv) != _ld(dxa):
-        raise RuntimeError("winattn_xpair_bwd: dxv / dxa must share one leading dimension")
-    for l_ in (lse_v, lse_a):
-        if l_ is None or l_.dtype != F32 or l_.numel() != g.P * g.H * 64:
-            raise RuntimeError("winattn_xpair_bwd: bad lse")
-    dq_v, dkv_a, dq_a, dkv_v = (torch.empty((hv.shape[0], g.H * 32), dtype=BF16, device=hv.device) for _ in range(4))
-    a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
-    a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
-    _lib.check(_lib.lib().stg_winattn_xpair_bwd(C.byref(a0), C.byref(a1), _p(gate_v), _p(gate_a), _p(dxv), _p(dxa), _ld(dxv), _p(dq_v), _p(dkv_a),
-                                                _p(dq_a), _p(dkv_v), _ld(dq_v), _stream()), "stg_winattn_xpair_bwd")
-    return dq_v, dkv_a, dq_a, dkv_v
 
 
 class TGeom:

@@ -25,7 +25,6 @@ USE_UPLN = _cfg.opt("upln")             # fused up-projection + residual + Layer
 # the MLP hidden's saved GELU derivative ([rows, 4C], the widest tensor of the step) as one byte per element (STG_U8_LIN) instead of bf16
 MLP_DACT = _cfg.opt("mlp_dact")
 RESIDUAL_DTYPE = _cfg.opt("residual")   # fp32 default; bf16 = A/B knob
-WGRAD_FUSED = _cfg.opt("wgrad_fused")   # adapter D_fc2 weight gradient inside ln_bwd_down (round 4)
 
 # ------------------------------------------------------------------------------------------------ weight shadows
 _shadow_cache = {}   # id(parameter) -> (weakref to it, {transpose: ((data_ptr, version), bf16 tensor)})
@@ -524,7 +523,6 @@ def _xwin_geom(spec, BT, dev):
     return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
 
 
-XWIN_PAIR = _cfg.opt("xwin_pair")  # 1: the window-level cross-modal pair (both directions + gates) in one launch each way (A/B knob)
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
 
 
@@ -561,9 +559,6 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
         wg = _xwin_geom(spec, BT, hv.device)
-        if XWIN_PAIR and hv.shape == ha.shape and hv.stride(0) == ha.stride(0):
-            hv2, ha2, rv, ra, lse_v, lse_a = K.winattn_xpair_fwd(wg, hv, ha, gate_v, gate_a)     # both directions + the gates: one launch
-            return hv2, ha2, (rv, ra, lse_v, lse_a, wg)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
@@ -587,11 +582,6 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
         if dgate_a is None:
             dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
-        if XWIN_PAIR and PAIR_EW and zs is not None and hv.shape == ha.shape and hv.stride(0) == ha.stride(0) and dhv2.shape == dha2.shape \
-                and dhv2.stride(0) == dha2.stride(0):
-            # the attention backward scales dX by the gate itself; the gates' gradients <dX, r> ride on the join that reads dX next
-            dq_v, dkv_a, dq_a, dkv_v = K.winattn_xpair_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, dhv2, dha2, gate_v, gate_a)
-            return K.add3_mul2(dhv2, dq_v, dkv_v, zs[0], dha2, dq_a, dkv_a, zs[1], outs=outs, gate_dot=(rv, ra, dgate_v, dgate_a))
         drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v

@@ -276,6 +276,7 @@ def capture_train_step_ddp(fwd_bwd, optimizer, sync, warmup=1, collective_in_gra
         def replay():
             g.replay()
             torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+        replay.release = lambda: None           # nothing to undo: the GradSync was never deferred (every replay form has .release())
     else:
         sync.defer, sync._pending, sync._bucket = True, [], None
         try:
@@ -339,7 +340,7 @@ def _concurrent_streams(n):
     return chosen, ok
 
 
-def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, warmup=1):
+def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, warmup=1, require_overlap=True):
     """One training step as `splits` MICRO-BATCHES that run CONCURRENTLY: each micro-batch's forward + backward is its own HIP graph,
     replayed on its own stream, then one join graph sums the gradients and runs the optimizer (round 4).
 
@@ -355,8 +356,12 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
       optimizer         build_optimizer's FusedAdam
       sync              ddp.attach(model) at N > 1: the micro-batch graphs run with the GradSync deferred, the summed arena is
                         all-reduced eagerly between the join graph and the optimizer graph (models with task-head buckets: not here)
+      require_overlap   (default) raise RuntimeError BEFORE capturing anything when no side stream measurably runs beside the launch stream:
+                        the chains would then serialise and the step would cost MORE than the plain one (132 vs 123 ms measured) -- the caller
+                        falls back to capture_train_step / eager steps.  False: capture anyway; `replay.streams_overlap` says what was found.
     Returns (replay, static_loss, how).  replay() must be called on the stream the tensors are produced on (it forks from and joins
-    back into the current stream)."""
+    back into the current stream).  If the capture raises, the parameters' .grad are reset to None (they would point into a discarded
+    graph pool) and a deferred GradSync is restored."""
     import torch
     B = tensors[0].shape[0]
     S = int(splits)
@@ -368,6 +373,10 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
     chunks = [tuple(t[i * h:(i + 1) * h] for t in tensors) for i in range(S)]
     params = [p for grp in optimizer.param_groups for p in grp["params"]]
     w = 1.0 / S
+    streams, overlap = _concurrent_streams(S - 1)
+    if require_overlap and not overlap:
+        raise RuntimeError("capture_train_step_mb: no side stream runs beside the launch stream in this process (HIP put them on one hardware "
+                           "queue): the micro-batch chains would serialise; use capture_train_step or pass require_overlap=False")
 
     def fb(chunk, zero=True):
         loss = fwd_loss(*chunk) * w
@@ -429,8 +438,9 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
     except BaseException:
         if sync is not None:
             sync.defer, sync._pending, sync._bucket = False, [], None
+        for p in params:                                    # they point into the discarded graphs' pools
+            p.grad = None
         raise
-    streams, overlap = _concurrent_streams(S - 1)
     red = flats[0] if same_layout else None
 
     def replay():

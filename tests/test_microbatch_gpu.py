@@ -55,7 +55,7 @@ def test_microbatched_step_equals_full_batch_step(stg, gpu):
     def fwd_loss(a_, v_, y_):
         return loss_fn(m1(a_, v_, "fusion"), y_.reshape(-1, y_.shape[-1]))
 
-    replay, static_loss, how = recipe.capture_train_step_mb(fwd_loss, (a, v, y), o1, splits=2, warmup=1)
+    replay, static_loss, how = recipe.capture_train_step_mb(fwd_loss, (a, v, y), o1, splits=2, warmup=1, require_overlap=False)
     assert "2 micro-batch graphs" in how
     m1.load_state_dict(sd)                     # undo the warm-up step: same start as the reference run
     for st in o1.state.values():               # fresh Adam state (moments and step counters are views of the optimizer's flat buffers)

@@ -151,73 +151,3 @@ def test_window_shared_kv_single_head_sums_dk_dv(stg, gpu):
     dq_g, dkv_g, _ = k.attn_bwd(ag, q, kv, kv, O2, lse2, dO, shared_kv=True)
     _close(dQ2.float() / scale, dq_g.float() / scale, tol=1.5e-2, what="dQ vs generic")
     _close(dKV.float() / scale, dkv_g.float() / scale, tol=1.5e-2, what="dK + dV vs generic")
-
-
-@pytest.mark.parametrize("images,heads,Himg,shift", [(37, 12, 14, 3), (5, 4, 28, 0), (64, 16, 14, 3)])
-def test_pipelined_forward_is_bit_identical(stg, gpu, images, heads, Himg, shift):
-    """winattn_fwd2_kernel (option winattn_pipe: persistent waves, next window's tiles in flight, 49-row tiles) against the shipped
-    forward: same O and lse bit for bit, for shifted (one table per window type) and plain blocks and ragged chunk counts."""
-    import stgcma
-    from stgcma import kernels as k, ops
-    import oracle.swin as OS
-    g = torch.Generator().manual_seed(21)
-    ws, n, N, C = 7, 49, Himg * Himg, heads * 32
-    qkv = torch.randn(images * N, 3 * C, generator=g).to(BF16).to(gpu)
-    table = (torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5).to(gpu)
-    index = OS.relative_position_index(ws).reshape(-1).to(gpu)
-    mask = ops.shift_mask(Himg, Himg, ws, shift).to(gpu) if shift > 0 else None
-    bm, bmT = k.winattn_table(table, index, mask, n)
-    wg = k.WinGeom(images, heads, Himg, Himg, ws, shift, 32 ** -0.5, bm, bmT)
-    Q, K_, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    O0, lse0 = k.winattn_fwd(wg, Q, K_, V)
-    try:
-        for pipe in (1, 4, 64):
-            stgcma.configure(lib_winattn_pipe=pipe)
-            O1, lse1 = k.winattn_fwd(wg, Q, K_, V)
-            assert torch.equal(O0.view(torch.int16), O1.view(torch.int16)), f"O differs at winattn_pipe={pipe}"
-            assert torch.equal(lse0[..., :n], lse1[..., :n]), f"lse differs at winattn_pipe={pipe}"
-    finally:
-        stgcma.configure(lib_winattn_pipe=0)
-
-
-@pytest.mark.parametrize("images,Himg,shift", [(6, 14, 3), (3, 28, 0), (5, 7, 0)])
-def test_cross_modal_pair_equals_the_launches_it_replaces(stg, gpu, images, Himg, shift):
-    """stg_winattn_xpair_fwd / _bwd (both directions of the window-level cross-modal pair + the gates, one launch each way) against
-    2 x winattn_fwd + gate_fwd2 resp. gate_bwd2 + 2 x winattn_bwd: x, r, lse, dq, dk bit for bit; dgate (atomically accumulated in both
-    forms) to 1e-5 relative."""
-    from stgcma import kernels as k
-    g = torch.Generator().manual_seed(31 + images)
-    ws, n, N = 7, 49, Himg * Himg
-    hv = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
-    ha = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
-    dxv = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
-    dxa = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
-    gate_v = torch.tensor([0.37], device=gpu)
-    gate_a = torch.tensor([-1.21], device=gpu)
-    bm, bmT = k.winattn_table(torch.zeros(((2 * ws - 1) ** 2, 1), device=gpu), torch.zeros(n * n, dtype=torch.int64, device=gpu), None, n)
-    wg = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, bm, bmT)
-    # the launches it replaces
-    rv, lse_v = k.winattn_fwd(wg, hv, ha, ha)
-    ra, lse_a = k.winattn_fwd(wg, ha, hv, hv)
-    xv, xa = k.gate_fwd2(hv, rv, gate_v, ha, ra, gate_a)
-    dg_v, dg_a = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
-    drv, dra = k.gate_bwd2(dxv, rv, gate_v, dg_v, dxa, ra, gate_a, dg_a)
-    dq_v, dkv_a, dq_a, dkv_v = (torch.full_like(hv, float("nan")) for _ in range(4))
-    k.winattn_bwd(wg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)
-    k.winattn_bwd(wg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)
-    # the pair
-    xv2, xa2, rv2, ra2, lse_v2, lse_a2 = k.winattn_xpair_fwd(wg, hv, ha, gate_v, gate_a)
-    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
-    assert eq(rv, rv2) and eq(ra, ra2), "attention outputs differ"
-    assert torch.equal(lse_v[..., :n], lse_v2[..., :n]) and torch.equal(lse_a[..., :n], lse_a2[..., :n])
-    assert eq(xv, xv2) and eq(xa, xa2), "gated hidden states differ"
-    dg_v2, dg_a2 = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
-    dq_v2, dkv_a2, dq_a2, dkv_v2 = k.winattn_xpair_bwd(wg, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a)
-    assert eq(dq_v, dq_v2) and eq(dkv_a, dkv_a2) and eq(dq_a, dq_a2) and eq(dkv_v, dkv_v2), "gradients differ"
-    # the join that follows: (dX + dq + dk) * z, with / without the gates' gradients riding on it
-    zv, za = torch.rand_like(hv), torch.rand_like(ha)
-    j0 = k.add3_mul2(dxv, dq_v, dkv_v, zv, dxa, dq_a, dkv_a, za)
-    j1 = k.add3_mul2(dxv, dq_v, dkv_v, zv, dxa, dq_a, dkv_a, za, gate_dot=(rv, ra, dg_v2, dg_a2))
-    assert eq(j0[0], j1[0]) and eq(j0[1], j1[1]), "joined gradients differ"
-    for a, b in ((dg_v, dg_v2), (dg_a, dg_a2)):
-        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(a))), (float(a), float(b))
