@@ -70,44 +70,61 @@ __device__ __forceinline__ bf16x8_t nat_frag(const bf16_t* s, int r, int hh, int
     return *reinterpret_cast<const bf16x8_t*>(s + r * DP + 16 * ks + 8 * hh);
 }
 
-// Cooperative staging of two [32][D] tiles (rows row0 .. row0+31 of frame p, clamped to the last token) by 256 threads:
-// D / 32 16-byte pieces per thread; `fetch` fills registers, `commit` writes them to LDS.
-template <int D>
-struct Stage2 {
-    static constexpr int PER = D / 32;             // pieces per thread (two tiles x 32 rows x D/8 pieces / 256)
+// Cooperative staging of NTILE [32][D] tiles (rows row0 .. row0+31 of frame p, clamped to the last token) by 256 threads with 16-byte
+// pieces: `stage_plan` fixes, once per thread, which pieces it moves (LDS offset, source column, row inside the tile); `stage_fetch` fills
+// registers, `stage_commit` writes them to LDS.  Round 5: plain local arrays passed by reference (as a struct with member functions the
+// staging registers lived in SCRATCH: 33 scratch_load / scratch_store per kernel on the critical path between the two barriers of a tile),
+// NTILE = 1 where K and V are one tensor (the adapters' cross-modal attention), LDS double-buffered: ONE barrier per tile.
+template <int N> using U4Arr = u32x4_t[N];      // a native vector type: arrays of HIP's uint4 struct are not promoted to registers
+template <int N> using IArr = int[N];
+template <int D, int NTILE> struct StageC {
+    static constexpr int TOTAL = NTILE * 4 * D;                 // 16-byte pieces: NTILE tiles x 32 rows x D / 8
+    static constexpr int PER = (TOTAL + 255) / 256;
     static constexpr int DP = D + 8;
-    uint4 v[PER];
-    __device__ __forceinline__ void fetch(const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1, int64_t frame_row0, int n,
-                                          int row0, int h, int tid) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int which = id / (4 * D), rem = id - which * 4 * D;
-            const int row = rem / (D / 8), c = rem - row * (D / 8);
-            int tok = row0 + row;
-            tok = tok < n ? tok : n - 1;
-            const bf16_t* src = which ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
-            v[i] = *reinterpret_cast<const uint4*>(src + h * D + 8 * c);
-        }
-    }
-    __device__ __forceinline__ void commit(bf16_t* s0, bf16_t* s1, int tid) const {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int which = id / (4 * D), rem = id - which * 4 * D;
-            const int row = rem / (D / 8), c = rem - row * (D / 8);
-            *reinterpret_cast<uint4*>((which ? s1 : s0) + row * DP + 8 * c) = v[i];
-        }
-    }
+    static constexpr int TILE = 32 * DP;                        // elements per LDS tile
 };
+template <int D, int NTILE>
+__device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE>::PER>& lds_off, IArr<StageC<D, NTILE>::PER>& src_col,
+                                           IArr<StageC<D, NTILE>::PER>& row) {
+    using C = StageC<D, NTILE>;
+#pragma unroll
+    for (int i = 0; i < C::PER; ++i) {
+        const int id = tid + 256 * i;
+        const int which = id / (4 * D), rem = id - which * 4 * D;
+        const int r = rem / (D / 8), c = rem - r * (D / 8);
+        row[i] = (C::TOTAL % 256 != 0 && id >= C::TOTAL) ? -1 : r + 32 * which;        // -1: this thread has no i-th piece; bit 5 = tile
+        lds_off[i] = which * C::TILE + r * C::DP + 8 * c;
+        src_col[i] = h * D + 8 * c;
+    }
+}
+template <int D, int NTILE>
+__device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE>::PER>& v, const IArr<StageC<D, NTILE>::PER>& src_col,
+                                            const IArr<StageC<D, NTILE>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
+                                            int64_t frame_row0, int n, int row0) {
+#pragma unroll
+    for (int i = 0; i < StageC<D, NTILE>::PER; ++i) {
+        if (row[i] < 0) continue;
+        int tok = row0 + (row[i] & 31);
+        tok = tok < n ? tok : n - 1;
+        const bf16_t* src = (NTILE == 2 && (row[i] & 32)) ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
+        v[i] = *reinterpret_cast<const u32x4_t*>(src + src_col[i]);
+    }
+}
+template <int D, int NTILE>
+__device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NTILE>::PER>& v, const IArr<StageC<D, NTILE>::PER>& lds_off,
+                                             const IArr<StageC<D, NTILE>::PER>& row) {
+#pragma unroll
+    for (int i = 0; i < StageC<D, NTILE>::PER; ++i)
+        if (row[i] >= 0) *reinterpret_cast<u32x4_t*>(s + lds_off[i]) = v[i];
+}
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int D>
+// KV1: K and V are the same tensor (one staged tile serves the score MFMA and, read transposed, the P.V MFMA)
+template <int D, bool KV1>
 __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
-    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 32 * DP];
-    bf16_t* sK = smem;
-    bf16_t* sV = smem + 32 * DP;
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
+    using SC = StageC<D, NTILE>;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];      // two buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
@@ -126,13 +143,16 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
     for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
     float m = NEG_BIG, l = 0.f;
 
-    Stage2<D> st;
-    st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 0, h, tid);
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, NTILE>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE>(smem, sv, lo, rw);
+    __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
-        __syncthreads();                               // every wave is done with the previous tile
-        st.commit(sK, sV, tid);
-        if (kt + 1 < a.nt) st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1), h, tid);
-        __syncthreads();
+        const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
+        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
         f32x16_t sc = zero16();                        // St[key][q]
 #pragma unroll
         for (int s = 0; s < KS; ++s) sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
@@ -169,6 +189,9 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
             o[dt] = MFMA32(tr_frag<DP>(sV, dt, 0, hh, r), p0, o[dt]);
             o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), p1, o[dt]);
         }
+        // the other buffer was last read in trip kt - 1, and every wave has passed that trip's barrier
+        if (kt + 1 < a.nt) stage_commit<D, NTILE>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
     }
     {
         const float inv = 1.0f / l;
@@ -180,12 +203,11 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int D>
+template <int D, bool KV1>
 __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
-    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 32 * DP];
-    bf16_t* sK = smem;
-    bf16_t* sV = smem + 32 * DP;
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
+    using SC = StageC<D, NTILE>;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
@@ -215,18 +237,22 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
 
-    Stage2<D> st;
-    st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 0, h, tid);
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, NTILE>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE>(smem, sv, lo, rw);
+    __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
-        __syncthreads();
-        st.commit(sK, sV, tid);
-        if (kt + 1 < a.nt) st.fetch(a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1), h, tid);
-        __syncthreads();
+        const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
+        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
         f32x16_t sc = zero16(), dp = zero16();         // St[key][q], dPt[key][q]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
-            dp = MFMA32(nat_frag<DP>(sV, r, hh, s), dof[s], dp);
+            const bf16x8_t kf = nat_frag<DP>(sK, r, hh, s);
+            sc = MFMA32(kf, qf[s], sc);
+            dp = MFMA32(KV1 ? kf : nat_frag<DP>(sV, r, hh, s), dof[s], dp);
         }
         float ds[16];
         const int kbase = 32 * kt;
@@ -243,6 +269,8 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
             dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 0, hh, r), d0, dq[dt]);
             dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), d1, dq[dt]);
         }
+        if (kt + 1 < a.nt) stage_commit<D, NTILE>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
     }
     {
         bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
@@ -252,19 +280,17 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int D>
+template <int D, bool KV1>
 __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
-    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
-    // shared Q / dO tiles + lse / delta of the current query tile, then per wave its own K and V tiles
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // dkv_lds_bytes(D): 66.8 KiB at D = 96 (dynamic: > 64 KiB)
-    bf16_t* sQ = smem;
-    bf16_t* sD = smem + 32 * DP;
-    float* sLse = reinterpret_cast<float*>(smem + 2 * 32 * DP);
-    float* sDel = sLse + 32;
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NKV = KV1 ? 1 : 2;
+    using SC = StageC<D, 2>;
+    // two buffers of {shared Q / dO tiles + lse / delta of the query tile}, then per wave its own K (and V) tile
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // dkv_lds_bytes(D, KV1) (dynamic: > 64 KiB at D = 96)
+    constexpr int BUF = 2 * 32 * DP + 128;                              // elements per buffer (64 floats of statistics = 128 bf16 slots)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    bf16_t* sK = smem + 2 * 32 * DP + 128 + wave * 2 * 32 * DP;
-    bf16_t* sV = sK + 32 * DP;
+    bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
+    bf16_t* sV = KV1 ? sK : sK + 32 * DP;
     const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
     const int64_t frow = (int64_t)p * a.n;
     const int key = 32 * (kb * 4 + wave) + r;
@@ -275,7 +301,7 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             *reinterpret_cast<bf16x8_t*>(sK + r * DP + 16 * s + 8 * hh) = ld_frag(kp + 16 * s);
-            *reinterpret_cast<bf16x8_t*>(sV + r * DP + 16 * s + 8 * hh) = ld_frag(vp + 16 * s);
+            if (!KV1) *reinterpret_cast<bf16x8_t*>(sV + r * DP + 16 * s + 8 * hh) = ld_frag(vp + 16 * s);
         }
     }
     f32x16_t dk[DT], dv[DT];
@@ -283,7 +309,9 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
     for (int dt = 0; dt < DT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
     const int64_t sbase = ((int64_t)p * a.H + h) * a.n;
 
-    Stage2<D> st;
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, 2>(tid, h, lo, sc_, rw);
     float nl = 0.f, nd = 0.f;
     auto fetch_stats = [&](int q0) {
         if (tid < 32) {
@@ -293,22 +321,30 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
             nd = a.delta[sbase + qi];
         }
     };
-    st.fetch(a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0, h, tid);
+    auto commit_all = [&](bf16_t* buf) {
+        stage_commit<D, 2>(buf, sv, lo, rw);
+        float* st = reinterpret_cast<float*>(buf + 2 * 32 * DP);
+        if (tid < 32) { st[tid] = nl; st[32 + tid] = nd; }
+    };
+    stage_fetch<D, 2>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
     fetch_stats(0);
+    commit_all(smem);
+    __syncthreads();
     for (int qt = 0; qt < a.nt; ++qt) {
-        __syncthreads();
-        st.commit(sQ, sD, tid);
-        if (tid < 32) { sLse[tid] = nl; sDel[tid] = nd; }
+        const bf16_t* sQ = smem + (qt & 1) * BUF;
+        const bf16_t* sD = sQ + 32 * DP;
+        const float* sLse = reinterpret_cast<const float*>(sQ + 2 * 32 * DP);
+        const float* sDel = sLse + 32;
         if (qt + 1 < a.nt) {
-            st.fetch(a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1), h, tid);
+            stage_fetch<D, 2>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1));
             fetch_stats(32 * (qt + 1));
         }
-        __syncthreads();
         f32x16_t sc = zero16(), dp = zero16();         // S[q][key], dP[q][key]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            sc = MFMA32(nat_frag<DP>(sQ, r, hh, s), nat_frag<DP>(sK, r, hh, s), sc);
-            dp = MFMA32(nat_frag<DP>(sD, r, hh, s), nat_frag<DP>(sV, r, hh, s), dp);
+            const bf16x8_t kf = nat_frag<DP>(sK, r, hh, s);
+            sc = MFMA32(nat_frag<DP>(sQ, r, hh, s), kf, sc);
+            dp = MFMA32(nat_frag<DP>(sD, r, hh, s), KV1 ? kf : nat_frag<DP>(sV, r, hh, s), dp);
         }
         float pr[16], ds[16];
         const int qbase = 32 * qt;
@@ -334,6 +370,8 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
             dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 0, hh, r), d0, dk[dt]);
             dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 1, hh, r), d1, dk[dt]);
         }
+        if (qt + 1 < a.nt) commit_all(smem + ((qt + 1) & 1) * BUF);
+        __syncthreads();
     }
     {
         const bool okk = key < a.n;
@@ -357,14 +395,14 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
     }
 }
 
-constexpr int dkv_lds_bytes(int D) { return (2 * 32 * (D + 8) + 128 + 4 * 2 * 32 * (D + 8)) * 2; }
+constexpr int dkv_lds_bytes(int D, bool kv1) { return (2 * (2 * 32 * (D + 8) + 128) + 4 * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
 
-template <int D>
+template <int D, bool KV1>
 int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D>, dkv_lds_bytes(D), done);
-    STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D));
-    hipLaunchKernelGGL(mha_dkv_kernel<D>, grid, dim3(256), dkv_lds_bytes(D), stream, p);
+    const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D, KV1>, dkv_lds_bytes(D, KV1), done);
+    STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D, KV1));
+    hipLaunchKernelGGL((mha_dkv_kernel<D, KV1>), grid, dim3(256), dkv_lds_bytes(D, KV1), stream, p);
     return 0;
 }
 
@@ -392,8 +430,10 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     if (rc) return rc;
     if (p.P == 0) return 0;
     const dim3 grid((p.nt + 3) / 4, p.H, p.P);
-    if (f->D == 64) hipLaunchKernelGGL(mha_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(mha_fwd_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const bool kv1 = f->K == f->V;
+    hipStream_t st = (hipStream_t)stream;
+    if (f->D == 64) { if (kv1) hipLaunchKernelGGL((mha_fwd_kernel<64, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((mha_fwd_kernel<64, false>), grid, dim3(256), 0, st, p); }
+    else { if (kv1) hipLaunchKernelGGL((mha_fwd_kernel<96, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((mha_fwd_kernel<96, false>), grid, dim3(256), 0, st, p); }
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -413,15 +453,12 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.delta = delta;
     const dim3 grid((p.nt + 3) / 4, p.H, p.P);
-    if (f->D == 64) {
-        hipLaunchKernelGGL(mha_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        STG_LAUNCH_CHECK();
-        rc = launch_dkv<64>(grid, p, (hipStream_t)stream);
-    } else {
-        hipLaunchKernelGGL(mha_dq_kernel<96>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        STG_LAUNCH_CHECK();
-        rc = launch_dkv<96>(grid, p, (hipStream_t)stream);
-    }
+    const bool kv1 = f->K == f->V;
+    hipStream_t st = (hipStream_t)stream;
+#define STG_MHA_BWD(DD, KV) { hipLaunchKernelGGL((mha_dq_kernel<DD, KV>), grid, dim3(256), 0, st, p); STG_LAUNCH_CHECK(); rc = launch_dkv<DD, KV>(grid, p, st); }
+    if (f->D == 64) { if (kv1) STG_MHA_BWD(64, true) else STG_MHA_BWD(64, false) }
+    else { if (kv1) STG_MHA_BWD(96, true) else STG_MHA_BWD(96, false) }
+#undef STG_MHA_BWD
     if (rc) return rc;
     STG_LAUNCH_CHECK();
     return 0;

@@ -65,15 +65,16 @@ __device__ __forceinline__ void fill_wfrag(uint4* wfrag, const bf16_t* w, int64_
     }
 }
 
-// NT = 16-column tiles per wave, NH = waves per row (column halves; statistics combined through LDS), C = 16 * NT * NH;
-// NW = waves per block (8 where the W fragments of one block take most of the LDS: C = 768 shares one copy among 8 waves)
+// NT = 16-column tiles per wave, NH = waves per row (column slices of 16 NT; statistics combined through LDS), C = 16 * NT * NH;
+// NW = waves per block (8 / 16 where the W fragments of one block take most of the LDS: at C = 768, K = 96 one 147 KiB copy serves 16 waves).
+// Round 5: NH = 4 and K <= 96 (KS = 3) -- the Swin-L widths 192 / 384 / 768 all run as NT = 12 with NH = 1 / 2 / 4.
 template <int NT, int NH, int KS, bool R16, int NW = 4>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLnP p) {
     extern __shared__ __attribute__((aligned(16))) uint4 wfrag[];
     constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int half = NH == 2 ? (wave & 1) : 0;
+    const int half = NH > 1 ? (wave % NH) : 0;
     int bid = blockIdx.x, nbk = gridDim.x;
     if (p.nb1 > 0) {                                                // pair launch: this workgroup's row group (block-uniform)
         if (bid >= p.nb1) {
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
     // bias / gamma / beta live in LDS and are re-read per row group through a laundered offset: as loop invariants the
     // compiler hoists all 3 * C / 64 * 4 values per lane out of the row loop (384 VGPRs at C = 512: spills)
     float* prm = reinterpret_cast<float*>(wfrag + TT * KS * 64);
-    float2* xch = reinterpret_cast<float2*>(prm + 3 * CC);          // [2 parities][NW waves][16 rows] (NH == 2 only)
+    float2* xch = reinterpret_cast<float2*>(prm + 3 * CC);          // [2 parities][NW waves][16 rows] (NH > 1 only)
     for (int c = tid; c < CC; c += NW * 64) {
         prm[c] = p.bias[c];
         prm[CC + c] = p.gamma[c];
@@ -197,6 +198,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
             const float dlt = (s - o.x) * (1.0f / (float)CW);
             q = q + o.y + dlt * dlt * (0.5f * (float)CW);
             mu = (s + o.x) * invC;
+        } else if (NH > 2) {                                // NH slices: M2 = sum_i (q_i + CW (mu_i - mu)^2), every wave in the same order
+            float2* xb = xch + par * (NW * 16);
+            if (g == 0) xb[wave * 16 + m] = make_float2(s, q);
+            __syncthreads();
+            const int w0 = wave - half;
+            float2 o[NH];
+            float st = 0.f;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) { o[i] = xb[(w0 + i) * 16 + m]; st += o[i].x; }
+            mu = st * invC;
+            q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) { const float dm = o[i].x * (1.0f / (float)CW) - mu; q += o[i].y + dm * dm * (float)CW; }
         }
         const float rstd = rsqrtf(q * invC + p.eps);
         if (valid) {
@@ -255,9 +269,9 @@ int launch_upln(const UpLnP& pin, hipStream_t st) {
     return 0;
 }
 
-template <int NT, int NH>
+template <int NT, int NH, int NW = 4>
 int dispatch_ks(const UpLnP& p, hipStream_t st) {
-    return p.K <= 32 ? launch_upln<NT, NH, 1>(p, st) : launch_upln<NT, NH, 2>(p, st);
+    return p.K <= 32 ? launch_upln<NT, NH, 1, NW>(p, st) : p.K <= 64 ? launch_upln<NT, NH, 2, NW>(p, st) : launch_upln<NT, NH, 3, NW>(p, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,7 +299,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
     constexpr int TT = NT * NH, CW = NT * 16, CC = TT * 16, NP = NT / 2, NPT = TT / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int half = NH == 2 ? (wave & 1) : 0;
+    const int half = NH > 1 ? (wave % NH) : 0;
     int bid = blockIdx.x, nbk = gridDim.x;
     if (p.nb1 > 0) {                                                // pair launch: this workgroup's row group (block-uniform)
         if (bid >= p.nb1) {
@@ -310,9 +324,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
                                                                 : 32 * (jt >> 1) + 8 * (slot >> 2) + 4 * (jt & 1) + (slot & 3);
         wfrag[f] = *reinterpret_cast<const uint4*>(p.wt + (int64_t)j * p.ldwt + 32 * pg + 8 * kq);
     }
-    float* gam = reinterpret_cast<float*>(wfrag + NJ * NPT * 64);
-    float2* xch = reinterpret_cast<float2*>(gam + CC);               // [NW waves][16 rows]
-    float* hx = reinterpret_cast<float*>(xch + NW * 16);             // [NW / 2 groups][NJ * 4][64 lanes]  (NH == 2)
+    float* gam = reinterpret_cast<float*>(wfrag + NJ * NPT * 64);    // not allocated in the x-hat form (gamma == 1)
+    float2* xch = reinterpret_cast<float2*>(gam + (XH ? 0 : CC));    // [NW waves][16 rows]
+    float* hx = reinterpret_cast<float*>(xch + NW * 16);             // [NW / NH groups][NJ * 4][64 lanes]  (NH > 1)
     if (!XH) for (int c = tid; c < CC; c += NW * 64) gam[c] = p.gamma[c];
     __syncthreads();
 
@@ -385,6 +399,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
             __syncthreads();
             const float2 o = xch[(wave ^ 1) * 16 + m];
             s1 += o.x; s2 += o.y;
+        } else if (NH > 2) {                                // every wave of the row group sums the NH slices in the same order
+            if (g == 0) xch[wave * 16 + m] = make_float2(s1, s2);
+            __syncthreads();
+            const int w0 = wave - half;
+            s1 = 0.f; s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) { const float2 o = xch[(w0 + i) * 16 + m]; s1 += o.x; s2 += o.y; }
         }
         s1 *= invC; s2 *= invC;
         f32x4_t acc[NJ];
@@ -439,6 +460,26 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] += hb[(jt * 4 + r) * 64 + lane];
             }
+        } else if (NH > 2) {                                // a chain through ONE buffer per row group (the W^T fragments leave no room for NH - 1):
+            float* hb = hx + (wave / NH) * (NJ * 4 * 64);   // slice NH - 1 writes, each lower slice adds its own and passes it on: ((s3 + s2) + s1) + s0
+#pragma unroll
+            for (int hs = NH - 1; hs >= 0; --hs) {
+                if (half == hs) {
+                    if (hs < NH - 1) {
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[jt][r] += hb[(jt * 4 + r) * 64 + lane];
+                    }
+                    if (hs > 0) {
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hb[(jt * 4 + r) * 64 + lane] = acc[jt][r];
+                    }
+                }
+                if (hs > 0) __syncthreads();
+            }
         }
         if (valid && half == 0) {
             float sc = 1.0f;
@@ -465,7 +506,8 @@ int launch_lnbd(const LnDownP& pin, hipStream_t st) {
     constexpr int GPB = NW / NH;
     LnDownP p = pin;
     const int64_t nblk = plan_grid(p, GPB);
-    const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (size_t)NT * NH * 16 * 4 + NW * 16 * sizeof(float2) + (size_t)(NW / 2) * NJ * 4 * 64 * 4;
+    const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (XH ? 0 : (size_t)NT * NH * 16 * 4) + NW * 16 * sizeof(float2) +
+                       (NH > 1 ? (size_t)(NW / NH) * NJ * 4 * 64 * 4 : 0);
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> d1{0}, d0{0};
         const bool ok = stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, true, NW, XH>, (int)lds, d1) && stg_reserve_lds(ln_bwd_down_kernel<NT, NH, NJ, false, NW, XH>, (int)lds, d0);
@@ -483,11 +525,21 @@ int dispatch_nj(const LnDownP& p, hipStream_t st) {
     if (p.J == 32) return launch_lnbd<NT, NH, 2, 4, XH>(p, st);
     return launch_lnbd<NT, NH, 4, 4, XH>(p, st);
 }
+// round 5: the NT = 12 family (C = 192 NH, NH = 1 / 2 / 4 -> 4 / 8 / 16 waves per block): Swin-L's J = 96, CLIP ViT-B's J = 48
+template <int NH, bool XH = false>
+int dispatch_nj12(const LnDownP& p, hipStream_t st) {
+    // 8 waves per block where a row spans several waves: the kernel needs 150 - 200 VGPRs (16 waves = 128 spill 250+ bytes per lane), and at
+    // C = 768, J = 96 the W^T fragments ([J, C] bf16 = 147 KiB) leave room for the partial-product buffers of two row groups only
+    constexpr int NW = NH == 1 ? 4 : 8;
+    if (p.J == 48) return launch_lnbd<12, NH, 3, NW, XH>(p, st);
+    return launch_lnbd<12, NH, 6, NW, XH>(p, st);
+}
 
 }  // namespace
 
 extern "C" int stg_up_ln_supported(int C, int K) {
-    return (C == 128 || C == 256 || C == 512 || C == 768) && K >= 8 && K <= 64 && K % 8 == 0;
+    if (C == 192 || C == 384 || C == 768) return K >= 8 && K <= 96 && K % 8 == 0;        // NT = 12 family: Swin-L (d_h = 96), CLIP ViT-B (d_h = 48)
+    return (C == 128 || C == 256 || C == 512) && K >= 8 && K <= 64 && K % 8 == 0;
 }
 
 static int up_ln_impl(const char* who, const void* h, int64_t ldh, const void* w, int64_t ldw, const float* bias, const float* res32,
@@ -496,7 +548,7 @@ static int up_ln_impl(const char* who, const void* h, int64_t ldh, const void* w
                       int64_t M, int C, int K, const void* h2, const void* w2, const float* bias2, const float* row_scale2, int64_t split_m,
                       void* stream) {
     STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "%s: null pointer", who);
-    STG_CHECK(stg_up_ln_supported(C, K), -2, "%s: unsupported C=%d K=%d (C in {128,256,512,768}, K <= 64, K %% 8 == 0)", who, C, K);
+    STG_CHECK(stg_up_ln_supported(C, K), -2, "%s: unsupported C=%d K=%d (C in {128,256,512}: K <= 64; C in {192,384,768}: K <= 96; K %% 8 == 0)", who, C, K);
     STG_CHECK(M >= 0, -2, "%s: bad M", who);
     STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "%s: ldh / ldw must be multiples of 8 and >= K", who);
     STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "%s: bad ld32 / ldx / ldy", who);
@@ -523,7 +575,9 @@ static int up_ln_impl(const char* who, const void* h, int64_t ldh, const void* w
         case 8: return dispatch_ks<8, 1>(p, st);
         case 16: return dispatch_ks<16, 1>(p, st);
         case 32: return dispatch_ks<16, 2>(p, st);
-        default: return p.K <= 32 ? launch_upln<24, 2, 1, 8>(p, st) : launch_upln<24, 2, 2, 8>(p, st);      // C = 768 (CLIP ViT-B)
+        case 12: return dispatch_ks<12, 1, 4>(p, st);                                                        // C = 192 (Swin-L stage 0)
+        case 24: return dispatch_ks<12, 2, 16>(p, st);                                                       // C = 384 (Swin-L stage 1)
+        default: return dispatch_ks<12, 4, 16>(p, st);                                                       // C = 768 (Swin-L stage 2, CLIP ViT-B)
     }
 }
 
@@ -546,8 +600,9 @@ extern "C" int stg_up_ln_fwd_pair(const void* h, const void* h2, int64_t ldh, co
 }
 
 extern "C" int stg_ln_bwd_down_supported(int C, int J) {
-    // C = 768 (CLIP ViT-B) is left to stg_layernorm_bwd + stg_gemm_nt: with 24 tiles per wave the kernel sits at the 256-VGPR cap
-    // with spills and one 8-wave block per CU, and measured 177 us against 125 us for the pair
+    // round 3 left C = 768 to stg_layernorm_bwd + stg_gemm_nt (24 tiles per wave: 256 VGPRs with spills, one 8-wave block per CU, 177 us
+    // against 125 us for the pair); round 5 runs it as 12 tiles per wave x 4 waves per row, 16 waves per block
+    if (C == 192 || C == 384 || C == 768) return J == 48 || J == 96;
     return (C == 128 || C == 256 || C == 512) && (J == 16 || J == 32 || J == 64);
 }
 
@@ -556,7 +611,7 @@ static int ln_bwd_down_impl(const char* who, bool xh, const void* dy, int64_t ld
                             const float* row_scale, int64_t rs_outer, int64_t rs_inner, void* dh, int64_t lddh, int64_t M, int C, int J,
                             const void* wt2, const float* row_scale2, void* dh2, int64_t split_m, void* stream) {
     STG_CHECK(dy && x && rstd && dx && wt && dh && (xh || (gamma && mean)), -1, "%s: null pointer", who);
-    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "%s: unsupported C=%d J=%d (C in {128,256,512}, J in {16,32,64})", who, C, J);
+    STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "%s: unsupported C=%d J=%d (C in {128,256,512}: J in {16,32,64}; C in {192,384,768}: J in {48,96})", who, C, J);
     STG_CHECK(M >= 0, -2, "%s: bad M", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % (xh ? 8 : 4) == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "%s: bad lddy / ldx / lddx", who);
     STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "%s: bad ldadd", who);
@@ -582,13 +637,19 @@ static int ln_bwd_down_impl(const char* who, bool xh, const void* dy, int64_t ld
         switch (C / 16) {
             case 8: return dispatch_nj<8, 1, true>(p, st);
             case 16: return dispatch_nj<16, 1, true>(p, st);
-            default: return dispatch_nj<16, 2, true>(p, st);
+            case 32: return dispatch_nj<16, 2, true>(p, st);
+            case 12: return dispatch_nj12<1, true>(p, st);
+            case 24: return dispatch_nj12<2, true>(p, st);
+            default: return dispatch_nj12<4, true>(p, st);
         }
     }
     switch (C / 16) {
         case 8: return dispatch_nj<8, 1>(p, st);
         case 16: return dispatch_nj<16, 1>(p, st);
-        default: return dispatch_nj<16, 2>(p, st);
+        case 32: return dispatch_nj<16, 2>(p, st);
+        case 12: return dispatch_nj12<1>(p, st);
+        case 24: return dispatch_nj12<2>(p, st);
+        default: return dispatch_nj12<4>(p, st);
     }
 }
 

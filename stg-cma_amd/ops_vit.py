@@ -196,7 +196,26 @@ def vit_block_forward(X, spec, P, training, save, pre=None, nxt=None):
     return X3, (S if save else None)
 
 
-def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
+def _ln_bwd_down(dY, X, gamma, mean, rstd, add_to, sl, ads, dps=None, n_tok=None):
+    """LayerNorm backward + the D_fc2 dgrad of the adapter that consumes its result, one launch per modality (or one for both where the
+    halves are 16-aligned and no DropPath row scale is involved): stg_ln_bwd_down.  Returns (dX, [dH per modality] or None)."""
+    if ads is None or not (_ops.USE_UPLN and X.dtype == torch.float32 and all(K.ln_bwd_down_supported(X.shape[1], A.dh) for A in ads)):
+        return K.layernorm_bwd(dY, X, gamma, mean, rstd, add_to=add_to), None
+    if dps is None or all(d is None for d in dps):
+        return _ops._ln_bwd_join(dY, X, gamma, mean, rstd, add_to, sl, [A.w2t for A in ads])
+    R = dY.shape[0]
+    dX = torch.empty(dY.shape, dtype=BF16, device=dY.device)
+    dH = []
+    for i, A in enumerate(ads):
+        r = sl[i]
+        kw = dict(row_scale=dps[i], rs_outer=R + 1, rs_inner=n_tok[i]) if dps[i] is not None else {}
+        dH.append(K.ln_bwd_down(dY[r], X[r], gamma, mean[r], rstd[r], A.w2t, add_to=None if add_to is None else add_to[r], dx_out=dX[r], **kw)[1])
+    return dX, dH
+
+
+def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None, dH3=None, prev_ads=None):
+    """dH3: the MLP_Adapter's D_fc2 dgrad of dX3, when the caller's LayerNorm backward already produced it; prev_ads: the adapters (of the
+    block in front of this one) whose D_fc2 dgrad rides on this block's last LayerNorm backward -- then returns (dX0, grads, dH0)."""
     R, D = dX3.shape
     BT, sl = _ranges(spec, R)
     G = _Grads(P, need, prefix, arena)
@@ -205,10 +224,11 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
     n1g = f32c(P["ln_1.weight"])
     wqkv_t, wout_t = shadow(P["attn.in_proj_weight"], True), shadow(P["attn.out_proj.weight"], True)
 
-    def adapters_bwd(base, HZ, H2, xs, Xin, dOut):
+    def adapters_bwd(base, HZ, H2, xs, Xin, dOut, dH2=None):
         """Gradient wrt the adapters' input tensor Xin (= res1 of the up-projection), joined with the direct path dOut."""
         ads = [_Adapter(P, base + _SFX[m]) for m in spec.mods]
-        dH2 = [K.gemm_nt(dOut[sl[i]], A.w2t) for i, A in enumerate(ads)]
+        if dH2 is None:
+            dH2 = [K.gemm_nt(dOut[sl[i]], A.w2t) for i, A in enumerate(ads)]
         if spec.fuse:
             dZs = list(_cross_modal_bwd(None, BT, HZ[0][0], HZ[1][0], gate_v, gate_a, False, None, xs, dH2[0], dH2[1], dgv, dga,
                                         geoms=_xgeoms(spec, BT, ads[0].dh), zs=(HZ[0][1], HZ[1][1])))
@@ -223,18 +243,18 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
 
     # ---- joint adaptation
     X2, mean, rstd, Zm, M, HZ, H2, xs = S.pop("f")
-    dM = adapters_bwd("MLP_Adapter", HZ, H2, xs, M, dX3)
+    dM = adapters_bwd("MLP_Adapter", HZ, H2, xs, M, dX3, dH3)
     del HZ, H2, xs, M
     dZm = K.gemm_nt(dM, shadow(P["mlp.c_proj.weight"], True), dact_src=Zm)
     del dM, Zm
     dY = K.gemm_nt(dZm, shadow(P["mlp.c_fc.weight"], True))
     del dZm
-    dX2 = K.layernorm_bwd(dY, X2, f32c(P["ln_2.weight"]), mean, rstd, add_to=dX3)
+    dX2, dH = _ln_bwd_down(dY, X2, f32c(P["ln_2.weight"]), mean, rstd, dX3, sl, [_Adapter(P, "S_Adapter" + _SFX[m]) for m in spec.mods])
     del dY, X2, dX3
 
     # ---- spatial adaptation
     X1, mean, rstd, QKV, AO, sg, slse, PO, HZ, H2, xs = S.pop("s")
-    dPO = adapters_bwd("S_Adapter", HZ, H2, xs, PO, dX2)
+    dPO = adapters_bwd("S_Adapter", HZ, H2, xs, PO, dX2, dH)
     del HZ, H2, xs, PO
     dAO = K.gemm_nt(dPO, wout_t)
     del dPO
@@ -242,17 +262,19 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
     del QKV, AO, dAO
     dY = K.gemm_nt(dQKV, wqkv_t)
     del dQKV
-    dX1 = K.layernorm_bwd(dY, X1, n1g, mean, rstd, add_to=dX2)
+    X0, mean0, rstd0, QKV0, AO0, tg, tlse, PO0, hz, dps = S.pop("t")
+    tads = [_Adapter(P, "T_Adapter" + _SFX[m]) for m in spec.mods]
+    dX1, dH = _ln_bwd_down(dY, X1, n1g, mean, rstd, dX2, sl, tads, dps, spec.n_tok)
     del dY, dX2, X1
 
     # ---- temporal adaptation
-    X0, mean, rstd, QKV, AO, tg, tlse, PO, hz, dps = S.pop("t")
+    mean, rstd, QKV, AO, PO = mean0, rstd0, QKV0, AO0, PO0
+    del QKV0, AO0, PO0
     dPO = torch.empty_like(dX1)
-    for i, m in enumerate(spec.mods):
-        A = _Adapter(P, "T_Adapter" + _SFX[m])
+    for i, A in enumerate(tads):
         Ht, Zt = hz[i]
         kw = dict(row_scale=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
-        dHt = K.gemm_nt(dX1[sl[i]], A.w2t, **kw)
+        dHt = dH[i] if dH is not None else K.gemm_nt(dX1[sl[i]], A.w2t, **kw)
         dZt = K.act_bwd(dHt, Zt)
         _adapter_wgrad(G, A.name, dZt, PO[sl[i]], dX1[sl[i]], Ht, rs=dps[i], rs_outer=R + 1, rs_inner=spec.n_tok[i])
         K.gemm_nt(dZt, A.w1t, out=dPO[sl[i]])
@@ -263,8 +285,10 @@ def vit_block_backward(S, spec, P, need, prefix, dX3, arena=None):
     del QKV, AO, dAO
     dY = K.gemm_nt(dQKV, wqkv_t)
     del dQKV
-    dX0 = K.layernorm_bwd(dY, X0, n1g, mean, rstd, add_to=dX1)
+    dX0, dH0 = _ln_bwd_down(dY, X0, n1g, mean, rstd, dX1, sl, prev_ads)
     G.flush()
+    if prev_ads is not None:
+        return dX0, G.g, dH0
     return dX0, G.g
 
 
@@ -435,9 +459,15 @@ class VitModelFn(torch.autograd.Function):
             dcls = K.layernorm_bwd(dsrc, cls_rows, f32c(P["ln_post.weight"]), stats[i][0], stats[i][1], dgamma=gpw, dbeta=gpb)
             dX[offs[i]:offs[i + 1]].view(BT, n_tok[i] * D)[:, :D].copy_(dcls)
         grads = dict(G.g)
+        dH = None
         while tape:
             spec, pre, Pb, S = tape.pop()
-            dX, g = vit_block_backward(S, spec, Pb, need, pre, dX, arena)
+            # the MLP_Adapter dgrad of the block in front rides on this block's last LayerNorm backward (stg_ln_bwd_down)
+            prev_ads = [_Adapter(tape[-1][2], "MLP_Adapter" + _SFX[m]) for m in tape[-1][0].mods] if tape else None
+            if prev_ads is not None:
+                dX, g, dH = vit_block_backward(S, spec, Pb, need, pre, dX, arena, dH3=dH, prev_ads=prev_ads)
+            else:
+                dX, g = vit_block_backward(S, spec, Pb, need, pre, dX, arena, dH3=dH)
             for k, val in g.items():
                 grads[pre + k] = val
         # embeddings: ln_pre backward, then d temporal_embedding(_audio)[t] = sum over (b, n) of dU (the only trainable part)

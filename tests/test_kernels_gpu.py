@@ -546,7 +546,8 @@ def test_mlp_fused_backward(stg, gpu, rows):
     assert float((out.float().cpu() - ref).norm() / ref.norm()) <= 6e-3
 
 
-@pytest.mark.parametrize("C,J,S,M2", [(512, 32, 64 * 37, 64 * 37), (128, 16, 16 * 5, 16 * 9 + 3), (256, 64, 4096, 1000)])
+@pytest.mark.parametrize("C,J,S,M2", [(512, 32, 64 * 37, 64 * 37), (128, 16, 16 * 5, 16 * 9 + 3), (256, 64, 4096, 1000),
+                                      (768, 96, 16 * 123, 16 * 123), (192, 96, 3136, 3136), (384, 96, 784, 800), (768, 48, 16 * 13, 700)])
 @pytest.mark.parametrize("with_rs", [False, True])
 def test_pair_launches_equal_two_single_launches(stg, gpu, C, J, S, M2, with_rs):
     """stg_up_ln_fwd_pair / stg_ln_bwd_down_pair (both modalities' adapters in one launch, round 4) against the two single launches they

@@ -22,7 +22,10 @@ def _ref_fwd(h, w, b, r32, r16, rs, gamma, beta, eps=1e-5):
 @pytest.mark.parametrize("M,C,K,r16,rs", [(64, 128, 16, True, False), (1000, 128, 16, False, True), (777, 256, 32, True, False),
                                           (4099, 512, 32, True, False), (2048, 512, 32, False, True), (513, 512, 64, True, True),
                                           (15, 256, 24, True, False), (1, 128, 8, False, False), (320, 512, 48, True, False),
-                                          (1970, 768, 48, True, False), (490, 768, 48, False, True), (33, 768, 64, True, True)])
+                                          (1970, 768, 48, True, False), (490, 768, 48, False, True), (33, 768, 64, True, True),
+                                          # round 5, the NT = 12 family (Swin-L: d_h = 96 at C = 192 / 384 / 768; K = 96 is three k-steps)
+                                          (3136, 192, 96, True, False), (1000, 192, 96, False, True), (785, 384, 96, True, True), (64, 384, 48, False, False),
+                                          (1961, 768, 96, True, False), (500, 768, 96, False, True), (17, 768, 96, True, True), (1, 192, 96, True, False)])
 def test_up_ln_fwd(stg, gpu, M, C, K, r16, rs):
     from stgcma import kernels as k
     assert k.up_ln_supported(C, K)
@@ -66,6 +69,7 @@ def test_up_ln_unsupported_raises(stg, gpu):
     from stgcma import kernels as k
     assert not k.up_ln_supported(1024, 128)
     assert not k.up_ln_supported(1536, 96)
+    assert not k.up_ln_supported(512, 96) and not k.up_ln_supported(768, 128) and not k.ln_bwd_down_supported(768, 64)
     h = torch.zeros(16, 96, dtype=BF16, device=gpu)
     w = torch.zeros(1536, 96, dtype=BF16, device=gpu)
     z = torch.zeros(1536, device=gpu)
@@ -75,7 +79,11 @@ def test_up_ln_unsupported_raises(stg, gpu):
 
 @pytest.mark.parametrize("M,C,J,add,rs", [(64, 128, 16, True, False), (1000, 128, 16, False, True), (777, 256, 32, True, False),
                                           (4099, 512, 32, True, False), (2048, 512, 32, False, True), (513, 512, 64, True, True),
-                                          (15, 256, 64, True, False), (1, 128, 16, False, False), (490, 256, 16, True, False)])
+                                          (15, 256, 64, True, False), (1, 128, 16, False, False), (490, 256, 16, True, False),
+                                          # round 5, the NT = 12 family: Swin-L (J = 96), CLIP ViT-B (C = 768, J = 48)
+                                          (3136, 192, 96, True, False), (1000, 192, 96, False, True), (785, 384, 96, True, True), (64, 384, 48, False, False),
+                                          (1961, 768, 96, True, False), (500, 768, 96, False, True), (1970, 768, 48, True, True), (17, 768, 48, False, False),
+                                          (1, 192, 96, True, False)])
 def test_ln_bwd_down(stg, gpu, M, C, J, add, rs):
     from stgcma import kernels as k
     assert k.ln_bwd_down_supported(C, J)
@@ -110,3 +118,28 @@ def test_ln_bwd_down(stg, gpu, M, C, J, add, rs):
         dh_ref = dh_ref * rs_rows[:, None]
     errh = (dh.float().cpu() - dh_ref).abs()
     assert float((errh / dh_ref.abs().clamp(min=1.0)).max()) <= 1e-2, float(errh.max())
+
+
+@pytest.mark.parametrize("M,C,J,dys", [(777, 512, 32, 1.0), (3136, 192, 96, 1.0), (785, 384, 96, 1.0), (1961, 768, 96, 1.0), (1970, 768, 48, 1.0), (33, 768, 96, 1.0),
+                                       (12544, 192, 48, 1e-3), (3136, 384, 48, 1e-4)])
+def test_ln_bwd_down_xhat_equals_the_fp32_row_form(stg, gpu, M, C, J, dys):
+    """stg_ln_bwd_down_xhat (the default product path: bf16 normalised rows, gamma == 1) against the same kernel fed the fp32 rows those
+    x_hat came from: dx to the bf16 rounding of x_hat, dh against the bf16 dx it was made from."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + C + J)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3).to(gpu)
+    dy = (torch.randn(M, C, generator=g) * dys).to(BF16).to(gpu)           # dys: gradient magnitudes as small as a deep model's (all bounds relative)
+    addt = (torch.randn(M, C, generator=g) * dys).to(BF16).to(gpu)
+    wt = (torch.randn(J, C, generator=g) * 0.1).to(BF16).to(gpu)
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    xhat = ((x - mean[:, None]) * rstd[:, None]).to(BF16)
+    dx0, dh0 = k.ln_bwd_down(dy, x, torch.ones(C, device=gpu), mean, rstd, wt, add_to=addt)
+    dx1, dh1 = k.ln_bwd_down_xhat(dy, xhat, rstd, wt, add_to=addt)
+    torch.cuda.synchronize()
+    sc = float(dx0.float().abs().max())
+    assert float((dx0.float() - dx1.float()).abs().max()) <= 2e-2 * sc
+    dh_ref = dx1.float() @ wt.float().t()
+    assert float((dh1.float() - dh_ref).abs().max()) <= 1e-2 * float(dh_ref.abs().max())
+    assert float((dh1.float() - dh_ref).norm()) <= 4e-3 * float(dh_ref.norm())                  # bf16 rounding of dh: 2^-9 per element
+    assert float((dh0.float() - dh1.float()).norm()) <= 2e-2 * float(dh_ref.norm())            # the two forms' dx differ by x_hat's bf16 rounding
