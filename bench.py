@@ -238,7 +238,7 @@ def pmc_step():
 
 
 LINE_MAX = 6144        # bytes of the final stdout line: the driver keeps an 8 KB tail and parses its last line (BENCH_r04 lost a 28 KB one)
-MFMA_FAMILIES = ("xattn_fwd", "xattn_bwd", "mlp_fused_fwd", "mlp_fused_bwd", "mha_fwd", "mha_bwd")
+MFMA_FAMILIES = ("xattn_fwd", "xattn_bwd", "mlp_fused_fwd", "mlp_fused_bwd", "mha_fwd", "mha_bwd", "dec_conv_wgrad", "dec_tpavi_bmm")
 METRIC_NAMES = {"swin_b": "Swin-B+STG-CMA AVE-shape", "swin_l": "Swin-L+STG-CMA AVE-shape", "vit_b": "ViT-B/16+STG-CMA AVE-shape",
                 "avs_backbone": "Swin-B+STG-CMA AVS-shape backbone", "avqa_backbone": "Swin-L+STG-CMA AVQA-shape backbone",
                 "avqa": "Swin-L+STG-CMA AVQA-shape (backbone + QA head)", "avs": "Swin-B+STG-CMA AVS-shape (backbone + dense decoder)"}

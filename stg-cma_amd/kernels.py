@@ -150,6 +150,45 @@ def _nb(*ts):
     return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
+def _family_io(name, flops=None):
+    """_family for the kernels whose algorithmic bytes are simply every tensor argument once + every returned tensor once (the AVS decoder's
+    im2col / bilinear / BatchNorm / TPAVI kernels, casts, the AVQA head's small kernels): key = shape of the first tensor argument;
+    flops(*args, **kwargs) optional.  The cost is computed AFTER the call (the outputs' sizes are part of it)."""
+    def deco(fn):
+        @_functools.wraps(fn)
+        def wrapped(*a, **kw):
+            prof = _fam_prof
+            if prof is None:
+                return fn(*a, **kw)
+            ts = [t for t in list(a) + list(kw.values()) if isinstance(t, torch.Tensor)]
+            ck = (name, tuple(ts[0].shape) if ts else ())
+            pc = prof["classes"].get(ck)
+            if pc is None:
+                pc = prof["classes"][ck] = {"launches": 0, "bytes": 0.0, "flops": 0.0, "rec": []}
+            pc["launches"] += 1
+            sampled = pc["launches"] % prof["stride"] == 0
+            if sampled:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            r = fn(*a, **kw)
+            if sampled:
+                e1.record()
+            outs = [t for t in (r if isinstance(r, (tuple, list)) else (r,)) if isinstance(t, torch.Tensor)]
+            seen, nbytes = set(), 0.0
+            for t in ts + outs:
+                if t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    nbytes += t.numel() * t.element_size()
+            fl = float(flops(*a, **kw)) if flops is not None else 0.0
+            pc["bytes"] += nbytes
+            pc["flops"] += fl
+            if sampled:
+                pc["rec"].append((e0, e1, nbytes, fl))
+            return r
+        return wrapped
+    return deco
+
+
 def conv3x3_gemm_supported(Cin):
     return Cin % 64 == 0 or Cin in (8, 16, 32)
 
@@ -277,13 +316,14 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
         zl = _zero_line(dev)
         a.conv_H, a.conv_W, a.conv_d, a.conv_C, a.conv_zero = int(Hc), int(Wc), int(dc), int(Cin), _p(zl)
     prof = _gemm_prof
-    if prof is not None and conv is None and M > 0:
+    if prof is not None and M > 0:
         # per-class accounting for bench.py: class = (kernel the C dispatch chose, N, K, epilogue signature).  The kernel of a call
         # signature is learnt from stg_gemm_nt's `kernel_chosen` on its first launch (no host-side copy of the dispatch rules).
         epi = ("b" if bias is not None else "") + ("a" if act else "") + (("p8" if want_dact == "u8" else "p") if want_dact else "") + \
               ("" if dact_src is None else ("d8" if dact_src.dtype == torch.uint8 else "d")) + \
               ("" if res1 is None else ("r" if res1.dtype == BF16 else "q")) + ("" if res2 is None else ("R" if res2.dtype == BF16 else "Q")) + \
-              ("s" if row_scale is not None else "") + ("A" if alpha != 1.0 else "") + ("" if out.dtype == BF16 else "F")
+              ("s" if row_scale is not None else "") + ("A" if alpha != 1.0 else "") + ("" if out.dtype == BF16 else "F") + \
+              ("" if conv is None else f"c{int(dc)}")      # implicit 3x3 convolution (dilation dc): A is read as [M, Cin], K = 9 Cin
         sig = (M, N, K, epi, fp8)
         kid = prof["kid"].get(sig)
         if kid is not None:
@@ -292,7 +332,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
             if pc is None:
                 pc = prof["classes"][ck] = {"launches": 0, "flops": 0.0, "bytes": 0.0, "rec": []}
             esz = 1.0 if fp8 else 2.0
-            nbytes = esz * M * K + esz * N * K + M * N * out.element_size() + (pre.element_size() * M * N if want_dact else 0.0) + \
+            nbytes = esz * M * (K if conv is None else K // 9) + esz * N * K + M * N * out.element_size() + (pre.element_size() * M * N if want_dact else 0.0) + \
                 (dact_src.element_size() * M * N if dact_src is not None else 0.0) + (M * N * res1.element_size() if res1 is not None else 0.0) + \
                 (M * N * res2.element_size() if res2 is not None else 0.0)          # algorithmic HBM bytes: every operand / output once
             pc["launches"] += 1
@@ -317,6 +357,7 @@ def gemm_nt(A, W, bias=None, *, out=None, out_dtype=BF16, alpha=1.0, act=ACT_NON
     return (out, pre) if want_dact else out
 
 
+@_family_io("dec_tpavi_bmm", flops=lambda A, W, *a, **kw: 2.0 * A.shape[0] * W.shape[1] * A.shape[1])
 def _gemm_nt_batched(A, W, bias, out, out_dtype, alpha, act, nb):
     """nb independent problems of one shape: A [nb * M, K] (consecutive row groups), W [nb, N, K] -> C [nb * M, N]."""
     _chk2d(A, "A", BF16)
@@ -356,6 +397,7 @@ def _sum_splits(ws, out=None, accumulate=False):
     return out
 
 
+@_family_io("dec_tpavi_bmm", flops=lambda A, B, rows: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
 def bmm_tn(A, B, rows):
     """[nb, N1, N2] fp32 = A_b^T B_b over consecutive groups of `rows` rows of A [nb*rows, N1] and B [nb*rows, N2] (bf16);
     N1, N2 multiples of 128."""
@@ -966,6 +1008,7 @@ def act_bwd(dh, z, out=None):
     return dz
 
 
+@_family_io("elementwise")
 def mul_mask(a, mask):
     _chk_flat(a, "a"); _chk_flat(mask, "mask", F32)
     if a.numel() != mask.numel():
@@ -975,6 +1018,7 @@ def mul_mask(a, mask):
     return out
 
 
+@_family_io("patch_embed")
 def im2col_patch(x, p, Kpad):
     """x: [B, Cin, T, H, W] fp32/bf16 contiguous -> [B*T*(H/p)*(W/p), Kpad] bf16."""
     if x.dim() != 5 or not x.is_contiguous() or not x.is_cuda or x.dtype not in (BF16, F32):
@@ -986,6 +1030,7 @@ def im2col_patch(x, p, Kpad):
     return out
 
 
+@_family_io("cast")
 def cast_bf16(w, transpose=False, pad_to=8):
     """fp32 [R, C] -> bf16 [R, C'] or (transpose) [C, R'], trailing dim zero-padded to a multiple of `pad_to`."""
     _chk_flat(w, "w", F32)
@@ -1007,6 +1052,7 @@ def cast_desc_table(entries, device):
     return host.to(device)
 
 
+@_family_io("cast")
 def cast_bf16_multi(desc, n, max_elems, arena):
     """One launch casting n fp32 matrices (device-resident descriptor table from cast_desc_table) into the zeroed bf16 arena."""
     if desc.dtype != torch.uint8 or not desc.is_cuda or desc.numel() != n * C.sizeof(_lib.CastDesc):
@@ -1015,6 +1061,7 @@ def cast_bf16_multi(desc, n, max_elems, arena):
     _lib.check(_lib.lib().stg_cast_bf16_multi(_p(desc), int(n), int(max_elems), _p(arena), _stream()), "stg_cast_bf16_multi")
 
 
+@_family_io("elementwise")
 def add_temporal(x, emb, B, T, N):
     """x fp32 [B*T*N, C] (a contiguous row slice) += emb fp32 [T, C] broadcast over clips and tokens, in place."""
     _chk_flat(x, "x", F32)
@@ -1044,6 +1091,7 @@ def adam_desc_table(entries, device, host=None):
     return dev, host
 
 
+@_family_io("optimizer")
 def adam_multi(desc, n, max_elems, hyper):
     """One optimizer step of torch.optim.Adam's arithmetic over n fp32 tensors (device-resident descriptor table from adam_desc_table);
     hyper: fp64 [groups, 8] = lr, beta1, beta2, eps, weight_decay, -, -, -; each tensor's own {step, lr / bc1, sqrt(bc2)} triple (the
@@ -1055,6 +1103,7 @@ def adam_multi(desc, n, max_elems, hyper):
     _lib.check(_lib.lib().stg_adam_multi(_p(desc), int(n), int(max_elems), _p(hyper), int(hyper.shape[0]), _stream()), "stg_adam_multi")
 
 
+@_family_io("cast")
 def cast_f32(x):
     _chk_flat(x, "x")
     out = torch.empty(x.shape, dtype=F32, device=x.device)
@@ -1062,6 +1111,7 @@ def cast_f32(x):
     return out
 
 
+@_family_io("head_small")
 def meanpool_fwd(x, G, n, out=None, out_dtype=BF16):
     """x: [G*n, C] bf16 contiguous -> [G, C]; `out` may be a column slice of a wider row-major buffer."""
     _chk_flat(x, "x")
@@ -1076,6 +1126,7 @@ def meanpool_fwd(x, G, n, out=None, out_dtype=BF16):
     return out
 
 
+@_family_io("head_small")
 def meanpool_bwd(dout, G, n, out=None):
     _chk2d(dout, "dout", BF16, rows=G)
     Cc = dout.shape[1]
@@ -1087,6 +1138,7 @@ def meanpool_bwd(dout, G, n, out=None):
     return din
 
 
+@_family_io("elementwise")
 def bias_gather(table, index, out=None):
     """table fp32 [L, H], index int64 [nn] -> fp32 [H, nn]."""
     _chk_flat(table, "table", F32); _chk_flat(index, "index", torch.int64)
@@ -1101,6 +1153,7 @@ def bias_gather(table, index, out=None):
     return out
 
 
+@_family_io("elementwise")
 def bias_scatter(dbias, index, dtable):
     _chk_flat(dbias, "dbias", F32); _chk_flat(index, "index", torch.int64); _chk_flat(dtable, "dtable", F32)
     L, H = dtable.shape
@@ -1499,6 +1552,7 @@ def mha_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     return dQ, dK, dV
 
 
+@_family_io("patch_embed")
 def vit_embed(patch, cls, pos, temb, BT, T):
     """ViT token assembly -> fp32 [BT*(np+1), D]; see stg_vit_embed."""
     _chk_flat(patch, "patch"); _chk_flat(cls, "cls", F32); _chk_flat(pos, "pos", F32); _chk_flat(temb, "temb", F32)
@@ -1516,6 +1570,7 @@ def vit_embed(patch, cls, pos, temb, BT, T):
 RELU, TANH = 0, 1
 
 
+@_family_io("head_small")
 def unary_fwd(op, x):
     _chk_flat(x, "x")
     y = torch.empty_like(x)
@@ -1523,6 +1578,7 @@ def unary_fwd(op, x):
     return y
 
 
+@_family_io("head_small")
 def unary_bwd(op, y, dy):
     _chk_flat(y, "y"); _chk_flat(dy, "dy")
     if y.numel() != dy.numel():
@@ -1532,6 +1588,7 @@ def unary_bwd(op, y, dy):
     return dx
 
 
+@_family_io("head_small")
 def mul(a, b):
     _chk_flat(a, "a"); _chk_flat(b, "b")
     if a.numel() != b.numel():
@@ -1541,6 +1598,7 @@ def mul(a, b):
     return out
 
 
+@_family_io("head_small")
 def embed_fwd(table, idx):
     _chk_flat(table, "table", F32); _chk_flat(idx, "idx", torch.int64)
     V, E = table.shape
@@ -1549,6 +1607,7 @@ def embed_fwd(table, idx):
     return out
 
 
+@_family_io("head_small")
 def embed_bwd(dout, idx, dtable):
     _chk_flat(dout, "dout"); _chk_flat(idx, "idx", torch.int64); _chk_flat(dtable, "dtable", F32)
     V, E = dtable.shape
@@ -1557,6 +1616,7 @@ def embed_bwd(dout, idx, dtable):
     _lib.check(_lib.lib().stg_embed_bwd(_p(dout), _p(idx), _p(dtable), idx.numel(), V, E, _stream()), "stg_embed_bwd")
 
 
+@_family_io("head_small")
 def lstm_cell_fwd(gates, c_prev):
     _chk_flat(gates, "gates", F32); _chk_flat(c_prev, "c_prev", F32)
     B, H = c_prev.shape
@@ -1568,6 +1628,7 @@ def lstm_cell_fwd(gates, c_prev):
     return h, c
 
 
+@_family_io("head_small")
 def lstm_cell_bwd(gates, c_prev, c, dh, dc):
     B, H = c_prev.shape
     for t, n, dt in ((gates, "gates", F32), (c_prev, "c_prev", F32), (c, "c", F32)):
@@ -1583,6 +1644,7 @@ def lstm_cell_bwd(gates, c_prev, c, dh, dc):
     return dgates, dc_prev
 
 
+@_family_io("head_small")
 def grounding_fwd(V, a):
     """V fp32 [F, n, C], a bf16 [F, C] -> (vmean bf16 [F, C], grd bf16 [F, C], saved = (p, rnorm, ra))."""
     _chk_flat(V, "V", F32); _chk_flat(a, "a")
@@ -1599,6 +1661,7 @@ def grounding_fwd(V, a):
     return vmean, grd, (p, rn, ra)
 
 
+@_family_io("head_small")
 def grounding_bwd(V, a, saved, dvmean, dgrd, want_dV=True):
     Fr, n, Cc = V.shape
     p, rn, ra = saved
@@ -1612,6 +1675,7 @@ def grounding_bwd(V, a, saved, dvmean, dgrd, want_dV=True):
     return dV, da
 
 
+@_family_io("head_small")
 def mha1_fwd(q, k, v, drop, H):
     """q bf16 [B, E], k / v bf16 [T*B, E] (row t*B + b), drop fp32 [B, H, T] or None -> (o bf16 [B, E], p fp32 [B, H, T])."""
     _chk_flat(q, "q"); _chk_flat(k, "k"); _chk_flat(v, "v")
@@ -1630,6 +1694,7 @@ def mha1_fwd(q, k, v, drop, H):
     return o, p
 
 
+@_family_io("head_small")
 def mha1_bwd(q, k, v, drop, p, dout, H):
     _chk_flat(dout, "dout")
     B, E = q.shape
@@ -1642,6 +1707,7 @@ def mha1_bwd(q, k, v, drop, p, dout, H):
 
 
 # ------------------------------------------------------------------------------------------------ AVS decoder kernels (dec.hip)
+@_family_io("dec_im2col3x3")
 def im2col3x3(x, F_, H, W, dilation):
     """x bf16 [F*H*W, C] (rows may be column slices of a wider buffer) -> bf16 [F*H*W, 9*C]."""
     _chk2d(x, "x", BF16, rows=F_ * H * W)
@@ -1655,6 +1721,7 @@ def conv3x3_wgrad_supported(O, I):
     return O % 8 == 0 and I % 128 == 0
 
 
+@_family_io("dec_conv_wgrad", flops=lambda dy, x, F_, H, W, dilation, want_db=False: 18.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
 def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     """dW [O, 9 * I] fp32 (columns ordered (kh, kw, i)) of a 3x3 convolution with padding = dilation, from dy [F*H*W, O] and
     x [F*H*W, I] (bf16, channels-last rows), without the im2col image; with want_db also db [O] = column sums of dy."""
@@ -1676,6 +1743,7 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     return dW
 
 
+@_family_io("dec_bilinear")
 def bilinear_up2_fwd(x, F_, H, W, align_corners):
     _chk_flat(x, "x")
     Cc = x.shape[-1]
@@ -1686,6 +1754,7 @@ def bilinear_up2_fwd(x, F_, H, W, align_corners):
     return y
 
 
+@_family_io("dec_bilinear")
 def bilinear_up2_bwd(dy, F_, H, W, align_corners):
     _chk_flat(dy, "dy")
     Cc = dy.shape[-1]
@@ -1696,6 +1765,7 @@ def bilinear_up2_bwd(dy, F_, H, W, align_corners):
     return dx
 
 
+@_family_io("dec_batchnorm")
 def bn_colsum(a, b=None, mean=None, rstd=None):
     """[2, C] fp32: (sum a, sum a^2) when b and mean are None; (sum (a - mean), sum (a - mean)^2) when only mean is given;
     (sum b, sum b * (a - mean) * rstd) when b is given."""
@@ -1713,6 +1783,7 @@ def bn_colsum(a, b=None, mean=None, rstd=None):
     return out
 
 
+@_family_io("dec_batchnorm")
 def bn_apply(x, mean, rstd, gamma, beta):
     _chk_flat(x, "x")
     R, Cc = x.shape
@@ -1723,6 +1794,7 @@ def bn_apply(x, mean, rstd, gamma, beta):
     return y
 
 
+@_family_io("dec_batchnorm")
 def bn_bwd(x, dy, mean, rstd, gamma, sums):
     _chk_flat(x, "x"); _chk_flat(dy, "dy")
     R, Cc = x.shape
@@ -1731,6 +1803,7 @@ def bn_bwd(x, dy, mean, rstd, gamma, sums):
     return dx
 
 
+@_family_io("ln_bwd")
 def ln_param_grad(dy, x, mean, rstd, dgamma, dbeta):
     """dgamma / dbeta (fp32 [C], accumulated) of a LayerNorm over the rows of bf16 [R, C] -- block-folded column sums."""
     _chk_flat(dy, "dy"); _chk_flat(x, "x")
