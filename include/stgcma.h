@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 213
+#define STG_VERSION 214
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -290,6 +290,17 @@ int stg_attn_bwd(const stg_attn_bwd_args* a, void* stream);
  * frame-global kernels with one geometry they share a launch (grid.y = 2), otherwise the call equals two stg_attn_fwd / _bwd. */
 int stg_attn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, void* stream);
 int stg_attn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream);
+/* Backward of a frame-global cross-modal PAIR in one pass per modality (round 5; replaces the two stg_attn_bwd calls and the torch.add of
+ * their results behind AVE/model/Swin_AVE.py:796-811's autograd): b0 = direction v (Q = h_v, K = V = h_a, O = r_v, lse_v, dO = d r_v), b1 = the
+ * mirror image (Q = h_a, K = V = h_v, ...); g0 / g1 [rows, D] bf16 (leading dimension ldg) receive the COMPLETE gradients of h_v / h_a through
+ * both directions (dQ of the own direction + dK + dV of the other) -- the b->dQ / dK / delta fields are not used.  One exponential per score
+ * instead of two while the frame's log-sum-exps span <= 120 binary orders, the plain two-exponential arithmetic otherwise (decided per frame on
+ * the device, no host synchronisation).  ws: stg_xattn_pair_bwd_ws_bytes(P, n0, n1, D) bytes of 16-byte-aligned scratch.  _supported: both
+ * directions eligible for the frame-global kernels (H = 1, D = 16 / 32, K == V, dense frames of >= 64 rows) and mirror images of each other. */
+int64_t stg_xattn_pair_bwd_ws_bytes(int64_t P, int n0, int n1, int D);
+int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_attn_args* f1);
+int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, void* ws, int64_t ws_bytes,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-window attention: WindowAttention.forward's spatial branch (Swin_AVE.py:256-276) with roll + window_partition /
@@ -454,6 +465,7 @@ int stg_gate_fwd2(const void* h0, const void* r0, const float* g0, void* out0, c
                   void* out1, int64_t numel, void* stream);
 int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, const void* dout1, const void* r1,
                   const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream);
+/* out = (a + b + c) z on two equally sized problems; c0 == c1 == NULL: (a + b) z (the join behind stg_xattn_pair_bwd) */
 int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                   const void* c1, const void* z1, void* out1, int64_t numel, void* stream);
 /* Test aid: fill the LDS of every CU with NaN bit patterns, so that a kernel reading an LDS byte nobody wrote produces a non-finite result

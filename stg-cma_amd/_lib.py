@@ -161,6 +161,9 @@ SIGNATURES = {
     "stg_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_vp]),
     "stg_attn_fwd2": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs), c_vp]),
     "stg_attn_bwd2": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp]),
+    "stg_xattn_pair_bwd_ws_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
+    "stg_xattn_pair_bwd_supported": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs)]),
+    "stg_xattn_pair_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -219,7 +222,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 213
+ABI_VERSION = 214
 _lib = None
 
 

@@ -180,9 +180,11 @@ __global__ void add3_mul2_kernel(Ew2 p, int64_t n8, int64_t numel) {
         unpack8(reinterpret_cast<const uint4*>(b)[i], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] += v[j];
-        unpack8(reinterpret_cast<const uint4*>(c)[i], v);
+        if (c) {                                           // block-uniform: c == NULL -> (a + b) z
+            unpack8(reinterpret_cast<const uint4*>(c)[i], v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] += v[j];
+            for (int j = 0; j < 8; ++j) x[j] += v[j];
+        }
         unpack8(reinterpret_cast<const uint4*>(z)[i], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] *= v[j];
@@ -190,7 +192,7 @@ __global__ void add3_mul2_kernel(Ew2 p, int64_t n8, int64_t numel) {
     }
     if (blockIdx.x == 0 && threadIdx.x < (numel & 7)) {
         const int64_t i = (n8 << 3) + threadIdx.x;
-        out[i] = f2bf((bf2f(a[i]) + bf2f(b[i]) + bf2f(c[i])) * bf2f(z[i]));
+        out[i] = f2bf((bf2f(a[i]) + bf2f(b[i]) + (c ? bf2f(c[i]) : 0.f)) * bf2f(z[i]));
     }
 }
 
@@ -514,7 +516,7 @@ extern "C" int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0,
 }
 extern "C" int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                              const void* c1, const void* z1, void* out1, int64_t numel, void* stream) {
-    STG_CHECK(a0 && b0 && c0 && z0 && out0 && a1 && b1 && c1 && z1 && out1, -1, "stg_add3_mul2: null pointer");
+    STG_CHECK(a0 && b0 && z0 && out0 && a1 && b1 && z1 && out1 && ((c0 == nullptr) == (c1 == nullptr)), -1, "stg_add3_mul2: null pointer (c0 / c1 may be NULL together)");
     STG_CHECK(al16(a0) && al16(b0) && al16(c0) && al16(z0) && al16(out0) && al16(a1) && al16(b1) && al16(c1) && al16(z1) && al16(out1), -2,
               "stg_add3_mul2: pointers must be 16-byte aligned");
     if (numel <= 0) return 0;

@@ -493,6 +493,216 @@ __global__ void __launch_bounds__(256, 2) xattn_dkv_kernel(XP2 pp) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward of a cross-modal PAIR, merged (round 5)
+// The two directions of the adapters' cross-modal attention share ONE score matrix: S[i, j] = h_v[i] . h_a[j], direction v normalises its rows
+// (P^v[i, j] = exp(S - lse_v[i])), direction a its columns (P^a[j, i] = exp(S - lse_a[j])).  The four backward passes of rounds 1-4 (dQ and
+// dK + dV per direction) each rebuilt S and exponentiated it: four exponentials per score.  Here the gradient of a modality's hidden states is
+// ONE pass over the score tiles of its rows -- for the v rows (the a rows mirror it):
+//     G_v[i] = scale sum_j dS^v[i, j] a[j]  +  scale sum_j dS^a[j, i] a[j]  +  sum_j P^a[j, i] dO_a[j]
+//              (dQ of direction v)            (dK of direction a)             (dV of direction a)
+//     dS^v = P^v (dO_v[i] . a[j] - delta_v[i]),   dS^a = P^a (dO_a[j] . v[i] - delta_a[j])
+// with ONE exponential per score: E = P^v comes out of the MFMA as exp2's argument (-lse_v[i] is the C operand), and
+//     P^a[j, i] = E r[i] c[j],   r[i] = 2^(lse2_v[i] - c0),   c[j] = 2^(c0 - lse2_a[j]),   c0 = the frame's mid-range log-sum-exp.
+// c[j] is folded into the OTHER side's operands by a preparation kernel (dOh[j] = c[j] dO_a[j], nd[j] = -c[j] delta_a[j]), r[i] is a per-lane
+// scalar: T = E (u + r y) with u = dP^v - delta_v and y = c (dP^a - delta_a) straight from two MFMAs, so per score the wave issues one v_exp, one
+// fma, one multiply and two bf16 conversions (E and T) against exp + mul + cvt (dQ) and exp + mul + 2 cvt (dK + dV) per direction before, and
+// 8 x KS MFMAs per 32 x 32 tile against 10.  G_v = scale Ga + r Gb with Ga += a^T T and Gb += dOh^T E.
+// Range: r, c and r y stay finite while every log-sum-exp of the frame lies within +-60 binary orders of c0; where E underflows (x < -126) the
+// true P^a is below 2^(-126 + 120), i.e. nothing.  The preparation kernel measures the spread per frame; a frame beyond 120 binary orders (or
+// with a non-finite lse) takes the kernel's SLOW path (wave-uniform): c = r = 1 and a second exponential E2 = exp2(x + lse2_v[i] - lse2_a[j])
+// per score, T = E u + E2 y, Gb += dO_a^T E2 -- the arithmetic of the four original passes, still in one.
+struct XM {
+    const bf16_t* Q; int64_t ldq;                 // own rows (hidden states), own dO
+    const bf16_t* dO; int64_t lddo;
+    const bf16_t* O; int64_t ldo;                 // own attention output (preparation kernel: delta)
+    const float* lse; float* delta;               // own rows
+    const bf16_t* KV; int64_t ldk;                // the other modality's rows
+    const bf16_t* dOh_other; const float* nd_other;     // c[j] dO[j] (dense [rows, D]) and -c[j] delta[j] of the other modality's rows
+    const float* lse_other;                       // slow path only
+    bf16_t* dOh_own; float* nd_own;               // what the preparation kernel writes for THIS side's rows (read by the other side's pass)
+    bf16_t* G; int64_t ldg;
+    int n, n_kv, tiles, total;
+};
+struct XM2 { XM a[2]; float* c0; int* ok; float scale, c2; int P; };
+
+template <int D>
+__global__ void __launch_bounds__(256) xattn_prep_kernel(XM2 pp) {
+    __shared__ float red[2][4];
+    const int p = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, tid = threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const XM& a = pp.a[y];
+        for (int r = tid; r < a.n; r += 256) {
+            const float l = a.lse[(int64_t)p * a.n + r] * LOG2E;
+            mn = l == l ? fminf(mn, l) : -INFINITY;         // a NaN poisons the range: the frame goes to the fallback
+            mx = l == l ? fmaxf(mx, l) : INFINITY;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = mn; red[1][tid >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    const bool ok = (mx - mn) <= 120.0f;                    // false for infinities / NaNs too
+    const float c0 = ok ? 0.5f * (mx + mn) : 0.f;
+    if (part == 0 && tid == 0) { pp.c0[p] = c0; pp.ok[p] = ok ? 1 : 0; }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const XM& a = pp.a[y];
+        const int chunk = (a.n + nparts - 1) / nparts;
+        const int r1 = min(a.n, (part + 1) * chunk);
+        for (int r = part * chunk + tid; r < r1; r += 256) {
+            const int64_t row = (int64_t)p * a.n + r;
+            const float c = ok ? __builtin_amdgcn_exp2f(c0 - a.lse[row] * LOG2E) : 1.0f;
+            float d = 0.f;
+            bf16_t* oh = a.dOh_own + row * D;
+#pragma unroll
+            for (int s = 0; s < D / 8; ++s) {
+                const bf16x8_t df = ld_frag(a.dO + row * a.lddo + 8 * s), of = ld_frag(a.O + row * a.ldo + 8 * s);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float x = bf2f((bf16_t)df[j]); d += x * bf2f((bf16_t)of[j]); v[j] = x * c; }
+                *reinterpret_cast<bf16x8_t*>(oh + 8 * s) = pack_frag(v);
+            }
+            a.delta[row] = d;
+            a.nd_own[row] = -c * d;
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) xattn_bwdm_kernel(XM2 pp) {
+    const XM a = pp.a[blockIdx.y];
+    constexpr int KS = D / 16;
+    constexpr int TILE = 32 * D;
+    constexpr int PER_WAVE = 2 * TILE + 128;                      // other-side rows tile + their prescaled dO tile + 32 floats of -c delta + 32 of lse2
+    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.total) return;
+    const int p = item / a.tiles, qt = item - p * a.tiles;
+    const bool fast = pp.ok[p] != 0;                              // wave-uniform
+    bf16_t* tK = smem + wave * PER_WAVE;
+    bf16_t* tH = tK + TILE;
+    float* sNd = reinterpret_cast<float*>(tH + TILE);
+    float* sL = sNd + 32;
+
+    int q = qt * 32 + r;
+    const bool okq = q < a.n;
+    q = okq ? q : a.n - 1;
+    const int64_t rowq = (int64_t)p * a.n + q;
+    bf16x8_t qf[KS], dof[KS], qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = ld_frag(a.Q + rowq * a.ldq + 8 * hh + 16 * s);
+        dof[s] = ld_frag(a.dO + rowq * a.lddo + 8 * hh + 16 * s);
+        scale_split(qf[s], pp.c2, qh[s], ql[s]);
+    }
+    const float lse2 = a.lse[rowq] * LOG2E;
+    const float rsc = fast ? __builtin_amdgcn_exp2f(lse2 - pp.c0[p]) : 1.0f;    // r[i]
+    const f32x16_t cl = splat16(-lse2), cd = splat16(-a.delta[rowq]);
+
+    const int64_t kbase = (int64_t)p * a.n_kv;
+    const int wr_off = r * D + 8 * hh;
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, c = r >> 4;
+    const int tr_off = (D == 16) ? (4 * hh + gq) * D + 4 * gp : (4 * hh + gq) * D + 16 * c + 4 * gp;   // D = 16: rows 16.. duplicate 0..15 (ignored)
+    const bf16_t* trK = tK + tr_off;
+    const bf16_t* trH = tH + tr_off;
+
+    f32x16_t Ga = zero16(), Gb = zero16();
+    bf16x8_t kf[KS], hf[KS];
+    float ndv, lov = 0.f;
+    auto load_tile = [&](int k0) {
+        int k = k0 + r;
+        k = k < a.n_kv ? k : a.n_kv - 1;
+        const int64_t row = kbase + k;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = ld_frag(a.KV + row * a.ldk + 8 * hh + 16 * s);
+            hf[s] = ld_frag(a.dOh_other + row * D + 8 * hh + 16 * s);
+        }
+        ndv = a.nd_other[row];
+        if (!fast) lov = a.lse_other[row] * LOG2E;
+    };
+    load_tile(0);
+    for (int k0 = 0; k0 < a.n_kv; k0 += 32) {
+        lds_sync();                                               // the previous trip's transposed reads are done
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(tK + wr_off + 16 * s) = kf[s];
+            *reinterpret_cast<bf16x8_t*>(tH + wr_off + 16 * s) = hf[s];
+        }
+        if (hh == 0) { sNd[r] = ndv; if (!fast) sL[r] = lov; }
+        f32x16_t x = MFMA32(kf[0], qh[0], cl);                    // c2 S - lse2_own: key on the accumulator row, own row on the lane
+        x = MFMA32(kf[0], ql[0], x);
+        f32x16_t u = MFMA32(kf[0], dof[0], cd);                   // dP(own direction) - delta_own
+#pragma unroll
+        for (int s = 1; s < KS; ++s) {
+            x = MFMA32(kf[s], qh[s], x);
+            x = MFMA32(kf[s], ql[s], x);
+            u = MFMA32(kf[s], dof[s], u);
+        }
+        lds_sync();                                               // tiles and -c delta visible
+        f32x16_t y;                                               // c[j] (dP(other direction) - delta_other[j]): C operand = -c[j] delta[j] per key
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 n4 = *reinterpret_cast<const float4*>(sNd + 8 * g + 4 * hh);
+            y[4 * g] = n4.x; y[4 * g + 1] = n4.y; y[4 * g + 2] = n4.z; y[4 * g + 3] = n4.w;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y = MFMA32(hf[s], qf[s], y);
+        const bool tail = k0 + 32 > a.n_kv;
+        if (k0 + 32 < a.n_kv) load_tile(k0 + 32);
+        float e[16], t[16];
+        if (tail) {                                               // wave-uniform: padded keys contribute nothing
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) x[reg] = k0 + (reg & 3) + 8 * (reg >> 2) + 4 * hh < a.n_kv ? x[reg] : -INFINITY;
+        }
+        if (fast) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg += 2) {
+                const f32x2_t ea = {__builtin_amdgcn_exp2f(x[reg]), __builtin_amdgcn_exp2f(x[reg + 1])};
+                const f32x2_t w = pk_fma(pk_splat(rsc), (f32x2_t){y[reg], y[reg + 1]}, (f32x2_t){u[reg], u[reg + 1]});
+                const f32x2_t tt = ea * w;
+                e[reg] = ea.x; e[reg + 1] = ea.y; t[reg] = tt.x; t[reg + 1] = tt.y;
+            }
+        } else {                                                  // slow path: the other direction's probabilities by their own exponential
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(sL + 8 * g + 4 * hh);
+                const float lo[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int reg = 4 * g + cc;
+                    const float e1 = __builtin_amdgcn_exp2f(x[reg]);
+                    const float e2 = __builtin_amdgcn_exp2f(x[reg] + (lse2 - lo[cc]));
+                    t[reg] = fmaf(e1, u[reg], e2 * y[reg]);
+                    e[reg] = e2;
+                }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            Ga = MFMA32(tr_frag(trK, s2, D), pack_frag(t + 8 * s2), Ga);
+            Gb = MFMA32(tr_frag(trH, s2, D), pack_frag(e + 8 * s2), Gb);
+        }
+    }
+    if (okq) {
+        bf16_t* op = a.G + rowq * a.ldg;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            uint2 w;
+            w.x = pack_bf2(fmaf(Ga[4 * g + 0], pp.scale, rsc * Gb[4 * g + 0]), fmaf(Ga[4 * g + 1], pp.scale, rsc * Gb[4 * g + 1]));
+            w.y = pack_bf2(fmaf(Ga[4 * g + 2], pp.scale, rsc * Gb[4 * g + 2]), fmaf(Ga[4 * g + 3], pp.scale, rsc * Gb[4 * g + 3]));
+            *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
+        }
+    }
+}
+
 XP make(const stg_attn_args* f) {
     XP p = {};
     p.Q = (const bf16_t*)f->Q; p.ldq = f->ldq;
@@ -577,3 +787,62 @@ static int xattn_bwd_launch(const stg_attn_bwd_args* b0, const stg_attn_bwd_args
 
 int stg_xattn_bwd(const stg_attn_bwd_args* b, void* stream) { return xattn_bwd_launch(b, nullptr, stream); }
 int stg_xattn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream) { return xattn_bwd_launch(b0, b1, stream); }
+
+// ---- the merged pair backward (see the comment above xattn_bwdm_kernel)
+extern "C" int64_t stg_xattn_pair_bwd_ws_bytes(int64_t P, int n0, int n1, int D) {
+    const int64_t rows = P * ((int64_t)n0 + n1);
+    return rows * D * 2 + rows * 4 * 2 + P * 8 + 256;            // dOh (bf16 [rows, D]) + nd + delta (fp32 [rows]) + c0, ok per frame (+ alignment)
+}
+
+extern "C" int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_attn_args* f1) {
+    // direction 0: queries = modality v, keys = modality a; direction 1 the mirror image (same tensors, roles swapped); dense frames
+    return stg_opt_xattn.load(std::memory_order_relaxed) != 0 && stg_xattn_eligible(f0, true) && stg_xattn_eligible(f1, true) &&
+           f0->P == f1->P && f0->D == f1->D && f0->n == f1->n_kv && f0->n_kv == f1->n && f0->outer_q == f0->n && f0->outer_kv == f0->n_kv &&
+           f1->outer_q == f1->n && f1->outer_kv == f1->n_kv && f0->Q == f1->K && f0->K == f1->Q && f0->scale == f1->scale && f0->O && f1->O &&
+           f0->P < (1 << 20) ? 1 : 0;
+}
+
+extern "C" int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+    STG_CHECK(b0 && b1 && g0 && g1 && ws, -1, "stg_xattn_pair_bwd: null pointer");
+    STG_CHECK(stg_xattn_pair_bwd_supported(&b0->f, &b1->f), -2, "stg_xattn_pair_bwd: not a frame-global cross-modal pair these kernels take");
+    const stg_attn_bwd_args* bs[2] = {b0, b1};
+    void* gs[2] = {g0, g1};
+    const int D = b0->f.D;
+    const int64_t P = b0->f.P;
+    if (P == 0) return 0;
+    STG_CHECK(ws_bytes >= stg_xattn_pair_bwd_ws_bytes(P, b0->f.n, b1->f.n, D) && ((uintptr_t)ws & 15) == 0, -2, "stg_xattn_pair_bwd: workspace too small / misaligned");
+    STG_CHECK(ldg % 4 == 0 && ldg >= D && (((uintptr_t)g0 | (uintptr_t)g1) & 7) == 0, -2, "stg_xattn_pair_bwd: bad G operands");
+    XM2 pp = {};
+    char* w = (char*)ws;
+    bf16_t* dOh[2]; float* nd[2]; float* dl[2];
+    for (int y = 0; y < 2; ++y) { dOh[y] = (bf16_t*)w; w += P * bs[y]->f.n * D * 2; }
+    for (int y = 0; y < 2; ++y) { nd[y] = (float*)w; w += P * bs[y]->f.n * 4; }
+    for (int y = 0; y < 2; ++y) { dl[y] = (float*)w; w += P * bs[y]->f.n * 4; }
+    pp.c0 = (float*)w; w += P * 4;
+    pp.ok = (int*)w;
+    pp.P = (int)P; pp.scale = b0->f.scale; pp.c2 = b0->f.scale * LOG2E;
+    for (int y = 0; y < 2; ++y) {
+        const stg_attn_bwd_args* b = bs[y];
+        STG_CHECK(b->dO && b->f.lse && b->lddo % 8 == 0 && ((uintptr_t)b->dO & 15) == 0 && b->f.ldo % 8 == 0 && ((uintptr_t)b->f.O & 15) == 0, -2,
+                  "stg_xattn_pair_bwd: misaligned operands");
+        XM& a = pp.a[y];
+        a.Q = (const bf16_t*)b->f.Q; a.ldq = b->f.ldq; a.dO = (const bf16_t*)b->dO; a.lddo = b->lddo; a.O = (const bf16_t*)b->f.O; a.ldo = b->f.ldo;
+        a.lse = b->f.lse; a.delta = dl[y]; a.KV = (const bf16_t*)b->f.K; a.ldk = b->f.ldk;
+        a.dOh_other = dOh[1 - y]; a.nd_other = nd[1 - y]; a.dOh_own = dOh[y]; a.nd_own = nd[y]; a.lse_other = bs[1 - y]->f.lse;
+        a.G = (bf16_t*)gs[y]; a.ldg = ldg; a.n = b->f.n; a.n_kv = b->f.n_kv;
+        a.tiles = (a.n + 31) / 32; a.total = (int)(P * a.tiles);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = 8;
+    const int tmax = pp.a[0].total > pp.a[1].total ? pp.a[0].total : pp.a[1].total;
+    if (D == 16) {
+        hipLaunchKernelGGL(xattn_prep_kernel<16>, dim3((unsigned)P, parts), dim3(256), 0, st, pp);
+        hipLaunchKernelGGL(xattn_bwdm_kernel<16>, dim3((tmax + 3) / 4, 2), dim3(256), 0, st, pp);
+    } else {
+        hipLaunchKernelGGL(xattn_prep_kernel<32>, dim3((unsigned)P, parts), dim3(256), 0, st, pp);
+        hipLaunchKernelGGL(xattn_bwdm_kernel<32>, dim3((tmax + 3) / 4, 2), dim3(256), 0, st, pp);
+    }
+    STG_LAUNCH_CHECK();
+    return 0;
+}

@@ -930,8 +930,12 @@ def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
 
 @_family("elementwise", lambda a0, *a, **kw: ("add3_mul2", 10.0 * _nb(a0), 0.0))
 def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
-    """add3_mul on two equally sized problems, one launch: returns (out0, out1)."""
+    """add3_mul on two equally sized problems, one launch: returns (out0, out1).  c0 = c1 = None: (a + b) * z."""
+    if (c0 is None) != (c1 is None):
+        raise RuntimeError("add3_mul2: c0 and c1 are given together or not at all")
     for t in (a0, b0, c0, z0, a1, b1, c1, z1):
+        if t is None:
+            continue
         _chk_flat(t, "add3_mul2 operand")
         if t.shape != a0.shape:
             raise RuntimeError("add3_mul2: shape mismatch")
@@ -1287,6 +1291,44 @@ def attn_bwd2(p0, p1):
         res.append((dQ, dK)); args.append(b); keep.append(delta)
     _lib.check(_lib.lib().stg_attn_bwd2(C.byref(args[0]), C.byref(args[1]), _stream()), "stg_attn_bwd2")
     return res[0], res[1]
+
+
+def _xpair_args(p0, p1):
+    args = []
+    for g, Q, KV, O, lse, dO in (p0, p1):
+        dev = Q.device
+        for t, name, nt, outer, mp in ((Q, "Q", g.n, g.outer, g.map_q), (KV, "K", g.n_kv, g.outer_kv, g.map_kv),
+                                       (O, "O", g.n, g.outer, g.map_q), (dO, "dO", g.n, g.outer, g.map_q)):
+            _attn_check_rows(t, name, g, nt, outer, mp, dev)
+        if lse.dtype != F32 or lse.numel() != g.P * g.H * g.n:
+            raise RuntimeError("xattn_pair_bwd: bad lse")
+        b = _lib.AttnBwdArgs()
+        _attn_fill(b.f, g, Q, KV, KV, O, lse)
+        b.dO, b.lddo = _p(dO), _ld(dO)
+        args.append(b)
+    return args
+
+
+def xattn_pair_bwd_supported(p0, p1):
+    """p = (g, Q, KV, O, lse, dO) per direction: can the pair's backward run as one merged pass per modality (stg_xattn_pair_bwd)?"""
+    a0, a1 = _xpair_args(p0, p1)
+    return bool(_lib.lib().stg_xattn_pair_bwd_supported(C.byref(a0.f), C.byref(a1.f)))
+
+
+@_family("xattn_bwd", lambda p0, p1: (("pair",) + tuple(_attn_cost(p0[0], 4, 2, 5)[0]), 2.0 * _attn_cost(p0[0], 5, 1, 5)[1], 2.0 * _attn_cost(p0[0], 4, 2, 5)[2]))
+def xattn_pair_bwd(p0, p1):
+    """Backward of a frame-global cross-modal pair, one pass per modality: p0 = (g, h_v, h_a, r_v, lse_v, d r_v), p1 = the mirror image.
+    Returns (G_v, G_a): the complete gradients of h_v / h_a through both directions (what attn_bwd2's dQ_0 + dKV_1 and dQ_1 + dKV_0 sum to)."""
+    a0, a1 = _xpair_args(p0, p1)
+    g0, g1 = p0[0], p1[0]
+    dev = p0[1].device
+    G0 = torch.empty((p0[1].shape[0], g0.D), dtype=BF16, device=dev)
+    G1 = torch.empty((p1[1].shape[0], g1.D), dtype=BF16, device=dev)
+    nb = int(_lib.lib().stg_xattn_pair_bwd_ws_bytes(g0.P, g0.n, g1.n, g0.D))
+    ws = torch.empty((nb + 15) // 16 * 4, dtype=F32, device=dev)
+    _lib.check(_lib.lib().stg_xattn_pair_bwd(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(ws), ws.numel() * 4, _stream()),
+               "stg_xattn_pair_bwd")
+    return G0, G1
 
 
 @_family("attn_bwd", lambda g, *a, **kw: _attn_cost(g, 5, 3, 5))

@@ -524,6 +524,7 @@ def _xwin_geom(spec, BT, dev):
 
 
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
+XATTN_MERGED = _cfg.opt("xattn_merged")   # 0 = the frame-global cross-modal pair's backward as four passes (dQ, dK + dV per direction: rounds 1-4)
 
 
 def _gate2(hv, rv, gate_v, ha, ra, gate_a):
@@ -599,8 +600,19 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
         K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
         return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
+    pv, pa = (ag_v, hv, ha, rv, lse_v, drv), (ag_a, ha, hv, ra, lse_a, dra)
+    if XATTN_MERGED and K.xattn_pair_bwd_supported(pv, pa):
+        # one pass per modality over the pair's shared score tiles (one exponential per score): G = dQ (own direction) + dK + dV (other)
+        G_v, G_a = K.xattn_pair_bwd(pv, pa)
+        if zs is None:
+            return K.add(dhv2, G_v), K.add(dha2, G_a)
+        if PAIR_EW and dhv2.shape == dha2.shape:
+            return K.add3_mul2(dhv2, G_v, None, zs[0], dha2, G_a, None, zs[1], outs=outs)
+        z_ = torch.zeros_like(G_v)
+        return K.add3_mul(dhv2, G_v, z_, zs[0], out=None if outs is None else outs[0]), \
+            K.add3_mul(dha2, G_a, torch.zeros_like(G_a), zs[1], out=None if outs is None else outs[1])
     if PAIR_EW:
-        (dq_v, dkv_a), (dq_a, dkv_v) = K.attn_bwd2((ag_v, hv, ha, rv, lse_v, drv), (ag_a, ha, hv, ra, lse_a, dra))
+        (dq_v, dkv_a), (dq_a, dkv_v) = K.attn_bwd2(pv, pa)
     else:
         dq_v, dkv_a, _ = K.attn_bwd(ag_v, hv, ha, ha, rv, lse_v, drv, shared_kv=True)   # direction a -> v
         dq_a, dkv_v, _ = K.attn_bwd(ag_a, ha, hv, hv, ra, lse_a, dra, shared_kv=True)   # direction v -> a

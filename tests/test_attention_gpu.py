@@ -220,3 +220,71 @@ def test_online_softmax_rescale_spike(stg, gpu):
     O, lse = k.attn_fwd(geom, Qb.to(gpu), kv, kv)
     _close(O, ref, what="spike O (K is V)")
     _close(lse.view(-1), torch.logsumexp(s, -1), tol=2e-2, what="spike lse (K is V)")
+
+
+def _pair_case(gpu, P, nv, na, D, scale, seed, mag, spike=0.0):
+    """The frame-global cross-modal PAIR (Swin_AVE.py:796-811): r_v = softmax(s h_v h_a^T) h_a, r_a = softmax(s h_a h_v^T) h_v; backward from
+    (d r_v, d r_a).  Returns fp32 autograd gradients, the four-pass path's (attn_bwd2) and the merged path's (xattn_pair_bwd).  spike > 0: a few
+    rows of h_v are scaled up so that the frame's log-sum-exps span more than 120 binary orders (the merged kernel's slow path)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(seed)
+    hv = (torch.randn(P * nv, D, generator=g) * mag)
+    ha = (torch.randn(P * na, D, generator=g) * mag)
+    if spike > 0:
+        hv.view(P, nv, D)[0, ::7] *= spike                      # frame 0 only: the other frames stay on the fast path
+    hv, ha = hv.to(BF16), ha.to(BF16)
+    dv = torch.randn(P * nv, D, generator=g).to(BF16)
+    da = torch.randn(P * na, D, generator=g).to(BF16)
+    # fp32 reference
+    xv, xa = hv.float().requires_grad_(True), ha.float().requires_grad_(True)
+    S = scale * torch.einsum("pid,pjd->pij", xv.view(P, nv, D), xa.view(P, na, D))
+    rv = torch.softmax(S, 2) @ xa.view(P, na, D)
+    ra = torch.softmax(S.transpose(1, 2), 2) @ xv.view(P, nv, D)
+    ((rv.reshape(-1, D) * dv.float()).sum() + (ra.reshape(-1, D) * da.float()).sum()).backward()
+    # device
+    gv = k.AttnGeom(P, 1, nv, D, G=1, outer=nv, n_kv=na, outer_kv=na, scale=scale)
+    ga = k.AttnGeom(P, 1, na, D, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=scale)
+    d = lambda t: t.to(gpu)
+    Hv, Ha, Dv, Da = d(hv), d(ha), d(dv), d(da)
+    (Rv, Lv), (Ra, La) = k.attn_fwd2(gv, Hv, Ha, Ha, ga, Ha, Hv, Hv)
+    pv, pa = (gv, Hv, Ha, Rv, Lv, Dv), (ga, Ha, Hv, Ra, La, Da)
+    (dq_v, dkv_a), (dq_a, dkv_v) = k.attn_bwd2(pv, pa)
+    four = (dq_v.float() + dkv_v.float(), dq_a.float() + dkv_a.float())
+    assert k.xattn_pair_bwd_supported(pv, pa)
+    Gv, Ga = k.xattn_pair_bwd(pv, pa)
+    torch.cuda.synchronize()
+    return (xv.grad, xa.grad), four, (Gv.float(), Ga.float())
+
+
+@pytest.mark.parametrize("P,nv,na,D,scale,mag", [(2, 3136, 3136, 16, 1.0, 0.7), (3, 784, 784, 32, 1.0, 0.7), (5, 196, 196, 32, 1.0, 1.0),
+                                                 (3, 197, 130, 32, 0.5, 1.0), (3, 130, 197, 16, 0.7, 1.0), (4, 64, 64, 16, 1.0, 1.0), (2, 97, 65, 32, 1.0, 0.7)])
+def test_cross_modal_pair_merged_backward(stg, gpu, P, nv, na, D, scale, mag):
+    """stg_xattn_pair_bwd (one pass per modality over the pair's shared score tiles, ONE exponential per score) against the fp32 autograd
+    gradients of the pair and against the four passes it replaces (dQ + dK + dV summed in fp32): stage-0 / 1 / 2 frame sizes, ragged tails,
+    n_v != n_a, non-unit scale."""
+    ref, four, got = _pair_case(gpu, P, nv, na, D, scale, seed=60 + nv + D, mag=mag)
+    for r, f, m, name in zip(ref, four, got, ("G_v", "G_a")):
+        sc = float(r.abs().max())
+        e_m = float((m.cpu() - r).abs().max()) / sc
+        e_f = float((f.cpu() - r).abs().max()) / sc
+        l_m = float((m.cpu() - r).norm() / r.norm())
+        l_f = float((f.cpu() - r).norm() / r.norm())
+        assert torch.isfinite(m).all(), name
+        # the merged pass rounds P and dS to bf16 once per score like each of the four passes: same error level
+        assert e_m <= max(2.5e-2, 2.5 * e_f) and l_m <= max(8e-3, 1.5 * l_f), f"{name}: merged max/scale {e_m:.2e} relL2 {l_m:.2e}; four-pass {e_f:.2e} {l_f:.2e}"
+
+
+def test_cross_modal_pair_merged_backward_slow_path(stg, gpu):
+    """Frame 0 carries rows whose scores are ~100x the others': its log-sum-exps span more than 120 binary orders, so the preparation kernel
+    sends it down the merged kernel's two-exponential path (no power-of-two factor can over- or underflow there); the other frames stay on the
+    one-exponential path.  Both must match the fp32 gradients."""
+    from stgcma import kernels as k
+    ref, four, got = _pair_case(gpu, 3, 196, 196, 32, 1.0, seed=77, mag=0.7, spike=40.0)
+    for r, f, m, name in zip(ref, four, got, ("G_v", "G_a")):
+        assert torch.isfinite(m).all(), name
+        for fr in range(3):
+            rows = slice(fr * 196, (fr + 1) * 196)
+            sc = float(r[rows].abs().max())
+            e_m = float((m.cpu()[rows] - r[rows]).abs().max()) / sc
+            e_f = float((f.cpu()[rows] - r[rows]).abs().max()) / sc
+            assert e_m <= max(2e-2, 2.0 * e_f), f"{name} frame {fr}: merged {e_m:.2e}, four-pass {e_f:.2e}"
