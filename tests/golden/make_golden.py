@@ -366,7 +366,7 @@ def avs_tpavi_vv_case(A, tag, seed):
     save(tag, seed=np.array([seed]), **arrs)
 
 
-def avs_full_case(AB, tag, *, cfg, B, seed):
+def avs_full_case(AB, tag, *, cfg, B, seed, state_fn=None):
     """The whole SwinTransformer2D_Adapter_AVS_Base.forward[fusion] (AVS/model/Swin_AVSModel_Base.py:1790-1894): backbone + dense
     decoder, train mode without DropPath (BatchNorm on batch statistics), seeded upstream gradients on pred, the returned feature
     maps and the audio features so that every output is pinned."""
@@ -377,7 +377,7 @@ def avs_full_case(AB, tag, *, cfg, B, seed):
     # train mode with drop_path_rate = 0: deterministic, and TPAVI's BatchNorm runs on BATCH statistics -- with seeded running
     # statistics (eval) single channels of W_z's output reach the hundreds and the LayerNorm behind it becomes a difference of large
     # numbers, which pins nothing at bf16
-    shapes = seed_module(m, seed)
+    shapes = seed_module(m, seed, state_fn)
     with torch.no_grad():                              # BatchNorm running statistics are buffers, not covered by float seeding rules
         gg = torch.Generator().manual_seed(seed + 50)
         for n, b in m.named_buffers():
@@ -803,6 +803,10 @@ def main(argv):
         "avs_tpavi_vv": lambda: avs_tpavi_vv_case(ref_avs_base(), "avs_tpavi_vv", 860),
         "avs_full_tiny": lambda: avs_full_case(ref_avs_base(), "avs_full_tiny", cfg=AVS_FULL_TINY, B=1, seed=820),
         "avs_full_b18": lambda: avs_full_case(ref_avs_base(), "avs_full_b18", cfg=AVS_FULL_B, B=1, seed=830),
+        # the same model at the REFERENCE's initialisation scale (GP.refinit_state; decoder convolutions at 0.02 ~ their kaiming-uniform
+        # default): BASELINE's absolute 1e-2 bound on pred is meaningful here, as for the Swin-B / Swin-L / ViT-B refinit fixtures
+        "avs_full_b18_refinit": lambda: avs_full_case(ref_avs_base(), "avs_full_b18_refinit", cfg=AVS_FULL_B, B=1, seed=850,
+                                                      state_fn=GP.refinit_state),
         "avs_full_tiny_evalbn": lambda: avs_full_evalbn_case(ref_avs_base(), "avs_full_tiny_evalbn", cfg=AVS_FULL_TINY, B=1, seed=840),
         "avqa_pretrained_ingest": lambda: avqa_ingest_case(ref_avqa(), "avqa_pretrained_ingest", 740),
         # (seed, frames, height, width): seeds picked so that the cases cover erase / no erase and flip / no flip

@@ -360,9 +360,9 @@ def test_avs_decoder_building_blocks_match_reference():
     _close(grads_of(P, ["m." + k for k, _ in shapes]), z["oc_grads"], what="oc grads")
 
 
-def _avs_full_state(z, cfg, shapes):
+def _avs_full_state(z, cfg, shapes, state_fn=None):
     """Parameters of the avs_full_tiny golden: seeded floats + the BatchNorm running statistics make_golden.py drew afterwards."""
-    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"])
+    P = build_state(shapes, cfg["seed"], kind="swin", T=cfg["num_frames"], state_fn=state_fn)
     gg = torch.Generator().manual_seed(cfg["seed"] + 50)
     # named_buffers() yields, per BatchNorm, running_mean then running_var (then num_batches_tracked): the order of the float keys
     for k, sh in shapes:
@@ -437,6 +437,26 @@ def test_avs_full_depth_model_forward_matches_reference():
     loss.backward()
     g, ref = _grads(P, names)[::97], torch.as_tensor(z["grads_sample"])
     assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) >= 0.999
+
+
+def test_avs_full_depth_refinit_forward_matches_reference():
+    """The same full-depth model at the REFERENCE's initialisation scale (fixture avs_full_b18_refinit, round 5: params.refinit_state; pred is
+    O(0.4), so BASELINE's absolute 1e-2 bound means something): the oracle's forward against the reference's outputs (forward only: the CPU suite's
+    time budget; its backward is the avs_full_b18 test's)."""
+    import oracle.avs_decoder as OD
+    from params import seeded_tensor, refinit_state
+    z, cfg, shapes, names = load_case("avs_full_b18_refinit")
+    P = _avs_full_state(z, cfg, shapes, state_fn=refinit_state)
+    B, seed = cfg["B"], cfg["seed"]
+    a = seeded_tensor((B, 5, 224, 224), seed + 1, 0.5)
+    v = seeded_tensor((B, 5, 3, 224, 224), seed + 2)
+    with torch.no_grad():
+        pred, fmaps, afeas = OD.avs_forward(P, a, v, cfg, bn_training=True)
+    assert float((pred - torch.as_tensor(z["pred"])).abs().max()) <= 1e-4
+    _close(pred, z["pred"], what="pred")
+    for i in range(4):
+        _close(fmaps[i][:, ::8], z[f"fmap{i}"], what=f"fmap{i}")
+        _close(afeas[i], z[f"afea{i}"], what=f"afea{i}")
 
 
 def _avs_evalbn_state(z, cfg, shapes):
