@@ -77,32 +77,33 @@ __device__ __forceinline__ bf16x8_t nat_frag(const bf16_t* s, int r, int hh, int
 // NTILE = 1 where K and V are one tensor (the adapters' cross-modal attention), LDS double-buffered: ONE barrier per tile.
 template <int N> using U4Arr = u32x4_t[N];      // a native vector type: arrays of HIP's uint4 struct are not promoted to registers
 template <int N> using IArr = int[N];
-template <int D, int NTILE> struct StageC {
+template <int D, int NTILE, int NW = 4> struct StageC {
+    static constexpr int NTHR = NW * 64;
     static constexpr int TOTAL = NTILE * 4 * D;                 // 16-byte pieces: NTILE tiles x 32 rows x D / 8
-    static constexpr int PER = (TOTAL + 255) / 256;
+    static constexpr int PER = (TOTAL + NTHR - 1) / NTHR;
     static constexpr int DP = D + 8;
     static constexpr int TILE = 32 * DP;                        // elements per LDS tile
 };
-template <int D, int NTILE>
-__device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE>::PER>& lds_off, IArr<StageC<D, NTILE>::PER>& src_col,
-                                           IArr<StageC<D, NTILE>::PER>& row) {
-    using C = StageC<D, NTILE>;
+template <int D, int NTILE, int NW>
+__device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE, NW>::PER>& lds_off, IArr<StageC<D, NTILE, NW>::PER>& src_col,
+                                           IArr<StageC<D, NTILE, NW>::PER>& row) {
+    using C = StageC<D, NTILE, NW>;
 #pragma unroll
     for (int i = 0; i < C::PER; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + C::NTHR * i;
         const int which = id / (4 * D), rem = id - which * 4 * D;
         const int r = rem / (D / 8), c = rem - r * (D / 8);
-        row[i] = (C::TOTAL % 256 != 0 && id >= C::TOTAL) ? -1 : r + 32 * which;        // -1: this thread has no i-th piece; bit 5 = tile
+        row[i] = (C::TOTAL % C::NTHR != 0 && id >= C::TOTAL) ? -1 : r + 32 * which;        // -1: this thread has no i-th piece; bit 5 = tile
         lds_off[i] = which * C::TILE + r * C::DP + 8 * c;
         src_col[i] = h * D + 8 * c;
     }
 }
-template <int D, int NTILE>
-__device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE>::PER>& v, const IArr<StageC<D, NTILE>::PER>& src_col,
-                                            const IArr<StageC<D, NTILE>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
+template <int D, int NTILE, int NW>
+__device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE, NW>::PER>& v, const IArr<StageC<D, NTILE, NW>::PER>& src_col,
+                                            const IArr<StageC<D, NTILE, NW>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
                                             int64_t frame_row0, int n, int row0) {
 #pragma unroll
-    for (int i = 0; i < StageC<D, NTILE>::PER; ++i) {
+    for (int i = 0; i < StageC<D, NTILE, NW>::PER; ++i) {
         if (row[i] < 0) continue;
         int tok = row0 + (row[i] & 31);
         tok = tok < n ? tok : n - 1;
@@ -110,26 +111,27 @@ __device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE>::PER>& v, con
         v[i] = *reinterpret_cast<const u32x4_t*>(src + src_col[i]);
     }
 }
-template <int D, int NTILE>
-__device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NTILE>::PER>& v, const IArr<StageC<D, NTILE>::PER>& lds_off,
-                                             const IArr<StageC<D, NTILE>::PER>& row) {
+template <int D, int NTILE, int NW>
+__device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NTILE, NW>::PER>& v, const IArr<StageC<D, NTILE, NW>::PER>& lds_off,
+                                             const IArr<StageC<D, NTILE, NW>::PER>& row) {
 #pragma unroll
-    for (int i = 0; i < StageC<D, NTILE>::PER; ++i)
+    for (int i = 0; i < StageC<D, NTILE, NW>::PER; ++i)
         if (row[i] >= 0) *reinterpret_cast<u32x4_t*>(s + lds_off[i]) = v[i];
 }
 
 // ------------------------------------------------------------------------------------------------ forward
 // KV1: K and V are the same tensor (one staged tile serves the score MFMA and, read transposed, the P.V MFMA)
-template <int D, bool KV1>
-__global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
-    using SC = StageC<D, NTILE>;
+    using SC = StageC<D, NTILE, NW>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];      // two buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
     const int64_t frow = (int64_t)p * a.n;
-    const int q0 = 32 * (qb * 4 + wave);
+    const int q0 = 32 * (qb * NW + wave);
+    const bool live = q0 < a.n;
     const int q = q0 + r;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS];
@@ -145,14 +147,15 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
 
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
-    stage_plan<D, NTILE>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
-    stage_commit<D, NTILE>(smem, sv, lo, rw);
+    stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
     __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
         const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (live) {                                    // wave-uniform: a wave whose query tile lies past the frame only stages and synchronises
         f32x16_t sc = zero16();                        // St[key][q]
 #pragma unroll
         for (int s = 0; s < KS; ++s) sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
@@ -189,8 +192,9 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
             o[dt] = MFMA32(tr_frag<DP>(sV, dt, 0, hh, r), p0, o[dt]);
             o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), p1, o[dt]);
         }
+        }
         // the other buffer was last read in trip kt - 1, and every wave has passed that trip's barrier
-        if (kt + 1 < a.nt) stage_commit<D, NTILE>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        if (kt + 1 < a.nt) stage_commit<D, NTILE, NW>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
         __syncthreads();
     }
     {
@@ -203,16 +207,17 @@ __global__ void __launch_bounds__(256, 2) mha_fwd_kernel(MP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int D, bool KV1>
-__global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
-    using SC = StageC<D, NTILE>;
+    using SC = StageC<D, NTILE, NW>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
     const int64_t frow = (int64_t)p * a.n;
-    const int q = 32 * (qb * 4 + wave) + r;
+    const int q = 32 * (qb * NW + wave) + r;
+    const bool live = 32 * (qb * NW + wave) < a.n;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS], dof[KS];
     float delta = 0.f;
@@ -239,14 +244,15 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
 
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
-    stage_plan<D, NTILE>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
-    stage_commit<D, NTILE>(smem, sv, lo, rw);
+    stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
     __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
         const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (live) {
         f32x16_t sc = zero16(), dp = zero16();         // St[key][q], dPt[key][q]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -269,7 +275,8 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
             dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 0, hh, r), d0, dq[dt]);
             dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), d1, dq[dt]);
         }
-        if (kt + 1 < a.nt) stage_commit<D, NTILE>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        }
+        if (kt + 1 < a.nt) stage_commit<D, NTILE, NW>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
         __syncthreads();
     }
     {
@@ -280,10 +287,10 @@ __global__ void __launch_bounds__(256, 2) mha_dq_kernel(MP a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int D, bool KV1>
-__global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NKV = KV1 ? 1 : 2;
-    using SC = StageC<D, 2>;
+    using SC = StageC<D, 2, NW>;
     // two buffers of {shared Q / dO tiles + lse / delta of the query tile}, then per wave its own K (and V) tile
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // dkv_lds_bytes(D, KV1) (dynamic: > 64 KiB at D = 96)
     constexpr int BUF = 2 * 32 * DP + 128;                              // elements per buffer (64 floats of statistics = 128 bf16 slots)
@@ -293,7 +300,8 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
     bf16_t* sV = KV1 ? sK : sK + 32 * DP;
     const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
     const int64_t frow = (int64_t)p * a.n;
-    const int key = 32 * (kb * 4 + wave) + r;
+    const int key = 32 * (kb * NW + wave) + r;
+    const bool live = 32 * (kb * NW + wave) < a.n;
     const int kc = key < a.n ? key : a.n - 1;
     {   // own K / V tile: natural rows (keys) -> wave-private LDS; read back as B operands (columns = keys)
         const bf16_t* kp = a.K + (frow + kc) * a.ld + h * D + 8 * hh;
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
 
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
-    stage_plan<D, 2>(tid, h, lo, sc_, rw);
+    stage_plan<D, 2, NW>(tid, h, lo, sc_, rw);
     float nl = 0.f, nd = 0.f;
     auto fetch_stats = [&](int q0) {
         if (tid < 32) {
@@ -322,11 +330,11 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
         }
     };
     auto commit_all = [&](bf16_t* buf) {
-        stage_commit<D, 2>(buf, sv, lo, rw);
+        stage_commit<D, 2, NW>(buf, sv, lo, rw);
         float* st = reinterpret_cast<float*>(buf + 2 * 32 * DP);
         if (tid < 32) { st[tid] = nl; st[32 + tid] = nd; }
     };
-    stage_fetch<D, 2>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
+    stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
     fetch_stats(0);
     commit_all(smem);
     __syncthreads();
@@ -336,9 +344,10 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
         const float* sLse = reinterpret_cast<const float*>(sQ + 2 * 32 * DP);
         const float* sDel = sLse + 32;
         if (qt + 1 < a.nt) {
-            stage_fetch<D, 2>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1));
+            stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1));
             fetch_stats(32 * (qt + 1));
         }
+        if (live) {
         f32x16_t sc = zero16(), dp = zero16();         // S[q][key], dP[q][key]
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -370,6 +379,7 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
             dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 0, hh, r), d0, dk[dt]);
             dk[dt] = MFMA32(tr_frag<DP>(sQ, dt, 1, hh, r), d1, dk[dt]);
         }
+        }
         if (qt + 1 < a.nt) commit_all(smem + ((qt + 1) & 1) * BUF);
         __syncthreads();
     }
@@ -395,15 +405,23 @@ __global__ void __launch_bounds__(256, 2) mha_dkv_kernel(MP a) {
     }
 }
 
-constexpr int dkv_lds_bytes(int D, bool kv1) { return (2 * (2 * 32 * (D + 8) + 128) + 4 * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
+constexpr int dkv_lds_bytes(int D, bool kv1, int nw) { return (2 * (2 * 32 * (D + 8) + 128) + nw * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
 
-template <int D, bool KV1>
+template <int D, bool KV1, int NW>
 int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
     static std::atomic<uint64_t> done{0};
-    const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D, KV1>, dkv_lds_bytes(D, KV1), done);
-    STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D, KV1));
-    hipLaunchKernelGGL((mha_dkv_kernel<D, KV1>), grid, dim3(256), dkv_lds_bytes(D, KV1), stream, p);
+    const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D, KV1, NW>, dkv_lds_bytes(D, KV1, NW), done);
+    STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D, KV1, NW));
+    hipLaunchKernelGGL((mha_dkv_kernel<D, KV1, NW>), grid, dim3(NW * 64), dkv_lds_bytes(D, KV1, NW), stream, p);
     return 0;
+}
+
+// waves per block: 8 where a frame has more than 4 query tiles (one staging of a K / V tile then serves 256 queries: ViT-B's 197 tokens take ONE
+// block per (frame, head)), 4 for short sequences; option mha_nw (tools) forces either
+int pick_nw(int nt) {
+    const int o = stg_opt_mha_nw.load(std::memory_order_relaxed);
+    if (o == 4 || o == 8) return o;
+    return nt > 4 ? 8 : 4;
 }
 
 int fill(const stg_mha_args* f, MP& p, const char* who) {
@@ -429,11 +447,16 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     int rc = fill(f, p, "stg_mha_fwd");
     if (rc) return rc;
     if (p.P == 0) return 0;
-    const dim3 grid((p.nt + 3) / 4, p.H, p.P);
+    const int nw = pick_nw(p.nt);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;
-    if (f->D == 64) { if (kv1) hipLaunchKernelGGL((mha_fwd_kernel<64, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((mha_fwd_kernel<64, false>), grid, dim3(256), 0, st, p); }
-    else { if (kv1) hipLaunchKernelGGL((mha_fwd_kernel<96, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((mha_fwd_kernel<96, false>), grid, dim3(256), 0, st, p); }
+#define STG_MHA_FWD(DD, KV, NW) hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p)
+#define STG_MHA_FWD2(DD, KV) { if (nw == 8) STG_MHA_FWD(DD, KV, 8); else STG_MHA_FWD(DD, KV, 4); }
+    if (f->D == 64) { if (kv1) STG_MHA_FWD2(64, true) else STG_MHA_FWD2(64, false) }
+    else { if (kv1) STG_MHA_FWD2(96, true) else STG_MHA_FWD2(96, false) }
+#undef STG_MHA_FWD2
+#undef STG_MHA_FWD
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -452,12 +475,15 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (p.P == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.delta = delta;
-    const dim3 grid((p.nt + 3) / 4, p.H, p.P);
+    const int nw = pick_nw(p.nt);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;
-#define STG_MHA_BWD(DD, KV) { hipLaunchKernelGGL((mha_dq_kernel<DD, KV>), grid, dim3(256), 0, st, p); STG_LAUNCH_CHECK(); rc = launch_dkv<DD, KV>(grid, p, st); }
-    if (f->D == 64) { if (kv1) STG_MHA_BWD(64, true) else STG_MHA_BWD(64, false) }
-    else { if (kv1) STG_MHA_BWD(96, true) else STG_MHA_BWD(96, false) }
+#define STG_MHA_BWD(DD, KV, NW) { hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); STG_LAUNCH_CHECK(); rc = launch_dkv<DD, KV, NW>(grid, p, st); }
+#define STG_MHA_BWD2(DD, KV) { if (nw == 8) STG_MHA_BWD(DD, KV, 8) else STG_MHA_BWD(DD, KV, 4) }
+    if (f->D == 64) { if (kv1) STG_MHA_BWD2(64, true) else STG_MHA_BWD2(64, false) }
+    else { if (kv1) STG_MHA_BWD2(96, true) else STG_MHA_BWD2(96, false) }
+#undef STG_MHA_BWD2
 #undef STG_MHA_BWD
     if (rc) return rc;
     STG_LAUNCH_CHECK();

@@ -275,7 +275,9 @@ def test_avs_full_depth_refinit_matches_reference(stg, gpu):
     cos = float(torch.dot(flat, ref) / (flat.norm() * ref.norm()))
     with open("gpurun_out/model_parity_report.txt", "a") as f:
         f.write(f"avs_full_b18_refinit grads: cos={cos:.4f} norm ratio median={med:.3f} share within 25%={share:.3f} min={min(ratios)} max={max(ratios)}\n")
-    assert cos >= 0.65 and 0.9 <= med <= 1.1 and share >= 0.6, f"gradient sample cosine {cos:.4f}, median norm ratio {med:.3f}, share within 25 % {share:.3f}"
+    # at the reference's initialisation scale the whole-model gradient IS well conditioned (measured, round 5: cosine 0.9984, median norm ratio 0.999,
+    # 99.8 % of the tensors within 25 %; the outliers are biases in front of a batch-statistics BatchNorm, whose true gradient is zero)
+    assert cos >= 0.99 and 0.97 <= med <= 1.03 and share >= 0.95, f"gradient sample cosine {cos:.4f}, median norm ratio {med:.3f}, share within 25 % {share:.3f}"
 
 
 def test_avs_full_model_matches_reference(stg, gpu):
