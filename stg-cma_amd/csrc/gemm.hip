@@ -1592,7 +1592,11 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // routings tried in tools/gemm_route_ab.py are within 1 % of each other, profiles/r03_gemm_route_ab.txt)
     // (r2, stage-1 shapes, microbenchmark: 501 760 x 768 x 256 + bias 437 -> 388 us, x 256 x 768 343 -> 297, x 1024 x 256 with GELU +
     // derivative 814 -> 763, x 256 x 256 156 -> 149: the 128 x 128 kernel's main loop is L2-bandwidth-bound there)
-    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8);
+    // round 5 (option gemm_d8m, default on): the fc2 dgrad's byte-derivative-source epilogue joins the wide-output classes when the MULTI-tile
+    // walk will take it (its derivative bytes are ordinary global loads in the epilogue: waiting for them also waits for the next tile's older
+    // prologue DMAs, which is safe -- the counted wait behind the epilogue only needs >= NST younger operations)
+    const bool d8m = p.epi_variant == EV_DSRC8 && stg_opt_gemm_d8m.load(std::memory_order_relaxed) != 0 && a->K <= 512 && a->N >= 1024;
+    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8 || d8m);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
@@ -1625,7 +1629,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
                               hipLaunchKernelGGL(gemm_nt_8phm_kernel<V>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p); launched = true; break;
             bool launched = false;
             switch (p.epi_variant) {
-                STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2)
+                STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2) STG_8PHM(EV_DSRC8, 3)
                 default: break;
             }
 #undef STG_8PHM

@@ -416,12 +416,13 @@ int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
     return 0;
 }
 
-// waves per block: 8 where a frame has more than 4 query tiles (one staging of a K / V tile then serves 256 queries: ViT-B's 197 tokens take ONE
-// block per (frame, head)), 4 for short sequences; option mha_nw (tools) forces either
-int pick_nw(int nt) {
+// waves per block.  Backward: 8 where a frame has more than 4 query tiles (one staging of a tile then serves 256 rows; ViT-B's 197 tokens take ONE
+// block per (frame, head)): measured -11 % at 3136 x 3136 x 96 (5589 -> 4971 us), -9 % at 8 x 197 x 197 x 96 (532 -> 485 us).  Forward: 4 -- with 8 it
+// measured +5 % on both shapes (its trip is shorter, the barrier among 8 waves weighs more).  Option mha_nw (tools) forces either.
+int pick_nw(int nt, bool bwd) {
     const int o = stg_opt_mha_nw.load(std::memory_order_relaxed);
     if (o == 4 || o == 8) return o;
-    return nt > 4 ? 8 : 4;
+    return bwd && nt > 4 ? 8 : 4;
 }
 
 int fill(const stg_mha_args* f, MP& p, const char* who) {
@@ -447,7 +448,7 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     int rc = fill(f, p, "stg_mha_fwd");
     if (rc) return rc;
     if (p.P == 0) return 0;
-    const int nw = pick_nw(p.nt);
+    const int nw = pick_nw(p.nt, false);
     const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;
@@ -475,7 +476,7 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (p.P == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.delta = delta;
-    const int nw = pick_nw(p.nt);
+    const int nw = pick_nw(p.nt, true);
     const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;

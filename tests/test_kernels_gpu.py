@@ -598,7 +598,8 @@ def test_pair_launches_equal_two_single_launches(stg, gpu, C, J, S, M2, with_rs)
 
 
 @pytest.mark.parametrize("M,N,Kd,gelu8,kernel", [(31360, 1024, 4096, False, "gemm_nt_8ph_kernel"), (7840, 512, 2048, False, "gemm_nt_8ph_kernel"),
-                                                 (62880, 1536, 512, False, "gemm_nt_8phm_kernel"), (125600, 2048, 512, True, "gemm_nt_8phm_kernel")])
+                                                 (62880, 1536, 512, False, "gemm_nt_8phm_kernel"), (125600, 2048, 512, True, "gemm_nt_8phm_kernel"),
+                                                 (125600, 2048, 512, "d8", "gemm_nt_8phm_kernel"), (62880, 2048, 512, "d8", "gemm_nt_8phm_kernel")])
 def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd, gelu8, kernel):
     """Regression test of a race found in round 4: the 8-phase kernel pre-read the next k-tile's A0 fragments one phase BEFORE the counted
     wait that retires their LDS-DMA (it relied on "issued a k-tile ago"); when a DMA was slow, one k-tile of some rows was computed from the
@@ -612,7 +613,15 @@ def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd, gelu8, kernel
     A = (torch.randn(M, Kd, device=gpu) * 0.5).to(torch.bfloat16)
     W = (torch.randn(N, Kd, device=gpu) * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device=gpu) * 0.1
-    run = (lambda: K.gemm_nt(A, W, b, act=ACT_GELU, want_dact="u8")) if gelu8 else (lambda: (K.gemm_nt(A, W, b),))
+    if gelu8 == "d8":                       # the fc2 dgrad's class (round 5: multi-tile kernel): x byte derivative, an ordinary global load in the epilogue
+        d8 = torch.randint(0, 256, (M, N), device=gpu, dtype=torch.uint8)
+        run = lambda: (K.gemm_nt(A, W, dact_src=d8),)
+        want = K.gemm_nt(A, W).float()      # against the plain product times the decoded derivative: the epilogue is the ONLY difference
+        got = run()[0].float()
+        dec = d8.float() * 0.005 - 0.14     # the byte code of the saved derivative (STG_U8_LIN)
+        assert float((got - want * dec).abs().max()) <= 2e-2 * float(want.abs().max())
+    else:
+        run = (lambda: K.gemm_nt(A, W, b, act=ACT_GELU, want_dact="u8")) if gelu8 else (lambda: (K.gemm_nt(A, W, b),))
     ref = [t.clone() for t in run()]
     assert K.LAST_GEMM_KERNEL.startswith(kernel), K.LAST_GEMM_KERNEL
     bad = torch.zeros((), device=gpu, dtype=torch.int64)
