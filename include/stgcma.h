@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 214
+#define STG_VERSION 215
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -301,6 +301,14 @@ int64_t stg_xattn_pair_bwd_ws_bytes(int64_t P, int n0, int n1, int D);
 int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_attn_args* f1);
 int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, void* ws, int64_t ws_bytes,
                        void* stream);
+/* The same with the join that follows it in the adapters' backward: g <- (jx + G) * jz per modality (jx = gradient of the gated hidden state,
+ * jz = saved activation derivative of D_fc1: stg_add3_mul2's arithmetic on the bf16-rounded G, no separate pass). */
+int stg_xattn_pair_bwd_join(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                            const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream);
+/* Forward of such a pair with its gates: O and lse per direction as stg_attn_fwd2 writes them, and x = q + gate[0] * o (stg_gate_fwd2's
+ * arithmetic on the bf16-rounded o) into x0 / x1 [rows, D] -- h_v' = h_v + gate_v softmax(h_v h_a^T) h_a, Swin_AVE.py:799-808. */
+int stg_xattn_fwd2_gate(const stg_attn_args* f0, const stg_attn_args* f1, const float* gate0, const float* gate1, void* x0, void* x1,
+                        int64_t ldx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-window attention: WindowAttention.forward's spatial branch (Swin_AVE.py:256-276) with roll + window_partition /

@@ -164,6 +164,8 @@ SIGNATURES = {
     "stg_xattn_pair_bwd_ws_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
     "stg_xattn_pair_bwd_supported": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs)]),
     "stg_xattn_pair_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "stg_xattn_pair_bwd_join": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "stg_xattn_fwd2_gate": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -222,7 +224,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 214
+ABI_VERSION = 215
 _lib = None
 
 

@@ -98,6 +98,7 @@ struct XP {
     bf16_t* dKV; int64_t lddk;
     float* delta;
     int tiles, total;
+    const float* gate; bf16_t* X; int64_t ldx;      // forward, optional (round 5): X = Q + gate[0] * O written beside O (the pair's gate_fwd)
 };
 
 // Key rows inside a problem (forward, dQ): a wave-uniform 64-bit base + a 32-bit byte offset per lane that ADVANCES by a uniform step per
@@ -257,6 +258,14 @@ __global__ void __launch_bounds__(256, 2) xattn_fwd_kernel(XP2 pp) {
             w.x = pack_bf2(o[4 * g + 0] * inv, o[4 * g + 1] * inv);
             w.y = pack_bf2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
+            if (a.X) {                                      // kernel-uniform: the gate on the bf16-ROUNDED output, gate_fwd's arithmetic
+                const uint2 qv = *reinterpret_cast<const uint2*>(a.Q + rowq * a.ldq + 8 * g + 4 * hh);
+                const float gv = a.gate[0];
+                uint2 xw;
+                xw.x = pack_bf2(fmaf(gv, __uint_as_float(w.x << 16), __uint_as_float(qv.x << 16)), fmaf(gv, __uint_as_float(w.x & 0xffff0000u), __uint_as_float(qv.x & 0xffff0000u)));
+                xw.y = pack_bf2(fmaf(gv, __uint_as_float(w.y << 16), __uint_as_float(qv.y << 16)), fmaf(gv, __uint_as_float(w.y & 0xffff0000u), __uint_as_float(qv.y & 0xffff0000u)));
+                *reinterpret_cast<uint2*>(a.X + rowq * a.ldx + 8 * g + 4 * hh) = xw;
+            }
         }
         if (hh == 0) a.lse[(int64_t)p * a.n + q] = (m2 + __log2f(l)) * LN2;
     }
@@ -523,6 +532,7 @@ struct XM {
     bf16_t* dOh_own; float* nd_own;               // what the preparation kernel writes for THIS side's rows (read by the other side's pass)
     bf16_t* G; int64_t ldg;
     int n, n_kv, tiles, total;
+    const bf16_t* jX; const bf16_t* jZ; int64_t ldjx, ldjz;     // optional join (round 5): G <- (jX + G) * jZ, the add3_mul that follows (jZ = saved act')
 };
 struct XM2 { XM a[2]; float* c0; int* ok; float scale, c2; int P; };
 
@@ -698,6 +708,14 @@ __global__ void __launch_bounds__(256, 2) xattn_bwdm_kernel(XM2 pp) {
             uint2 w;
             w.x = pack_bf2(fmaf(Ga[4 * g + 0], pp.scale, rsc * Gb[4 * g + 0]), fmaf(Ga[4 * g + 1], pp.scale, rsc * Gb[4 * g + 1]));
             w.y = pack_bf2(fmaf(Ga[4 * g + 2], pp.scale, rsc * Gb[4 * g + 2]), fmaf(Ga[4 * g + 3], pp.scale, rsc * Gb[4 * g + 3]));
+            if (a.jZ) {                                     // kernel-uniform: (dX + G) * act' on the bf16-ROUNDED G, add3_mul's arithmetic
+                const uint2 xv = *reinterpret_cast<const uint2*>(a.jX + rowq * a.ldjx + 8 * g + 4 * hh);
+                const uint2 zv = *reinterpret_cast<const uint2*>(a.jZ + rowq * a.ldjz + 8 * g + 4 * hh);
+                w.x = pack_bf2((__uint_as_float(xv.x << 16) + __uint_as_float(w.x << 16)) * __uint_as_float(zv.x << 16),
+                               (__uint_as_float(xv.x & 0xffff0000u) + __uint_as_float(w.x & 0xffff0000u)) * __uint_as_float(zv.x & 0xffff0000u));
+                w.y = pack_bf2((__uint_as_float(xv.y << 16) + __uint_as_float(w.y << 16)) * __uint_as_float(zv.y << 16),
+                               (__uint_as_float(xv.y & 0xffff0000u) + __uint_as_float(w.y & 0xffff0000u)) * __uint_as_float(zv.y & 0xffff0000u));
+            }
             *reinterpret_cast<uint2*>(op + 8 * g + 4 * hh) = w;
         }
     }
@@ -717,6 +735,8 @@ XP make(const stg_attn_args* f) {
 
 }  // namespace
 
+extern "C" int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_attn_args* f1);
+
 // Eligibility of a generic attention description for these kernels (see xattn.h)
 bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse) {
     return f->H == 1 && (f->D == 16 || f->D == 32) && f->map_kind == 0 && !f->map_q && !f->map_kv && !f->bias && !f->mask &&
@@ -728,11 +748,16 @@ bool stg_xattn_eligible(const stg_attn_args* f, bool need_lse) {
            (int64_t)f->n_kv * f->ldk < (1ll << 30);              // 32-bit byte offsets of the key rows inside a problem
 }
 
-static int xattn_fwd_launch(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) {
+static int xattn_fwd_launch(const stg_attn_args* f0, const stg_attn_args* f1, void* stream, const float* gate0 = nullptr,
+                            const float* gate1 = nullptr, void* x0 = nullptr, void* x1 = nullptr, int64_t ldx = 0) {
     XP2 pp = {};
     pp.a[0] = make(f0);
     const int ny = f1 ? 2 : 1;
     if (f1) pp.a[1] = make(f1);
+    if (x0) {
+        pp.a[0].gate = gate0; pp.a[0].X = (bf16_t*)x0; pp.a[0].ldx = ldx;
+        pp.a[1].gate = gate1; pp.a[1].X = (bf16_t*)x1; pp.a[1].ldx = ldx;
+    }
     if (pp.a[0].P == 0) return 0;
     for (int y = 0; y < ny; ++y) {
         XP& p = pp.a[y];
@@ -754,6 +779,15 @@ bool stg_xattn_pairable(const stg_attn_args* f0, const stg_attn_args* f1) {
     return f0->P == f1->P && f0->n == f1->n && f0->n_kv == f1->n_kv && f0->D == f1->D;
 }
 int stg_xattn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, void* stream) { return xattn_fwd_launch(f0, f1, stream); }
+
+// both directions of a frame-global cross-modal pair AND its gates (x = q + gate o) in one launch
+extern "C" int stg_xattn_fwd2_gate(const stg_attn_args* f0, const stg_attn_args* f1, const float* gate0, const float* gate1, void* x0, void* x1,
+                                   int64_t ldx, void* stream) {
+    STG_CHECK(f0 && f1 && gate0 && gate1 && x0 && x1, -1, "stg_xattn_fwd2_gate: null pointer");
+    STG_CHECK(stg_xattn_pair_bwd_supported(f0, f1), -2, "stg_xattn_fwd2_gate: not a frame-global cross-modal pair these kernels take");
+    STG_CHECK(ldx % 4 == 0 && ldx >= f0->D && (((uintptr_t)x0 | (uintptr_t)x1) & 7) == 0, -2, "stg_xattn_fwd2_gate: bad x operands");
+    return xattn_fwd_launch(f0, f1, stream, gate0, gate1, x0, x1, ldx);
+}
 
 static int xattn_bwd_launch(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* stream) {
     XP2 pp = {};
@@ -802,8 +836,26 @@ extern "C" int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_a
            f0->P < (1 << 20) ? 1 : 0;
 }
 
+static int xattn_pair_bwd_impl(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream);
+
 extern "C" int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, void* ws,
                                   int64_t ws_bytes, void* stream) {
+    return xattn_pair_bwd_impl(b0, b1, g0, g1, ldg, nullptr, nullptr, 0, nullptr, nullptr, 0, ws, ws_bytes, stream);
+}
+
+/* stg_xattn_pair_bwd followed by the join of the adapters' backward in the same launch: g <- (jx + G) * jz per modality (jx = the gradient of
+ * the gated hidden state, jz = the saved activation derivative of D_fc1: what stg_add3_mul2 did in its own pass). */
+extern "C" int stg_xattn_pair_bwd_join(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                                       const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    STG_CHECK(jx0 && jx1 && jz0 && jz1 && ldjx % 4 == 0 && ldjz % 4 == 0 && (((uintptr_t)jx0 | (uintptr_t)jx1 | (uintptr_t)jz0 | (uintptr_t)jz1) & 7) == 0, -2,
+              "stg_xattn_pair_bwd_join: bad join operands");
+    return xattn_pair_bwd_impl(b0, b1, g0, g1, ldg, jx0, jx1, ldjx, jz0, jz1, ldjz, ws, ws_bytes, stream);
+}
+
+static int xattn_pair_bwd_impl(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream) {
     STG_CHECK(b0 && b1 && g0 && g1 && ws, -1, "stg_xattn_pair_bwd: null pointer");
     STG_CHECK(stg_xattn_pair_bwd_supported(&b0->f, &b1->f), -2, "stg_xattn_pair_bwd: not a frame-global cross-modal pair these kernels take");
     const stg_attn_bwd_args* bs[2] = {b0, b1};
@@ -831,6 +883,7 @@ extern "C" int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bw
         a.lse = b->f.lse; a.delta = dl[y]; a.KV = (const bf16_t*)b->f.K; a.ldk = b->f.ldk;
         a.dOh_other = dOh[1 - y]; a.nd_other = nd[1 - y]; a.dOh_own = dOh[y]; a.nd_own = nd[y]; a.lse_other = bs[1 - y]->f.lse;
         a.G = (bf16_t*)gs[y]; a.ldg = ldg; a.n = b->f.n; a.n_kv = b->f.n_kv;
+        a.jX = (const bf16_t*)(y ? jx1 : jx0); a.jZ = (const bf16_t*)(y ? jz1 : jz0); a.ldjx = ldjx; a.ldjz = ldjz;
         a.tiles = (a.n + 31) / 32; a.total = (int)(P * a.tiles);
     }
     hipStream_t st = (hipStream_t)stream;

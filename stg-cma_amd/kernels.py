@@ -1315,20 +1315,69 @@ def xattn_pair_bwd_supported(p0, p1):
     return bool(_lib.lib().stg_xattn_pair_bwd_supported(C.byref(a0.f), C.byref(a1.f)))
 
 
-@_family("xattn_bwd", lambda p0, p1: (("pair",) + tuple(_attn_cost(p0[0], 4, 2, 5)[0]), 2.0 * _attn_cost(p0[0], 5, 1, 5)[1], 2.0 * _attn_cost(p0[0], 4, 2, 5)[2]))
-def xattn_pair_bwd(p0, p1):
+@_family("xattn_bwd", lambda p0, p1, join=None, outs=None: (("pair",) + tuple(_attn_cost(p0[0], 4, 2, 5)[0]), 2.0 * _attn_cost(p0[0], 5 if join is None else 7, 1, 5)[1],
+                                                             2.0 * _attn_cost(p0[0], 4, 2, 5)[2]))
+def xattn_pair_bwd(p0, p1, join=None, outs=None):
     """Backward of a frame-global cross-modal pair, one pass per modality: p0 = (g, h_v, h_a, r_v, lse_v, d r_v), p1 = the mirror image.
-    Returns (G_v, G_a): the complete gradients of h_v / h_a through both directions (what attn_bwd2's dQ_0 + dKV_1 and dQ_1 + dKV_0 sum to)."""
+    Returns (G_v, G_a): the complete gradients of h_v / h_a through both directions (what attn_bwd2's dQ_0 + dKV_1 and dQ_1 + dKV_0 sum to).
+    join = (dX_v, Z_v, dX_a, Z_a): returns ((dX_v + G_v) * Z_v, (dX_a + G_a) * Z_a) instead -- the join of the adapters' backward (add3_mul2)
+    inside the same launch; outs = destination tensors."""
     a0, a1 = _xpair_args(p0, p1)
     g0, g1 = p0[0], p1[0]
     dev = p0[1].device
-    G0 = torch.empty((p0[1].shape[0], g0.D), dtype=BF16, device=dev)
-    G1 = torch.empty((p1[1].shape[0], g1.D), dtype=BF16, device=dev)
+    if outs is None:
+        outs = (torch.empty((p0[1].shape[0], g0.D), dtype=BF16, device=dev), torch.empty((p1[1].shape[0], g1.D), dtype=BF16, device=dev))
+    G0, G1 = outs
+    for t, ref in ((G0, p0[1]), (G1, p1[1])):
+        _chk2d(t, "G", BF16, cols=g0.D, rows=ref.shape[0])
+    if _ld(G0) != _ld(G1):
+        raise RuntimeError("xattn_pair_bwd: the two outputs must share one leading dimension")
     nb = int(_lib.lib().stg_xattn_pair_bwd_ws_bytes(g0.P, g0.n, g1.n, g0.D))
     ws = torch.empty((nb + 15) // 16 * 4, dtype=F32, device=dev)
-    _lib.check(_lib.lib().stg_xattn_pair_bwd(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(ws), ws.numel() * 4, _stream()),
-               "stg_xattn_pair_bwd")
+    if join is None:
+        _lib.check(_lib.lib().stg_xattn_pair_bwd(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(ws), ws.numel() * 4, _stream()),
+                   "stg_xattn_pair_bwd")
+        return G0, G1
+    dx0, z0, dx1, z1 = join
+    for t, ref in ((dx0, p0[1]), (z0, p0[1]), (dx1, p1[1]), (z1, p1[1])):
+        _chk2d(t, "join operand", BF16, cols=g0.D, rows=ref.shape[0])
+    if _ld(dx0) != _ld(dx1) or _ld(z0) != _ld(z1):
+        raise RuntimeError("xattn_pair_bwd: the join operands of the two modalities must share leading dimensions")
+    _lib.check(_lib.lib().stg_xattn_pair_bwd_join(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(dx0), _p(dx1), _ld(dx0), _p(z0), _p(z1),
+                                                  _ld(z0), _p(ws), ws.numel() * 4, _stream()), "stg_xattn_pair_bwd_join")
     return G0, G1
+
+
+@_family("xattn_fwd", lambda g0, Q0, K0, g1, Q1, K1, gate0, gate1: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(g0, 2, 2, 2))))
+def xattn_fwd2_gate(g0, Q0, K0, g1, Q1, K1, gate0, gate1):
+    """Forward of a frame-global cross-modal pair (K == V) with its gates in one launch: returns ((O0, lse0, X0), (O1, lse1, X1)) with
+    X = Q + gate * O.  Needs xattn_pair_bwd_supported's geometry (check with xattn_pair_fwd_supported)."""
+    outs, args = [], []
+    for g, Q, K_, gate in ((g0, Q0, K0, gate0), (g1, Q1, K1, gate1)):
+        dev = Q.device
+        _attn_check_rows(Q, "Q", g, g.n, g.outer, g.map_q, dev)
+        _attn_check_rows(K_, "K", g, g.n_kv, g.outer_kv, g.map_kv, dev)
+        if gate.dtype != F32 or not gate.is_cuda or gate.numel() != 1:
+            raise RuntimeError("xattn_fwd2_gate: a gate must be a one-element fp32 GPU tensor")
+        out = torch.empty((Q.shape[0], g.D), dtype=BF16, device=dev)
+        x = torch.empty((Q.shape[0], g.D), dtype=BF16, device=dev)
+        lse = torch.empty((g.P, g.H, g.n), dtype=F32, device=dev)
+        a = _lib.AttnArgs()
+        _attn_fill(a, g, Q, K_, K_, out, lse)
+        outs.append((out, lse, x)); args.append(a)
+    _lib.check(_lib.lib().stg_xattn_fwd2_gate(C.byref(args[0]), C.byref(args[1]), _p(gate0), _p(gate1), _p(outs[0][2]), _p(outs[1][2]),
+                                              _ld(outs[0][2]), _stream()), "stg_xattn_fwd2_gate")
+    return outs[0], outs[1]
+
+
+def xattn_pair_fwd_supported(g0, Q0, K0, g1, Q1, K1):
+    """Can the pair's forward (and backward) run on the frame-global kernels as one mirror-image pair (stg_xattn_fwd2_gate / _pair_bwd)?"""
+    args = []
+    for g, Q, K_ in ((g0, Q0, K0), (g1, Q1, K1)):
+        a = _lib.AttnArgs()
+        _attn_fill(a, g, Q, K_, K_, Q, Q)             # O / lse only have to be non-null for the geometry check (never dereferenced)
+        args.append(a)
+    return bool(_lib.lib().stg_xattn_pair_bwd_supported(C.byref(args[0]), C.byref(args[1])))
 
 
 @_family("attn_bwd", lambda g, *a, **kw: _attn_cost(g, 5, 3, 5))

@@ -564,6 +564,10 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
+    if XATTN_MERGED and PAIR_EW and not window and hv.stride(0) == ha.stride(0) and K.xattn_pair_fwd_supported(ag_v, hv, ha, ag_a, ha, hv):
+        # both directions and the gates in one launch (the frame-global kernels write x = q + gate o beside o)
+        (rv, lse_v, hv2), (ra, lse_a, ha2) = K.xattn_fwd2_gate(ag_v, hv, ha, ag_a, ha, hv, gate_v, gate_a)
+        return hv2, ha2, (rv, ra, lse_v, lse_a)
     if PAIR_EW:
         (rv, lse_v), (ra, lse_a) = K.attn_fwd2(ag_v, hv, ha, ha, ag_a, ha, hv, hv)
     else:
@@ -603,6 +607,9 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     pv, pa = (ag_v, hv, ha, rv, lse_v, drv), (ag_a, ha, hv, ra, lse_a, dra)
     if XATTN_MERGED and K.xattn_pair_bwd_supported(pv, pa):
         # one pass per modality over the pair's shared score tiles (one exponential per score): G = dQ (own direction) + dK + dV (other)
+        if zs is not None and dhv2.stride(0) == dha2.stride(0) and zs[0].stride(0) == zs[1].stride(0) and \
+                (outs is None or outs[0].stride(0) == outs[1].stride(0)):
+            return K.xattn_pair_bwd(pv, pa, join=(dhv2, zs[0], dha2, zs[1]), outs=outs)      # ... and the join (dX + G) * act' in the same launch
         G_v, G_a = K.xattn_pair_bwd(pv, pa)
         if zs is None:
             return K.add(dhv2, G_v), K.add(dha2, G_a)

@@ -288,3 +288,35 @@ def test_cross_modal_pair_merged_backward_slow_path(stg, gpu):
             e_m = float((m.cpu()[rows] - r[rows]).abs().max()) / sc
             e_f = float((f.cpu()[rows] - r[rows]).abs().max()) / sc
             assert e_m <= max(2e-2, 2.0 * e_f), f"{name} frame {fr}: merged {e_m:.2e}, four-pass {e_f:.2e}"
+
+
+@pytest.mark.parametrize("P,n,D", [(3, 196, 32), (2, 3136, 16), (2, 130, 16)])
+def test_cross_modal_pair_fused_gate_and_join(stg, gpu, P, n, D):
+    """Round 5: the frame-global pair's forward writes the gated hidden states itself (stg_xattn_fwd2_gate) and its merged backward applies the
+    join (dX + G) * act' itself (stg_xattn_pair_bwd_join): against the launches they replace -- attn_fwd2 + gate_fwd2, xattn_pair_bwd + add3_mul2 --
+    bit for bit (the gate's fma against gate_fwd2's multiply-add: at most one bf16 ulp)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(90 + n)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(BF16).to(gpu)
+    hv, ha = bf(P * n, D, sc=0.7), bf(P * n, D, sc=0.7)
+    gate_v, gate_a = torch.tensor([0.37], device=gpu), torch.tensor([-1.21], device=gpu)
+    gv = k.AttnGeom(P, 1, n, D, G=1, outer=n, n_kv=n, outer_kv=n, scale=1.0)
+    assert k.xattn_pair_fwd_supported(gv, hv, ha, gv, ha, hv)
+    (rv, lv), (ra, la) = k.attn_fwd2(gv, hv, ha, ha, gv, ha, hv, hv)
+    xv, xa = k.gate_fwd2(hv, rv, gate_v, ha, ra, gate_a)
+    (rv2, lv2, xv2), (ra2, la2, xa2) = k.xattn_fwd2_gate(gv, hv, ha, gv, ha, hv, gate_v, gate_a)
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert eq(rv, rv2) and eq(ra, ra2) and torch.equal(lv, lv2) and torch.equal(la, la2)
+    for a, b in ((xv, xv2), (xa, xa2)):
+        d = (a.float() - b.float()).abs()
+        assert float((d / a.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7, "gated hidden state differs by more than one bf16 ulp"
+    dxv, dxa, zv, za = bf(P * n, D), bf(P * n, D), bf(P * n, D, sc=0.5), bf(P * n, D, sc=0.5)
+    dg_v, dg_a = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    drv, dra = k.gate_bwd2(dxv, rv, gate_v, dg_v, dxa, ra, gate_a, dg_a)
+    pv, pa = (gv, hv, ha, rv, lv, drv), (gv, ha, hv, ra, la, dra)
+    Gv, Ga = k.xattn_pair_bwd(pv, pa)
+    j0 = k.add3_mul2(dxv, Gv, None, zv, dxa, Ga, None, za)
+    buf = torch.full((2 * P * n, D), float("nan"), dtype=BF16, device=gpu)
+    j1 = k.xattn_pair_bwd(pv, pa, join=(dxv, zv, dxa, za), outs=(buf[:P * n], buf[P * n:]))
+    torch.cuda.synchronize()
+    assert eq(j0[0], j1[0]) and eq(j0[1], j1[1]), "fused join differs from add3_mul2 on the merged kernel's output"
