@@ -75,10 +75,12 @@ __device__ __forceinline__ bf16x8_t cw_frag(const bf16_t* tile, int t, int s, in
     return f;
 }
 
+// Round 5: (1) the LDS tiles are DOUBLE-BUFFERED -- the DMA of row block mb + 64 is issued right after the barrier that publishes block mb and lands
+// while block mb is multiplied: one barrier per 64 rows instead of two, and the DMA's trip to HBM no longer sits between them (the single-buffered
+// form ran at 0.12-0.49 PFLOP/s); (2) a 128-column tile may span TWO taps: I % 64 == 0 suffices (each 16-byte piece knows its own tap), which takes
+// the ASPP convolutions over the 64- and 320-channel maps off the im2col + atomic-wgrad path; columns >= taps * I are zero-filled and never stored.
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 64 * 128];
-    bf16_t* sY = smem;
-    bf16_t* sX = smem + 64 * 128;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];             // 2 buffers x (dY tile + X tile) x [64][128] bf16 = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave >> 1, wc = wave & 1;
@@ -88,15 +90,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
     const int tile = blockIdx.x % (p.nto * p.ntc), split = blockIdx.x / (p.nto * p.ntc);
     const int to = tile / p.ntc, tc = tile - to * p.ntc;
     const int o0 = to * 128, col0 = tc * 128;
-    const int tap = col0 / p.I, i0 = col0 - tap * p.I;
-    const int dy = p.taps == 9 ? (tap / 3 - 1) * p.d : 0, dx = p.taps == 9 ? (tap % 3 - 1) * p.d : 0;
-    const int64_t shift = (int64_t)dy * p.W + dx;
+    const int ncol = p.taps * p.I;
     const int64_t r0 = (int64_t)split * p.rows_per_split;
     int64_t r1 = r0 + p.rows_per_split;
     r1 = r1 < p.M ? r1 : p.M;
 
-    // DMA pieces: chunk q = j * 256 + tid (j = 0..3) -> tile row q >> 4 (0..63), position q & 15 <- source chunk (q & 15) ^ swz(row)
-    int prow[4], pch[4], py[4], px[4];
+    // DMA pieces: chunk q = j * 256 + tid (j = 0..3) -> tile row q >> 4 (0..63), position q & 15 <- source chunk (q & 15) ^ swz(row);
+    // the source chunk fixes the piece's column, hence its tap and its pixel shift
+    int prow[4], pch[4], py[4], px[4], pdy[4], pdx[4], pi0[4];
+    int64_t pshift[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = j * 256 + tid;
@@ -106,6 +108,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
         const int rem = (int)(m % ((int64_t)p.H * p.W));
         py[j] = rem / p.W;
         px[j] = rem - py[j] * p.W;
+        const int col = col0 + pch[j] * 8;
+        const int tap = col / p.I;
+        pi0[j] = col < ncol ? col - tap * p.I : -1;                      // -1: a column past the last tap (zero-filled)
+        pdy[j] = p.taps == 9 ? (tap / 3 - 1) * p.d : 0;
+        pdx[j] = p.taps == 9 ? (tap % 3 - 1) * p.d : 0;
+        pshift[j] = (int64_t)pdy[j] * p.W + pdx[j];
     }
     const int adv_y = 64 / p.W, adv_x = 64 - adv_y * p.W;
 
@@ -123,25 +131,34 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
     bf16x8_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
-    for (int64_t mb = r0; mb < r1; mb += 64) {
+
+    auto issue = [&](int64_t mb, int buf) {                  // row block mb -> buffer buf; advances the pieces' pixel coordinates by 64 rows
+        bf16_t* sY = smem + buf * (2 * 64 * 128);
+        bf16_t* sX = sY + 64 * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t m = mb + prow[j];
             const bool live = m < r1;
-            const int yy = py[j] + dy, xx = px[j] + dx;
-            const bool in = live && (p.taps == 1 || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W));
+            const int yy = py[j] + pdy[j], xx = px[j] + pdx[j];
+            const bool in = live && pi0[j] >= 0 && (p.taps == 1 || (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W));
             const bf16_t* sy = (live && o0 + pch[j] * 8 < p.O) ? p.dy + m * p.lddy + o0 + pch[j] * 8 : p.zero;      // O % 128 != 0: zero columns
-            const bf16_t* sx = in ? p.x + (m + shift) * p.ldx + i0 + pch[j] * 8 : p.zero;
+            const bf16_t* sx = in ? p.x + (m + pshift[j]) * p.ldx + pi0[j] : p.zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
                                              (__attribute__((address_space(3))) void*)(sY + (j * 256 + wave * 64) * 8), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
                                              (__attribute__((address_space(3))) void*)(sX + (j * 256 + wave * 64) * 8), 16, 0, 0);
-            // this row's pixel 64 rows further on
-            px[j] += adv_x; py[j] += adv_y;
+            px[j] += adv_x; py[j] += adv_y;                  // this row's pixel 64 rows further on
             if (px[j] >= p.W) { px[j] -= p.W; py[j] += 1; }
             if (py[j] >= p.H) { py[j] -= p.H; if (py[j] >= p.H) py[j] -= p.H; }
         }
-        __syncthreads();                                    // (drains vmcnt) the tile has landed
+    };
+    issue(r0, 0);
+    int cur = 0;
+    for (int64_t mb = r0; mb < r1; mb += 64, cur ^= 1) {
+        __syncthreads();                                    // (drains vmcnt) block mb has landed; every wave is done reading the OTHER buffer
+        if (mb + 64 < r1) issue(mb + 64, cur ^ 1);          // lands while this block is multiplied
+        const bf16_t* sY = smem + cur * (2 * 64 * 128);
+        const bf16_t* sX = sY + 64 * 128;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8_t fy[4], fx[4];
@@ -160,7 +177,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
                 for (int ot = 0; ot < 4; ++ot) accb[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fy[ot], accb[ot], 0, 0, 0);
             }
         }
-        __syncthreads();                                    // every wave is done reading before the next tile's DMA
     }
     // partial tile -> workspace: lane (o = l & 15, g = l >> 4) holds columns 4 g .. 4 g + 3 of each 16-column tile
     const int o_l = lane & 15, g = lane >> 4;
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(CwP p) {
     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-            if (o0 + wo * 64 + ot * 16 + o_l < p.O)
+            if (o0 + wo * 64 + ot * 16 + o_l < p.O && col0 + wc * 64 + ct * 16 + 4 * g < ncol)
                 *reinterpret_cast<f32x4_t*>(wsp + (int64_t)(ot * 16 + o_l) * ldws + ct * 16 + 4 * g) = acc[ct][ot];
 }
 
@@ -416,8 +432,8 @@ extern "C" int stg_bn_bwd(const void* x, const void* dy, const float* mean, cons
 }
 
 static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) {
-    if (M <= 0 || O <= 0 || I <= 0 || O % 8 != 0 || I % 128 != 0) return -1;      // O is padded to 128 with zero columns inside the kernel
-    const int tiles = ((O + 127) / 128) * (taps * I / 128);
+    if (M <= 0 || O <= 0 || I <= 0 || O % 8 != 0 || I % 64 != 0) return -1;       // O and taps * I are padded to 128 with zero columns inside the kernel
+    const int tiles = ((O + 127) / 128) * ((taps * I + 127) / 128);
     int64_t splits = (1024 + tiles - 1) / tiles;                       // ~4 blocks per CU
     const int64_t max_splits = (M + 2047) / 2048;                      // >= 2048 rows per block
     if (splits > max_splits) splits = max_splits;
@@ -430,8 +446,8 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
                      int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1,
                      float* dbws = nullptr) {
     STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
-    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 128 == 0 && O > 0 && I > 0, -2,
-              "%s: needs O %% 8 == 0 and I %% 128 == 0", who);
+    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 64 == 0 && O > 0 && I > 0, -2,
+              "%s: needs O %% 8 == 0 and I %% 64 == 0", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "%s: bad leading dimensions", who);
     STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;
@@ -445,8 +461,11 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
     p.M = M; p.H = H; p.W = W; p.d = dilation; p.O = O; p.I = I; p.taps = taps;
     p.splits = splits;
     p.rows_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
-    p.nto = (O + 127) / 128; p.ntc = taps * I / 128;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits), (unsigned)batch), dim3(256), 0, ST, p);
+    p.nto = (O + 127) / 128; p.ntc = (taps * I + 127) / 128;
+    static std::atomic<uint64_t> lds_done{0};
+    constexpr int CW_LDS = 2 * 2 * 64 * 128 * 2;
+    STG_CHECK(stg_reserve_lds(conv_wgrad_kernel, CW_LDS, lds_done), -101, "%s: cannot reserve %d bytes of LDS", who, CW_LDS);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(p.nto * p.ntc * splits), (unsigned)batch), dim3(256), CW_LDS, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -1809,7 +1809,7 @@ def im2col3x3(x, F_, H, W, dilation):
 
 
 def conv3x3_wgrad_supported(O, I):
-    return O % 8 == 0 and I % 128 == 0
+    return O % 8 == 0 and I % 64 == 0
 
 
 @_family_io("dec_conv_wgrad", flops=lambda dy, x, F_, H, W, dilation, want_db=False: 18.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
@@ -1823,7 +1823,7 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     splits = C.c_int(0)
     n = _lib.lib().stg_conv3x3_wgrad_ws_floats(M, O, I, C.byref(splits))
     if n <= 0:
-        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 128 == 0)")
+        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 64 == 0)")
     ws = torch.empty((splits.value, O, 9 * I), dtype=F32, device=x.device)
     dbw = torch.empty((splits.value, O), dtype=F32, device=x.device) if want_db else None
     _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), _p(dbw), F_, H, W, O, I,

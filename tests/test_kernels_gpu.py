@@ -264,6 +264,10 @@ def test_elementwise(stg, gpu):
     _close(big[:, C:], x.float().view(G, n, C).mean(1), tol=1e-3, what="meanpool")
     d = _bf(torch.randn(G, C, generator=g))
     _close(k.meanpool_bwd(d.to(gpu), G, n), (d.float() / n)[:, None, :].expand(G, n, C).reshape(G * n, C), what="meanpool bwd")
+    for G2, n2, C2 in ((5, 3136, 128), (3, 784, 256), (2, 300, 24), (4, 257, 1024)):      # long groups: the workgroup-per-group kernel (round 5)
+        x2 = _bf(torch.randn(G2 * n2, C2, generator=g))
+        _close(k.meanpool_fwd(x2.to(gpu), G2, n2), x2.float().view(G2, n2, C2).mean(1), tol=4e-3, what=f"meanpool {G2}x{n2}x{C2}")
+        _close(k.meanpool_fwd(x2.to(gpu), G2, n2, out_dtype=F32), x2.float().view(G2, n2, C2).mean(1), tol=1e-4, what=f"meanpool f32 {G2}x{n2}x{C2}")
     # bias gather / scatter
     L, H, nn_ = 13, 4, 49
     table = torch.randn(L, H, generator=g); index = torch.randint(0, L, (nn_,), generator=g)
@@ -371,7 +375,10 @@ def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
 
 
 @pytest.mark.parametrize("F_,H,W,I,O,d", [(3, 14, 14, 128, 128, 1), (2, 28, 28, 256, 256, 3), (7, 7, 7, 256, 128, 1), (2, 14, 14, 256, 256, 18),
-                                          (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1), (2, 28, 28, 128, 32, 1), (1, 14, 14, 128, 200, 2)])
+                                          (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1), (2, 28, 28, 128, 32, 1), (1, 14, 14, 128, 200, 2),
+                                          # round 5: I % 64 == 0 (a 128-column tile spans two taps; 9 I not a multiple of 128: a zero-filled tail) and
+                                          # odd row-block counts for the double-buffered ring
+                                          (3, 56, 56, 64, 256, 3), (2, 14, 14, 320, 256, 12), (1, 7, 7, 64, 128, 1), (5, 28, 28, 192, 64, 2), (1, 9, 7, 64, 8, 1)])
 def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
     """The conv weight gradient without the im2col image against autograd of F.conv2d in fp32 (same bf16-rounded operands)."""
     from stgcma import kernels as k
