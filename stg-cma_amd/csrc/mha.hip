@@ -77,45 +77,45 @@ __device__ __forceinline__ bf16x8_t nat_frag(const bf16_t* s, int r, int hh, int
 // NTILE = 1 where K and V are one tensor (the adapters' cross-modal attention), LDS double-buffered: ONE barrier per tile.
 template <int N> using U4Arr = u32x4_t[N];      // a native vector type: arrays of HIP's uint4 struct are not promoted to registers
 template <int N> using IArr = int[N];
-template <int D, int NTILE, int NW = 4> struct StageC {
+template <int D, int NTILE, int NW = 4, int TH = 32> struct StageC {      // TH = rows per staged tile (32, or 64 in the two-tiles-per-trip kernels)
     static constexpr int NTHR = NW * 64;
-    static constexpr int TOTAL = NTILE * 4 * D;                 // 16-byte pieces: NTILE tiles x 32 rows x D / 8
+    static constexpr int TOTAL = NTILE * (TH / 8) * D;          // 16-byte pieces: NTILE tiles x TH rows x D / 8
     static constexpr int PER = (TOTAL + NTHR - 1) / NTHR;
     static constexpr int DP = D + 8;
-    static constexpr int TILE = 32 * DP;                        // elements per LDS tile
+    static constexpr int TILE = TH * DP;                        // elements per LDS tile
 };
-template <int D, int NTILE, int NW>
-__device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE, NW>::PER>& lds_off, IArr<StageC<D, NTILE, NW>::PER>& src_col,
-                                           IArr<StageC<D, NTILE, NW>::PER>& row) {
-    using C = StageC<D, NTILE, NW>;
+template <int D, int NTILE, int NW, int TH = 32>
+__device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE, NW, TH>::PER>& lds_off, IArr<StageC<D, NTILE, NW, TH>::PER>& src_col,
+                                           IArr<StageC<D, NTILE, NW, TH>::PER>& row) {
+    using C = StageC<D, NTILE, NW, TH>;
 #pragma unroll
     for (int i = 0; i < C::PER; ++i) {
         const int id = tid + C::NTHR * i;
-        const int which = id / (4 * D), rem = id - which * 4 * D;
+        const int which = id / ((TH / 8) * D), rem = id - which * (TH / 8) * D;
         const int r = rem / (D / 8), c = rem - r * (D / 8);
-        row[i] = (C::TOTAL % C::NTHR != 0 && id >= C::TOTAL) ? -1 : r + 32 * which;        // -1: this thread has no i-th piece; bit 5 = tile
+        row[i] = (C::TOTAL % C::NTHR != 0 && id >= C::TOTAL) ? -1 : r + TH * which;        // -1: this thread has no i-th piece; bit log2(TH) = tile
         lds_off[i] = which * C::TILE + r * C::DP + 8 * c;
         src_col[i] = h * D + 8 * c;
     }
 }
-template <int D, int NTILE, int NW>
-__device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE, NW>::PER>& v, const IArr<StageC<D, NTILE, NW>::PER>& src_col,
-                                            const IArr<StageC<D, NTILE, NW>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
+template <int D, int NTILE, int NW, int TH = 32>
+__device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE, NW, TH>::PER>& v, const IArr<StageC<D, NTILE, NW, TH>::PER>& src_col,
+                                            const IArr<StageC<D, NTILE, NW, TH>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
                                             int64_t frame_row0, int n, int row0) {
 #pragma unroll
-    for (int i = 0; i < StageC<D, NTILE, NW>::PER; ++i) {
+    for (int i = 0; i < StageC<D, NTILE, NW, TH>::PER; ++i) {
         if (row[i] < 0) continue;
-        int tok = row0 + (row[i] & 31);
+        int tok = row0 + (row[i] & (TH - 1));
         tok = tok < n ? tok : n - 1;
-        const bf16_t* src = (NTILE == 2 && (row[i] & 32)) ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
+        const bf16_t* src = (NTILE == 2 && (row[i] & TH)) ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
         v[i] = *reinterpret_cast<const u32x4_t*>(src + src_col[i]);
     }
 }
-template <int D, int NTILE, int NW>
-__device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NTILE, NW>::PER>& v, const IArr<StageC<D, NTILE, NW>::PER>& lds_off,
-                                             const IArr<StageC<D, NTILE, NW>::PER>& row) {
+template <int D, int NTILE, int NW, int TH = 32>
+__device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NTILE, NW, TH>::PER>& v, const IArr<StageC<D, NTILE, NW, TH>::PER>& lds_off,
+                                             const IArr<StageC<D, NTILE, NW, TH>::PER>& row) {
 #pragma unroll
-    for (int i = 0; i < StageC<D, NTILE, NW>::PER; ++i)
+    for (int i = 0; i < StageC<D, NTILE, NW, TH>::PER; ++i)
         if (row[i] >= 0) *reinterpret_cast<u32x4_t*>(s + lds_off[i]) = v[i];
 }
 
@@ -286,6 +286,194 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward / dQ, TWO key tiles per trip (round 5)
+// The one-tile kernels above run a tile's phases one after the other inside a wave -- score MFMAs, wait, softmax VALU, transposed reads, P.V MFMAs --
+// and met only other WAVES' work to fill the gaps (SQ counters: waves waiting 52-57 % of their cycles, matrix pipe busy 28-30 %,
+// profiles/r05_mha_sq_counters.txt).  Here a trip covers 64 keys: the two tiles' MFMA chains are independent, so tile B's score MFMAs execute while
+// tile A's softmax issues, the statistics are updated once per 64 keys, and there is one barrier per 64 keys.  Staged tiles are [64][D + 8].
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
+    using SC = StageC<D, NTILE, NW, 64>;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];                  // two buffers x NTILE x [64][DP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int q0 = 32 * (qb * NW + wave);
+    const bool live = q0 < a.n;
+    const int q = q0 + r;
+    const int qc = q < a.n ? q : a.n - 1;
+    bf16x8_t qf[KS];
+    {
+        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
+    }
+    f32x16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+    float m = NEG_BIG, l = 0.f;
+
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
+    __syncthreads();
+    const int np = (a.nt + 1) >> 1;
+    for (int kp = 0; kp < np; ++kp) {
+        const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
+        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 64 * (kp + 1));
+        if (live) {
+        f32x16_t sA = zero16(), sB = zero16();         // St[key][q] of keys 64 kp .. + 31 / + 32 .. + 63
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sA = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sA);
+            sB = MFMA32(nat_frag<DP>(sK + 32 * DP, r, hh, s), qf[s], sB);
+        }
+        float xA[16], xB[16];
+        float mx = m;
+        const int kbase = 64 * kp;
+        const bool tail = kbase + 64 > a.n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            xA[reg] = sA[reg] * a.scale2;
+            xB[reg] = sB[reg] * a.scale2;
+            if (tail) {
+                if (kbase + ACC_ROW(reg, hh) >= a.n) xA[reg] = NEG_BIG;
+                if (kbase + 32 + ACC_ROW(reg, hh) >= a.n) xB[reg] = NEG_BIG;
+            }
+            mx = fmaxf(mx, fmaxf(xA[reg], xB[reg]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);
+        m = mx;
+        float ls = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            xA[reg] = __builtin_amdgcn_exp2f(xA[reg] - mx);
+            xB[reg] = __builtin_amdgcn_exp2f(xB[reg] - mx);
+            ls += xA[reg] + xB[reg];
+        }
+        ls += __shfl_xor(ls, 32, 64);
+        l = l * alpha + ls;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // rescale only when some query's maximum moved
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) o[dt][reg] *= alpha;
+        }
+        const bf16x8_t pA0 = pack8(xA), pA1 = pack8(xA + 8), pB0 = pack8(xB), pB1 = pack8(xB + 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 0, hh, r), pA0, o[dt]);
+            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), pA1, o[dt]);
+            o[dt] = MFMA32(tr_frag<DP>(sV + 32 * DP, dt, 0, hh, r), pB0, o[dt]);
+            o[dt] = MFMA32(tr_frag<DP>(sV + 32 * DP, dt, 1, hh, r), pB1, o[dt]);
+        }
+        }
+        if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
+    }
+    {
+        const float inv = 1.0f / l;
+        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, q < a.n);
+        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
+    }
+}
+
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
+    using SC = StageC<D, NTILE, NW, 64>;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int q = 32 * (qb * NW + wave) + r;
+    const bool live = 32 * (qb * NW + wave) < a.n;
+    const int qc = q < a.n ? q : a.n - 1;
+    bf16x8_t qf[KS], dof[KS];
+    float delta = 0.f;
+    {
+        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* dp = a.dO + (frow + qc) * a.lddo + h * D + 8 * hh;
+        const bf16_t* op = a.O + (frow + qc) * a.ldo + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = ld_frag(qp + 16 * s);
+            dof[s] = ld_frag(dp + 16 * s);
+            const bf16x8_t of = ld_frag(op + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const int64_t si = ((int64_t)p * a.H + h) * a.n + qc;
+    const float lse = a.lse[si];
+    if (q < a.n && hh == 0) a.delta[si] = delta;
+    f32x16_t dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
+    __syncthreads();
+    const int np = (a.nt + 1) >> 1;
+    for (int kp = 0; kp < np; ++kp) {
+        const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
+        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 64 * (kp + 1));
+        if (live) {
+        f32x16_t scA = zero16(), dpA = zero16(), scB = zero16(), dpB = zero16();         // St[key][q], dPt[key][q] of the two key tiles
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8_t kA = nat_frag<DP>(sK, r, hh, s), kB = nat_frag<DP>(sK + 32 * DP, r, hh, s);
+            scA = MFMA32(kA, qf[s], scA);
+            scB = MFMA32(kB, qf[s], scB);
+            dpA = MFMA32(KV1 ? kA : nat_frag<DP>(sV, r, hh, s), dof[s], dpA);
+            dpB = MFMA32(KV1 ? kB : nat_frag<DP>(sV + 32 * DP, r, hh, s), dof[s], dpB);
+        }
+        float dsA[16], dsB[16];
+        const int kbase = 64 * kp;
+        const bool tail = kbase + 64 > a.n;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float pa = __builtin_amdgcn_exp2f(scA[reg] * a.scale2 - lse), pb = __builtin_amdgcn_exp2f(scB[reg] * a.scale2 - lse);
+            if (tail) {
+                if (kbase + ACC_ROW(reg, hh) >= a.n) pa = 0.f;
+                if (kbase + 32 + ACC_ROW(reg, hh) >= a.n) pb = 0.f;
+            }
+            dsA[reg] = pa * (dpA[reg] - delta);
+            dsB[reg] = pb * (dpB[reg] - delta);
+        }
+        const bf16x8_t a0 = pack8(dsA), a1 = pack8(dsA + 8), b0 = pack8(dsB), b1 = pack8(dsB + 8);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 0, hh, r), a0, dq[dt]);
+            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), a1, dq[dt]);
+            dq[dt] = MFMA32(tr_frag<DP>(sK + 32 * DP, dt, 0, hh, r), b0, dq[dt]);
+            dq[dt] = MFMA32(tr_frag<DP>(sK + 32 * DP, dt, 1, hh, r), b1, dq[dt]);
+        }
+        }
+        if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
+    }
+    {
+        bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, dq[dt], a.scale, hh, q < a.n);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int D, bool KV1, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a) {
@@ -405,6 +593,131 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
     }
 }
 
+// two QUERY tiles per trip (round 5): the staged Q / dO tiles are [64][D + 8], one barrier per 64 queries
+template <int D, bool KV1, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NKV = KV1 ? 1 : 2;
+    using SC = StageC<D, 2, NW, 64>;
+    // two buffers of {shared Q / dO tiles + lse / delta of the query tile}, then per wave its own K (and V) tile
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // dkv_lds_bytes(D, KV1) (dynamic: > 64 KiB at D = 96)
+    constexpr int BUF = 2 * 64 * DP + 256;                              // elements per buffer: Q and dO tiles of 64 queries + 128 floats of statistics
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
+    bf16_t* sV = KV1 ? sK : sK + 32 * DP;
+    const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int64_t frow = (int64_t)p * a.n;
+    const int key = 32 * (kb * NW + wave) + r;
+    const bool live = 32 * (kb * NW + wave) < a.n;
+    const int kc = key < a.n ? key : a.n - 1;
+    {   // own K / V tile: natural rows (keys) -> wave-private LDS; read back as B operands (columns = keys)
+        const bf16_t* kp = a.K + (frow + kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* vp = a.V + (frow + kc) * a.ld + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(sK + r * DP + 16 * s + 8 * hh) = ld_frag(kp + 16 * s);
+            if (!KV1) *reinterpret_cast<bf16x8_t*>(sV + r * DP + 16 * s + 8 * hh) = ld_frag(vp + 16 * s);
+        }
+    }
+    f32x16_t dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+    const int64_t sbase = ((int64_t)p * a.H + h) * a.n;
+
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, 2, NW, 64>(tid, h, lo, sc_, rw);
+    float nl = 0.f, nd = 0.f;
+    auto fetch_stats = [&](int q0) {
+        if (tid < 64) {
+            int qi = q0 + tid;
+            qi = qi < a.n ? qi : a.n - 1;
+            nl = a.lse[sbase + qi];
+            nd = a.delta[sbase + qi];
+        }
+    };
+    auto commit_all = [&](bf16_t* buf) {
+        stage_commit<D, 2, NW, 64>(buf, sv, lo, rw);
+        float* st = reinterpret_cast<float*>(buf + 2 * 64 * DP);
+        if (tid < 64) { st[tid] = nl; st[64 + tid] = nd; }
+    };
+    stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
+    fetch_stats(0);
+    commit_all(smem);
+    __syncthreads();
+    const int np = (a.nt + 1) >> 1;
+    for (int qp = 0; qp < np; ++qp) {
+        const bf16_t* sQ = smem + (qp & 1) * BUF;
+        const bf16_t* sD = sQ + 64 * DP;
+        const float* sLse = reinterpret_cast<const float*>(sQ + 2 * 64 * DP);
+        const float* sDel = sLse + 64;
+        if (qp + 1 < np) {
+            stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 64 * (qp + 1));
+            fetch_stats(64 * (qp + 1));
+        }
+        if (live) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {             // the two query tiles of the trip: independent MFMA chains behind one barrier
+            const bf16_t* tQ = sQ + half * 32 * DP;
+            const bf16_t* tD = sD + half * 32 * DP;
+            f32x16_t sc = zero16(), dp = zero16();         // S[q][key], dP[q][key]
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8_t kf = nat_frag<DP>(sK, r, hh, s);
+                sc = MFMA32(nat_frag<DP>(tQ, r, hh, s), kf, sc);
+                dp = MFMA32(nat_frag<DP>(tD, r, hh, s), KV1 ? kf : nat_frag<DP>(sV, r, hh, s), dp);
+            }
+            float pr[16], ds[16];
+            const int qbase = 64 * qp + 32 * half;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ls = *reinterpret_cast<const float4*>(sLse + 32 * half + 8 * g4 + 4 * hh);
+                const float4 de = *reinterpret_cast<const float4*>(sDel + 32 * half + 8 * g4 + 4 * hh);
+                const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int reg = 4 * g4 + c;
+                    const bool okq = qbase + 8 * g4 + 4 * hh + c < a.n;              // padded query rows contribute nothing
+                    const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 - lsv[c]) : 0.f;
+                    pr[reg] = pv;
+                    ds[reg] = pv * (dp[reg] - dev[c]);
+                }
+            }
+            const bf16x8_t p0 = pack8(pr), p1 = pack8(pr + 8), d0 = pack8(ds), d1 = pack8(ds + 8);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = MFMA32(tr_frag<DP>(tD, dt, 0, hh, r), p0, dv[dt]);
+                dv[dt] = MFMA32(tr_frag<DP>(tD, dt, 1, hh, r), p1, dv[dt]);
+                dk[dt] = MFMA32(tr_frag<DP>(tQ, dt, 0, hh, r), d0, dk[dt]);
+                dk[dt] = MFMA32(tr_frag<DP>(tQ, dt, 1, hh, r), d1, dk[dt]);
+            }
+        }
+        }
+        if (qp + 1 < np) commit_all(smem + ((qp + 1) & 1) * BUF);
+        __syncthreads();
+    }
+    {
+        const bool okk = key < a.n;
+        bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
+        if (a.dV == nullptr) {                         // K and V are ONE tensor (cross-modal attention): its gradient is dK + dV
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x16_t c;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c[i] = fmaf(dk[dt][i], a.scale, dv[dt][i]);
+                store_tile32(kp + 32 * dt, c, 1.0f, hh, okk);
+            }
+            return;
+        }
+        bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            store_tile32(kp + 32 * dt, dk[dt], a.scale, hh, okk);
+            store_tile32(vp + 32 * dt, dv[dt], 1.0f, hh, okk);
+        }
+    }
+}
+
 constexpr int dkv_lds_bytes(int D, bool kv1, int nw) { return (2 * (2 * 32 * (D + 8) + 128) + nw * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
 
 template <int D, bool KV1, int NW>
@@ -413,6 +726,32 @@ int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
     const bool attr_set = stg_reserve_lds(mha_dkv_kernel<D, KV1, NW>, dkv_lds_bytes(D, KV1, NW), done);
     STG_CHECK(attr_set, -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv_lds_bytes(D, KV1, NW));
     hipLaunchKernelGGL((mha_dkv_kernel<D, KV1, NW>), grid, dim3(NW * 64), dkv_lds_bytes(D, KV1, NW), stream, p);
+    return 0;
+}
+
+template <int D, bool KV1, int NW>
+int launch_fwd2(const dim3& grid, const MP& p, hipStream_t stream) {
+    static std::atomic<uint64_t> done{0};
+    constexpr int lds = 2 * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
+    STG_CHECK(stg_reserve_lds(mha_fwd2_kernel<D, KV1, NW>, lds, done), -101, "stg_mha_fwd: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL((mha_fwd2_kernel<D, KV1, NW>), grid, dim3(NW * 64), lds, stream, p);
+    return 0;
+}
+template <int D, bool KV1, int NW>
+int launch_dq2(const dim3& grid, const MP& p, hipStream_t stream) {
+    static std::atomic<uint64_t> done{0};
+    constexpr int lds = 2 * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
+    STG_CHECK(stg_reserve_lds(mha_dq2_kernel<D, KV1, NW>, lds, done), -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL((mha_dq2_kernel<D, KV1, NW>), grid, dim3(NW * 64), lds, stream, p);
+    return 0;
+}
+
+constexpr int dkv2_lds_bytes(int D, bool kv1, int nw) { return (2 * (2 * 64 * (D + 8) + 256) + nw * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
+template <int D, bool KV1, int NW>
+int launch_dkv2(const dim3& grid, const MP& p, hipStream_t stream) {
+    static std::atomic<uint64_t> done{0};
+    STG_CHECK(stg_reserve_lds(mha_dkv2_kernel<D, KV1, NW>, dkv2_lds_bytes(D, KV1, NW), done), -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", dkv2_lds_bytes(D, KV1, NW));
+    hipLaunchKernelGGL((mha_dkv2_kernel<D, KV1, NW>), grid, dim3(NW * 64), dkv2_lds_bytes(D, KV1, NW), stream, p);
     return 0;
 }
 
@@ -452,8 +791,9 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;
-#define STG_MHA_FWD(DD, KV, NW) hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p)
-#define STG_MHA_FWD2(DD, KV) { if (nw == 8) STG_MHA_FWD(DD, KV, 8); else STG_MHA_FWD(DD, KV, 4); }
+    const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
+#define STG_MHA_FWD(DD, KV, NW) { if (kt2) { rc = launch_fwd2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); }
+#define STG_MHA_FWD2(DD, KV) { if (nw == 8) STG_MHA_FWD(DD, KV, 8) else STG_MHA_FWD(DD, KV, 4) }
     if (f->D == 64) { if (kv1) STG_MHA_FWD2(64, true) else STG_MHA_FWD2(64, false) }
     else { if (kv1) STG_MHA_FWD2(96, true) else STG_MHA_FWD2(96, false) }
 #undef STG_MHA_FWD2
@@ -480,7 +820,9 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
     hipStream_t st = (hipStream_t)stream;
-#define STG_MHA_BWD(DD, KV, NW) { hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); STG_LAUNCH_CHECK(); rc = launch_dkv<DD, KV, NW>(grid, p, st); }
+    const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
+#define STG_MHA_BWD(DD, KV, NW) { if (kt2) { rc = launch_dq2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); \
+                                  STG_LAUNCH_CHECK(); rc = (kt2 && dkv2_lds_bytes(DD, KV, NW) <= 160 * 1024 && !(DD == 96 && !KV && NW == 4) /* 256 VGPRs + spills */ && !stg_opt_mha_dkv1.load(std::memory_order_relaxed)) ? launch_dkv2<DD, KV, NW>(grid, p, st) : launch_dkv<DD, KV, NW>(grid, p, st); }
 #define STG_MHA_BWD2(DD, KV) { if (nw == 8) STG_MHA_BWD(DD, KV, 8) else STG_MHA_BWD(DD, KV, 4) }
     if (f->D == 64) { if (kv1) STG_MHA_BWD2(64, true) else STG_MHA_BWD2(64, false) }
     else { if (kv1) STG_MHA_BWD2(96, true) else STG_MHA_BWD2(96, false) }
