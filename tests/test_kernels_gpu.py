@@ -689,3 +689,19 @@ def test_hot_kernels_are_reproducible(stg, gpu):
     dq = torch.empty_like(qkv)
     stress("winattn_fwd", lambda: (K.winattn_fwd(wg, Q, Kk, V)[0],))
     stress("winattn_bwd", lambda: (K.winattn_bwd(wg, Q, Kk, V, O, lse, dO, dQ=dq[:, :C], dK=dq[:, C:2 * C], dV=dq[:, 2 * C:]) and dq,))
+    # round 5's new kernels: the merged cross-modal backward (+ join), the two-tiles-per-trip mha kernels, the double-buffered conv wgrad
+    P_, nv, na, D = 3, 197, 130, 16
+    hv, ha, dv, da = bf(P_ * nv, D, sc=0.7), bf(P_ * na, D, sc=0.7), bf(P_ * nv, D), bf(P_ * na, D)
+    gv = K.AttnGeom(P_, 1, nv, D, G=1, outer=nv, n_kv=na, outer_kv=na, scale=1.0)
+    ga = K.AttnGeom(P_, 1, na, D, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=1.0)
+    (Rv, Lv), (Ra, La) = K.attn_fwd2(gv, hv, ha, ha, ga, ha, hv, hv)
+    stress("xattn_pair_bwd", lambda: K.xattn_pair_bwd((gv, hv, ha, Rv, Lv, dv), (ga, ha, hv, Ra, La, da)), reps=300)
+    mg = K.MhaGeom(6, 8, 197, 96, 96 ** -0.5)
+    qkv2, dO2 = bf(6 * 197, 3 * 768, sc=0.5), bf(6 * 197, 768)
+    Q2, K2, V2 = qkv2[:, :768], qkv2[:, 768:1536], qkv2[:, 1536:]
+    O2, l2 = K.mha_fwd(mg, Q2, K2, V2)
+    dqkv2 = torch.empty_like(qkv2)
+    stress("mha_fwd", lambda: (K.mha_fwd(mg, Q2, K2, V2)[0],), reps=300)
+    stress("mha_bwd", lambda: (K.mha_bwd(mg, Q2, K2, V2, O2, l2, dO2, dQ=dqkv2[:, :768], dK=dqkv2[:, 768:1536], dV=dqkv2[:, 1536:]) and dqkv2,), reps=300)
+    xc, dyc = bf(3 * 28 * 28, 64), bf(3 * 28 * 28, 256)
+    stress("conv3x3_wgrad", lambda: (K.conv3x3_wgrad(dyc, xc, 3, 28, 28, 3),), reps=200)
