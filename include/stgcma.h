@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 215
+#define STG_VERSION 216
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -386,6 +386,10 @@ typedef struct {
     float* lse;
     int64_t P; int H; int n; int D;
     float scale;
+    /* window map (ABI 216; all zero = rows p*n + i): win_size > 0 makes problem p the window p % nW of frame p / nW of a [win_h, win_w] token
+     * image (nW = (win_h / win_size) * (win_w / win_size), n = win_size^2, cyclic shift win_shift) -- the geometry of stg_attn's
+     * map_kind 1 -- for the adapters' WINDOW-level cross-modal attention at widths 64 / 96 (Swin_AVE.py:750-760 with d_h = 96 in Swin-L). */
+    int win_h, win_w, win_size, win_shift;
 } stg_mha_args;
 int stg_mha_supported(int n, int D);
 int stg_mha_fwd(const stg_mha_args* a, void* stream);

@@ -101,6 +101,7 @@ class MhaArgs(C.Structure):
         ("lse", c_vp),
         ("P", c_i64), ("H", C.c_int), ("n", C.c_int), ("D", C.c_int),
         ("scale", C.c_float),
+        ("win_h", C.c_int), ("win_w", C.c_int), ("win_size", C.c_int), ("win_shift", C.c_int),
     ]
 
 
@@ -224,7 +225,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 215
+ABI_VERSION = 216
 _lib = None
 
 

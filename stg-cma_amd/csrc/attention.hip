@@ -471,7 +471,7 @@ __device__ __forceinline__ void flush_dbias(const AttnP& a, f32x16_t& dbacc, int
 template <int D, bool PK>
 // D = 96 / 128 (ViT heads): at two waves per SIMD the accumulators spill 300+ VGPRs to scratch; one wave per SIMD (AGPRs) measured
 // 130 -> 81 ms over the ViT-B step, the other variants are faster at two
-__global__ void __launch_bounds__(256, (D > 64 && !PK ? 1 : 2)) attn_bwd_dkv_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D >= 48 && !PK ? 1 : 2)) attn_bwd_dkv_kernel(AttnP a) {
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     constexpr bool PREFETCH = D <= 64;                 // register budget: two extra tiles in flight only for small D

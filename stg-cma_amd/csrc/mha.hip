@@ -33,7 +33,23 @@ struct MP {
     float scale, scale2;
     const bf16_t* dO; int64_t lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
+    int wh, ww, ws, wshift, nwin;     // window map (ws > 0): problem p = window p % nwin of frame p / nwin of a [wh, ww] token image, cyclic shift wshift
 };
+
+// row of token `tok` of problem p in the token tensors: p * n + tok, or -- window map, round 5: the adapters' WINDOW-level cross-modal attention
+// at widths 64 / 96 (Swin-L) -- the token's place in its frame (the arithmetic of attention.hip's map_kind 1)
+__device__ __forceinline__ int64_t mrow(const MP& a, int p, int tok) {
+    if (a.ws == 0) return (int64_t)p * a.n + tok;
+    const int f = p / a.nwin, g = p - f * a.nwin;
+    const int nww = a.ww / a.ws;
+    const int wi = g / nww, wj = g - wi * nww;
+    const int ti = tok / a.ws, tj = tok - ti * a.ws;
+    int y = wi * a.ws + ti + a.wshift;
+    y = y >= a.wh ? y - a.wh : y;
+    int x = wj * a.ws + tj + a.wshift;
+    x = x >= a.ww ? x - a.ww : x;
+    return (int64_t)f * a.wh * a.ww + y * a.ww + x;
+}
 
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -101,13 +117,13 @@ __device__ __forceinline__ void stage_plan(int tid, int h, IArr<StageC<D, NTILE,
 template <int D, int NTILE, int NW, int TH = 32>
 __device__ __forceinline__ void stage_fetch(U4Arr<StageC<D, NTILE, NW, TH>::PER>& v, const IArr<StageC<D, NTILE, NW, TH>::PER>& src_col,
                                             const IArr<StageC<D, NTILE, NW, TH>::PER>& row, const bf16_t* t0, int64_t ld0, const bf16_t* t1, int64_t ld1,
-                                            int64_t frame_row0, int n, int row0) {
+                                            const MP& a, int p, int n, int row0) {
 #pragma unroll
     for (int i = 0; i < StageC<D, NTILE, NW, TH>::PER; ++i) {
         if (row[i] < 0) continue;
         int tok = row0 + (row[i] & (TH - 1));
         tok = tok < n ? tok : n - 1;
-        const bf16_t* src = (NTILE == 2 && (row[i] & TH)) ? t1 + (frame_row0 + tok) * ld1 : t0 + (frame_row0 + tok) * ld0;
+        const bf16_t* src = (NTILE == 2 && (row[i] & TH)) ? t1 + mrow(a, p, tok) * ld1 : t0 + mrow(a, p, tok) * ld0;
         v[i] = *reinterpret_cast<const u32x4_t*>(src + src_col[i]);
     }
 }
@@ -129,14 +145,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int q0 = 32 * (qb * NW + wave);
     const bool live = q0 < a.n;
     const int q = q0 + r;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS];
     {
-        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
     }
@@ -148,13 +163,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a)
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
     stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
     __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
         const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 32 * (kt + 1));
         if (live) {                                    // wave-uniform: a wave whose query tile lies past the frame only stages and synchronises
         f32x16_t sc = zero16();                        // St[key][q]
 #pragma unroll
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a)
     }
     {
         const float inv = 1.0f / l;
-        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;                  // 16-byte stores (store_tile32: every lane takes part)
+        bf16_t* op = a.O + mrow(a, p, q) * a.ldo + h * D;                  // 16-byte stores (store_tile32: every lane takes part)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, q < a.n);
         if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
@@ -215,16 +230,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int q = 32 * (qb * NW + wave) + r;
     const bool live = 32 * (qb * NW + wave) < a.n;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS], dof[KS];
     float delta = 0.f;
     {
-        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
-        const bf16_t* dp = a.dO + (frow + qc) * a.lddo + h * D + 8 * hh;
-        const bf16_t* op = a.O + (frow + qc) * a.ldo + h * D + 8 * hh;
+        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* dp = a.dO + mrow(a, p, qc) * a.lddo + h * D + 8 * hh;
+        const bf16_t* op = a.O + mrow(a, p, qc) * a.ldo + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             qf[s] = ld_frag(qp + 16 * s);
@@ -245,13 +259,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) 
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
     stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
     __syncthreads();
     for (int kt = 0; kt < a.nt; ++kt) {
         const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 32 * (kt + 1));
+        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 32 * (kt + 1));
         if (live) {
         f32x16_t sc = zero16(), dp = zero16();         // St[key][q], dPt[key][q]
 #pragma unroll
@@ -280,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) 
         __syncthreads();
     }
     {
-        bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
+        bf16_t* op = a.dQ + mrow(a, p, q) * a.lddqkv + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, dq[dt], a.scale, hh, q < a.n);
     }
@@ -299,14 +313,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int q0 = 32 * (qb * NW + wave);
     const bool live = q0 < a.n;
     const int q = q0 + r;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS];
     {
-        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
     }
@@ -318,14 +331,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
     stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
     __syncthreads();
     const int np = (a.nt + 1) >> 1;
     for (int kp = 0; kp < np; ++kp) {
         const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 64 * (kp + 1));
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
         if (live) {
         f32x16_t sA = zero16(), sB = zero16();         // St[key][q] of keys 64 kp .. + 31 / + 32 .. + 63
 #pragma unroll
@@ -379,7 +392,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a
     }
     {
         const float inv = 1.0f / l;
-        bf16_t* op = a.O + (frow + q) * a.ldo + h * D;
+        bf16_t* op = a.O + mrow(a, p, q) * a.ldo + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, q < a.n);
         if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
@@ -394,16 +407,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int q = 32 * (qb * NW + wave) + r;
     const bool live = 32 * (qb * NW + wave) < a.n;
     const int qc = q < a.n ? q : a.n - 1;
     bf16x8_t qf[KS], dof[KS];
     float delta = 0.f;
     {
-        const bf16_t* qp = a.Q + (frow + qc) * a.ld + h * D + 8 * hh;
-        const bf16_t* dp = a.dO + (frow + qc) * a.lddo + h * D + 8 * hh;
-        const bf16_t* op = a.O + (frow + qc) * a.ldo + h * D + 8 * hh;
+        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* dp = a.dO + mrow(a, p, qc) * a.lddo + h * D + 8 * hh;
+        const bf16_t* op = a.O + mrow(a, p, qc) * a.ldo + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             qf[s] = ld_frag(qp + 16 * s);
@@ -424,14 +436,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a)
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 0);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
     stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
     __syncthreads();
     const int np = (a.nt + 1) >> 1;
     for (int kp = 0; kp < np; ++kp) {
         const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, frow, a.n, 64 * (kp + 1));
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
         if (live) {
         f32x16_t scA = zero16(), dpA = zero16(), scB = zero16(), dpB = zero16();         // St[key][q], dPt[key][q] of the two key tiles
 #pragma unroll
@@ -468,7 +480,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a)
         __syncthreads();
     }
     {
-        bf16_t* op = a.dQ + (frow + q) * a.lddqkv + h * D;
+        bf16_t* op = a.dQ + mrow(a, p, q) * a.lddqkv + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, dq[dt], a.scale, hh, q < a.n);
     }
@@ -487,13 +499,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
     bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
     bf16_t* sV = KV1 ? sK : sK + 32 * DP;
     const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int key = 32 * (kb * NW + wave) + r;
     const bool live = 32 * (kb * NW + wave) < a.n;
     const int kc = key < a.n ? key : a.n - 1;
     {   // own K / V tile: natural rows (keys) -> wave-private LDS; read back as B operands (columns = keys)
-        const bf16_t* kp = a.K + (frow + kc) * a.ld + h * D + 8 * hh;
-        const bf16_t* vp = a.V + (frow + kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* kp = a.K + mrow(a, p, kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* vp = a.V + mrow(a, p, kc) * a.ld + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             *reinterpret_cast<bf16x8_t*>(sK + r * DP + 16 * s + 8 * hh) = ld_frag(kp + 16 * s);
@@ -522,7 +533,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
         float* st = reinterpret_cast<float*>(buf + 2 * 32 * DP);
         if (tid < 32) { st[tid] = nl; st[32 + tid] = nd; }
     };
-    stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
+    stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, a, p, a.n, 0);
     fetch_stats(0);
     commit_all(smem);
     __syncthreads();
@@ -532,7 +543,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
         const float* sLse = reinterpret_cast<const float*>(sQ + 2 * 32 * DP);
         const float* sDel = sLse + 32;
         if (qt + 1 < a.nt) {
-            stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 32 * (qt + 1));
+            stage_fetch<D, 2, NW>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, a, p, a.n, 32 * (qt + 1));
             fetch_stats(32 * (qt + 1));
         }
         if (live) {
@@ -573,7 +584,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
     }
     {
         const bool okk = key < a.n;
-        bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
+        bf16_t* kp = a.dK + mrow(a, p, key) * a.lddqkv + h * D;
         if (a.dV == nullptr) {                         // K and V are ONE tensor (cross-modal attention): its gradient is dK + dV
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -584,7 +595,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
             }
             return;
         }
-        bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
+        bf16_t* vp = a.dV + mrow(a, p, key) * a.lddqkv + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             store_tile32(kp + 32 * dt, dk[dt], a.scale, hh, okk);
@@ -606,13 +617,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a
     bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
     bf16_t* sV = KV1 ? sK : sK + 32 * DP;
     const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
-    const int64_t frow = (int64_t)p * a.n;
     const int key = 32 * (kb * NW + wave) + r;
     const bool live = 32 * (kb * NW + wave) < a.n;
     const int kc = key < a.n ? key : a.n - 1;
     {   // own K / V tile: natural rows (keys) -> wave-private LDS; read back as B operands (columns = keys)
-        const bf16_t* kp = a.K + (frow + kc) * a.ld + h * D + 8 * hh;
-        const bf16_t* vp = a.V + (frow + kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* kp = a.K + mrow(a, p, kc) * a.ld + h * D + 8 * hh;
+        const bf16_t* vp = a.V + mrow(a, p, kc) * a.ld + h * D + 8 * hh;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             *reinterpret_cast<bf16x8_t*>(sK + r * DP + 16 * s + 8 * hh) = ld_frag(kp + 16 * s);
@@ -641,7 +651,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a
         float* st = reinterpret_cast<float*>(buf + 2 * 64 * DP);
         if (tid < 64) { st[tid] = nl; st[64 + tid] = nd; }
     };
-    stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 0);
+    stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, a, p, a.n, 0);
     fetch_stats(0);
     commit_all(smem);
     __syncthreads();
@@ -652,7 +662,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a
         const float* sLse = reinterpret_cast<const float*>(sQ + 2 * 64 * DP);
         const float* sDel = sLse + 64;
         if (qp + 1 < np) {
-            stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, frow, a.n, 64 * (qp + 1));
+            stage_fetch<D, 2, NW, 64>(sv, sc_, rw, a.Q, a.ld, a.dO, a.lddo, a, p, a.n, 64 * (qp + 1));
             fetch_stats(64 * (qp + 1));
         }
         if (live) {
@@ -698,7 +708,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a
     }
     {
         const bool okk = key < a.n;
-        bf16_t* kp = a.dK + (frow + key) * a.lddqkv + h * D;
+        bf16_t* kp = a.dK + mrow(a, p, key) * a.lddqkv + h * D;
         if (a.dV == nullptr) {                         // K and V are ONE tensor (cross-modal attention): its gradient is dK + dV
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -709,7 +719,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a
             }
             return;
         }
-        bf16_t* vp = a.dV + (frow + key) * a.lddqkv + h * D;
+        bf16_t* vp = a.dV + mrow(a, p, key) * a.lddqkv + h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             store_tile32(kp + 32 * dt, dk[dt], a.scale, hh, okk);
@@ -774,6 +784,13 @@ int fill(const stg_mha_args* f, MP& p, const char* who) {
     p.O = (bf16_t*)f->O; p.ldo = f->ldo; p.lse = f->lse;
     p.P = (int)f->P; p.H = f->H; p.n = f->n; p.nt = (f->n + 31) / 32;
     p.scale = f->scale; p.scale2 = f->scale * LOG2E;
+    if (f->win_size != 0) {
+        STG_CHECK(f->win_size > 0 && f->win_h > 0 && f->win_w > 0 && f->win_h % f->win_size == 0 && f->win_w % f->win_size == 0 &&
+                  f->n == f->win_size * f->win_size && f->win_shift >= 0 && f->win_shift < f->win_size, -2, "%s: bad window map", who);
+        p.wh = f->win_h; p.ww = f->win_w; p.ws = f->win_size; p.wshift = f->win_shift;
+        p.nwin = (f->win_h / f->win_size) * (f->win_w / f->win_size);
+        STG_CHECK(f->P % p.nwin == 0, -2, "%s: P must be a whole number of frames (%d windows each)", who, p.nwin);
+    }
     return 0;
 }
 

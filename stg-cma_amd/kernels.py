@@ -1584,13 +1584,22 @@ def tattn_bwd(g, Q, K, V, dO, *, dQ, dK, dV, dbias=None):
 
 class MhaGeom:
     """ViT multi-head self-attention over the fused in_proj output: P frames x H heads, n tokens per frame at rows p*n + i,
-    head dim D in {64, 96}."""
+    head dim D in {64, 96}.  window = (Himg, Wimg, ws, shift): P = frames * nW window problems of n = ws^2 tokens, each token at its
+    place in the frame's [Himg, Wimg] image (cyclic shift included) -- the window-level cross-modal attention of wide adapters."""
 
-    def __init__(self, P, H, n, D, scale):
+    def __init__(self, P, H, n, D, scale, window=None):
         self.P, self.H, self.n, self.D, self.scale = int(P), int(H), int(n), int(D), float(scale)
         if not mha_supported(self.n, self.D):
             raise RuntimeError(f"mha: unsupported geometry n={n} D={D}")
         self.rows = self.P * self.n
+        self.window = (0, 0, 0, 0)
+        if window is not None:
+            Hi, Wi, ws, shift = (int(x) for x in window)
+            nW = (Hi // ws) * (Wi // ws)
+            if ws < 1 or Hi % ws or Wi % ws or self.n != ws * ws or self.P % nW or not 0 <= shift < ws:
+                raise RuntimeError(f"mha: bad window geometry {window} for P={P}, n={n}")
+            self.window = (Hi, Wi, ws, shift)
+            self.n_kv, self.outer = self.n, Hi * Wi        # (what _attn_cost reads)
 
 
 def mha_supported(n, D):
@@ -1611,6 +1620,7 @@ def _mha_fill(g, Q, K, V, O, lse):
     a.O, a.ldo = _p(O), _ld(O)
     a.lse = _p(lse)
     a.P, a.H, a.n, a.D, a.scale = g.P, g.H, g.n, g.D, g.scale
+    a.win_h, a.win_w, a.win_size, a.win_shift = g.window
     return a
 
 

@@ -558,6 +558,12 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
         ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
+    if geoms is None and window and USE_MHA_X and USE_XWIN and K.mha_supported(spec.ws * spec.ws, hv.shape[1]) and BT * spec.nW < 65536:
+        # wide adapters, window level (Swin-L: d_h = 96): the same flash kernels with the window map (one 64-key trip per window)
+        mg = K.MhaGeom(BT * spec.nW, 1, spec.ws * spec.ws, hv.shape[1], 1.0, window=(spec.H, spec.W, spec.ws, spec.shift))
+        rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
+        ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
+        return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
         wg = _xwin_geom(spec, BT, hv.device)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)

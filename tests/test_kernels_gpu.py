@@ -705,3 +705,51 @@ def test_hot_kernels_are_reproducible(stg, gpu):
     stress("mha_bwd", lambda: (K.mha_bwd(mg, Q2, K2, V2, O2, l2, dO2, dQ=dqkv2[:, :768], dK=dqkv2[:, 768:1536], dV=dqkv2[:, 1536:]) and dqkv2,), reps=300)
     xc, dyc = bf(3 * 28 * 28, 64), bf(3 * 28 * 28, 256)
     stress("conv3x3_wgrad", lambda: (K.conv3x3_wgrad(dyc, xc, 3, 28, 28, 3),), reps=200)
+
+
+@pytest.mark.parametrize("R,C", [(1037, 256), (4099, 128), (33, 64), (517, 24), (260, 2056), (7, 256)])
+def test_batchnorm_passes_ragged_rows(stg, gpu, R, C):
+    """The decoder's BatchNorm passes (column sums, apply, backward) on row counts that are no multiple of the row lanes / the 4-row
+    trips of the 16-byte forms (C % 8 == 0, C / 8 dividing 256) and on widths that take the scalar forms (24, 2056)."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(R + C)
+    x = _bf(torch.randn(R, C, generator=g) * 1.5 + 0.7)
+    dy = _bf(torch.randn(R, C, generator=g))
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xf, df = x.float(), dy.float()
+    s = k.bn_colsum(x.to(gpu))
+    _close(s[0], xf.sum(0), tol=2e-3, what="sum x")
+    mean = (s[0] / R).contiguous()
+    s2 = k.bn_colsum(x.to(gpu), mean=mean)
+    mc = mean.cpu()
+    _close(s2[1], ((xf - mc) ** 2).sum(0), tol=2e-3, what="centred sum of squares")
+    rstd = torch.rsqrt(s2[1] / R + 1e-5).contiguous()
+    rc = rstd.cpu()
+    y = k.bn_apply(x.to(gpu), mean, rstd, gam.to(gpu), bet.to(gpu))
+    _close(y, (xf - mc) * rc * gam + bet, what="bn apply")
+    sb = k.bn_colsum(x.to(gpu), dy.to(gpu), mean, rstd)
+    xhat = (xf - mc) * rc
+    _close(sb[0], df.sum(0), tol=2e-3, what="sum dy")
+    _close(sb[1] / math.sqrt(R), (df * xhat).sum(0) / math.sqrt(R), tol=4e-3, what="sum dy xhat")
+    sbc = sb.cpu()
+    dx = k.bn_bwd(x.to(gpu), dy.to(gpu), mean, rstd, gam.to(gpu), sb)
+    _close(dx, gam * rc * (df - sbc[0] / R - xhat * sbc[1] / R), what="bn bwd (training)")
+    dxe = k.bn_bwd(x.to(gpu), dy.to(gpu), mean, rstd, gam.to(gpu), None)
+    _close(dxe, gam * rc * df, what="bn bwd (eval)")
+
+
+@pytest.mark.parametrize("F,H,W,C,align", [(3, 7, 9, 16, True), (2, 14, 14, 256, False), (11, 5, 3, 8, True), (1, 1, 1, 8, False), (9, 2, 28, 128, False)])
+def test_bilinear_up2_rows_spread_over_xcds(stg, gpu, F, H, W, C, align):
+    """x2 bilinear resize and its adjoint against torch's interpolate; F * H row counts that are no multiple of 8 exercise the
+    XCD-banded row mapping's ragged last band."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(F * 131 + H * 17 + W + C)
+    x = _bf(torch.randn(F * H * W, C, generator=g))
+    xi = x.float().view(F, H, W, C).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xi, scale_factor=2, mode="bilinear", align_corners=align)
+    y = k.bilinear_up2_fwd(x.to(gpu), F, H, W, align)
+    _close(y, ref.permute(0, 2, 3, 1).reshape(F * 4 * H * W, C), what="bilinear fwd")
+    dy = _bf(torch.randn(F * 4 * H * W, C, generator=g))
+    ref.backward(dy.float().view(F, 2 * H, 2 * W, C).permute(0, 3, 1, 2))
+    dx = k.bilinear_up2_bwd(dy.to(gpu), F, H, W, align)
+    _close(dx, xi.grad.permute(0, 2, 3, 1).reshape(F * H * W, C), tol=1.5e-2, what="bilinear bwd")

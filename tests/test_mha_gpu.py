@@ -103,3 +103,56 @@ def test_mha_cross_modal_shared_kv(stg, gpu, D, n):
     gs = float(max(hq.grad.abs().max(), hk.grad.abs().max()))
     _close(dq / gs, hq.grad / gs, tol=1.5e-2, what="dq")
     _close(dkv / gs, hk.grad / gs, tol=1.5e-2, what="dkv")
+
+
+def _window_index(F, Hi, Wi, ws, shift):
+    """rows of the [F * Hi * Wi] token tensor in window order: [F * nW, ws * ws] (torch.roll by -shift, then window_partition:
+    Swin_AVE.py:151-165 / :262-266 -- window (wi, wj) token (ti, tj) sits at ((wi ws + ti + shift) % Hi, (wj ws + tj + shift) % Wi))."""
+    f, wi, wj, ti, tj = torch.meshgrid(torch.arange(F), torch.arange(Hi // ws), torch.arange(Wi // ws), torch.arange(ws), torch.arange(ws),
+                                       indexing="ij")
+    y = (wi * ws + ti + shift) % Hi
+    x = (wj * ws + tj + shift) % Wi
+    return (f * Hi * Wi + y * Wi + x).reshape(F * (Hi // ws) * (Wi // ws), ws * ws)
+
+
+@pytest.mark.parametrize("D,F,Hi,Wi,ws,shift", [(96, 3, 14, 14, 7, 0), (96, 2, 28, 14, 7, 3), (64, 2, 7, 7, 7, 0), (64, 1, 12, 8, 4, 2),
+                                                (96, 1, 24, 24, 8, 4)])
+def test_mha_window_map_cross_modal(stg, gpu, D, F, Hi, Wi, ws, shift):
+    """The WINDOW-level cross-modal attention of a wide adapter (Swin-L, d_h = 96) on the flash kernels: problem p = window p % nW of
+    frame p / nW, tokens addressed in place (cyclic shift included), K == V.  Reference: gather the windows, attend, scatter back.
+    Rows no window writes do not exist (the windows tile the image), so O / dQ / dK are checked whole."""
+    from stgcma import kernels as k
+    n, N = ws * ws, Hi * Wi
+    idx = _window_index(F, Hi, Wi, ws, shift)                                 # [P, n]
+    P = idx.shape[0]
+    g = torch.Generator().manual_seed(D + F * 7 + Hi + shift)
+    hq_b = (torch.randn(F * N, D, generator=g) * 0.4).to(BF16)
+    hk_b = (torch.randn(F * N, D, generator=g) * 0.4).to(BF16)
+    dO_b = torch.randn(F * N, D, generator=g).to(BF16)
+    hq = hq_b.float().requires_grad_(True)
+    hk = hk_b.float().requires_grad_(True)
+    qw, kw = hq[idx.reshape(-1)].view(P, n, D), hk[idx.reshape(-1)].view(P, n, D)
+    s = qw @ kw.transpose(1, 2)
+    rw = torch.softmax(s, -1) @ kw
+    r_ref = torch.zeros(F * N, D).index_add(0, idx.reshape(-1), rw.reshape(P * n, D))
+    r_ref.backward(dO_b.float())
+    geo = k.MhaGeom(P, 1, n, D, 1.0, window=(Hi, Wi, ws, shift))
+    q, kv = hq_b.to(gpu), hk_b.to(gpu)
+    r, lse = k.mha_fwd(geo, q, kv, kv)
+    _close(r, r_ref, what="r")
+    _close(lse, (torch.logsumexp(s, -1) * 1.4426950408889634).detach().view(P, 1, n), tol=2e-2, what="lse")
+    dq = torch.full_like(q, float("nan")); dkv = torch.full_like(kv, float("nan"))
+    k.mha_bwd(geo, q, kv, kv, r, lse, dO_b.to(gpu), dQ=dq, dK=dkv, dV=None)
+    gs = float(max(hq.grad.abs().max(), hk.grad.abs().max()))
+    _close(dq / gs, hq.grad / gs, tol=1.5e-2, what="dq")
+    _close(dkv / gs, hk.grad / gs, tol=1.5e-2, what="dkv")
+
+
+def test_mha_window_map_rejects_bad_geometry(stg, gpu):
+    from stgcma import kernels as k
+    with pytest.raises(RuntimeError):
+        k.MhaGeom(8, 1, 49, 96, 1.0, window=(14, 14, 7, 7))          # shift must be < ws
+    with pytest.raises(RuntimeError):
+        k.MhaGeom(6, 1, 49, 96, 1.0, window=(14, 14, 7, 0))          # 4 windows per frame: P must be a multiple of 4
+    with pytest.raises(RuntimeError):
+        k.MhaGeom(4, 1, 36, 96, 1.0, window=(14, 14, 7, 0))          # n != ws^2
