@@ -508,6 +508,7 @@ def _xattn_geom(spec, BT, dh, window, g):
 
 
 USE_XWIN = _cfg.opt("xwin")     # 0 = window-level cross-modal attention on the generic kernels (A/B knob)
+USE_MHA_WIN = _cfg.opt("mha_win")   # 0 = WIDE (d_h = 64 / 96) window-level cross-modal attention on the generic kernels (A/B knob)
 _xwin_tabs = {}
 
 
@@ -558,7 +559,7 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
         ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
-    if geoms is None and window and USE_MHA_X and USE_XWIN and K.mha_supported(spec.ws * spec.ws, hv.shape[1]) and BT * spec.nW < 65536:
+    if geoms is None and window and USE_MHA_WIN and K.mha_supported(spec.ws * spec.ws, hv.shape[1]) and BT * spec.nW < 65536:
         # wide adapters, window level (Swin-L: d_h = 96): the same flash kernels with the window map (one 64-key trip per window)
         mg = K.MhaGeom(BT * spec.nW, 1, spec.ws * spec.ws, hv.shape[1], 1.0, window=(spec.H, spec.W, spec.ws, spec.shift))
         rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
