@@ -647,7 +647,10 @@ def main():
     # pass as the measurement; N > 1 replays recipe.capture_train_step_ddp's two graphs.  Every rank must take the same path: the ranks
     # agree on "captured" before the first replay and fall back to eager steps together.
     replay, static_loss, step_how = None, None, "eager, one stream"
-    want_graph = (nmb > 1 or world > 1) and not args.eager
+    # a workload that cannot be split into micro-batches (the AVS model: BatchNorm over the batch) replays ONE graph of the whole step at N = 1 --
+    # no second stream to overlap with, but no launch gaps either; the eager pass stays the measurement if that graph is not faster on the box
+    whole_step_graph = world == 1 and nmb == 1 and args.microbatch > 1 and not args.fp8
+    want_graph = (nmb > 1 or world > 1 or whole_step_graph) and not args.eager
 
     def timed2(fn):
         fence()
@@ -698,6 +701,9 @@ def main():
                     raise RuntimeError("capture failure forced by STG_BENCH_FAIL_CAPTURE")
                 if nmb > 1:
                     replay, static_loss, step_how = recipe.capture_train_step_mb(fwd_loss, mb_tensors, opt, splits=nmb, sync=sync, warmup=1)
+                elif world == 1:
+                    replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, None, warmup=1, collective_in_graph=True)
+                    step_how = "one graph of the whole step (forward + backward + Adam), one stream"
                 else:
                     replay, static_loss, step_how = recipe.capture_train_step_ddp(fwd_bwd, opt, sync, warmup=1, collective_in_graph=args.ddp_one_graph)
             except Exception as e:                                       # noqa: BLE001  (any capture failure -> eager, on every rank)

@@ -494,3 +494,60 @@ def test_avs_train_mode_loop(stg, gpu):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert not torch.equal(m.avstask_tpavi_b1.W_z[1].running_mean, rm0)
     assert int(m.avstask_tpavi_b1.W_z[1].num_batches_tracked) == 5
+
+
+def test_avs_whole_step_graph_equals_eager_steps(stg, gpu):
+    """bench.py's N = 1 form for the AVS model (BatchNorm over the batch: no micro-batches): ONE HIP graph of forward + loss + backward + Adam
+    (recipe.capture_train_step_ddp(..., collective_in_graph=True) without a GradSync).  Replayed steps must walk the same losses as eager
+    steps from the same state, and move the BatchNorm running statistics the same way (DropPath off: its masks are random)."""
+    from stgcma import recipe
+    from stgcma.model import Swin_AVSModel
+
+    def build():
+        torch.manual_seed(0)
+        m = Swin_AVSModel.SwinTransformer2D_Adapter_AVS_Base(pretrained=None, num_frames=5, embed_dim=128, depths=[2, 2, 2, 2],
+                                                        num_heads=[4, 8, 16, 32], ftmode="fusion", drop_path_rate=0.0,
+                                                        adapter_mlp_ratio=[0.25, 0.25, 0.125, 0.125]).to(gpu).train()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "W_z.1.weight" in n:
+                    p.fill_(0.5)
+        recipe.apply_freeze(m)
+        return m, recipe.build_optimizer(m, lr=2e-5, capturable=True)      # small steps: the comparison is of trajectories, keep them tame
+
+    g = torch.Generator().manual_seed(1)
+    a = (torch.randn(2, 5, 224, 224, generator=g) * 0.5).to(gpu)
+    v = torch.randn(2, 5, 3, 224, 224, generator=g).to(gpu)
+    mask = (torch.rand(2, 1, 224, 224, generator=g) < 0.3).float().to(gpu)
+    bce = torch.nn.BCELoss()
+
+    def make_fwd_bwd(m, opt):
+        def fwd_bwd():
+            pred, _, _ = m(a, v, "fusion")
+            loss = bce(torch.sigmoid(pred)[::5], mask)
+            opt.zero_grad()
+            loss.backward()
+            return loss
+        return fwd_bwd
+
+    m_e, opt_e = build()
+    fb = make_fwd_bwd(m_e, opt_e)
+    eager = []
+    for _ in range(4):
+        loss = fb(); opt_e.step()
+        eager.append(float(loss))
+    m_r, opt_r = build()
+    replay, static_loss, how = recipe.capture_train_step_ddp(make_fwd_bwd(m_r, opt_r), opt_r, None, warmup=1, collective_in_graph=True)
+    assert how == "one_graph"
+    replayed = []
+    for _ in range(3):
+        replay()
+        replayed.append(float(static_loss))
+    assert all(np.isfinite(replayed)), replayed
+    for k in range(3):
+        assert abs(replayed[k] - eager[k + 1]) <= 5e-3 * max(1.0, abs(eager[k + 1])), (eager, replayed)
+    bn_e, bn_r = m_e.avstask_tpavi_b1.W_z[1], m_r.avstask_tpavi_b1.W_z[1]
+    assert int(bn_r.num_batches_tracked) == int(bn_e.num_batches_tracked) == 4
+    assert torch.allclose(bn_r.running_mean, bn_e.running_mean, rtol=2e-2, atol=2e-3)
+    # (the parameters themselves are not compared: Adam moves a parameter by ~lr per step whatever its gradient's size, so the ones whose
+    # gradients are noise -- zero-initialised gates -- differ by sign between two runs of the SAME form; the losses above depend on all of them)
