@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WrMulti pm) {
 
 struct Plan { bool ok; int nt1, ncg, S; int64_t rows_per_block, ws_floats; bool y_narrow; };
 
-Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* dY, const void* X) {
+Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* dY, const void* X, int nprob = 1) {
     Plan pl = {};
     const bool y_narrow = N1 <= N2;
     const int NA = y_narrow ? N1 : N2, NB = y_narrow ? N2 : N1;
@@ -282,11 +282,24 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
     pl.ok = true; pl.y_narrow = y_narrow;
     pl.nt1 = (NA + 15) / 16;                       // 1 .. 6 column tiles of the narrow operand
     pl.ncg = (NB + WNB - 1) / WNB;
-    // ~2 blocks per CU, and at least 4 chunks per wave so that the partial tile stays a small fraction of the operand bytes
-    int64_t S = 512 / pl.ncg;
+    // Row splits S (round 5b).  The workgroups of a launch (ncg x S x nprob, all the same size) run in ROUNDS of `slots` (one per CU for nt1 > 2: 350+
+    // VGPRs; two otherwise), and each pays a fixed price on top of its rows -- the first chunk's exposed HBM trip and the partial tile it leaves in
+    // the workspace (57 KiB at nt1 = 6), priced here as OVH rows.  Rounds 1-5a took S = 512 / ncg whatever nprob was: twelve Swin-L problems of
+    // 62 720 x (96, 768) ran as 6 120 workgroups of 768 rows (24 chunks: 6 per wave) at 1.9 TB/s, the fixed price about half of each.  Now: the S that
+    // minimises rounds x (rows per workgroup + OVH), at least 4 chunks per wave (profiles/r05b_wgrad_split_sweep.txt: 25-40 % less time on every
+    // adapter shape of the four models, the chosen S within 3 % of the best of a sweep).
+    const int64_t slots = 256 * (pl.nt1 > 2 ? 1 : 2);
     const int64_t smax = (M + 4 * 4 * WK - 1) / (4 * 4 * WK);
-    if (S > smax) S = smax;
-    if (S < 1) S = 1;
+    const int64_t per_s = (int64_t)pl.ncg * nprob;
+    const int64_t OVH = 512;
+    int64_t S = 1;
+    double best = 1e300;
+    for (int64_t c = 1; c <= smax && c <= 1024; ++c) {
+        const int64_t rounds = (per_s * c + slots - 1) / slots;
+        const int64_t rows = ((M + c - 1) / c + WK - 1) / WK * WK;
+        const double cost = (double)rounds * (double)(rows + OVH);
+        if (cost < best * 0.98) { best = cost; S = c; }           // a later (finer) split must win by 2 %: fewer partial tiles to fold otherwise
+    }
     int64_t rpb = (M + S - 1) / S;
     rpb = (rpb + WK - 1) / WK * WK;
     S = (M + rpb - 1) / rpb;
@@ -299,8 +312,13 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
 
 extern "C" int64_t stg_wgrad_ws_floats(int64_t M, int N1, int N2) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
-    const Plan pl = plan_for(M, N1, N2, (N1 + 7) & ~7, (N2 + 7) & ~7, nullptr, nullptr);
-    return pl.ok ? pl.ws_floats : 0;
+    int64_t need = 0;                               // per problem, whatever the number of problems its launch carries (the split depends on it)
+    for (int n = 1; n <= WMAX; ++n) {
+        const Plan pl = plan_for(M, N1, N2, (N1 + 7) & ~7, (N2 + 7) & ~7, nullptr, nullptr, n);
+        if (!pl.ok) return 0;
+        need = pl.ws_floats > need ? pl.ws_floats : need;
+    }
+    return need;
 }
 
 namespace {
@@ -364,7 +382,7 @@ extern "C" int stg_wgrad_tn_ws_multi(const stg_wgrad_desc* d, int n, float* ws, 
         STG_CHECK(q.dY && q.X && q.dW && q.M > 0 && q.N1 > 0 && q.N2 > 0 && q.lddy >= q.N1 && q.ldx >= q.N2 && q.lddw >= q.N2, -2,
                   "stg_wgrad_tn_ws_multi: bad problem %d", i);
         if (q.row_scale) STG_CHECK(q.rs_outer > 0 && q.rs_inner > 0, -2, "stg_wgrad_tn_ws_multi: bad row_scale params");
-        const Plan pl = plan_for(q.M, q.N1, q.N2, q.lddy, q.ldx, q.dY, q.X);
+        const Plan pl = plan_for(q.M, q.N1, q.N2, q.lddy, q.ldx, q.dY, q.X, n);
         STG_CHECK(pl.ok, -7, "stg_wgrad_tn_ws_multi: problem %d is not eligible for the workspace path", i);
         if (i == 0) {
             pl0 = plm = pl;
