@@ -286,19 +286,24 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
     // VGPRs; two otherwise), and each pays a fixed price on top of its rows -- the first chunk's exposed HBM trip and the partial tile it leaves in
     // the workspace (57 KiB at nt1 = 6), priced here as OVH rows.  Rounds 1-5a took S = 512 / ncg whatever nprob was: twelve Swin-L problems of
     // 62 720 x (96, 768) ran as 6 120 workgroups of 768 rows (24 chunks: 6 per wave) at 1.9 TB/s, the fixed price about half of each.  Now: the S that
-    // minimises rounds x (rows per workgroup + OVH), at least 4 chunks per wave (profiles/r05b_wgrad_split_sweep.txt: 25-40 % less time on every
-    // adapter shape of the four models, the chosen S within 3 % of the best of a sweep).
+    // minimises rounds x (rows per workgroup + OVH), at least 4 chunks per wave -- for nt1 > 2 (one workgroup per CU, 40-57 KiB partial tiles): in the
+    // step, wgrad_ws_kernel<4> 211 -> 200 us and 133 -> 92 us (Swin-B stage 3), the Swin-L step 240.9 -> 232.1 ms (profiles/r05b_wgrad_split_sweep.txt
+    // is the stand-alone sweep).
     const int64_t slots = 256 * (pl.nt1 > 2 ? 1 : 2);
     const int64_t smax = (M + 4 * 4 * WK - 1) / (4 * 4 * WK);
     const int64_t per_s = (int64_t)pl.ncg * nprob;
     const int64_t OVH = 512;
-    int64_t S = 1;
-    double best = 1e300;
-    for (int64_t c = 1; c <= smax && c <= 1024; ++c) {
-        const int64_t rounds = (per_s * c + slots - 1) / slots;
-        const int64_t rows = ((M + c - 1) / c + WK - 1) / WK * WK;
-        const double cost = (double)rounds * (double)(rows + OVH);
-        if (cost < best * 0.98) { best = cost; S = c; }           // a later (finer) split must win by 2 %: fewer partial tiles to fold otherwise
+    int64_t S = 512 / pl.ncg;                      // nt1 <= 2: two light workgroups per CU hide each other's fixed price -- measured INSIDE the Swin-B
+    if (S > smax) S = smax;                        // step (rocprofv3, profiles/r05_final_ledger.md) the round-1 rule stays ahead there: twelve
+    if (S < 1) S = 1;                              // 62 720 x (32, 512) problems 222 us as 5 904 workgroups, 304 us as 480 (the stand-alone sweep said
+    if (pl.nt1 > 2) {                              // the opposite; the measurement inside the step decides)
+        double best = 1e300;
+        for (int64_t c = 1; c <= smax && c <= 1024; ++c) {
+            const int64_t rounds = (per_s * c + slots - 1) / slots;
+            const int64_t rows = ((M + c - 1) / c + WK - 1) / WK * WK;
+            const double cost = (double)rounds * (double)(rows + OVH);
+            if (cost < best * 0.98) { best = cost; S = c; }           // a later (finer) split must win by 2 %: fewer partial tiles to fold otherwise
+        }
     }
     int64_t rpb = (M + S - 1) / S;
     rpb = (rpb + WK - 1) / WK * WK;
