@@ -272,7 +272,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WrMulti pm) {
 
 struct Plan { bool ok; int nt1, ncg, S; int64_t rows_per_block, ws_floats; bool y_narrow; };
 
-Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* dY, const void* X, int nprob = 1) {
+Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* dY, const void* X, int nprob = 1, int mode = -1) {
+    if (mode < 0) mode = stg_opt_wgrad_plan.load(std::memory_order_relaxed);      // option wgrad_plan (A/B knob; default 2)
     Plan pl = {};
     const bool y_narrow = N1 <= N2;
     const int NA = y_narrow ? N1 : N2, NB = y_narrow ? N2 : N1;
@@ -286,17 +287,20 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
     // VGPRs; two otherwise), and each pays a fixed price on top of its rows -- the first chunk's exposed HBM trip and the partial tile it leaves in
     // the workspace (57 KiB at nt1 = 6), priced here as OVH rows.  Rounds 1-5a took S = 512 / ncg whatever nprob was: twelve Swin-L problems of
     // 62 720 x (96, 768) ran as 6 120 workgroups of 768 rows (24 chunks: 6 per wave) at 1.9 TB/s, the fixed price about half of each.  Now: the S that
-    // minimises rounds x (rows per workgroup + OVH), at least 4 chunks per wave -- for nt1 > 2 (one workgroup per CU, 40-57 KiB partial tiles): in the
-    // step, wgrad_ws_kernel<4> 211 -> 200 us and 133 -> 92 us (Swin-B stage 3), the Swin-L step 240.9 -> 232.1 ms (profiles/r05b_wgrad_split_sweep.txt
-    // is the stand-alone sweep).
+    // minimises rounds x (rows per workgroup + OVH), at least 4 chunks per wave.  Same-box A/Bs of the REPLAYED step (option wgrad_plan 0 / 1 / 2 =
+    // old rule / chooser for nt1 > 2 / chooser for every width): Swin-L 133.4 -> 137.6 clips/s (0 -> 1), ViT-B 477.7 -> 481.1, Swin-B 286.8 (0) /
+    // 286.7 (1) / 288.4 (2).  NOTE for narrow adapters (nt1 <= 2) the kernel ALONE, as rocprofv3 times it in the one-stream eager chain, is slower
+    // with the chooser (twelve 62 720 x (32, 512) problems: 222 us as 5 904 workgroups, 304 us as 480) while the two-stream step is faster: few long
+    // workgroups leave CUs to the other chain's kernels.  `value` is the two-stream step, so 2 is the default; profiles/r05b_wgrad_split_sweep.txt
+    // is the stand-alone sweep.
     const int64_t slots = 256 * (pl.nt1 > 2 ? 1 : 2);
     const int64_t smax = (M + 4 * 4 * WK - 1) / (4 * 4 * WK);
     const int64_t per_s = (int64_t)pl.ncg * nprob;
     const int64_t OVH = 512;
-    int64_t S = 512 / pl.ncg;                      // nt1 <= 2: two light workgroups per CU hide each other's fixed price -- measured INSIDE the Swin-B
-    if (S > smax) S = smax;                        // step (rocprofv3, profiles/r05_final_ledger.md) the round-1 rule stays ahead there: twelve
-    if (S < 1) S = 1;                              // 62 720 x (32, 512) problems 222 us as 5 904 workgroups, 304 us as 480 (the stand-alone sweep said
-    if (pl.nt1 > 2) {                              // the opposite; the measurement inside the step decides)
+    int64_t S = 512 / pl.ncg;
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if ((pl.nt1 > 2 && mode != 0) || mode == 2) {
         double best = 1e300;
         for (int64_t c = 1; c <= smax && c <= 1024; ++c) {
             const int64_t rounds = (per_s * c + slots - 1) / slots;
@@ -318,11 +322,12 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
 extern "C" int64_t stg_wgrad_ws_floats(int64_t M, int N1, int N2) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
     int64_t need = 0;                               // per problem, whatever the number of problems its launch carries (the split depends on it)
-    for (int n = 1; n <= WMAX; ++n) {
-        const Plan pl = plan_for(M, N1, N2, (N1 + 7) & ~7, (N2 + 7) & ~7, nullptr, nullptr, n);
-        if (!pl.ok) return 0;
-        need = pl.ws_floats > need ? pl.ws_floats : need;
-    }
+    for (int n = 1; n <= WMAX; ++n)
+        for (int mode = 0; mode < 3; ++mode) {          // ... and whichever way option wgrad_plan stands when the launch comes
+            const Plan pl = plan_for(M, N1, N2, (N1 + 7) & ~7, (N2 + 7) & ~7, nullptr, nullptr, n, mode);
+            if (!pl.ok) return 0;
+            need = pl.ws_floats > need ? pl.ws_floats : need;
+        }
     return need;
 }
 
