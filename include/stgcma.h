@@ -538,8 +538,10 @@ int stg_mha1_bwd(const void* q, const void* k, const void* v, const float* drop,
 int stg_im2col3x3(const void* x, int64_t ldx, void* out, int64_t F, int H, int W, int C, int dilation, void* stream);
 /* Weight gradient of the same convolution without the im2col image (autograd of nn.Conv2d(I, O, 3, padding = dilation) at
  * Swin_AVSModel_Base.py:27,37-38,117): ws[s, o, (kh, kw, i)] = sum over the s-th slice of the rows m of dy[m, o] * x[pixel(m) shifted
- * by tap (kh, kw), i]; dW = sum_s ws[s] (fp32; the caller reduces and owns the workspace).  O % 8 == 0 (tiles of 128, zero-padded
- * inside the kernel), I % 128 == 0.
+ * by tap (kh, kw), i]; dW = sum_s ws[s] (fp32; the caller reduces and owns the workspace).  O % 8 == 0 and I % 8 == 0 (tiles of 128 x 128,
+ * zero-padded inside the kernel).  A convolution with FEW output channels is cheaper with the operands swapped -- stg_conv3x3_wgrad(x, dy) gives
+ * T[i, (kh, kw, o)] with dW[o, (kh, kw, i)] = T[i, (2 - kh, 2 - kw, o)] (the shift moves to the small operand; kernels.conv3x3_wgrad does this
+ * below 64 output channels).
  * stg_conv3x3_wgrad_ws_floats returns the workspace size in floats (and the number of slices), -1 when the shape is unsupported. */
 int64_t stg_conv3x3_wgrad_ws_floats(int64_t M, int O, int I, int* splits_out);
 int stg_conv3x3_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* zero_line, float* ws, int64_t ws_floats,

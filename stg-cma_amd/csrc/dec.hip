@@ -97,7 +97,7 @@ __device__ __forceinline__ void cw_wait8(bf16x8_t (&a)[4], bf16x8_t (&b)[4]) {
 // lands while block mb is multiplied; the wait in front of a barrier is COUNTED (only the oldest block must have landed).  Measured on the decoder's
 // shapes: <64, 2> (one block ahead, 64 KiB, two workgroups per CU) 529-584 TFLOP/s, <32, 4> (three ahead, twice the barriers) 485-554 -- the
 // kernel is not bound by the DMA's latency once the compiler's hidden vmcnt(0) is gone (cw_frag); <64, 2> is what runs.  (2) A 128-column tile may
-// span TWO taps: I % 64 == 0 suffices (each 16-byte piece knows its own tap), which takes the ASPP convolutions over the 64- and 320-channel maps
+// span SEVERAL taps: I % 8 == 0 suffices (each 16-byte piece knows its own tap: round 5a I % 64, round 5b any multiple of 8), which takes the ASPP convolutions over the 64- and 320-channel maps
 // off the im2col + atomic-wgrad path; columns >= taps * I are zero-filled and never stored.  (3) Row splits chosen to fill the launch's last round
 // of workgroups (cw_ws_floats): 470-520 -> 600-680 TFLOP/s together with (1).
 template <int ROWS, int NBUF>
@@ -624,7 +624,7 @@ extern "C" int stg_bn_bwd(const void* x, const void* dy, const float* mean, cons
 }
 
 static int64_t cw_ws_floats(int64_t M, int O, int I, int taps, int* splits_out) {
-    if (M <= 0 || O <= 0 || I <= 0 || O % 8 != 0 || I % 64 != 0) return -1;       // O and taps * I are padded to 128 with zero columns inside the kernel
+    if (M <= 0 || O <= 0 || I <= 0 || O % 8 != 0 || I % 8 != 0) return -1;       // O and taps * I are padded to 128 with zero columns inside the kernel
     const int tiles = ((O + 127) / 128) * ((taps * I + 127) / 128);
     // Row splits.  Every workgroup does the same work and two fit a CU (64 KiB of LDS each), so a launch runs in ROUNDS of 64 workgroups per XCD; a
     // split's tiles all go to one XCD (conv_wgrad_kernel), split s to XCD s % 8.  Choose splits = 8 k so that k * tiles workgroups per XCD fill
@@ -648,8 +648,8 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
                      int64_t ws_floats, int64_t M, int H, int W, int O, int I, int dilation, int taps, void* stream, int batch = 1,
                      float* dbws = nullptr) {
     STG_CHECK(dy && x && zero_line && ws, -1, "%s: null pointer", who);
-    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 64 == 0 && O > 0 && I > 0, -2,
-              "%s: needs O %% 8 == 0 and I %% 64 == 0", who);
+    STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 8 == 0 && O > 0 && I > 0, -2,
+              "%s: needs O %% 8 == 0 and I %% 8 == 0", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "%s: bad leading dimensions", who);
     STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;

@@ -1819,21 +1819,38 @@ def im2col3x3(x, F_, H, W, dilation):
 
 
 def conv3x3_wgrad_supported(O, I):
-    return O % 8 == 0 and I % 64 == 0
+    return O % 8 == 0 and I % 8 == 0
 
 
 @_family_io("dec_conv_wgrad", flops=lambda dy, x, F_, H, W, dilation, want_db=False: 18.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
 def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     """dW [O, 9 * I] fp32 (columns ordered (kh, kw, i)) of a 3x3 convolution with padding = dilation, from dy [F*H*W, O] and
-    x [F*H*W, I] (bf16, channels-last rows), without the im2col image; with want_db also db [O] = column sums of dy."""
+    x [F*H*W, I] (bf16, channels-last rows), without the im2col image; with want_db also db [O] = column sums of dy.
+    Few output channels (O < 64 <= I): the operands are SWAPPED -- the kernel's 128-wide "output channel" tile carries x's channels (no zero
+    columns), the taps shift the narrow dy (64 bytes per pixel and tap instead of x's rows re-read once per tap), and
+    dW[o, (kh, kw, i)] = T[i, (2 - kh, 2 - kw, o)]: the 448 x 448 output convolution of the AVS decoder (128 -> 32) 3.1 -> 1.2 ms."""
     M = F_ * H * W
     _chk2d(dy, "dy", BF16, rows=M)
     _chk2d(x, "x", BF16, rows=M)
     O, I = dy.shape[1], x.shape[1]
+    if O < 64 <= I and conv3x3_wgrad_supported(I, O):
+        T = _conv3x3_wgrad_raw(x, dy, F_, H, W, dilation, False)                       # [I, (kh', kw', o)]
+        dW = T.view(I, 3, 3, O).flip(1, 2).permute(3, 1, 2, 0).reshape(O, 9 * I).contiguous()
+        if not want_db:
+            return dW
+        sums = torch.zeros((2, O), dtype=F32, device=dy.device)                        # db = column sums of dy (stg_bn_colsum, mode 0)
+        _lib.check(_lib.lib().stg_bn_colsum(_p(dy), None, None, None, _p(sums), M, O, 0, _stream()), "stg_bn_colsum")
+        return dW, sums[0].contiguous()
+    return _conv3x3_wgrad_raw(dy, x, F_, H, W, dilation, want_db)
+
+
+def _conv3x3_wgrad_raw(dy, x, F_, H, W, dilation, want_db):
+    M = F_ * H * W
+    O, I = dy.shape[1], x.shape[1]
     splits = C.c_int(0)
     n = _lib.lib().stg_conv3x3_wgrad_ws_floats(M, O, I, C.byref(splits))
     if n <= 0:
-        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 64 == 0)")
+        raise RuntimeError("conv3x3_wgrad: unsupported shape (O % 8 == 0 and I % 8 == 0)")
     ws = torch.empty((splits.value, O, 9 * I), dtype=F32, device=x.device)
     dbw = torch.empty((splits.value, O), dtype=F32, device=x.device) if want_db else None
     _lib.check(_lib.lib().stg_conv3x3_wgrad(_p(dy), _ld(dy), _p(x), _ld(x), _p(_zero_line(x.device)), _p(ws), ws.numel(), _p(dbw), F_, H, W, O, I,

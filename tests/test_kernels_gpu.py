@@ -378,7 +378,11 @@ def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
                                           (4, 56, 56, 128, 256, 6), (1, 14, 14, 256, 256, 1), (2, 28, 28, 128, 32, 1), (1, 14, 14, 128, 200, 2),
                                           # round 5: I % 64 == 0 (a 128-column tile spans two taps; 9 I not a multiple of 128: a zero-filled tail) and
                                           # odd row-block counts for the double-buffered ring
-                                          (3, 56, 56, 64, 256, 3), (2, 14, 14, 320, 256, 12), (1, 7, 7, 64, 128, 1), (5, 28, 28, 192, 64, 2), (1, 9, 7, 64, 8, 1)])
+                                          (3, 56, 56, 64, 256, 3), (2, 14, 14, 320, 256, 12), (1, 7, 7, 64, 128, 1), (5, 28, 28, 192, 64, 2), (1, 9, 7, 64, 8, 1),
+                                          # round 5b: any I % 8 == 0 (a 128-column tile spans up to 16 taps' pieces), and O < 64 <= I = the swapped-operand
+                                          # call (the taps move to dy, the result comes back tap-flipped and transposed), with dilation
+                                          (2, 14, 14, 32, 128, 1), (1, 9, 7, 8, 64, 2), (2, 12, 10, 24, 72, 1), (2, 28, 28, 128, 32, 3), (1, 14, 14, 256, 16, 6),
+                                          (3, 7, 7, 64, 56, 1)])
 def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
     """The conv weight gradient without the im2col image against autograd of F.conv2d in fp32 (same bf16-rounded operands)."""
     from stgcma import kernels as k
@@ -395,7 +399,7 @@ def test_conv3x3_wgrad(stg, gpu, F_, H, W, I, O, d):
     scale = float(ref.abs().max())
     err = float((got.cpu() - ref).abs().max())
     assert err <= 2e-3 * scale, (err, scale)
-    assert db.cpu().allclose(dy.float().sum(0), rtol=1e-4, atol=2e-2)          # bias gradient = column sums of dy, from the same launch
+    assert db.cpu().allclose(dy.float().sum(0), rtol=1e-4, atol=2e-2)          # bias gradient = column sums of dy (same launch, or stg_bn_colsum when swapped)
 
 
 @pytest.mark.parametrize("M,N1,N2", [(5000, 128, 128), (20000, 256, 1024), (4096, 256, 128), (31360, 128, 256)])
