@@ -245,18 +245,25 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
 
 // grid of a (pair) launch: one group -> up to 2048 workgroups; two groups -> up to 1024 each, group 1 first (sets nb1)
 template <typename P>
-int64_t plan_grid(P& p, int GPB) {
-    auto blocks = [&](int64_t rows, int64_t cap) { const int64_t n = ((rows + 15) / 16 + GPB - 1) / GPB; return n > cap ? cap : n; };
-    if (p.split_m <= 0) { p.nb1 = 0; return blocks(p.M, 2048); }
-    p.nb1 = (int)blocks(p.split_m, 1024);
-    return p.nb1 + blocks(p.M - p.split_m, 1024);
+int64_t plan_grid(P& p, int GPB, int64_t cap = 2048) {
+    // cap = workgroups of the launch.  Every workgroup first fills LDS with the adapter's weight matrix in fragment order; the wide variants (NW >= 8:
+    // C = 384 / 768 with K / J up to 96, 73-147 KiB of weights, ONE workgroup per CU) ran as 2 048 workgroups of ~61 rows until round 5b -- eight
+    // rounds per CU, each paying the 147 KiB prologue (40 % of the bytes it then streams, latency exposed) -- and are now ONE round of 256.
+    auto blocks = [&](int64_t rows, int64_t c) { const int64_t n = ((rows + 15) / 16 + GPB - 1) / GPB; return n > c ? c : n; };
+    if (p.split_m <= 0) { p.nb1 = 0; return blocks(p.M, cap); }
+    // pair launch: the two row groups share the cap in proportion to their rows (ViT-B: 63 040 video rows, 15 680 audio rows -- equal halves left
+    // the audio half's workgroups done four times earlier)
+    int64_t c1 = (cap * p.split_m + p.M / 2) / p.M;
+    c1 = c1 < 1 ? 1 : c1 > cap - 1 ? cap - 1 : c1;
+    p.nb1 = (int)blocks(p.split_m, c1);
+    return p.nb1 + blocks(p.M - p.split_m, cap - c1);
 }
 
 template <int NT, int NH, int KS, int NW = 4>
 int launch_upln(const UpLnP& pin, hipStream_t st) {
     constexpr int GPB = NW / NH;
     UpLnP p = pin;
-    const int64_t nblk = plan_grid(p, GPB);
+    const int64_t nblk = plan_grid(p, GPB, NW >= 8 ? stg_opt_upln_cap.load(std::memory_order_relaxed) : 2048);
     const size_t lds = (size_t)NT * NH * KS * 64 * 16 + (size_t)3 * NT * NH * 16 * 4 + 2 * NW * 16 * sizeof(float2);
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> d1{0}, d0{0};
@@ -505,7 +512,7 @@ template <int NT, int NH, int NJ, int NW = 4, bool XH = false>
 int launch_lnbd(const LnDownP& pin, hipStream_t st) {
     constexpr int GPB = NW / NH;
     LnDownP p = pin;
-    const int64_t nblk = plan_grid(p, GPB);
+    const int64_t nblk = plan_grid(p, GPB, NW >= 8 ? stg_opt_upln_cap.load(std::memory_order_relaxed) : 2048);
     const size_t lds = (size_t)NJ * (NT * NH / 2) * 64 * 16 + (XH ? 0 : (size_t)NT * NH * 16 * 4) + NW * 16 * sizeof(float2) +
                        (NH > 1 ? (size_t)(NW / NH) * NJ * 4 * 64 * 4 : 0);
     if (lds > 64 * 1024) {
