@@ -446,9 +446,12 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     // the fences around the P / dS tiles keep the compiler from sinking the loads back to their use
     float4 addc[4], addn[4];
     auto load_add = [&](float4 (&dst)[4], int kt, int qt) {
-        const float* bmq = a.bm + tb + 4 * (32 * qt + r);
+        const float* bmq = a.bm + tb + 4 * (32 * qt + (32 * qt + r < a.n ? r : 0));       // (padded queries: lane 0's address; see winattn_fwd1_kernel)
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (NKEY > 0 && 32 * kt + 8 * g4 >= NKEY) { dst[g4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+        }
     };
     load_add(addc, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -589,18 +592,24 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kp + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vp + off), (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
     }
+    // The additive table is 16 KiB per (window, head) -- more bytes through the CU's vector-memory path than the q / k / v / o tiles (12.5 KiB), all
+    // L2 hits; with the loads removed (wrong results: a probe) the forward ran 10-22 % faster.  Round 5b: key groups entirely past NKEY are not
+    // fetched and the lanes of padded queries read lane 0's address (-1..-2 %).  Tried and not kept: one wave taking the same window position of 2 / 4
+    // consecutive frames with ONE table fetch (0 .. -8 % at stage 0, +2 .. +5 % at the others: the frames of a wave then run one after the other).
     const float* bmq[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
-        bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + r);       // tiled: see win_table_kernel
+        bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + (32 * t + r < a.n ? r : 0));       // tiled: see win_table_kernel
     float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (NKEY > 0 && 32 * kt + 8 * g4 >= NKEY) { add[qt][kt][g4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // every key of the group is padding
+                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));      // (a half-padded group needs its -1e30s)
+            }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_fence();
 
