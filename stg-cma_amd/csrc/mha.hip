@@ -138,7 +138,7 @@ __device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NT
 // ------------------------------------------------------------------------------------------------ forward
 // KV1: K and V are the same tensor (one staged tile serves the score MFMA and, read transposed, the P.V MFMA)
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];      // two buffers
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd_kernel(MP a)
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq_kernel(MP a) 
 // profiles/r05_mha_sq_counters.txt).  Here a trip covers 64 keys: the two tiles' MFMA chains are independent, so tile B's score MFMAs execute while
 // tile A's softmax issues, the statistics are updated once per 64 keys, and there is one barrier per 64 keys.  Staged tiles are [64][D + 8].
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW, 64>;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];                  // two buffers x NTILE x [64][DP]
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_fwd2_kernel(MP a
 }
 
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq2_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW, 64>;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dq2_kernel(MP a)
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dkv_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NKV = KV1 ? 1 : 2;
     using SC = StageC<D, 2, NW>;
     // two buffers of {shared Q / dO tiles + lse / delta of the query tile}, then per wave its own K (and V) tile
@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv_kernel(MP a)
 
 // two QUERY tiles per trip (round 5): the staged Q / dO tiles are [64][D + 8], one barrier per 64 queries
 template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) mha_dkv2_kernel(MP a) {
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dkv2_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NKV = KV1 ? 1 : 2;
     using SC = StageC<D, 2, NW, 64>;
     // two buffers of {shared Q / dO tiles + lse / delta of the query tile}, then per wave its own K (and V) tile
@@ -768,9 +768,12 @@ int launch_dkv2(const dim3& grid, const MP& p, hipStream_t stream) {
 // waves per block.  Backward: 8 where a frame has more than 4 query tiles (one staging of a tile then serves 256 rows; ViT-B's 197 tokens take ONE
 // block per (frame, head)): measured -11 % at 3136 x 3136 x 96 (5589 -> 4971 us), -9 % at 8 x 197 x 197 x 96 (532 -> 485 us).  Forward: 4 -- with 8 it
 // measured +5 % on both shapes (its trip is shorter, the barrier among 8 waves weighs more).  Option mha_nw (tools) forces either.
-int pick_nw(int nt, bool bwd) {
+// Round 5b: 2 where a problem has at most two query tiles and K == V (the window-level cross-modal pairs: 49 tokens) -- with 4 waves per block half of
+// every block idled and a CU held 4 live waves; option mha_nw = 4 restores that.
+int pick_nw(int nt, bool bwd, bool kv1 = false) {
     const int o = stg_opt_mha_nw.load(std::memory_order_relaxed);
     if (o == 4 || o == 8) return o;
+    if (kv1 && nt <= 2) return 2;
     return bwd && nt > 4 ? 8 : 4;
 }
 
@@ -804,14 +807,15 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     int rc = fill(f, p, "stg_mha_fwd");
     if (rc) return rc;
     if (p.P == 0) return 0;
-    const int nw = pick_nw(p.nt, false);
-    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
+    const int nw = pick_nw(p.nt, false, kv1);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     hipStream_t st = (hipStream_t)stream;
     const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
 #define STG_MHA_FWD(DD, KV, NW) { if (kt2) { rc = launch_fwd2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); }
 #define STG_MHA_FWD2(DD, KV) { if (nw == 8) STG_MHA_FWD(DD, KV, 8) else STG_MHA_FWD(DD, KV, 4) }
-    if (f->D == 64) { if (kv1) STG_MHA_FWD2(64, true) else STG_MHA_FWD2(64, false) }
+    if (nw == 2) { if (f->D == 64) STG_MHA_FWD(64, true, 2) else STG_MHA_FWD(96, true, 2) }
+    else if (f->D == 64) { if (kv1) STG_MHA_FWD2(64, true) else STG_MHA_FWD2(64, false) }
     else { if (kv1) STG_MHA_FWD2(96, true) else STG_MHA_FWD2(96, false) }
 #undef STG_MHA_FWD2
 #undef STG_MHA_FWD
@@ -833,15 +837,16 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (p.P == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.delta = delta;
-    const int nw = pick_nw(p.nt, true);
-    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     const bool kv1 = f->K == f->V;
+    const int nw = pick_nw(p.nt, true, kv1);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
     hipStream_t st = (hipStream_t)stream;
     const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
 #define STG_MHA_BWD(DD, KV, NW) { if (kt2) { rc = launch_dq2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); \
-                                  STG_LAUNCH_CHECK(); rc = (kt2 && dkv2_lds_bytes(DD, KV, NW) <= 160 * 1024 && !(DD == 96 && !KV && NW == 4) /* 256 VGPRs + spills */ && !stg_opt_mha_dkv1.load(std::memory_order_relaxed)) ? launch_dkv2<DD, KV, NW>(grid, p, st) : launch_dkv<DD, KV, NW>(grid, p, st); }
+                                  STG_LAUNCH_CHECK(); rc = (kt2 && dkv2_lds_bytes(DD, KV, NW) <= 160 * 1024 && !(DD == 96 && !KV && NW == 4) && !(DD == 96 && NW == 2) /* 256 VGPRs + spills */ && !stg_opt_mha_dkv1.load(std::memory_order_relaxed)) ? launch_dkv2<DD, KV, NW>(grid, p, st) : launch_dkv<DD, KV, NW>(grid, p, st); }
 #define STG_MHA_BWD2(DD, KV) { if (nw == 8) STG_MHA_BWD(DD, KV, 8) else STG_MHA_BWD(DD, KV, 4) }
-    if (f->D == 64) { if (kv1) STG_MHA_BWD2(64, true) else STG_MHA_BWD2(64, false) }
+    if (nw == 2) { if (f->D == 64) STG_MHA_BWD(64, true, 2) else STG_MHA_BWD(96, true, 2) }
+    else if (f->D == 64) { if (kv1) STG_MHA_BWD2(64, true) else STG_MHA_BWD2(64, false) }
     else { if (kv1) STG_MHA_BWD2(96, true) else STG_MHA_BWD2(96, false) }
 #undef STG_MHA_BWD2
 #undef STG_MHA_BWD
