@@ -57,6 +57,8 @@ struct AttnP {
     int total_items;
 };
 
+struct AttnP2 { AttnP a[2]; };     // the two directions of a cross-modal pair in one launch (blockIdx.y); a single call fills a[0] only
+
 __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -186,7 +188,8 @@ struct RowTerms {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D, bool PK>
-__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_fwd_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_fwd_kernel(AttnP2 pp) {
+    const AttnP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
@@ -318,7 +321,8 @@ __global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_fwd_kernel(A
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
 template <int D, bool PK>
-__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_bwd_dq_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D > 64 && PK ? 1 : 2)) attn_bwd_dq_kernel(AttnP2 pp) {
+    const AttnP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * D];
@@ -471,7 +475,8 @@ __device__ __forceinline__ void flush_dbias(const AttnP& a, f32x16_t& dbacc, int
 template <int D, bool PK>
 // D = 96 / 128 (ViT heads): at two waves per SIMD the accumulators spill 300+ VGPRs to scratch; one wave per SIMD (AGPRs) measured
 // 130 -> 81 ms over the ViT-B step, the other variants are faster at two
-__global__ void __launch_bounds__(256, (D >= 48 && !PK ? 1 : 2)) attn_bwd_dkv_kernel(AttnP a) {
+__global__ void __launch_bounds__(256, (D >= 48 && !PK ? 1 : 2)) attn_bwd_dkv_kernel(AttnP2 pp) {
+    const AttnP a = pp.a[blockIdx.y];
     constexpr int KS = D / 16;
     constexpr int DB = (D + 31) / 32;
     constexpr bool PREFETCH = D <= 64;                 // register budget: two extra tiles in flight only for small D
@@ -650,16 +655,20 @@ int fill(const stg_attn_args* f, AttnP& p, const char* who) {
     return 0;
 }
 
+// p1 != nullptr: a second problem of the same head dim and packing in the same launch (grid.y = 2; the shorter one's surplus workgroups leave at once)
 template <template <int, bool> class Launcher>
-int dispatch_d(int D, const AttnP& p, hipStream_t st) {
+int dispatch_d(int D, const AttnP& p, hipStream_t st, const AttnP* p1 = nullptr) {
     const bool pk = p.pack > 1;
+    AttnP2 pp;
+    pp.a[0] = p; pp.a[1] = p1 ? *p1 : p;
+    const int ny = p1 ? 2 : 1;
     switch (D) {
-        case 16: return pk ? Launcher<16, true>::run(p, st) : Launcher<16, false>::run(p, st);
-        case 32: return pk ? Launcher<32, true>::run(p, st) : Launcher<32, false>::run(p, st);
-        case 48: return pk ? Launcher<48, true>::run(p, st) : Launcher<48, false>::run(p, st);
-        case 64: return pk ? Launcher<64, true>::run(p, st) : Launcher<64, false>::run(p, st);
-        case 96: return pk ? Launcher<96, true>::run(p, st) : Launcher<96, false>::run(p, st);
-        case 128: return pk ? Launcher<128, true>::run(p, st) : Launcher<128, false>::run(p, st);
+        case 16: return pk ? Launcher<16, true>::run(pp, ny, st) : Launcher<16, false>::run(pp, ny, st);
+        case 32: return pk ? Launcher<32, true>::run(pp, ny, st) : Launcher<32, false>::run(pp, ny, st);
+        case 48: return pk ? Launcher<48, true>::run(pp, ny, st) : Launcher<48, false>::run(pp, ny, st);
+        case 64: return pk ? Launcher<64, true>::run(pp, ny, st) : Launcher<64, false>::run(pp, ny, st);
+        case 96: return pk ? Launcher<96, true>::run(pp, ny, st) : Launcher<96, false>::run(pp, ny, st);
+        case 128: return pk ? Launcher<128, true>::run(pp, ny, st) : Launcher<128, false>::run(pp, ny, st);
     }
     return -2;
 }
@@ -672,28 +681,28 @@ inline int grid_of(int64_t items, unsigned& g) {
 }
 
 template <int D, bool PK> struct FwdL {
-    static int run(const AttnP& p, hipStream_t st) {
-        unsigned g;
-        STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
+    static int run(const AttnP2& pp, int ny, hipStream_t st) {
+        unsigned g, g1 = 0;
+        STG_CHECK(grid_of(pp.a[0].total_items, g) == 0 && (ny == 1 || grid_of(pp.a[1].total_items, g1) == 0), -2, "attention: grid out of range");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<D, PK>), dim3(g > g1 ? g : g1, ny), dim3(256), 0, st, pp);
         STG_LAUNCH_CHECK();
         return 0;
     }
 };
 template <int D, bool PK> struct DqL {
-    static int run(const AttnP& p, hipStream_t st) {
-        unsigned g;
-        STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dq_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
+    static int run(const AttnP2& pp, int ny, hipStream_t st) {
+        unsigned g, g1 = 0;
+        STG_CHECK(grid_of(pp.a[0].total_items, g) == 0 && (ny == 1 || grid_of(pp.a[1].total_items, g1) == 0), -2, "attention: grid out of range");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dq_kernel<D, PK>), dim3(g > g1 ? g : g1, ny), dim3(256), 0, st, pp);
         STG_LAUNCH_CHECK();
         return 0;
     }
 };
 template <int D, bool PK> struct DkvL {
-    static int run(const AttnP& p, hipStream_t st) {
-        unsigned g;
-        STG_CHECK(grid_of(p.total_items, g) == 0, -2, "attention: grid out of range");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dkv_kernel<D, PK>), dim3(g), dim3(256), 0, st, p);
+    static int run(const AttnP2& pp, int ny, hipStream_t st) {
+        unsigned g, g1 = 0;
+        STG_CHECK(grid_of(pp.a[0].total_items, g) == 0 && (ny == 1 || grid_of(pp.a[1].total_items, g1) == 0), -2, "attention: grid out of range");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_bwd_dkv_kernel<D, PK>), dim3(g > g1 ? g : g1, ny), dim3(256), 0, st, pp);
         STG_LAUNCH_CHECK();
         return 0;
     }
@@ -772,6 +781,21 @@ extern "C" int stg_attn_fwd2(const stg_attn_args* f0, const stg_attn_args* f1, v
         STG_CHECK(f0->O && f1->O && f0->ldo % 4 == 0 && f1->ldo % 4 == 0 && ((((uintptr_t)f0->O) | ((uintptr_t)f1->O)) & 7) == 0, -2, "stg_attn_fwd2: bad O");
         return stg_xattn_fwd2(f0, f1, stream);
     }
+    // otherwise the generic kernels: one launch for both directions where they share head dim and packing (ViT-B's pair: 197 video and 49 audio
+    // tokens at d = 48 -- two launches of ~17 us each were mostly ramp)
+    if (f0->P > 0 && f1->P > 0 && f0->D == f1->D && !(xattn_on() && (stg_xattn_eligible(f0, true) || stg_xattn_eligible(f1, true)))) {
+        AttnP p0 = {}, p1 = {};
+        int rc = fill(f0, p0, "stg_attn_fwd2");
+        if (rc) return rc;
+        rc = fill(f1, p1, "stg_attn_fwd2");
+        if (rc) return rc;
+        STG_CHECK(f0->O && f1->O && f0->ldo % 4 == 0 && f1->ldo % 4 == 0 && ((((uintptr_t)f0->O) | ((uintptr_t)f1->O)) & 7) == 0, -2, "stg_attn_fwd2: bad O");
+        const int64_t i0 = groups(p0) * f0->H * tiles_q(p0), i1 = groups(p1) * f1->H * tiles_q(p1);
+        if ((p0.pack > 1) == (p1.pack > 1) && i0 < (1ll << 31) && i1 < (1ll << 31)) {
+            p0.total_items = (int)i0; p1.total_items = (int)i1;
+            return dispatch_d<FwdL>(f0->D, p0, (hipStream_t)stream, &p1);
+        }
+    }
     const int rc = stg_attn_fwd(f0, stream);
     return rc ? rc : stg_attn_fwd(f1, stream);
 }
@@ -787,6 +811,35 @@ extern "C" int stg_attn_bwd2(const stg_attn_bwd_args* b0, const stg_attn_bwd_arg
         rc = fill(&b1->f, p, "stg_attn_bwd2");
         if (rc) return rc;
         return stg_xattn_bwd2(b0, b1, stream);
+    }
+    if (b0->f.P > 0 && b1->f.P > 0 && b0->f.D == b1->f.D && !b0->dbias && !b1->dbias &&
+        !(xattn_on() && ((b0->dV == nullptr && stg_xattn_eligible(&b0->f, true)) || (b1->dV == nullptr && stg_xattn_eligible(&b1->f, true))))) {
+        AttnP p[2] = {};
+        const stg_attn_bwd_args* bb[2] = {b0, b1};
+        for (int i = 0; i < 2; ++i) {                                 // the checks of stg_attn_bwd, per problem
+            const stg_attn_bwd_args* b = bb[i];
+            const stg_attn_args* f = &b->f;
+            int rc = fill(f, p[i], "stg_attn_bwd2");
+            if (rc) return rc;
+            STG_CHECK(f->O && f->lse && b->dO && b->dQ && b->dK && b->delta, -1, "stg_attn_bwd2: null O/lse/dO/dQ/dK/delta");
+            STG_CHECK(f->ldo % 8 == 0 && b->lddo % 8 == 0 && b->lddq % 4 == 0 && b->lddk % 4 == 0 && (b->dV == nullptr || b->lddv % 4 == 0),
+                      -2, "stg_attn_bwd2: bad leading dims");
+            STG_CHECK((((uintptr_t)f->O | (uintptr_t)b->dO) & 15) == 0, -2, "stg_attn_bwd2: O/dO must be 16-byte aligned");
+            STG_CHECK((((uintptr_t)b->dQ | (uintptr_t)b->dK | (uintptr_t)b->dV) & 7) == 0, -2, "stg_attn_bwd2: dQ/dK/dV must be 8-byte aligned");
+            p[i].dO = (const bf16_t*)b->dO; p[i].lddo = b->lddo;
+            p[i].dQ = (bf16_t*)b->dQ; p[i].lddq = b->lddq; p[i].dK = (bf16_t*)b->dK; p[i].lddk = b->lddk;
+            p[i].dV = (bf16_t*)b->dV; p[i].lddv = b->lddv; p[i].delta = b->delta; p[i].dbias = nullptr;
+            p[i].pchunk = 1;
+        }
+        const int64_t q0 = groups(p[0]) * p[0].H * tiles_q(p[0]), q1 = groups(p[1]) * p[1].H * tiles_q(p[1]);
+        const int64_t k0 = groups(p[0]) * p[0].H * tiles_kv(p[0]), k1 = groups(p[1]) * p[1].H * tiles_kv(p[1]);
+        if ((p[0].pack > 1) == (p[1].pack > 1) && q0 < (1ll << 31) && q1 < (1ll << 31) && k0 < (1ll << 31) && k1 < (1ll << 31)) {
+            p[0].total_items = (int)q0; p[1].total_items = (int)q1;
+            int rc = dispatch_d<DqL>(b0->f.D, p[0], (hipStream_t)stream, &p[1]);          // dQ (+ delta) of both directions ...
+            if (rc) return rc;
+            p[0].total_items = (int)k0; p[1].total_items = (int)k1;
+            return dispatch_d<DkvL>(b0->f.D, p[0], (hipStream_t)stream, &p[1]);          // ... then dK / dV of both
+        }
     }
     const int rc = stg_attn_bwd(b0, stream);
     return rc ? rc : stg_attn_bwd(b1, stream);
