@@ -1595,7 +1595,10 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // round 5 (option gemm_d8m, default on): the fc2 dgrad's byte-derivative-source epilogue joins the wide-output classes when the MULTI-tile
     // walk will take it (its derivative bytes are ordinary global loads in the epilogue: waiting for them also waits for the next tile's older
     // prologue DMAs, which is safe -- the counted wait behind the epilogue only needs >= NST younger operations)
-    const bool d8m = p.epi_variant == EV_DSRC8 && stg_opt_gemm_d8m.load(std::memory_order_relaxed) != 0 && a->K <= 512 && a->N >= 1024;
+    // (round 5b: option value 2, the default, extends this to K <= 1024 -- Swin-L's and ViT-B's fc2 dgrad, 3072 x 768, ran on the 128 x 128 kernel
+    // at 0.81 PFLOP/s, 13 ms of the Swin-L step; on the one-tile 8-phase kernel the step's GEMM time drops 122.1 -> 119.6 ms)
+    const int d8opt = stg_opt_gemm_d8m.load(std::memory_order_relaxed);
+    const bool d8m = p.epi_variant == EV_DSRC8 && d8opt != 0 && a->K <= (d8opt >= 2 ? 1024 : 512) && a->N >= 1024;
     const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8 || d8m);
     if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
         const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
