@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 216
+#define STG_VERSION 217
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -480,6 +480,13 @@ int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0,
 /* out = (a + b + c) z on two equally sized problems; c0 == c1 == NULL: (a + b) z (the join behind stg_xattn_pair_bwd) */
 int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                   const void* c1, const void* z1, void* out1, int64_t numel, void* stream);
+/* The same three with a size per problem (ABI 217): ViT's pair has 197 video and 49 audio tokens per frame (CLIP_AVE.py:379-401). */
+int stg_gate_fwd2n(const void* h0, const void* r0, const float* g0, void* out0, int64_t numel0, const void* h1, const void* r1,
+                   const float* g1, void* out1, int64_t numel1, void* stream);
+int stg_gate_bwd2n(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, int64_t numel0, const void* dout1,
+                   const void* r1, const float* g1, void* dr1, float* dgate1, int64_t numel1, void* stream);
+int stg_add3_mul2n(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, int64_t numel0, const void* a1,
+                   const void* b1, const void* c1, const void* z1, void* out1, int64_t numel1, void* stream);
 /* Test aid: fill the LDS of every CU with NaN bit patterns, so that a kernel reading an LDS byte nobody wrote produces a non-finite result
  * (stgcma._lib wraps every launch with it under STG_LDS_POISON=1; tests/test_lds_poison_gpu.py). */
 int stg_debug_poison_lds(void* stream);

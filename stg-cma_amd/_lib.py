@@ -194,6 +194,9 @@ SIGNATURES = {
     "stg_gate_fwd2": (C.c_int, [c_vp] * 8 + [c_i64, c_vp]),
     "stg_gate_bwd2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
     "stg_add3_mul2": (C.c_int, [c_vp] * 10 + [c_i64, c_vp]),
+    "stg_gate_fwd2n": (C.c_int, [c_vp] * 4 + [c_i64] + [c_vp] * 4 + [c_i64, c_vp]),
+    "stg_gate_bwd2n": (C.c_int, [c_vp] * 5 + [c_i64] + [c_vp] * 5 + [c_i64, c_vp]),
+    "stg_add3_mul2n": (C.c_int, [c_vp] * 5 + [c_i64] + [c_vp] * 5 + [c_i64, c_vp]),
     "stg_debug_poison_lds": (C.c_int, [c_vp]),
     "stg_mul_mask": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_bias_gather": (C.c_int, [c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
@@ -225,7 +228,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 216
+ABI_VERSION = 217
 _lib = None
 
 

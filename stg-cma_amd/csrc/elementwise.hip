@@ -123,9 +123,11 @@ __global__ void add3_mul_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* 
 struct Ew2 {
     const bf16_t* a[2]; const bf16_t* b[2]; const bf16_t* c[2]; const bf16_t* z[2];
     const float* g[2]; bf16_t* out[2]; float* dg[2];
+    int64_t n[2];                    // elements per problem (round 5b: the two may differ -- ViT's 197 video and 49 audio tokens)
 };
-__global__ void gate_fwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+__global__ void gate_fwd2_kernel(Ew2 p) {
     const int y = blockIdx.y;
+    const int64_t numel = p.n[y], n8 = numel >> 3;
     const bf16_t* h = p.a[y]; const bf16_t* r = p.b[y]; bf16_t* out = p.out[y];
     const float g = p.g[y][0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -141,8 +143,9 @@ __global__ void gate_fwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
         out[i] = f2bf(bf2f(h[i]) + g * bf2f(r[i]));
     }
 }
-__global__ void gate_bwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+__global__ void gate_bwd2_kernel(Ew2 p) {
     const int y = blockIdx.y;
+    const int64_t numel = p.n[y], n8 = numel >> 3;
     const bf16_t* dout = p.a[y]; const bf16_t* r = p.b[y]; bf16_t* dr = p.out[y];
     const float g = p.g[y][0];
     float acc = 0.f;
@@ -171,8 +174,9 @@ __global__ void gate_bwd2_kernel(Ew2 p, int64_t n8, int64_t numel) {
         atomicAdd(p.dg[y], t);
     }
 }
-__global__ void add3_mul2_kernel(Ew2 p, int64_t n8, int64_t numel) {
+__global__ void add3_mul2_kernel(Ew2 p) {
     const int y = blockIdx.y;
+    const int64_t numel = p.n[y], n8 = numel >> 3;
     const bf16_t* a = p.a[y]; const bf16_t* b = p.b[y]; const bf16_t* c = p.c[y]; const bf16_t* z = p.z[y]; bf16_t* out = p.out[y];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         float x[8], v[8];
@@ -525,47 +529,59 @@ extern "C" int stg_add3_mul(const void* a, const void* b, const void* c, const v
     return 0;
 }
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-extern "C" int stg_gate_fwd2(const void* h0, const void* r0, const float* g0, void* out0, const void* h1, const void* r1, const float* g1,
-                             void* out1, int64_t numel, void* stream) {
+extern "C" int stg_gate_fwd2n(const void* h0, const void* r0, const float* g0, void* out0, int64_t numel0, const void* h1, const void* r1,
+                              const float* g1, void* out1, int64_t numel1, void* stream) {
     STG_CHECK(h0 && r0 && g0 && out0 && h1 && r1 && g1 && out1, -1, "stg_gate_fwd2: null pointer");
     STG_CHECK(al16(h0) && al16(r0) && al16(out0) && al16(h1) && al16(r1) && al16(out1), -2, "stg_gate_fwd2: pointers must be 16-byte aligned");
-    if (numel <= 0) return 0;
+    if (numel0 <= 0 && numel1 <= 0) return 0;
     Ew2 p = {};
-    p.a[0] = (const bf16_t*)h0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)out0;
-    p.a[1] = (const bf16_t*)h1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)out1;
-    const int64_t n8 = numel >> 3;
-    hipLaunchKernelGGL(gate_fwd2_kernel, dim3(grid_for(n8, 256), 2), dim3(256), 0, ST, p, n8, numel);
+    p.a[0] = (const bf16_t*)h0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)out0; p.n[0] = numel0 < 0 ? 0 : numel0;
+    p.a[1] = (const bf16_t*)h1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)out1; p.n[1] = numel1 < 0 ? 0 : numel1;
+    const int64_t n8 = (p.n[0] > p.n[1] ? p.n[0] : p.n[1]) >> 3;
+    hipLaunchKernelGGL(gate_fwd2_kernel, dim3(grid_for(n8 > 0 ? n8 : 1, 256), 2), dim3(256), 0, ST, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int stg_gate_fwd2(const void* h0, const void* r0, const float* g0, void* out0, const void* h1, const void* r1, const float* g1,
+                             void* out1, int64_t numel, void* stream) {
+    return stg_gate_fwd2n(h0, r0, g0, out0, numel, h1, r1, g1, out1, numel, stream);
+}
+extern "C" int stg_gate_bwd2n(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, int64_t numel0, const void* dout1,
+                              const void* r1, const float* g1, void* dr1, float* dgate1, int64_t numel1, void* stream) {
+    STG_CHECK(dout0 && r0 && g0 && dr0 && dgate0 && dout1 && r1 && g1 && dr1 && dgate1, -1, "stg_gate_bwd2: null pointer");
+    STG_CHECK(al16(dout0) && al16(r0) && al16(dr0) && al16(dout1) && al16(r1) && al16(dr1), -2, "stg_gate_bwd2: pointers must be 16-byte aligned");
+    if (numel0 <= 0 && numel1 <= 0) return 0;
+    Ew2 p = {};
+    p.a[0] = (const bf16_t*)dout0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)dr0; p.dg[0] = dgate0; p.n[0] = numel0 < 0 ? 0 : numel0;
+    p.a[1] = (const bf16_t*)dout1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)dr1; p.dg[1] = dgate1; p.n[1] = numel1 < 0 ? 0 : numel1;
+    const int64_t n8 = (p.n[0] > p.n[1] ? p.n[0] : p.n[1]) >> 3;
+    unsigned gb = grid_for(n8 > 0 ? n8 : 1, 256);
+    if (gb > 256) gb = 256;      // one memory-side atomic per block and address (see stg_gate_bwd)
+    hipLaunchKernelGGL(gate_bwd2_kernel, dim3(gb, 2), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int stg_gate_bwd2(const void* dout0, const void* r0, const float* g0, void* dr0, float* dgate0, const void* dout1, const void* r1,
                              const float* g1, void* dr1, float* dgate1, int64_t numel, void* stream) {
-    STG_CHECK(dout0 && r0 && g0 && dr0 && dgate0 && dout1 && r1 && g1 && dr1 && dgate1, -1, "stg_gate_bwd2: null pointer");
-    STG_CHECK(al16(dout0) && al16(r0) && al16(dr0) && al16(dout1) && al16(r1) && al16(dr1), -2, "stg_gate_bwd2: pointers must be 16-byte aligned");
-    if (numel <= 0) return 0;
+    return stg_gate_bwd2n(dout0, r0, g0, dr0, dgate0, numel, dout1, r1, g1, dr1, dgate1, numel, stream);
+}
+extern "C" int stg_add3_mul2n(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, int64_t numel0, const void* a1,
+                              const void* b1, const void* c1, const void* z1, void* out1, int64_t numel1, void* stream) {
+    STG_CHECK(a0 && b0 && z0 && out0 && a1 && b1 && z1 && out1 && ((c0 == nullptr) == (c1 == nullptr)), -1, "stg_add3_mul2: null pointer (c0 / c1 may be NULL together)");
+    STG_CHECK(al16(a0) && al16(b0) && al16(c0) && al16(z0) && al16(out0) && al16(a1) && al16(b1) && al16(c1) && al16(z1) && al16(out1), -2,
+              "stg_add3_mul2: pointers must be 16-byte aligned");
+    if (numel0 <= 0 && numel1 <= 0) return 0;
     Ew2 p = {};
-    p.a[0] = (const bf16_t*)dout0; p.b[0] = (const bf16_t*)r0; p.g[0] = g0; p.out[0] = (bf16_t*)dr0; p.dg[0] = dgate0;
-    p.a[1] = (const bf16_t*)dout1; p.b[1] = (const bf16_t*)r1; p.g[1] = g1; p.out[1] = (bf16_t*)dr1; p.dg[1] = dgate1;
-    const int64_t n8 = numel >> 3;
-    unsigned gb = grid_for(n8, 256);
-    if (gb > 256) gb = 256;      // one memory-side atomic per block and address (see stg_gate_bwd)
-    hipLaunchKernelGGL(gate_bwd2_kernel, dim3(gb, 2), dim3(256), 0, ST, p, n8, numel);
+    p.a[0] = (const bf16_t*)a0; p.b[0] = (const bf16_t*)b0; p.c[0] = (const bf16_t*)c0; p.z[0] = (const bf16_t*)z0; p.out[0] = (bf16_t*)out0; p.n[0] = numel0 < 0 ? 0 : numel0;
+    p.a[1] = (const bf16_t*)a1; p.b[1] = (const bf16_t*)b1; p.c[1] = (const bf16_t*)c1; p.z[1] = (const bf16_t*)z1; p.out[1] = (bf16_t*)out1; p.n[1] = numel1 < 0 ? 0 : numel1;
+    const int64_t n8 = (p.n[0] > p.n[1] ? p.n[0] : p.n[1]) >> 3;
+    hipLaunchKernelGGL(add3_mul2_kernel, dim3(grid_for(n8 > 0 ? n8 : 1, 256), 2), dim3(256), 0, ST, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int stg_add3_mul2(const void* a0, const void* b0, const void* c0, const void* z0, void* out0, const void* a1, const void* b1,
                              const void* c1, const void* z1, void* out1, int64_t numel, void* stream) {
-    STG_CHECK(a0 && b0 && z0 && out0 && a1 && b1 && z1 && out1 && ((c0 == nullptr) == (c1 == nullptr)), -1, "stg_add3_mul2: null pointer (c0 / c1 may be NULL together)");
-    STG_CHECK(al16(a0) && al16(b0) && al16(c0) && al16(z0) && al16(out0) && al16(a1) && al16(b1) && al16(c1) && al16(z1) && al16(out1), -2,
-              "stg_add3_mul2: pointers must be 16-byte aligned");
-    if (numel <= 0) return 0;
-    Ew2 p = {};
-    p.a[0] = (const bf16_t*)a0; p.b[0] = (const bf16_t*)b0; p.c[0] = (const bf16_t*)c0; p.z[0] = (const bf16_t*)z0; p.out[0] = (bf16_t*)out0;
-    p.a[1] = (const bf16_t*)a1; p.b[1] = (const bf16_t*)b1; p.c[1] = (const bf16_t*)c1; p.z[1] = (const bf16_t*)z1; p.out[1] = (bf16_t*)out1;
-    const int64_t n8 = numel >> 3;
-    hipLaunchKernelGGL(add3_mul2_kernel, dim3(grid_for(n8, 256), 2), dim3(256), 0, ST, p, n8, numel);
-    STG_LAUNCH_CHECK();
-    return 0;
+    return stg_add3_mul2n(a0, b0, c0, z0, out0, numel, a1, b1, c1, z1, out1, numel, stream);
 }
 // Test aid (tests/test_lds_poison_gpu.py, STG_LDS_POISON=1): fill the LDS of every CU with NaN bit patterns (0x7FC07FC0: a NaN as fp32 and as two
 // bf16 values).  A kernel that reads an LDS byte nobody wrote -- harmless while the previous tenant of the CU left finite data there, e.g. padded

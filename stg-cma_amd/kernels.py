@@ -902,51 +902,48 @@ def gate_fwd(h, r, gate):
 
 @_family("elementwise", lambda h0, *a: ("gate_fwd2", 6.0 * _nb(h0), 0.0))
 def gate_fwd2(h0, r0, g0, h1, r1, g1):
-    """gate_fwd on two equally sized problems, one launch: returns (out0, out1)."""
+    """gate_fwd on two problems (sizes may differ), one launch: returns (out0, out1)."""
     for t in (h0, r0, h1, r1):
         _chk_flat(t, "gate_fwd2 operand")
     _chk_flat(g0, "gate", F32); _chk_flat(g1, "gate", F32)
-    if not (h0.shape == r0.shape == h1.shape == r1.shape) or g0.numel() != 1 or g1.numel() != 1:
+    if h0.shape != r0.shape or h1.shape != r1.shape or g0.numel() != 1 or g1.numel() != 1:
         raise RuntimeError("gate_fwd2: shape mismatch")
     o0, o1 = torch.empty_like(h0), torch.empty_like(h1)
-    _lib.check(_lib.lib().stg_gate_fwd2(_p(h0), _p(r0), _p(g0), _p(o0), _p(h1), _p(r1), _p(g1), _p(o1), h0.numel(), _stream()), "stg_gate_fwd2")
+    _lib.check(_lib.lib().stg_gate_fwd2n(_p(h0), _p(r0), _p(g0), _p(o0), h0.numel(), _p(h1), _p(r1), _p(g1), _p(o1), h1.numel(), _stream()), "stg_gate_fwd2n")
     return o0, o1
 
 
 @_family("elementwise", lambda d0, *a: ("gate_bwd2", 6.0 * _nb(d0), 0.0))
 def gate_bwd2(d0, r0, g0, dg0, d1, r1, g1, dg1):
-    """gate_bwd on two equally sized problems, one launch: returns (dr0, dr1); dgate0 / dgate1 accumulate."""
+    """gate_bwd on two problems (sizes may differ), one launch: returns (dr0, dr1); dgate0 / dgate1 accumulate."""
     for t in (d0, r0, d1, r1):
         _chk_flat(t, "gate_bwd2 operand")
     for t in (g0, g1, dg0, dg1):
         _chk_flat(t, "gate", F32)
-    if not (d0.shape == r0.shape == d1.shape == r1.shape) or any(t.numel() != 1 for t in (g0, g1, dg0, dg1)):
+    if d0.shape != r0.shape or d1.shape != r1.shape or any(t.numel() != 1 for t in (g0, g1, dg0, dg1)):
         raise RuntimeError("gate_bwd2: shape mismatch")
     o0, o1 = torch.empty_like(d0), torch.empty_like(d1)
-    _lib.check(_lib.lib().stg_gate_bwd2(_p(d0), _p(r0), _p(g0), _p(o0), _p(dg0), _p(d1), _p(r1), _p(g1), _p(o1), _p(dg1), d0.numel(), _stream()),
-               "stg_gate_bwd2")
+    _lib.check(_lib.lib().stg_gate_bwd2n(_p(d0), _p(r0), _p(g0), _p(o0), _p(dg0), d0.numel(), _p(d1), _p(r1), _p(g1), _p(o1), _p(dg1), d1.numel(),
+                                         _stream()), "stg_gate_bwd2n")
     return o0, o1
 
 
 @_family("elementwise", lambda a0, *a, **kw: ("add3_mul2", 10.0 * _nb(a0), 0.0))
 def add3_mul2(a0, b0, c0, z0, a1, b1, c1, z1, outs=None):
-    """add3_mul on two equally sized problems, one launch: returns (out0, out1).  c0 = c1 = None: (a + b) * z."""
+    """add3_mul on two problems (sizes may differ), one launch: returns (out0, out1).  c0 = c1 = None: (a + b) * z."""
     if (c0 is None) != (c1 is None):
         raise RuntimeError("add3_mul2: c0 and c1 are given together or not at all")
-    for t in (a0, b0, c0, z0, a1, b1, c1, z1):
-        if t is None:
-            continue
-        _chk_flat(t, "add3_mul2 operand")
-        if t.shape != a0.shape:
-            raise RuntimeError("add3_mul2: shape mismatch")
     if outs is None:
         outs = (torch.empty_like(a0), torch.empty_like(a1))
-    for t in outs:
-        _chk_flat(t, "out")
-        if t.shape != a0.shape:
-            raise RuntimeError("add3_mul2: shape mismatch")
-    _lib.check(_lib.lib().stg_add3_mul2(_p(a0), _p(b0), _p(c0), _p(z0), _p(outs[0]), _p(a1), _p(b1), _p(c1), _p(z1), _p(outs[1]),
-                                        a0.numel(), _stream()), "stg_add3_mul2")
+    for ref, ts in ((a0, (a0, b0, c0, z0, outs[0])), (a1, (a1, b1, c1, z1, outs[1]))):
+        for t in ts:
+            if t is None:
+                continue
+            _chk_flat(t, "add3_mul2 operand")
+            if t.shape != ref.shape:
+                raise RuntimeError("add3_mul2: shape mismatch")
+    _lib.check(_lib.lib().stg_add3_mul2n(_p(a0), _p(b0), _p(c0), _p(z0), _p(outs[0]), a0.numel(), _p(a1), _p(b1), _p(c1), _p(z1), _p(outs[1]),
+                                         a1.numel(), _stream()), "stg_add3_mul2n")
     return outs[0], outs[1]
 
 

@@ -529,13 +529,13 @@ XATTN_MERGED = _cfg.opt("xattn_merged")   # 0 = the frame-global cross-modal pai
 
 
 def _gate2(hv, rv, gate_v, ha, ra, gate_a):
-    if PAIR_EW and hv.shape == ha.shape:
+    if PAIR_EW:
         return K.gate_fwd2(hv, rv, gate_v, ha, ra, gate_a)
     return K.gate_fwd(hv, rv, gate_v), K.gate_fwd(ha, ra, gate_a)
 
 
 def _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a):
-    if PAIR_EW and dhv2.shape == dha2.shape:
+    if PAIR_EW:
         return K.gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
     return K.gate_bwd(dhv2, rv, gate_v, dgate_v), K.gate_bwd(dha2, ra, gate_a, dgate_a)
 
@@ -544,7 +544,7 @@ def _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs):
     """The three gradient paths into each adapter hidden state joined (and, with zs, multiplied by the saved activation derivative)."""
     if zs is None:
         return K.add(dhv2, dq_v, dkv_v), K.add(dha2, dq_a, dkv_a)
-    if PAIR_EW and dhv2.shape == dha2.shape:
+    if PAIR_EW:
         return K.add3_mul2(dhv2, dq_v, dkv_v, zs[0], dha2, dq_a, dkv_a, zs[1], outs=outs)
     return K.add3_mul(dhv2, dq_v, dkv_v, zs[0], out=None if outs is None else outs[0]), \
         K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
