@@ -54,7 +54,7 @@ SPEC = {
 # options of the C library (stg_set_option): environment variable -> option name
 LIB_SPEC = {"STG_GEMM_EPI": "gemm_epi", "STG_GEMM_KTAIL": "gemm_ktail", "STG_GEMM_BIG": "gemm_big", "STG_GEMM_8PH": "gemm_8ph",
             "STG_GEMM_8PHM": "gemm_8phm", "STG_GEMM_DBG": "gemm_dbg", "STG_XATTN": "xattn", "STG_WINATTN_BWD_OCC": "winattn_bwd_occ",
-            "STG_TATTN_KERNELS": "tattn", "STG_MHA_NW": "mha_nw", "STG_GEMM_D8M": "gemm_d8m", "STG_MHA_KT": "mha_kt", "STG_MHA_DKV1": "mha_dkv1", "STG_WGRAD_PLAN": "wgrad_plan", "STG_UPLN_CAP": "upln_cap"}
+            "STG_TATTN_KERNELS": "tattn", "STG_MHA_NW": "mha_nw", "STG_GEMM_D8M": "gemm_d8m", "STG_MHA_KT": "mha_kt", "STG_MHA_DKV1": "mha_dkv1", "STG_WGRAD_PLAN": "wgrad_plan", "STG_UPLN_CAP": "upln_cap", "STG_LN_FIT": "ln_fit"}
 
 _values = {k: v[2] for k, v in SPEC.items()}
 _lib_values = {}

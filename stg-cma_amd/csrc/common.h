@@ -186,6 +186,7 @@ extern std::atomic<int> stg_opt_winattn_bwd_occ;   // window attention: 1 (defau
 extern std::atomic<int> stg_opt_tattn;        // temporal attention (head dim 32): 1 the coalesced round-2 kernels, 0 the round-1 kernels
 extern std::atomic<int> stg_opt_gemm_d8m;     // 1 (default): the byte-derivative-source epilogue (fc2 dgrad, K <= 512, N >= 1024) on the multi-tile 8-phase kernel; 0: 128 x 128 kernel
 extern std::atomic<int> stg_opt_mha_dkv1;     // 1: keep the dK / dV kernel at one query tile per trip (A/B knob)
+extern std::atomic<int> stg_opt_ln_fit;       // 0: LayerNorm forward on the generic kernel for every width (A/B knob)
 extern std::atomic<int> stg_opt_upln_cap;     // workgroups per launch of the wide (NW >= 8) join kernels of upln.hip: 256 = one round (default), 2048 = rounds 1-5a
 extern std::atomic<int> stg_opt_wgrad_plan;   // wgrad_ws row splits: 0 = the round-1 rule (512 / column groups); 1 = per-launch chooser for nt1 > 2 only; 2 = for every width (default)
 extern std::atomic<int> stg_opt_mha_kt;       // mha.hip forward / dQ: key tiles per trip, 2 (default) or 1 (the round-4 structure)

@@ -118,6 +118,72 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnParams p) {
     }
 }
 
+// Shape-fitted forward (round 5b): NC chunks per lane with EVERY lane of a row busy (C = 8 * LPR * NC), RU row sets per wave -- NC * RU = 3-4 independent
+// 32-byte loads per lane and 24-32 data registers instead of the generic kernel's 64 (MAXCH = 8 whatever C is: at C <= 768 a lane had one or two loads in
+// flight and the kernel ran at 3.4-4.3 TB/s where the 1 024 / 1 536-wide rows, two or three chunks per lane, reached 5.2-5.6).
+template <int LPR, int NC, int RU>
+__global__ void __launch_bounds__(256) ln_fwd_fit_kernel(LnParams p) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    float v[RU][NC][8];
+    int64_t row[RU];
+    bool valid[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        row[u] = (((int64_t)blockIdx.x * 4 + wave) * RU + u) * RPW + sub;
+        valid[u] = row[u] < p.rows;
+        const int64_t rc = valid[u] ? row[u] : p.rows - 1;               // (a clamped row keeps every load unconditional; nothing of it is stored)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) load8(p, p.x, p.x_f32, src_off(p, rc, (sl + c * LPR) * 8, p.ldx), v[u][c]);
+    }
+    float g[NC][8], b[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = sl + c * LPR;
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + ch * 8), b1 = *reinterpret_cast<const float4*>(p.beta + ch * 8 + 4);
+        g[c][0] = g0.x; g[c][1] = g0.y; g[c][2] = g0.z; g[c][3] = g0.w; g[c][4] = g1.x; g[c][5] = g1.y; g[c][6] = g1.z; g[c][7] = g1.w;
+        b[c][0] = b0.x; b[c][1] = b0.y; b[c][2] = b0.z; b[c][3] = b0.w; b[c][4] = b1.x; b[c][5] = b1.y; b[c][6] = b1.z; b[c][7] = b1.w;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[u][c][j];
+        s = wave_sum<LPR>(s);
+        const float mu = s / (float)p.C;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[u][c][j] - mu; q += d * d; }
+        q = wave_sum<LPR>(q);
+        const float rs = rsqrtf(q / (float)p.C + p.eps);
+        if (!valid[u]) continue;
+        if (sl == 0) {
+            if (p.mean) p.mean[row[u]] = mu;
+            if (p.rstd) p.rstd[row[u]] = rs;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ch = sl + c * LPR;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[u][c][j] - mu) * rs * g[c][j] + b[c][j];
+            if (p.y_f32) {
+                float* yp = reinterpret_cast<float*>(p.y) + row[u] * p.ldy + ch * 8;
+                *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+                store8(reinterpret_cast<bf16_t*>(p.y) + row[u] * p.ldy + ch * 8, o);
+            }
+        }
+    }
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))  [+ add_to]
 template <int LPR>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(LnParams p) {
@@ -189,6 +255,62 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnParams p) {
     }
 }
 
+// The backward in the same shape-fitted form (frozen LayerNorms: no parameter gradients; plain rows): NC chunks of x (or x_hat) and of dy per lane,
+// 16 NC data registers instead of 128.
+template <int LPR, int NC>
+__global__ void __launch_bounds__(256) ln_bwd_fit_kernel(LnParams p) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + sub;
+    const bool valid = row < p.rows;
+    const int64_t rc = valid ? row : p.rows - 1;
+    float xh[NC][8], gd[NC][8];
+    const float mu = p.xhat ? 0.f : p.mean[rc];
+    const float rs = p.rstd[rc];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = sl + c * LPR;
+        float xv[8], dv[8];
+        load8(p, p.x, p.x_f32, rc * p.ldx + ch * 8, xv);
+        load8(p, p.dy, 0, rc * p.lddy + ch * 8, dv);
+        float g[8];
+        if (p.xhat) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = 1.0f;
+        } else {
+            const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ch * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + ch * 8 + 4);
+            g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[c][j] = p.xhat ? xv[j] : (xv[j] - mu) * rs;
+            gd[c][j] = g[j] * dv[j];
+            s1 += gd[c][j];
+            s2 += gd[c][j] * xh[c][j];
+        }
+    }
+    s1 = wave_sum<LPR>(s1) / (float)p.C;
+    s2 = wave_sum<LPR>(s2) / (float)p.C;
+    if (!valid) return;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int ch = sl + c * LPR;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (gd[c][j] - s1 - xh[c][j] * s2);
+        if (p.add_to) {
+            float av[8];
+            load8(p, p.add_to, 0, row * p.ldadd + ch * 8, av);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += av[j];
+        }
+        store8(p.dx + row * p.lddx + ch * 8, o);
+    }
+}
+
 template <int LPR>
 int launch_ln(bool bwd, const LnParams& p, hipStream_t st) {
     constexpr int RPW = 64 / LPR;
@@ -200,8 +322,37 @@ int launch_ln(bool bwd, const LnParams& p, hipStream_t st) {
     return 0;
 }
 
+template <int LPR, int NC>
+int launch_ln_fit(bool bwd, const LnParams& p, hipStream_t st) {
+    constexpr int RU = NC == 2 ? 2 : 1;
+    if (bwd) {
+        const int64_t rows_per_block = 4 * (64 / LPR);
+        hipLaunchKernelGGL((ln_bwd_fit_kernel<LPR, NC>), dim3((unsigned)((p.rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, p);
+    } else {
+        const int64_t rows_per_block = 4 * (64 / LPR) * RU;
+        hipLaunchKernelGGL((ln_fwd_fit_kernel<LPR, NC, RU>), dim3((unsigned)((p.rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, p);
+    }
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
 int dispatch_ln(bool bwd, const LnParams& p, hipStream_t st) {
     const int nch = p.C / 8;
+    if (!p.gather4 && !(bwd && p.dgamma) && stg_opt_ln_fit.load(std::memory_order_relaxed) != 0) {
+        // the widths of the four backbones: C = 8 * LPR * NC exactly
+        switch (nch) {
+            case 16: return launch_ln_fit<8, 2>(bwd, p, st);       // 128
+            case 24: return launch_ln_fit<8, 3>(bwd, p, st);       // 192
+            case 32: return launch_ln_fit<16, 2>(bwd, p, st);      // 256
+            case 48: return launch_ln_fit<16, 3>(bwd, p, st);      // 384
+            case 64: return launch_ln_fit<32, 2>(bwd, p, st);      // 512
+            case 96: return launch_ln_fit<32, 3>(bwd, p, st);      // 768
+            case 128: return launch_ln_fit<64, 2>(bwd, p, st);     // 1024
+            case 192: return launch_ln_fit<64, 3>(bwd, p, st);     // 1536
+            case 256: return launch_ln_fit<64, 4>(bwd, p, st);     // 2048
+            default: break;
+        }
+    }
     if (nch <= 16) return launch_ln<16>(bwd, p, st);
     if (nch <= 32) return launch_ln<32>(bwd, p, st);
     return launch_ln<64>(bwd, p, st);
