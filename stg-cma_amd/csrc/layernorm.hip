@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnParams p) {
     }
 }
 
-// The backward in the same shape-fitted form (frozen LayerNorms: no parameter gradients; plain rows): NC chunks of x (or x_hat) and of dy per lane,
+// The backward in the same shape-fitted form (frozen LayerNorms: no parameter gradients): NC chunks of x (or x_hat) and of dy per lane,
 // 16 NC data registers instead of 128.
 template <int LPR, int NC>
 __global__ void __launch_bounds__(256) ln_bwd_fit_kernel(LnParams p) {
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) ln_bwd_fit_kernel(LnParams p) {
     for (int c = 0; c < NC; ++c) {
         const int ch = sl + c * LPR;
         float xv[8], dv[8];
-        load8(p, p.x, p.x_f32, rc * p.ldx + ch * 8, xv);
+        load8(p, p.x, p.x_f32, src_off(p, rc, ch * 8, p.ldx), xv);
         load8(p, p.dy, 0, rc * p.lddy + ch * 8, dv);
         float g[8];
         if (p.xhat) {
@@ -303,11 +303,11 @@ __global__ void __launch_bounds__(256) ln_bwd_fit_kernel(LnParams p) {
         for (int j = 0; j < 8; ++j) o[j] = rs * (gd[c][j] - s1 - xh[c][j] * s2);
         if (p.add_to) {
             float av[8];
-            load8(p, p.add_to, 0, row * p.ldadd + ch * 8, av);
+            load8(p, p.add_to, 0, src_off(p, row, ch * 8, p.ldadd), av);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += av[j];
         }
-        store8(p.dx + row * p.lddx + ch * 8, o);
+        store8(p.dx + src_off(p, row, ch * 8, p.lddx), o);           // dx addressed like x (scatter back through the 2x2 gather when gather4)
     }
 }
 
@@ -338,7 +338,7 @@ int launch_ln_fit(bool bwd, const LnParams& p, hipStream_t st) {
 
 int dispatch_ln(bool bwd, const LnParams& p, hipStream_t st) {
     const int nch = p.C / 8;
-    if (!(bwd && (p.dgamma || p.gather4)) && stg_opt_ln_fit.load(std::memory_order_relaxed) != 0) {   // (the fitted backward: frozen, plain rows only)
+    if (!(bwd && p.dgamma) && stg_opt_ln_fit.load(std::memory_order_relaxed) != 0) {   // (the fitted backward: frozen LayerNorms only)
         // the widths of the four backbones: C = 8 * LPR * NC exactly
         switch (nch) {
             case 16: return launch_ln_fit<8, 2>(bwd, p, st);       // 128
