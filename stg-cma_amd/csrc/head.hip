@@ -32,6 +32,52 @@ __global__ void unary_bwd_kernel(int op, const bf16_t* x, const bf16_t* dy, bf16
         dx[i] = f2bf(op == 0 ? (v > 0.f ? g : 0.f) : g * (1.0f - t * t));
     }
 }
+// The same two on 16-byte pieces, two pieces per lane and trip (round 5b: the scalar forms above moved 2 bytes per lane and load -- and the backward
+// paid a tanhf per element even for ReLU; the AVS decoder's ReLUs over 8 M x 32 / 2 M x 256 maps cost 2.8 ms per step).  16-byte aligned pointers;
+// the caller handles the last n % 8 elements with the scalar kernels.
+__global__ void __launch_bounds__(256) unary_fwd_v8_kernel(int op, const bf16_t* x, bf16_t* y, int64_t n8) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += 2 * stride) {
+        const bool two = i + stride < n8;
+        const u16x8 a = reinterpret_cast<const u16x8*>(x)[i];
+        const u16x8 b = two ? reinterpret_cast<const u16x8*>(x)[i + stride] : a;
+        u16x8 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float va = bf2f(a.v[j]), vb = bf2f(b.v[j]);
+            oa.v[j] = f2bf(op == 0 ? fmaxf(va, 0.f) : tanhf(va));
+            ob.v[j] = f2bf(op == 0 ? fmaxf(vb, 0.f) : tanhf(vb));
+        }
+        reinterpret_cast<u16x8*>(y)[i] = oa;
+        if (two) reinterpret_cast<u16x8*>(y)[i + stride] = ob;
+    }
+}
+__global__ void __launch_bounds__(256) unary_bwd_v8_kernel(int op, const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n8) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += 2 * stride) {
+        const bool two = i + stride < n8;
+        const int64_t i1 = two ? i + stride : i;
+        const u16x8 xa = reinterpret_cast<const u16x8*>(x)[i], ga = reinterpret_cast<const u16x8*>(dy)[i];
+        const u16x8 xb = reinterpret_cast<const u16x8*>(x)[i1], gb = reinterpret_cast<const u16x8*>(dy)[i1];
+        u16x8 oa, ob;
+        if (op == 0) {                                       // kernel-uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                oa.v[j] = bf2f(xa.v[j]) > 0.f ? ga.v[j] : (bf16_t)0;          // g or +0: the bf16 bits pass through
+                ob.v[j] = bf2f(xb.v[j]) > 0.f ? gb.v[j] : (bf16_t)0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ta = tanhf(bf2f(xa.v[j])), tb = tanhf(bf2f(xb.v[j]));
+                oa.v[j] = f2bf(bf2f(ga.v[j]) * (1.0f - ta * ta));
+                ob.v[j] = f2bf(bf2f(gb.v[j]) * (1.0f - tb * tb));
+            }
+        }
+        reinterpret_cast<u16x8*>(dx)[i] = oa;
+        if (two) reinterpret_cast<u16x8*>(dx)[i1] = ob;
+    }
+}
 __global__ void mul_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = f2bf(bf2f(a[i]) * bf2f(b[i]));
@@ -290,17 +336,36 @@ extern "C" int stg_unary_fwd(int op, const void* x, void* y, int64_t numel, void
     STG_CHECK(x && y, -1, "stg_unary_fwd: null pointer");
     STG_CHECK(op == 0 || op == 1, -2, "stg_unary_fwd: op must be 0 (relu) or 1 (tanh)");
     if (numel <= 0) return 0;
-    hipLaunchKernelGGL(unary_fwd_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, ST, op, (const bf16_t*)x, (bf16_t*)y, numel);
-    STG_LAUNCH_CHECK();
+    int64_t done = 0;
+    if (numel >= 8 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const int64_t n8 = numel >> 3;
+        hipLaunchKernelGGL(unary_fwd_v8_kernel, dim3(grid_for((n8 + 1) / 2, 256)), dim3(256), 0, ST, op, (const bf16_t*)x, (bf16_t*)y, n8);
+        STG_LAUNCH_CHECK();
+        done = n8 << 3;
+    }
+    if (done < numel) {
+        hipLaunchKernelGGL(unary_fwd_kernel, dim3(grid_for(numel - done, 256)), dim3(256), 0, ST, op, (const bf16_t*)x + done, (bf16_t*)y + done, numel - done);
+        STG_LAUNCH_CHECK();
+    }
     return 0;
 }
 extern "C" int stg_unary_bwd(int op, const void* x, const void* dy, void* dx, int64_t numel, void* stream) {
     STG_CHECK(x && dy && dx, -1, "stg_unary_bwd: null pointer");
     STG_CHECK(op == 0 || op == 1, -2, "stg_unary_bwd: op must be 0 (relu) or 1 (tanh)");
     if (numel <= 0) return 0;
-    hipLaunchKernelGGL(unary_bwd_kernel, dim3(grid_for(numel, 256)), dim3(256), 0, ST, op, (const bf16_t*)x, (const bf16_t*)dy,
-                       (bf16_t*)dx, numel);
-    STG_LAUNCH_CHECK();
+    int64_t done = 0;
+    if (numel >= 8 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+        const int64_t n8 = numel >> 3;
+        hipLaunchKernelGGL(unary_bwd_v8_kernel, dim3(grid_for((n8 + 1) / 2, 256)), dim3(256), 0, ST, op, (const bf16_t*)x, (const bf16_t*)dy,
+                           (bf16_t*)dx, n8);
+        STG_LAUNCH_CHECK();
+        done = n8 << 3;
+    }
+    if (done < numel) {
+        hipLaunchKernelGGL(unary_bwd_kernel, dim3(grid_for(numel - done, 256)), dim3(256), 0, ST, op, (const bf16_t*)x + done,
+                           (const bf16_t*)dy + done, (bf16_t*)dx + done, numel - done);
+        STG_LAUNCH_CHECK();
+    }
     return 0;
 }
 extern "C" int stg_mul(const void* a, const void* b, void* out, int64_t numel, void* stream) {

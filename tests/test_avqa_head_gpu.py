@@ -51,6 +51,19 @@ def test_unary_mul_embed(stg, gpu):
         y.backward(dy.to(BF16).to(gpu))
         _close(y, ref(x), what=f"{ref.__name__} fwd")
         _close(xg.grad, xr.grad, what=f"{ref.__name__} bwd")
+    # sizes around the 16-byte pieces of the vector kernels: a tail of n % 8 elements, an odd piece count (one lane's second piece missing),
+    # more pieces than one pass of the grid, and a misaligned view (the scalar kernels take it whole)
+    for n, off in ((8 * 1031 + 5, 0), (8 * 3, 0), (7, 0), (8 * 256 * 4096 * 2 + 8 * 17 + 3, 0), (8 * 100, 1)):
+        xx = _bf(torch.randn(n + off, generator=g) * 2)[off:]
+        dd = _bf(torch.randn(n + off, generator=g))[off:]
+        for fn, ref in ((H.relu, F.relu), (H.tanh, torch.tanh)):
+            xr = xx.clone().requires_grad_(True)
+            ref(xr).backward(dd)
+            xg = xx.to(BF16).to(gpu)[:].requires_grad_(True) if off == 0 else torch.cat([xx[:1], xx]).to(BF16).to(gpu)[1:].requires_grad_(True)
+            y = fn(xg)
+            y.backward(dd.to(BF16).to(gpu))
+            _close(y, ref(xx), what=f"{ref.__name__} fwd n={n}")
+            _close(xg.grad, xr.grad, what=f"{ref.__name__} bwd n={n}")
     a, b = _bf(torch.randn(20, 64, generator=g)), _bf(torch.randn(20, 64, generator=g))
     ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     (ar * br).backward(dy[:20, :].repeat(1, 2)[:, :64])
