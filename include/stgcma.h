@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 217
+#define STG_VERSION 218
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -395,6 +395,11 @@ int stg_mha_supported(int n, int D);
 int stg_mha_fwd(const stg_mha_args* a, void* stream);
 int stg_mha_bwd(const stg_mha_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
                 float* delta, void* stream);
+/* Two problems of ONE geometry (P, H, n, D, scale, window map, leading dimensions, K == V or not) in one launch each -- the two directions of a
+ * cross-modal pair (Swin_AVE.py:750-760, :799-808) -- ABI 218.  Same results as two calls. */
+int stg_mha_fwd_pair(const stg_mha_args* a0, const stg_mha_args* a1, void* stream);
+int stg_mha_bwd_pair(const stg_mha_args* a0, const void* dO0, void* dQ0, void* dK0, void* dV0, float* delta0, const stg_mha_args* a1,
+                     const void* dO1, void* dQ1, void* dK1, void* dV1, float* delta1, int64_t lddo, int64_t lddqkv, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels

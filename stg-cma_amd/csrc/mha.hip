@@ -33,8 +33,18 @@ struct MP {
     float scale, scale2;
     const bf16_t* dO; int64_t lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
+    // pair launch (round 5b): blockIdx.z >= P addresses the SECOND problem set (the other direction of a cross-modal pair, same geometry)
+    const bf16_t* Q1; const bf16_t* K1; const bf16_t* V1; bf16_t* O1; float* lse1; float* delta1;
+    const bf16_t* dO1; bf16_t* dQ1; bf16_t* dK1; bf16_t* dV1;
     int wh, ww, ws, wshift, nwin;     // window map (ws > 0): problem p = window p % nwin of frame p / nwin of a [wh, ww] token image, cyclic shift wshift
 };
+
+__device__ __forceinline__ int pair_select(MP& a, int z) {          // block-uniform: which problem set, and the problem inside it
+    if (z < a.P) return z;
+    a.Q = a.Q1; a.K = a.K1; a.V = a.V1; a.O = a.O1; a.lse = a.lse1; a.delta = a.delta1;
+    a.dO = a.dO1; a.dQ = a.dQ1; a.dK = a.dK1; a.dV = a.dV1;
+    return z - a.P;
+}
 
 // row of token `tok` of problem p in the token tensors: p * n + tok, or -- window map, round 5: the adapters' WINDOW-level cross-modal attention
 // at widths 64 / 96 (Swin-L) -- the token's place in its frame (the arithmetic of attention.hip's map_kind 1)
@@ -144,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd_kernel(MP a)
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];      // two buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int q0 = 32 * (qb * NW + wave);
     const bool live = q0 < a.n;
     const int q = q0 + r;
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq_kernel(MP a) 
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int q = 32 * (qb * NW + wave) + r;
     const bool live = 32 * (qb * NW + wave) < a.n;
     const int qc = q < a.n ? q : a.n - 1;
@@ -312,7 +322,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];                  // two buffers x NTILE x [64][DP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int q0 = 32 * (qb * NW + wave);
     const bool live = q0 < a.n;
     const int q = q0 + r;
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq2_kernel(MP a)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int q = 32 * (qb * NW + wave) + r;
     const bool live = 32 * (qb * NW + wave) < a.n;
     const int qc = q < a.n ? q : a.n - 1;
@@ -498,7 +508,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dkv_kernel(MP a)
     const int r = lane & 31, hh = lane >> 5;
     bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
     bf16_t* sV = KV1 ? sK : sK + 32 * DP;
-    const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int kb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int key = 32 * (kb * NW + wave) + r;
     const bool live = 32 * (kb * NW + wave) < a.n;
     const int kc = key < a.n ? key : a.n - 1;
@@ -616,7 +626,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dkv2_kernel(MP a
     const int r = lane & 31, hh = lane >> 5;
     bf16_t* sK = smem + 2 * BUF + wave * NKV * 32 * DP;
     bf16_t* sV = KV1 ? sK : sK + 32 * DP;
-    const int kb = blockIdx.x, h = blockIdx.y, p = blockIdx.z;
+    const int kb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
     const int key = 32 * (kb * NW + wave) + r;
     const bool live = 32 * (kb * NW + wave) < a.n;
     const int kc = key < a.n ? key : a.n - 1;
@@ -801,15 +811,27 @@ int fill(const stg_mha_args* f, MP& p, const char* who) {
 
 extern "C" int stg_mha_supported(int n, int D) { return (D == 64 || D == 96) && n >= 1 ? 1 : 0; }
 
-extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
-    STG_CHECK(f != nullptr, -1, "stg_mha_fwd: null args");
+static int mha_pair_ok(const stg_mha_args* f0, const stg_mha_args* f1, const char* who) {
+    STG_CHECK(f0->P == f1->P && f0->H == f1->H && f0->n == f1->n && f0->D == f1->D && f0->scale == f1->scale && f0->ld == f1->ld && f0->ldo == f1->ldo &&
+              f0->win_h == f1->win_h && f0->win_w == f1->win_w && f0->win_size == f1->win_size && f0->win_shift == f1->win_shift &&
+              (f0->K == f0->V) == (f1->K == f1->V), -2, "%s: the two problems of a pair need one geometry", who);
+    return 0;
+}
+
+static int mha_fwd_impl(const stg_mha_args* f, const stg_mha_args* f1, void* stream) {
     MP p = {};
     int rc = fill(f, p, "stg_mha_fwd");
     if (rc) return rc;
     if (p.P == 0) return 0;
+    if (f1) {
+        MP q = {};
+        rc = fill(f1, q, "stg_mha_fwd");
+        if (rc) return rc;
+        p.Q1 = q.Q; p.K1 = q.K; p.V1 = q.V; p.O1 = q.O; p.lse1 = q.lse;
+    }
     const bool kv1 = f->K == f->V;
     const int nw = pick_nw(p.nt, false, kv1);
-    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, f1 ? 2 * p.P : p.P);
     hipStream_t st = (hipStream_t)stream;
     const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
 #define STG_MHA_FWD(DD, KV, NW) { if (kt2) { rc = launch_fwd2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); }
@@ -823,9 +845,23 @@ extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
     return 0;
 }
 
-extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
-                           float* delta, void* stream) {
-    STG_CHECK(f != nullptr, -1, "stg_mha_bwd: null args");
+extern "C" int stg_mha_fwd(const stg_mha_args* f, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_mha_fwd: null args");
+    return mha_fwd_impl(f, nullptr, stream);
+}
+
+// Both directions of a cross-modal pair (same geometry) in ONE launch, grid.z = 2 P: half the launches, and the rounds of a launch fill better
+// (320 frames on 256 CUs are 1.25 rounds per direction, 2.5 for the pair).  Falls back to two launches where 2 P exceeds the grid's z limit.
+extern "C" int stg_mha_fwd_pair(const stg_mha_args* f0, const stg_mha_args* f1, void* stream) {
+    STG_CHECK(f0 != nullptr && f1 != nullptr, -1, "stg_mha_fwd_pair: null args");
+    const int rc = mha_pair_ok(f0, f1, "stg_mha_fwd_pair");
+    if (rc) return rc;
+    if (2 * f0->P >= 65536) { const int r0 = mha_fwd_impl(f0, nullptr, stream); return r0 ? r0 : mha_fwd_impl(f1, nullptr, stream); }
+    return mha_fwd_impl(f0, f1, stream);
+}
+
+static int mha_bwd_impl(const stg_mha_args* f, const void* dO, void* dQ, void* dK, void* dV, float* delta, const stg_mha_args* f1, const void* dO1,
+                        void* dQ1, void* dK1, void* dV1, float* delta1, int64_t lddo, int64_t lddqkv, void* stream) {
     MP p = {};
     int rc = fill(f, p, "stg_mha_bwd");
     if (rc) return rc;
@@ -837,9 +873,18 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (p.P == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
     p.delta = delta;
+    if (f1) {
+        MP q = {};
+        rc = fill(f1, q, "stg_mha_bwd");
+        if (rc) return rc;
+        STG_CHECK(dO1 && dQ1 && dK1 && delta1 && ((dV1 == nullptr) == (dV == nullptr)), -1, "stg_mha_bwd_pair: null pointer / dV given for one problem only");
+        STG_CHECK((((uintptr_t)dO1) & 15) == 0 && (((uintptr_t)dQ1 | (uintptr_t)dK1 | (uintptr_t)dV1) & 15) == 0, -2, "stg_mha_bwd_pair: misaligned pointers");
+        p.Q1 = q.Q; p.K1 = q.K; p.V1 = q.V; p.O1 = q.O; p.lse1 = q.lse; p.delta1 = delta1;
+        p.dO1 = (const bf16_t*)dO1; p.dQ1 = (bf16_t*)dQ1; p.dK1 = (bf16_t*)dK1; p.dV1 = (bf16_t*)dV1;
+    }
     const bool kv1 = f->K == f->V;
     const int nw = pick_nw(p.nt, true, kv1);
-    const dim3 grid((p.nt + nw - 1) / nw, p.H, p.P);
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, f1 ? 2 * p.P : p.P);
     hipStream_t st = (hipStream_t)stream;
     const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
 #define STG_MHA_BWD(DD, KV, NW) { if (kt2) { rc = launch_dq2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); \
@@ -853,4 +898,22 @@ extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, 
     if (rc) return rc;
     STG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int stg_mha_bwd(const stg_mha_args* f, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV, int64_t lddqkv,
+                           float* delta, void* stream) {
+    STG_CHECK(f != nullptr, -1, "stg_mha_bwd: null args");
+    return mha_bwd_impl(f, dO, dQ, dK, dV, delta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lddo, lddqkv, stream);
+}
+
+extern "C" int stg_mha_bwd_pair(const stg_mha_args* f0, const void* dO0, void* dQ0, void* dK0, void* dV0, float* delta0, const stg_mha_args* f1,
+                                const void* dO1, void* dQ1, void* dK1, void* dV1, float* delta1, int64_t lddo, int64_t lddqkv, void* stream) {
+    STG_CHECK(f0 != nullptr && f1 != nullptr, -1, "stg_mha_bwd_pair: null args");
+    const int rc = mha_pair_ok(f0, f1, "stg_mha_bwd_pair");
+    if (rc) return rc;
+    if (2 * f0->P >= 65536) {
+        const int r0 = mha_bwd_impl(f0, dO0, dQ0, dK0, dV0, delta0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lddo, lddqkv, stream);
+        return r0 ? r0 : mha_bwd_impl(f1, dO1, dQ1, dK1, dV1, delta1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lddo, lddqkv, stream);
+    }
+    return mha_bwd_impl(f0, dO0, dQ0, dK0, dV0, delta0, f1, dO1, dQ1, dK1, dV1, delta1, lddo, lddqkv, stream);
 }

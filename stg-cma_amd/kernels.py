@@ -1650,6 +1650,41 @@ def mha_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     return dQ, dK, dV
 
 
+@_family("mha_fwd", lambda g, *a, **kw: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(g, 3, 1, 2))))
+def mha_fwd_pair(g, qkv0, qkv1):
+    """mha_fwd on two problems of one geometry (the two directions of a cross-modal pair), one launch: ((O0, lse0), (O1, lse1))."""
+    outs, args = [], []
+    for Q, K_, V in (qkv0, qkv1):
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=Q.device)
+        lse = torch.empty((g.P, g.H, g.n), dtype=F32, device=Q.device)
+        args.append(_mha_fill(g, Q, K_, V, out, lse)); outs.append((out, lse))
+    _lib.check(_lib.lib().stg_mha_fwd_pair(C.byref(args[0]), C.byref(args[1]), _stream()), "stg_mha_fwd_pair")
+    return outs[0], outs[1]
+
+
+@_family("mha_bwd", lambda g, *a, **kw: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(g, 5, 3, 5))))
+def mha_bwd_pair(g, p0, p1):
+    """mha_bwd on two problems of one geometry, one launch per kernel: p = (Q, K, V, O, lse, dO, dQ, dK, dV) with dV None where K is V."""
+    args, ptrs, keep = [], [], []
+    lddo = lddq = None
+    for Q, K_, V, O, lse, dO, dQ, dK, dV in (p0, p1):
+        if dV is None and K_.data_ptr() != V.data_ptr():
+            raise RuntimeError("mha_bwd_pair: dV=None needs K and V to be the same tensor")
+        for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK")) + (((dV, "dV"),) if dV is not None else ()):
+            _chk2d(t, name, BF16)
+            if t.shape[1] < g.H * g.D or t.shape[0] < g.rows:
+                raise RuntimeError(f"mha_bwd_pair {name}: needs >= {g.rows} rows x {g.H * g.D} columns")
+        if not (_ld(dQ) == _ld(dK) == (_ld(dV) if dV is not None else _ld(dK))):
+            raise RuntimeError("mha_bwd_pair: dQ, dK, dV must share one leading dimension")
+        if lddo is None:
+            lddo, lddq = _ld(dO), _ld(dQ)
+        elif (lddo, lddq) != (_ld(dO), _ld(dQ)):
+            raise RuntimeError("mha_bwd_pair: the two problems must share their leading dimensions")
+        delta = torch.empty((g.P, g.H, g.n), dtype=F32, device=Q.device)
+        args.append(_mha_fill(g, Q, K_, V, O, lse)); ptrs.append((_p(dO), _p(dQ), _p(dK), _p(dV), _p(delta))); keep.append(delta)
+    _lib.check(_lib.lib().stg_mha_bwd_pair(C.byref(args[0]), *ptrs[0], C.byref(args[1]), *ptrs[1], lddo, lddq, _stream()), "stg_mha_bwd_pair")
+
+
 @_family_io("patch_embed")
 def vit_embed(patch, cls, pos, temb, BT, T):
     """ViT token assembly -> fp32 [BT*(np+1), D]; see stg_vit_embed."""

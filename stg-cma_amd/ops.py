@@ -550,20 +550,27 @@ def _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs):
         K.add3_mul(dha2, dq_a, dkv_a, zs[1], out=None if outs is None else outs[1])
 
 
+MHA_PAIR = _cfg.opt("mha_pair")     # 0 = one mha launch per direction of a cross-modal pair (A/B knob)
+
+
+def _mha_pair_fwd(mg, hv, ha):
+    if MHA_PAIR and hv.stride(0) == ha.stride(0):
+        return K.mha_fwd_pair(mg, (hv, ha, ha), (ha, hv, hv))        # both directions, one launch
+    return K.mha_fwd(mg, hv, ha, ha), K.mha_fwd(mg, ha, hv, hv)
+
+
 def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=None):
     """h' = h + gate * softmax(h hother^T) hother, both directions (Swin_AVE.py:750-760 / :799-808).
     geoms = (video-queries geometry, audio-queries geometry) when the two token counts differ (ViT)."""
     if geoms is None and not window and USE_MHA_X and K.mha_supported(spec.N, hv.shape[1]):
         # wide adapters (d_h = 64 / 96): the frame-global pair runs on the flash kernels of mha.hip (H = 1, K = V, scale 1)
         mg = K.MhaGeom(BT, 1, spec.N, hv.shape[1], 1.0)
-        rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
-        ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
+        (rv, lse_v), (ra, lse_a) = _mha_pair_fwd(mg, hv, ha)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_MHA_WIN and K.mha_supported(spec.ws * spec.ws, hv.shape[1]) and BT * spec.nW < 65536:
         # wide adapters, window level (Swin-L: d_h = 96): the same flash kernels with the window map (one 64-key trip per window)
         mg = K.MhaGeom(BT * spec.nW, 1, spec.ws * spec.ws, hv.shape[1], 1.0, window=(spec.H, spec.W, spec.ws, spec.shift))
-        rv, lse_v = K.mha_fwd(mg, hv, ha, ha)
-        ra, lse_a = K.mha_fwd(mg, ha, hv, hv)
+        (rv, lse_v), (ra, lse_a) = _mha_pair_fwd(mg, hv, ha)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
         wg = _xwin_geom(spec, BT, hv.device)
@@ -608,8 +615,11 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
     if mg is not None:
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
-        K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
-        K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
+        if MHA_PAIR and hv.stride(0) == ha.stride(0) and rv.stride(0) == ra.stride(0) and drv.stride(0) == dra.stride(0):
+            K.mha_bwd_pair(mg, (hv, ha, ha, rv, lse_v, drv, dq_v, dkv_a, None), (ha, hv, hv, ra, lse_a, dra, dq_a, dkv_v, None))
+        else:
+            K.mha_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)           # direction a -> v
+            K.mha_bwd(mg, ha, hv, hv, ra, lse_a, dra, dQ=dq_a, dK=dkv_v, dV=None)           # direction v -> a
         return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
     pv, pa = (ag_v, hv, ha, rv, lse_v, drv), (ag_a, ha, hv, ra, lse_a, dra)
     if XATTN_MERGED and K.xattn_pair_bwd_supported(pv, pa):

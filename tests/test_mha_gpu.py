@@ -156,3 +156,35 @@ def test_mha_window_map_rejects_bad_geometry(stg, gpu):
         k.MhaGeom(6, 1, 49, 96, 1.0, window=(14, 14, 7, 0))          # 4 windows per frame: P must be a multiple of 4
     with pytest.raises(RuntimeError):
         k.MhaGeom(4, 1, 36, 96, 1.0, window=(14, 14, 7, 0))          # n != ws^2
+
+
+@pytest.mark.parametrize("D,n,window", [(96, 196, None), (64, 49, (14, 14, 7, 3)), (96, 3136, None)])
+def test_mha_pair_launch_equals_two_launches(stg, gpu, D, n, window):
+    """stg_mha_fwd_pair / stg_mha_bwd_pair (both directions of a cross-modal pair, grid.z = 2 P) against two single launches: bit-identical."""
+    from stgcma import kernels as k
+    if window is None:
+        P, rows = (2 if n > 1000 else 5), None
+        geo = k.MhaGeom(P, 1, n, D, 1.0)
+        rows = P * n
+    else:
+        Hi, Wi, ws, shift = window
+        F = 3
+        P = F * (Hi // ws) * (Wi // ws)
+        geo = k.MhaGeom(P, 1, n, D, 1.0, window=window)
+        rows = F * Hi * Wi
+    g = torch.Generator().manual_seed(n + D)
+    hv = (torch.randn(rows, D, generator=g) * 0.35).to(BF16).to(gpu)
+    ha = (torch.randn(rows, D, generator=g) * 0.35).to(BF16).to(gpu)
+    d0 = torch.randn(rows, D, generator=g).to(BF16).to(gpu)
+    d1 = torch.randn(rows, D, generator=g).to(BF16).to(gpu)
+    rv, lv = k.mha_fwd(geo, hv, ha, ha)
+    ra, la = k.mha_fwd(geo, ha, hv, hv)
+    (rv2, lv2), (ra2, la2) = k.mha_fwd_pair(geo, (hv, ha, ha), (ha, hv, hv))
+    assert torch.equal(rv, rv2) and torch.equal(ra, ra2) and torch.equal(lv, lv2) and torch.equal(la, la2)
+    single = [torch.full_like(hv, float("nan")) for _ in range(4)]
+    k.mha_bwd(geo, hv, ha, ha, rv, lv, d0, dQ=single[0], dK=single[1], dV=None)
+    k.mha_bwd(geo, ha, hv, hv, ra, la, d1, dQ=single[2], dK=single[3], dV=None)
+    pair = [torch.full_like(hv, float("nan")) for _ in range(4)]
+    k.mha_bwd_pair(geo, (hv, ha, ha, rv, lv, d0, pair[0], pair[1], None), (ha, hv, hv, ra, la, d1, pair[2], pair[3], None))
+    for a, b in zip(single, pair):
+        assert torch.equal(a, b)
