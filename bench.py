@@ -676,7 +676,7 @@ def main():
 
         def fire():
             # a hang is a FAILURE: rank 0 still prints the line from the eager measurement (so the number is not lost), then every rank
-            # leaves with exit code 3.  The timer thread is NOT a daemon, so the interpreter waits for it and os._exit decides the code
+            # leaves with exit code 4 (not 3: gpurun's own 3 means "no box free, nothing ran" and tools/grun.sh retries on it -- ADVICE r5).  The timer thread is NOT a daemon, so the interpreter waits for it and os._exit decides the code
             try:
                 if rank == 0 and last_eager_loss == last_eager_loss and abs(last_eager_loss) != float("inf"):
                     emit(ms_e_pre * 2 / 1e3, 2, f"eager, one stream (WATCHDOG: the replayed form did not finish within {limit_s:.0f} s; value = the two eager steps "
@@ -684,7 +684,7 @@ def main():
                 else:
                     time.sleep(5.0)           # the launcher tears every rank down when the first one fails: let rank 0 print first
             finally:
-                os._exit(3)
+                os._exit(4)
         watchdog = threading.Timer(limit_s, fire)
         watchdog.daemon = False
         watchdog.start()

@@ -651,6 +651,8 @@ static int cw_launch(const char* who, const void* dy, int64_t lddy, const void* 
     STG_CHECK(M > 0 && H > 0 && W > 0 && dilation >= 1 && O % 8 == 0 && I % 8 == 0 && O > 0 && I > 0, -2,
               "%s: needs O %% 8 == 0 and I %% 8 == 0", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= O && ldx % 8 == 0 && ldx >= I, -2, "%s: bad leading dimensions", who);
+    // the kernel moves a piece's pixel 64 rows per block and wraps its row coordinate at most twice: needs 64 / W < 2 H
+    STG_CHECK(taps == 1 || (int64_t)H * W > 32, -2, "%s: a 3x3 weight gradient needs maps of more than 32 pixels per frame (H * W = %d)", who, H * W);
     STG_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)zero_line | (uintptr_t)ws) & 15) == 0, -2, "%s: pointers must be 16-byte aligned", who);
     int splits = 0;
     const int64_t need = cw_ws_floats(M, O, I, taps, &splits);

@@ -765,7 +765,10 @@ static int xattn_fwd_launch(const stg_attn_args* f0, const stg_attn_args* f1, vo
         p.tiles = (p.n + 31) / 32;
         p.total = p.P * p.tiles;
     }
-    const dim3 grid((pp.a[0].total + 3) / 4, ny), block(256);
+    // the pair's grid covers the LARGER direction (with n_v != n_a, direction 1's extra query tiles never ran); a workgroup
+    // whose items lie beyond its direction's total returns at once
+    const int tmax = ny == 2 && pp.a[1].total > pp.a[0].total ? pp.a[1].total : pp.a[0].total;
+    const dim3 grid((tmax + 3) / 4, ny), block(256);
     if (f0->D == 16) hipLaunchKernelGGL(xattn_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, pp);
     else hipLaunchKernelGGL(xattn_fwd_kernel<32>, grid, block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
@@ -808,13 +811,14 @@ static int xattn_bwd_launch(const stg_attn_bwd_args* b0, const stg_attn_bwd_args
         p.delta = b->delta;
     }
     const dim3 block(256);
+    auto tmax = [&]() { return ny == 2 && pp.a[1].total > pp.a[0].total ? pp.a[1].total : pp.a[0].total; };
     for (int y = 0; y < ny; ++y) { pp.a[y].tiles = (pp.a[y].n + 31) / 32; pp.a[y].total = pp.a[y].P * pp.a[y].tiles; }
-    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dq_kernel<16>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
-    else hipLaunchKernelGGL(xattn_dq_kernel<32>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dq_kernel<16>, dim3((tmax() + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(xattn_dq_kernel<32>, dim3((tmax() + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
     for (int y = 0; y < ny; ++y) { pp.a[y].tiles = (pp.a[y].n_kv + 31) / 32; pp.a[y].total = pp.a[y].P * pp.a[y].tiles; }
-    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dkv_kernel<16>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
-    else hipLaunchKernelGGL(xattn_dkv_kernel<32>, dim3((pp.a[0].total + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    if (b0->f.D == 16) hipLaunchKernelGGL(xattn_dkv_kernel<16>, dim3((tmax() + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(xattn_dkv_kernel<32>, dim3((tmax() + 3) / 4, ny), block, 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -506,7 +506,7 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
         if db is not None:
             db.add_(dbw.sum(0))                           # [splits, N1] -> [N1]: a few hundred floats
         return
-    nws = L.stg_wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
+    nws = _wgrad_ws_floats(M, N1, N2) if USE_WGRAD_WS else 0
     if nws > 0:                                          # partial tiles + reduce (no memory-side atomics)
         ws = torch.empty((nws,), dtype=F32, device=dY.device)
         _lib.check(L.stg_wgrad_tn_ws(_p(dY), _ld(dY), _p(X), _ld(X), _p(dW), _ld(dW), _p(db), M, N1, N2,
@@ -517,6 +517,19 @@ def wgrad_tn(dY, X, dW, db=None, *, n1=None, row_scale=None, rs_outer=1, rs_inne
 
 
 _mlp_perm_cache = {}
+_wgrad_ws_cache = {}
+
+
+def _wgrad_ws_floats(M, N1, N2):
+    """stg_wgrad_ws_floats evaluates every launch plan of (M, N1, N2) on the host (WMAX x 3 plans, each a loop of up to 1 024 candidates) and it
+    sat on the eager launch path: its value depends on the shape alone, so it is cached here.  Note that the row split of a problem
+    depends on how many problems its launch carries and on option wgrad_plan: a single and a multi launch sum the same gradient in a different
+    order -- equal to fp32 rounding, not bit-identical."""
+    key = (int(M), int(N1), int(N2))
+    v = _wgrad_ws_cache.get(key)
+    if v is None:
+        v = _wgrad_ws_cache[key] = int(_lib.lib().stg_wgrad_ws_floats(*key))
+    return v
 
 
 def mlp_fused_supported(C_):
@@ -583,7 +596,7 @@ def wgrad_tn_multi(problems):
     for pr in problems:
         dY, X, dW, db, rs, ro, ri = pr
         M, N1, N2 = dY.shape[0], dY.shape[1], X.shape[1]
-        nws = L.stg_wgrad_ws_floats(M, N1, N2) if (USE_WGRAD_WS and USE_WGRAD_MULTI) else 0
+        nws = _wgrad_ws_floats(M, N1, N2) if (USE_WGRAD_WS and USE_WGRAD_MULTI) else 0
         if nws > 0 and dW.is_contiguous() and dY.dtype == BF16 and X.dtype == BF16 and X.shape[0] == M and dY.stride(1) == 1 and X.stride(1) == 1 \
                 and tuple(dW.shape) == (N1, N2):
             groups.setdefault((M, (min(N1, N2) + 15) // 16, max(N1, N2), nws), []).append(pr)
@@ -1850,8 +1863,10 @@ def im2col3x3(x, F_, H, W, dilation):
     return out
 
 
-def conv3x3_wgrad_supported(O, I):
-    return O % 8 == 0 and I % 8 == 0
+def conv3x3_wgrad_supported(O, I, H=None, W=None):
+    """conv_wgrad_kernel advances a piece's pixel 64 rows per block and wraps its row coordinate at most twice: maps of <= 32 pixels per
+    frame (H * W <= 32) are refused by the C entry and take the im2col path."""
+    return O % 8 == 0 and I % 8 == 0 and (H is None or H * W > 32)
 
 
 @_family_io("dec_conv_wgrad", flops=lambda dy, x, F_, H, W, dilation, want_db=False: 18.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
@@ -1865,12 +1880,14 @@ def conv3x3_wgrad(dy, x, F_, H, W, dilation, want_db=False):
     _chk2d(dy, "dy", BF16, rows=M)
     _chk2d(x, "x", BF16, rows=M)
     O, I = dy.shape[1], x.shape[1]
-    if O < 64 <= I and conv3x3_wgrad_supported(I, O):
+    if O < 64 <= I and conv3x3_wgrad_supported(I, O, H, W):
         T = _conv3x3_wgrad_raw(x, dy, F_, H, W, dilation, False)                       # [I, (kh', kw', o)]
         dW = T.view(I, 3, 3, O).flip(1, 2).permute(3, 1, 2, 0).reshape(O, 9 * I).contiguous()
         if not want_db:
             return dW
         sums = torch.zeros((2, O), dtype=F32, device=dy.device)                        # db = column sums of dy (stg_bn_colsum, mode 0)
+        if dy.stride(0) != O:                             # stg_bn_colsum takes dense [M, O] rows (no leading dimension): ADVICE r5
+            dy = dy.contiguous()
         _lib.check(_lib.lib().stg_bn_colsum(_p(dy), None, None, None, _p(sums), M, O, 0, _stream()), "stg_bn_colsum")
         return dW, sums[0].contiguous()
     return _conv3x3_wgrad_raw(dy, x, F_, H, W, dilation, want_db)

@@ -47,7 +47,7 @@ class Conv3x3Fn(torch.autograd.Function):
             dx = K.gemm_nt(dyb, Wf, conv=(H, Wd, d)) if K.conv3x3_gemm_supported(O) else K.gemm_nt(K.im2col3x3(dyb, F_, H, Wd, d), Wf)
         if ctx.needs_input_grad[1]:
             want_db = ctx.has_b and ctx.needs_input_grad[2]
-            if K.conv3x3_wgrad_supported(O, I):        # tn-GEMM with the tap gather inside: no im2col image, no atomics
+            if K.conv3x3_wgrad_supported(O, I, H, Wd):      # tn-GEMM with the tap gather inside: no im2col image, no atomics
                 res = K.conv3x3_wgrad(dyb.contiguous(), x.contiguous(), F_, H, Wd, d, want_db=want_db)
                 dWm, db = res if want_db else (res, None)
             else:

@@ -290,6 +290,36 @@ def test_cross_modal_pair_merged_backward_slow_path(stg, gpu):
             assert e_m <= max(2e-2, 2.0 * e_f), f"{name} frame {fr}: merged {e_m:.2e}, four-pass {e_f:.2e}"
 
 
+@pytest.mark.parametrize("P,nv,na,D", [(3, 130, 197, 32), (2, 197, 130, 16), (2, 64, 640, 16)])
+def test_cross_modal_pair_fused_gate_unequal_token_counts(stg, gpu, P, nv, na, D):
+    """with n_v != n_a the pair launch's grid was sized from direction 0 alone and direction 1's extra query tiles never ran
+    (O1 / X1 / lse1 kept torch.empty's bytes).  Both directions of stg_xattn_fwd2_gate against single-direction launches, in both orders of
+    (smaller, larger); every output row must be written and finite."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(300 + nv + na)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(BF16).to(gpu)
+    hv, ha = bf(P * nv, D, sc=0.7), bf(P * na, D, sc=0.7)
+    gate_v, gate_a = torch.tensor([0.37], device=gpu), torch.tensor([-1.21], device=gpu)
+    gv = k.AttnGeom(P, 1, nv, D, G=1, outer=nv, n_kv=na, outer_kv=na, scale=1.0)
+    ga = k.AttnGeom(P, 1, na, D, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=1.0)
+    assert k.xattn_pair_fwd_supported(gv, hv, ha, ga, ha, hv)
+    rv, lv = k.attn_fwd(gv, hv, ha, ha)
+    ra, la = k.attn_fwd(ga, ha, hv, hv)
+    # poison the allocator's free blocks so that an unwritten row cannot look right by accident
+    for n_ in (nv, na):
+        t = torch.full((P * n_, D), float("nan"), dtype=BF16, device=gpu); del t
+        t = torch.full((P, 1, n_), float("nan"), dtype=torch.float32, device=gpu); del t
+    (rv2, lv2, xv2), (ra2, la2, xa2) = k.xattn_fwd2_gate(gv, hv, ha, ga, ha, hv, gate_v, gate_a)
+    torch.cuda.synchronize()
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for t in (rv2, ra2, xv2, xa2, lv2, la2):
+        assert torch.isfinite(t.float()).all(), "a pair output has unwritten rows"
+    assert eq(rv, rv2) and eq(ra, ra2) and torch.equal(lv, lv2) and torch.equal(la, la2)
+    for h, r, gt, x in ((hv, rv, gate_v, xv2), (ha, ra, gate_a, xa2)):
+        want = h.float() + float(gt) * r.float()
+        assert float(((x.float() - want).abs() / want.abs().clamp_min(1e-3)).max()) <= 2.0 ** -7
+
+
 @pytest.mark.parametrize("P,n,D", [(3, 196, 32), (2, 3136, 16), (2, 130, 16)])
 def test_cross_modal_pair_fused_gate_and_join(stg, gpu, P, n, D):
     """Round 5: the frame-global pair's forward writes the gated hidden states itself (stg_xattn_fwd2_gate) and its merged backward applies the

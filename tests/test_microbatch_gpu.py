@@ -122,7 +122,7 @@ def test_bench_launches_its_own_ranks(stg, gpu):
 def test_bench_watchdog_prints_the_eager_line_when_the_replayed_form_never_returns(stg, gpu):
     """N > 1 safety net: RCCL has never run under the replayed step form on this pool's hardware, so bench.py times the eager form before it
     captures anything and arms a watchdog around pass 2; when that fires (here: forced after 1 s) rank 0 prints ONE complete line from the
-    eager measurement, says so in config.step, and every rank exits with code 3: a hang is a failure, the line keeps the number."""
+    eager measurement, says so in config.step, and every rank exits with code 4 (a code gpurun itself never returns): a hang is a failure, the line keeps the number."""
     env = dict(os.environ, STG_DDP_BACKEND="gloo", OMP_NUM_THREADS="4", STG_BENCH_WATCHDOG_S="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
