@@ -177,6 +177,7 @@ void stg_set_error(const char* fmt, ...);
 // stg_set_option -- nothing on a launch path reads the environment.
 extern std::atomic<int> stg_opt_gemm_epi;     // 0: every GEMM epilogue option a run-time test (EV_GENERIC)
 extern std::atomic<int> stg_opt_gemm_ktail;   // K % 64 != 0 shapes: 0 register-staged kernel, 1 LDS-DMA k-tail kernel for K > 64, 2 (default) for every K
+extern std::atomic<int> stg_opt_gemm_nx;      // 8-phase kernels for N % 64 == 0 / K % 64 == 0 shapes (NX forms, round 6): 0 off, 1 (default) the classes measured faster (N < 256, K >= 768), 2 every legal shape
 extern std::atomic<int> stg_opt_gemm_big;     // 256 x 256 simple-loop kernel: 0 off, 1 auto, 2 whenever legal
 extern std::atomic<int> stg_opt_gemm_8phm;    // multi-tile 8-phase kernel: 0 off, 1 auto (default), n >= 2: at most n column tiles per workgroup
 extern std::atomic<int> stg_opt_gemm_8ph;     // 8-phase kernel: 0 off, 1 auto (default), 2 every legal shape, 3 long-K shapes only

@@ -617,6 +617,9 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
 // epilogue is not overlapped by a neighbour, so it only wins where the epilogue is a small share of the tile.
 constexpr int GBM = 256, GBN = 256;
 
+// 16 bytes of zeros for the NX forms of the 8-phase kernels below (a zero-filled k-tile: every lane's LDS-DMA reads these)
+__device__ __attribute__((aligned(16))) const uint32_t gemm_zero16[4] = {0u, 0u, 0u, 0u};
+
 __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_big[];          // 2 x (GBM + GBN) x BK bf16 = 128 KiB
     bf16_t* smem = smem_big;
@@ -729,6 +732,13 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
 // RAW: A1(t+1), W0(t+1) are retired by that wait >= 1 barrier before any wave reads them (phase 0 / 2 of t+1, the late group
 // included); A0(t+2), W1(t+2) by the wait of tile t+1.  WAR: a slot is re-staged >= 3 barrier intervals after its last ds_read
 // (late group included): A0 p0 -> p2, W1 p1 -> p3, A1 p2 -> p0', W0 p3 -> p1'.
+// NX (round 6; Swin-L's widths 192 / 384 / 576 / 1152): N % 64 == 0 instead of N % 256 == 0 and K % 64 == 0 instead of K % 128 == 0.
+//   * the last column tile may hold 64 / 128 / 192 valid columns: W rows beyond N are clamped to row N - 1 (their products are never
+//     stored); when its W1 half (columns 128..255) is entirely out of range, the two phases that multiply by W1 skip their MFMA clusters
+//     (a workgroup-uniform branch; barriers and DMAs unchanged, so the counted waits stay exact) -- N = 1152 costs 4.5 tiles, not 5;
+//   * an odd number of k-tiles (K = 192, 576) is rounded up with a ZERO k-tile: its DMAs read gemm_zero16 (all lanes the same 16 bytes).
+// NX = false compiles to the round-5 kernel (every NX test is a compile-time constant).
+template <bool NX>
 __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 128 rows x 64 bf16 = 128 KiB
     const int nblk = p.nbm * p.nbn;
@@ -758,22 +768,33 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
             const int row = hf * 128 + (q >> 3), c = (q & 7) ^ ((q >> 3) & 7);
             const int64_t rm = p.M - 1 - m0;
             const int ra = row < rm ? row : (int)rm;     // rows beyond M are clamped (their products are never stored)
+            const int rn = p.N - 1 - n0;
+            const int rw = NX ? (row < rn ? row : rn) : row;                     // NX = false: N % 256 == 0, always in range
             oa[hf][j] = (uint32_t)(((int64_t)ra * p.lda + c * 8) * 2);
-            ow[hf][j] = (uint32_t)(((int64_t)row * p.ldw + c * 8) * 2);          // N % 256 == 0: always in range
+            ow[hf][j] = (uint32_t)(((int64_t)rw * p.ldw + c * 8) * 2);
         }
     const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda);
     const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
-    const int nk = p.K / BK;
+    const int nkr = p.K / BK;                            // k-tiles that exist
+    const int nk = NX ? (nkr + 1) & ~1 : nkr;            // k-tiles the ring walks (even)
+    const bool w1_live = NX ? p.N - n0 > 128 : true;     // does the tile's W1 half hold any column of C?
+    const char* zsrc = reinterpret_cast<const char*>(gemm_zero16);
     auto issue = [&](int which, int kt) {                // which: HA0 / HA1 / HW0 / HW1 of k-tile kt (clamped: a dummy re-load past the end)
         kt = kt < nk ? kt : nk - 1;
         bf16_t* dst = smem8 + ((kt & 1) * 4 + which) * SLOT + wave * 512;
         const bool isw = which >= HW0;
         const int hf = which & 1;
         const char* g = (isw ? baseW : baseA) + (size_t)kt * (BK * 2);
+        const bool z = NX && kt >= nkr;                  // the zero k-tile (wave-uniform): scalar base = the zero line, lane offsets masked to 0
+        if (NX) g = z ? zsrc : g;
+        const uint32_t om = z ? 0u : 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (isw ? ow[hf][j] : oa[hf][j])),
+        for (int j = 0; j < 2; ++j) {
+            uint32_t off = isw ? ow[hf][j] : oa[hf][j];
+            if (NX) off &= om;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
                                              (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+        }
     };
 
     f32x4_t acc[2][2][2][4];                             // [mh][nh][ni][mi]
@@ -857,7 +878,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_setprio(1);
-                if (!DIAG_ON(p, 2))
+                if (!DIAG_ON(p, 2) && (!NX || nh == 0 || w1_live))
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -910,7 +931,8 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
 //     main loop's per-lane offsets stay live across it without spills);
 //   * before the next main loop: s_waitcnt vmcnt(NST) with NST = the global stores the epilogue issued behind the DMAs (in-order
 //     completion: everything older than the NST youngest operations has landed), then the workgroup barrier.
-template <int V>
+// NX: see gemm_nt_8ph_kernel.  Only the LAST column tile of C can be partial: it takes a second set of clamped W-row offsets.
+template <int V, bool NX>
 __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem8[];            // 8 slots x 16 KiB + 32 KiB of epilogue staging
     const int ntl = p.ntl;
@@ -944,7 +966,9 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
             ow[hf][j] = (uint32_t)(((int64_t)row * p.ldw + c * 8) * 2);
         }
     const char* baseA = reinterpret_cast<const char*>(p.A + m0 * p.lda);
-    const int nk = p.K / BK;
+    const int nkr = p.K / BK;
+    const int nk = NX ? (nkr + 1) & ~1 : nkr;
+    const char* zsrc = reinterpret_cast<const char*>(gemm_zero16);
 
     int offA[4][2], offW[2][2];
 #pragma unroll
@@ -967,6 +991,11 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
         const char* baseW = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
         const bool has_next = t + 1 < ntl;
         const char* baseWn = reinterpret_cast<const char*>(p.W + (int64_t)(n0 + (has_next ? GBN : 0)) * p.ldw);
+        // NX: valid 64-row groups of this tile's / the next tile's W rows (N % 64 == 0; 4 = a full tile).  DMA piece (hf, j) covers W rows
+        // 64 (2 hf + j) .. + 63: a group beyond N re-reads rows 0-63 of the tile (always valid; its products are never stored)
+        const int nvg_cur = NX ? ((p.N - n0) >> 6 < 4 ? (p.N - n0) >> 6 : 4) : 4;
+        const int nvg_next = NX ? ((p.N - n0 - GBN) >> 6 < 4 ? (p.N - n0 - GBN) >> 6 : 4) : 4;
+        const bool w1_live = nvg_cur > 2;
         // which: HA0 / HA1 / HW0 / HW1 of k-tile kt; past the end of K: the next tile's k-tile kt - nk (same A panel, next W tile), or --
         // behind the group's last tile -- a dummy re-load of the last k-tile (keeps the counted waits exact)
         auto issue = [&](int which, int kt) {
@@ -974,15 +1003,22 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
             const int hf = which & 1;
             const int par = kt & 1;                      // nk is even: the slot parity continues across the tile boundary
             const char* g = isw ? baseW : baseA;
+            int nvg = nvg_cur;
             if (kt >= nk) {
-                if (has_next) { kt -= nk; g = isw ? baseWn : baseA; } else kt = nk - 1;
+                if (has_next) { kt -= nk; g = isw ? baseWn : baseA; nvg = nvg_next; } else kt = nk - 1;
             }
             bf16_t* dst = smem8 + (par * 4 + which) * SLOT + wave * 512;
             g += (size_t)kt * (BK * 2);
+            const bool z = NX && kt >= nkr;              // the zero k-tile (wave-uniform): scalar base = the zero line, lane offsets masked to 0
+            if (NX) g = z ? zsrc : g;
+            const uint32_t om = z ? 0u : 0xffffffffu;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (isw ? ow[hf][j] : oa[hf][j])),
+            for (int j = 0; j < 2; ++j) {
+                uint32_t off = isw ? ((NX && 2 * hf + j >= nvg) ? ow[0][0] : ow[hf][j]) : oa[hf][j];
+                if (NX) off &= om;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
                                                  (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+            }
         };
         f32x4_t acc[2][2][2][4];
 #pragma unroll
@@ -1041,6 +1077,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
                     __builtin_amdgcn_s_barrier();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_setprio(1);
+                    if (!NX || nh == 0 || w1_live)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -1057,7 +1094,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8phm_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
 
         // epilogue of tile t through the wave's 8 KiB staging region (slots 5 / 6 and the extra 32 KiB: nothing in flight writes them)
-        const bool full = mt + GBM <= p.M;               // N % 256 == 0: only the last row panel can be partial (wave-uniform)
+        const bool full = mt + GBM <= p.M && (!NX || n0 + GBN <= p.N);      // wave-uniform (NX = false: N % 256 == 0, only the last row panel can be partial)
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             AccTile tl;
@@ -1465,7 +1502,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
     }
 }
 
-std::atomic<uint64_t> lds_8ph_done{0}, lds_big_done{0}, lds_8phm_done[6];
+std::atomic<uint64_t> lds_8ph_done[2], lds_big_done{0}, lds_8phm_done[8];
 
 }  // namespace
 
@@ -1583,7 +1620,12 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
     const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
     const int ph8_mode = stg_opt_gemm_8ph.load(std::memory_order_relaxed);   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
-    const bool ph8_ok = !split && !conv && p.batch == 1 && a->K % (2 * BK) == 0 && a->M >= GBM && a->N % GBN == 0 && p.epi_variant >= 0;
+    // round 6, the NX forms (template flag of both 8-phase kernels): N % 64 == 0 with N >= 192 and K % 64 == 0 with K >= 192 -- Swin-L's widths
+    // (C = 192 / 384: qkv N = 576 / 1152, K = 192 / 576, the N = 192 / 384 projections) kept 45-65 ms of its step on the 128 x 128 kernel
+    const int nx_mode = stg_opt_gemm_nx.load(std::memory_order_relaxed);     // 0: the round-5 shape rules (A/B)
+    const bool nx = nx_mode != 0 && (a->N % GBN != 0 || a->K % (2 * BK) != 0);
+    const bool ph8_ok = !split && !conv && p.batch == 1 && a->M >= GBM && p.epi_variant >= 0 &&
+                        (nx ? (a->K % BK == 0 && a->K >= 3 * BK && a->N % 64 == 0 && a->N >= 192) : (a->K % (2 * BK) == 0 && a->N % GBN == 0));
     // mode 1: the long-K shapes (K >= 1024), and K >= 512 with a wide [M, >= 1536] output behind a plain / activation epilogue
     // (measured +4..5 % on 125440 x 1536 x 512, +2..4 % on x 2048 x 512 with GELU + derivative; the derivative-source epilogue
     // of the fc2 dgrad and the N = 512 shapes are faster on the 128 x 128 kernel)
@@ -1598,10 +1640,16 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     // (round 5b: option value 2, the default, extends this to K <= 1024 -- Swin-L's and ViT-B's fc2 dgrad, 3072 x 768, ran on the 128 x 128 kernel
     // at 0.81 PFLOP/s, 13 ms of the Swin-L step; on the one-tile 8-phase kernel the step's GEMM time drops 122.1 -> 119.6 ms)
     const int d8opt = stg_opt_gemm_d8m.load(std::memory_order_relaxed);
-    const bool d8m = p.epi_variant == EV_DSRC8 && d8opt != 0 && a->K <= (d8opt >= 2 ? 1024 : 512) && a->N >= 1024;
-    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && (p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8 || d8m);
-    if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
-        const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = a->N / GBN;
+    const bool d8m = p.epi_variant == EV_DSRC8 && d8opt != 0 && a->K <= (d8opt >= 2 ? 1024 : 512) && a->N >= (nx ? 768 : 1024);
+    const bool plainish = p.epi_variant == EV_PLAIN || p.epi_variant == EV_GELU || p.epi_variant == EV_QGELU || p.epi_variant == EV_GELU8 || p.epi_variant == EV_QGELU8 || d8m;
+    const bool ph8_wide = a->K >= 256 && a->N >= 256 && a->M >= 8192 && plainish;
+    // NX shapes, measured per class of the Swin-L step (profiles/r06_gemm_nx_ab.txt): the K = 192 / 384 classes are store-bound (output 3-4 x the
+    // input, 3.0-3.1 TB/s) and run 0-18 % SLOWER here than on the 128 x 128 kernel, whose four workgroups per CU overlap one tile's stores with the
+    // others' main loops; the NX forms win where the main loop is long and the output narrow (N = 192, K = 768: fc2 and the fc1 dgrad of stage 0,
+    // 967 -> 893 us).  Default (1): those; option value 2: every legal NX shape (tests, A/B)
+    const bool ph8_nx = nx && a->M >= 8192 && (nx_mode >= 2 || (plainish && a->N < GBN && a->K >= 768));
+    if (ph8_ok && ((ph8_mode == 1 && (big || ph8_wide || ph8_nx)) || ph8_mode == 2 || (ph8_mode == 3 && big))) {      // 3 = long-K shapes only (A/B knob)
+        const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
         p.nbm = (int)gbm; p.nbn = (int)gbn;
         // multi-tile form (option gemm_8phm, default on): ntl >= 3 consecutive column tiles per workgroup where the tile is short
         // (K <= 512: turnover + epilogue are a third of it; at K = 768 -- ViT-B, Swin-L stage 2 -- the whole-model A/B is neutral to -0.8 %) and the group count still fills the chip twice.  Measured per class of the
@@ -1628,8 +1676,11 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
             p.ntl = ntl;
             const int lds = 8 * 128 * BK * 2 + 8 * 4096;
             const unsigned grid = (unsigned)(gbm * (gbn / ntl));
-#define STG_8PHM(V, slot) case V: STG_CHECK(stg_reserve_lds(gemm_nt_8phm_kernel<V>, lds, lds_8phm_done[slot]), -101, "stg_gemm_nt: cannot reserve 160 KiB of LDS"); \
-                              hipLaunchKernelGGL(gemm_nt_8phm_kernel<V>, dim3(grid), dim3(512), lds, (hipStream_t)stream, p); launched = true; break;
+#define STG_8PHM(V, slot) case V: if (nx) { STG_CHECK(stg_reserve_lds(gemm_nt_8phm_kernel<V, true>, lds, lds_8phm_done[4 + slot]), -101, "stg_gemm_nt: cannot reserve 160 KiB of LDS"); \
+                                            hipLaunchKernelGGL((gemm_nt_8phm_kernel<V, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p); } \
+                                  else { STG_CHECK(stg_reserve_lds(gemm_nt_8phm_kernel<V, false>, lds, lds_8phm_done[slot]), -101, "stg_gemm_nt: cannot reserve 160 KiB of LDS"); \
+                                         hipLaunchKernelGGL((gemm_nt_8phm_kernel<V, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, p); } \
+                                  launched = true; break;
             bool launched = false;
             switch (p.epi_variant) {
                 STG_8PHM(EV_PLAIN, 0) STG_8PHM(EV_GELU8, 1) STG_8PHM(EV_QGELU8, 2) STG_8PHM(EV_DSRC8, 3)
@@ -1642,9 +1693,14 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
                 return 0;
             }
         }
-        STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel, 8 * 128 * BK * 2, lds_8ph_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
         a->kernel_chosen = STG_GEMM_KERNEL_8PH;
-        hipLaunchKernelGGL(gemm_nt_8ph_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
+        if (nx) {
+            STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel<true>, 8 * 128 * BK * 2, lds_8ph_done[1]), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
+            hipLaunchKernelGGL(gemm_nt_8ph_kernel<true>, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
+        } else {
+            STG_CHECK(stg_reserve_lds(gemm_nt_8ph_kernel<false>, 8 * 128 * BK * 2, lds_8ph_done[0]), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
+            hipLaunchKernelGGL(gemm_nt_8ph_kernel<false>, dim3((unsigned)(gbm * gbn)), dim3(512), 8 * 128 * BK * 2, (hipStream_t)stream, p);
+        }
         STG_LAUNCH_CHECK();
         return 0;
     }

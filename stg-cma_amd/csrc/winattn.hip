@@ -81,250 +81,7 @@ __device__ __forceinline__ int64_t tok_row(const WinP& a, int pg, int g, int i) 
     return (int64_t)pg * a.outer + h * a.Wimg + w;
 }
 
-// transposed fragment of a row-major [64 x 32] LDS tile: A[i = d][k slot j] = tile[32*kt + kappa(s2, hh, j)][d], d = lane & 31,
-// by two ds_read_b64_tr_b16 (each 16-lane group reads a 4-row x 16-column block and receives it column-major: lane
-// 4q + p of the group supplies the address of row q, columns 4p..4p+3; 4 rows x 64 B per 32-lane half: conflict-free).
-// EXEC must be all ones here (whole waves only leave at the top of the kernels).
 typedef short s4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int kt, int s2, int hh, int d) {
-    const int gi = d & 15, c = d >> 4;
-    const bf16_t* p = s + (32 * kt + 16 * s2 + 4 * hh + (gi >> 2)) * WD + 16 * c + 4 * (gi & 3);
-    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p);
-    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)(p + 8 * WD));
-    bf16x8_t f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
-}
-
-
-// stage rows (tokens 0..63, clamped) of one of Q/K/V/dO for head h into a [64][32] LDS tile (zeros beyond n)
-__device__ __forceinline__ void stage64(const WinP& a, bf16_t* s, const bf16_t* src, int64_t ld, int pg, int g, int h, int lane) {
-    uint4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = lane + 64 * i;           // 64 rows x 4 chunks
-        const int tr = idx >> 2, ch = idx & 3;
-        v[i] = *reinterpret_cast<const uint4*>(src + tok_row(a, pg, g, tr) * ld + h * WD + ch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = lane + 64 * i;
-        const int tr = idx >> 2, ch = idx & 3;
-        *reinterpret_cast<uint4*>(s + tr * WD + ch * 8) = tr < a.n ? v[i] : make_uint4(0, 0, 0, 0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(256, 2) winattn_fwd_kernel(WinP a) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 64 * WD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= a.total) return;
-    const int h = item % a.H;
-    const int p = item / a.H;
-    const int pg = p / a.G, g = p - pg * a.G;
-    bf16_t* sV = smem + wave * 64 * WD;
-
-    // operand fragments straight from HBM/L2 (token on the row / column index, head dims contiguous): all issued up front
-    bf16x8_t qf[2][2], kf[2][2];
-    int64_t rowq[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        rowq[t] = tok_row(a, pg, g, 32 * t + r);
-        const bf16_t* qp = a.Q + rowq[t] * a.ld + h * WD + 8 * hh;
-        const bf16_t* kp = a.K + rowq[t] * a.ld + h * WD + 8 * hh;
-        qf[t][0] = ld_frag(qp); qf[t][1] = ld_frag(qp + 16);
-        kf[t][0] = ld_frag(kp); kf[t][1] = ld_frag(kp + 16);
-    }
-    stage64(a, sV, a.V, a.ld, pg, g, h, lane);
-    const float* bmq[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + r);       // tiled: see win_table_kernel
-    float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));
-
-    // St[key][q] for the 2 x 2 tiles
-    f32x16_t st[2][2];               // [q tile][key tile]
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            st[qt][kt] = zero16();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) st[qt][kt] = MFMA32(kf[kt][s], qf[qt][s], st[qt][kt]);
-        }
-    lds_fence();
-    f32x16_t o[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        float x[2][16];
-        float m = NEG_BIG;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float4 ad = add[qt][kt][reg >> 2];
-                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
-                x[kt][reg] = st[qt][kt][reg] * a.scale2 + av;
-                m = fmaxf(m, x[kt][reg]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                x[kt][reg] = __builtin_amdgcn_exp2f(x[kt][reg] - m);
-                l += x[kt][reg];
-            }
-        l += __shfl_xor(l, 32, 64);
-        o[qt] = zero16();
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) o[qt] = MFMA32(tr_frag(sV, kt, s2, hh, r), pack8(x[kt] + 8 * s2), o[qt]);
-        const int q = 32 * qt + r;
-        store_tile32(a.O + rowq[qt] * a.ldo + h * WD, o[qt], 1.0f / l, hh, q < a.n);
-        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward (dQ, dK, dV)
-// WPS = waves per SIMD the register allocation is held to: 2 (174 VGPRs, no spills) or 3 (<= 168: 12 spilled VGPRs, but the loads of one
-// problem hide behind two others; 3 x 51 KB of LDS still fit) -- option "winattn_bwd_occ"
-template <int WPS>
-__global__ void __launch_bounds__(256, WPS) winattn_bwd_kernel(WinP a) {
-    // per wave: K tile, Q tile, dO tile ([64][32] bf16 each) + lse[64] + delta[64]
-    constexpr int PER_WAVE = 3 * 64 * WD + 256;     // in bf16 units (2 * 64 floats = 256 bf16 slots)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= a.total) return;
-    const int h = item % a.H;
-    const int p = item / a.H;
-    const int pg = p / a.G, g = p - pg * a.G;
-    bf16_t* sK = smem + wave * PER_WAVE;
-    bf16_t* sQ = sK + 64 * WD;
-    bf16_t* sD = sQ + 64 * WD;
-    float* sLse = reinterpret_cast<float*>(sD + 64 * WD);
-    float* sDel = sLse + 64;
-
-    bf16x8_t qf[2][2], kf[2][2], vf[2][2], dof[2][2];
-    int64_t row[2];
-    float delta[2], lse_q[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        row[t] = tok_row(a, pg, g, 32 * t + r);
-        const int64_t off = row[t] * a.ld + h * WD + 8 * hh;
-        qf[t][0] = ld_frag(a.Q + off); qf[t][1] = ld_frag(a.Q + off + 16);
-        kf[t][0] = ld_frag(a.K + off); kf[t][1] = ld_frag(a.K + off + 16);
-        vf[t][0] = ld_frag(a.V + off); vf[t][1] = ld_frag(a.V + off + 16);
-        const bf16_t* dp = a.dO + row[t] * a.lddo + h * WD + 8 * hh;
-        const bf16_t* op = a.O + row[t] * a.ldo + h * WD + 8 * hh;
-        dof[t][0] = ld_frag(dp); dof[t][1] = ld_frag(dp + 16);
-        const bf16x8_t o0 = ld_frag(op), o1 = ld_frag(op + 16);
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            d += bf2f((bf16_t)dof[t][0][j]) * bf2f((bf16_t)o0[j]) + bf2f((bf16_t)dof[t][1][j]) * bf2f((bf16_t)o1[j]);
-        d += __shfl_xor(d, 32, 64);
-        delta[t] = d;
-        const int q = 32 * t + r;
-        lse_q[t] = a.lse[((int64_t)p * a.H + h) * 64 + (q < a.n ? q : a.n - 1)] * 1.4426950408889634f;
-    }
-    stage64(a, sK, a.K, a.ld, pg, g, h, lane);
-    stage64(a, sQ, a.Q, a.ld, pg, g, h, lane);
-    stage64(a, sD, a.dO, a.lddo, pg, g, h, lane);
-    if (hh == 0) {
-        sLse[r] = lse_q[0]; sLse[32 + r] = lse_q[1];
-        sDel[r] = delta[0]; sDel[32 + r] = delta[1];
-    }
-    const int64_t tb = ((int64_t)(g % a.Gt) * a.H + h) * 64 * 64;
-    lds_fence();
-
-    // ---------------- phase A: query on the lane -> dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const float* bmq = a.bm + tb + 4 * (32 * qt + r);
-        f32x16_t dq = zero16();
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            float4 add[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
-            f32x16_t st = zero16(), dpt = zero16();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                st = MFMA32(kf[kt][s], qf[qt][s], st);
-                dpt = MFMA32(vf[kt][s], dof[qt][s], dpt);
-            }
-            float ds[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float4 ad = add[reg >> 2];
-                const float av = (reg & 3) == 0 ? ad.x : (reg & 3) == 1 ? ad.y : (reg & 3) == 2 ? ad.z : ad.w;
-                const float pr = __builtin_amdgcn_exp2f(st[reg] * a.scale2 + av - lse_q[qt]);      // padded keys: av = -1e30 -> 0
-                ds[reg] = pr * (dpt[reg] - delta[qt]);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) dq = MFMA32(tr_frag(sK, kt, s2, hh, r), pack8(ds + 8 * s2), dq);
-        }
-        store_tile32(a.dQ + row[qt] * a.lddqkv + h * WD, dq, a.scale, hh, 32 * qt + r < a.n);
-    }
-
-    // ---------------- phase B: key on the lane -> dV^T[d][key] = sum_q dO^T[d][q] P[q][key], dK^T = sum_q Q^T[d][q] dS[q][key]
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const float* bmk = a.bmT + tb + 4 * (32 * kt + r);                  // tiled, lane axis = key
-        f32x16_t dv = zero16(), dk = zero16();
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float4 add[4], ls[4], de[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int q4 = 32 * qt + 8 * g4 + 4 * hh;
-                add[g4] = *reinterpret_cast<const float4*>(bmk + 256 * ((qt * 4 + g4) * 2 + hh));
-                ls[g4] = *reinterpret_cast<const float4*>(sLse + q4);
-                de[g4] = *reinterpret_cast<const float4*>(sDel + q4);
-            }
-            f32x16_t sc = zero16(), dp = zero16();
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {          // rows = queries (A = Q / dO fragments), columns = keys (B = K / V fragments)
-                sc = MFMA32(qf[qt][s], kf[kt][s], sc);
-                dp = MFMA32(dof[qt][s], vf[kt][s], dp);
-            }
-            float pr[16], ds[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int c = reg & 3;
-                const float av = c == 0 ? add[reg >> 2].x : c == 1 ? add[reg >> 2].y : c == 2 ? add[reg >> 2].z : add[reg >> 2].w;
-                const float lv = c == 0 ? ls[reg >> 2].x : c == 1 ? ls[reg >> 2].y : c == 2 ? ls[reg >> 2].z : ls[reg >> 2].w;
-                const float dl = c == 0 ? de[reg >> 2].x : c == 1 ? de[reg >> 2].y : c == 2 ? de[reg >> 2].z : de[reg >> 2].w;
-                const bool okq = 32 * qt + ACC_ROW(reg, hh) < a.n;                 // padded query rows contribute nothing
-                const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 + av - lv) : 0.f;
-                pr[reg] = pv;
-                ds[reg] = pv * (dp[reg] - dl);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dv = MFMA32(tr_frag(sD, qt, s2, hh, r), pack8(pr + 8 * s2), dv);
-                dk = MFMA32(tr_frag(sQ, qt, s2, hh, r), pack8(ds + 8 * s2), dk);
-            }
-        }
-        store_tile32(a.dK + row[kt] * a.lddqkv + h * WD, dk, a.scale, hh, 32 * kt + r < a.n);
-        store_tile32(a.dV + row[kt] * a.lddqkv + h * WD, dv, 1.0f, hh, 32 * kt + r < a.n);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ backward, one pass (round 2)
 // Two things the two-orientation kernel above pays for, removed:
@@ -394,23 +151,86 @@ __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const
     }
 }
 
+
+// ---- round 6: the additive table shared through LDS (template flag LT, used with NKEY = 49) --------------------------------------------------
+// The table is 16 KiB per (window type, head) -- more bytes through a CU's vector-memory path than the q / k / v / o tiles of a problem
+// (12.5 KiB), every wave fetching its own copy (L2 hits; a no-table probe ran the forward 10-22 % faster).  In the LT form a workgroup is
+// FOUR FRAMES of one (window position g, head h): the four problems share one table, which the workgroup stages ONCE by LDS-DMA (key groups
+// below NKEY only: 13 x 1 KiB) and reads with conflict-free ds_read_b128 (a lane's float4s are consecutive in x = query).  A wave still moves
+// 64-byte pieces of its head per token row; the heads of one (frame quad, window) are CONSECUTIVE workgroups of ONE XCD (blockIdx -> XCD is
+// round-robin), so the other half of every 128-byte line is wanted by the neighbour in that XCD's L2 at the same time.
+//     unit u = (frame quad fq, window g), g fastest; XCD x takes units x, x + 8, ...;  block b: x = b & 7, idx = b >> 3, h = idx % H,
+//     u = (idx / H) * 8 + x;  wave w of the block: frame 4 fq + w.
+// Same arithmetic on the same table values as the per-wave form: bit-identical results.
+template <int NKEY> struct LtTab { static constexpr int GROUPS = (NKEY + 3) / 4; static constexpr int FLOATS = GROUPS > 0 ? GROUPS * 256 : 4; };
+
+struct LtItem { int p, pg, g, h; bool block_live, wave_live; };
+__device__ __forceinline__ LtItem lt_item(const WinP& a, int wave) {
+    LtItem it;
+    const int F = a.P / a.G, nq = (F + 3) >> 2, U = nq * a.G;
+    const int b = blockIdx.x, x = b & 7, idx = b >> 3;
+    it.h = idx % a.H;
+    const int u = (idx / a.H) * 8 + x;
+    it.block_live = u < U;
+    const int fq = u / a.G;
+    it.g = u - fq * a.G;
+    it.pg = 4 * fq + wave;
+    it.wave_live = it.block_live && it.pg < F;
+    it.p = it.pg * a.G + it.g;
+    return it;
+}
 template <int NKEY>
+__device__ __forceinline__ void lt_stage_table(const WinP& a, float* stab, int g, int h, int wave, int lane) {
+    const float* src = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < (LtTab<NKEY>::GROUPS + 3) / 4; ++i) {
+        const int grp = 4 * i + wave;                     // wave-uniform
+        if (grp < LtTab<NKEY>::GROUPS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + grp * 256),
+                                             (__attribute__((address_space(3))) void*)(stab + grp * 256), 16, 0, 0);
+    }
+}
+// float4 of keys 32 kt + 8 g4 + 4 hh + 0..3 for query x: group 8 kt + 2 g4 + hh; a group past the staged ones is all padding keys (-1e30)
+template <int NKEY>
+__device__ __forceinline__ float4 lt_read(const float* stab, int kt, int g4, int hh, int x) {
+    const int grp0 = 8 * kt + 2 * g4;                     // compile-time after unrolling
+    if (grp0 + 1 < LtTab<NKEY>::GROUPS) return *reinterpret_cast<const float4*>(stab + ((grp0 + hh) * 64 + x) * 4);
+    const float4 v = *reinterpret_cast<const float4*>(stab + (grp0 * 64 + x) * 4);
+    return hh ? make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG) : v;
+}
+
+template <int NKEY, bool LT>
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
     constexpr int PER_WAVE = 4 * 64 * WD + 128;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
+    __shared__ __attribute__((aligned(16))) float stab[LT ? LtTab<NKEY>::FLOATS : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    int item = blockIdx.x * 4 + wave;
     const bf16_t *Qp = a.Q, *Kp = a.K, *Vp = a.V, *Op = a.O, *dOp = a.dO;
     const float* lsep = a.lse;
     bf16_t* dQp = a.dQ;
     bf16_t* dKp = a.dK;
-    if (item >= a.total) return;
-    const int h = item % a.H;
-    const int p = item / a.H;
-    const int pg = p / a.G, g = p - pg * a.G;
+    int h, p, pg, g;
+    bool live = true;
+    if (LT) {
+        const LtItem it = lt_item(a, wave);
+        if (!it.block_live) return;                        // whole workgroup
+        h = it.h; p = it.p; pg = it.pg; g = it.g; live = it.wave_live;
+        lt_stage_table<NKEY>(a, stab, g, h, wave, lane);
+    } else {
+        const int item = blockIdx.x * 4 + wave;
+        if (item >= a.total) return;
+        h = item % a.H;
+        p = item / a.H;
+        pg = p / a.G; g = p - pg * a.G;
+    }
+    if (LT && !live) {                                     // a frame past the last one: the wave only helped to stage the table
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return;
+    }
     bf16_t* sK = smem + wave * PER_WAVE;
     bf16_t* sQ = sK + 64 * WD;
     bf16_t* sD = sQ + 64 * WD;
@@ -450,11 +270,13 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             if (NKEY > 0 && 32 * kt + 8 * g4 >= NKEY) { dst[g4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-            dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
+            if (LT) dst[g4] = lt_read<NKEY>(stab, kt, g4, hh, 32 * qt + r);
+            else dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
         }
     };
-    load_add(addc, 0, 0);
+    if (!LT) load_add(addc, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LT) { __syncthreads(); load_add(addc, 0, 0); }     // the table's pieces were staged by all four waves
     lds_fence();
     // delta[q] = sum_d dO[q][d] O[q][d]: the lane's own 16-byte piece of dO (back from LDS) times the same piece of O, summed over the
     // four lanes of the row
@@ -600,6 +422,8 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
         bmq[t] = a.bm + ((int64_t)(g % a.Gt) * a.H + h) * 4096 + 4 * (32 * t + (32 * t + r < a.n ? r : 0));       // tiled: see win_table_kernel
+    // (round 6: the LDS-shared table of winattn_bwd1_kernel<.., LT> was measured here too: bit-identical, 10-18 % SLOWER -- 13 KiB more LDS per
+    // workgroup takes the forward from 3 to 2 workgroups per CU)
     float4 add[2][2][4];             // [q tile][key tile][row group g4]: keys 32*kt + 8*g4 + 4*hh + 0..3
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
@@ -719,6 +543,12 @@ int fill(const stg_winattn_args* f, WinP& p, const char* who) {
     return 0;
 }
 
+// grid of the LT form: 8 XCD lanes x ceil(units / 8) x H workgroups (units = frame quads x windows)
+unsigned lt_grid(const WinP& p) {
+    const int64_t F = p.P / p.G, U = ((F + 3) / 4) * p.G;
+    return (unsigned)(((U + 7) / 8) * 8 * p.H);
+}
+
 }  // namespace
 
 extern "C" int stg_winattn_table(const float* table, const int64_t* index, const float* mask, float* bm, float* bmT, int L, int H,
@@ -740,11 +570,8 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
-    if (stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed) <= 1) {
-        if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    }
-    else hipLaunchKernelGGL(winattn_fwd_kernel, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -755,17 +582,18 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     WinP p = {};
     int rc = fill(f, p, "stg_winattn_bwd");
     if (rc) return rc;
-    const int occ = stg_opt_winattn_bwd_occ.load(std::memory_order_relaxed);      // 1 (default): the one-pass kernel; 2 / 3: the two-orientation kernel
-    STG_CHECK(f->O && f->lse && dO && dQ && dK && (dV || occ <= 1), -1, "stg_winattn_bwd: null pointer (dV == NULL -> dK receives dK + dV: round-2 kernel only)");
+    // LT (the additive table staged once per workgroup of four same-(window, head) frames): measured on one box, bit-identical, stage 2 (16 heads)
+    // 255.8 -> 242.5 us, stage 1 (8) 477 -> 461, stage 0 (4 heads) 905 -> 947: taken from 8 heads up
+    const bool lt = p.n == 49 && p.H >= 8;
+    STG_CHECK(f->O && f->lse && dO && dQ && dK, -1, "stg_winattn_bwd: null pointer (dV == NULL -> dK receives dK + dV)");
     STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_winattn_bwd: bad leading dims");
     STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    if (occ <= 1 && p.n == 49) hipLaunchKernelGGL(winattn_bwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    else if (occ <= 1) hipLaunchKernelGGL(winattn_bwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    else if (occ >= 3) hipLaunchKernelGGL(winattn_bwd_kernel<3>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(winattn_bwd_kernel<2>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (lt) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(lt_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (p.n == 49) hipLaunchKernelGGL((winattn_bwd1_kernel<49, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winattn_bwd1_kernel<0, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

@@ -352,6 +352,53 @@ def test_gemm_long_k_shapes(stg, gpu, M, N, K, epi):
     _close(out, ref, tol=2e-2 if K >= 2048 else 1e-2, what=f"gemm {epi} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,epi,kernel", [(98400, 576, 192, "b", "gemm_nt_8phm"), (98500, 1152, 384, "b", "gemm_nt_8phm"), (98304 + 77, 768, 192, "bap8", "gemm_nt_8phm"),
+                                              (98304 + 200, 768, 192, "d8", "gemm_nt_8phm"), (8300, 576, 192, "b", "gemm_nt_8ph_"), (8193, 1152, 384, "bap8", "gemm_nt_8ph_"), (8200, 192, 768, "b", "gemm_nt_8ph_"), (8200, 192, 576, "", "gemm_nt_8ph_"),
+                                              (8300, 384, 1152, "", "gemm_nt_8ph_"), (8200, 384, 1536, "b", "gemm_nt_8ph_"), (8200, 192, 192, "b", "gemm_nt_8ph_"),
+                                              (8211, 384, 384, "", "gemm_nt_8ph_"), (8448, 320, 192, "", "gemm_nt_8ph_"), (8192, 448, 320, "b", "gemm_nt_8ph_"),
+                                              (8250, 1344, 448, "bap8", "gemm_nt_8ph")])
+def test_gemm_nx_shapes(stg, gpu, M, N, K, epi, kernel):
+    """Round 6: the NX forms of the 8-phase kernels -- N % 64 == 0 (a last column tile of 64 / 128 / 192 valid columns, its W1 half skipped
+    when empty) and K % 64 == 0 (an odd k-tile count padded with a zero k-tile): Swin-L's widths (192 / 384 / 576 / 1152) and a few others,
+    row tails everywhere; against the fp32 product, and the dispatch must really have taken an 8-phase kernel."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = _bf(torch.randn(M, K, generator=g))
+    W = _bf(torch.randn(N, K, generator=g) * 0.05)
+    b = torch.randn(N, generator=g) if "b" in epi else None
+    z = A.float() @ W.float().t() + (b if b is not None else 0.)
+    kw, ref = {}, z
+    if "a" in epi:
+        kw.update(act=k.ACT_GELU, want_dact="u8")
+        ref = torch.nn.functional.gelu(z)
+    if "d8" in epi:
+        d8 = torch.randint(0, 256, (M, N), generator=g, dtype=torch.uint8)
+        kw["dact_src"] = d8.to(gpu)
+        ref = z * (d8.float() * 0.005 - 0.14)
+    # poison the allocator's free blocks: a column the kernel fails to write must not look right by accident
+    t = torch.full((M, N), float("nan"), dtype=BF16, device=gpu); del t
+    stg.configure(lib_gemm_nx=2)        # every legal NX shape (the default routes only the classes measured faster: N < 256, K >= 768)
+    try:
+        out = k.gemm_nt(A.to(gpu), W.to(gpu), None if b is None else b.to(gpu), **kw)
+    finally:
+        stg.configure(lib_gemm_nx=1)
+    assert k.LAST_GEMM_KERNEL.startswith(kernel), k.LAST_GEMM_KERNEL
+    if "a" in epi:
+        out, dact = out
+        assert float((dact.float().cpu() * 0.005 - 0.14 - _gelu_grad(z)).abs().max()) <= 1.5e-2
+    assert torch.isfinite(out.float()).all()
+    _close(out, ref, tol=1e-2, what=f"gemm nx {epi} {M}x{N}x{K}")
+    # the same call on the round-5 route (128 x 128 kernel): equal up to the bf16 rounding of the output
+    stg.configure(lib_gemm_nx=0)
+    try:
+        o0 = k.gemm_nt(A.to(gpu), W.to(gpu), None if b is None else b.to(gpu), **kw)
+        assert not k.LAST_GEMM_KERNEL.startswith("gemm_nt_8ph"), k.LAST_GEMM_KERNEL
+    finally:
+        stg.configure(lib_gemm_nx=1)
+    o0 = o0[0] if isinstance(o0, tuple) else o0
+    assert float((o0.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(out.float().abs().max())
+
+
 @pytest.mark.parametrize("F_,H,W,Cin,Cout,d", [(3, 14, 14, 64, 64, 1), (2, 28, 28, 256, 256, 3), (1, 7, 7, 128, 32, 1), (2, 14, 14, 256, 256, 18),
                                                (5, 56, 56, 64, 128, 6), (2, 28, 28, 32, 128, 1), (3, 14, 14, 16, 64, 2), (1, 14, 14, 8, 32, 1)])
 def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
@@ -610,7 +657,12 @@ def test_pair_launches_equal_two_single_launches(stg, gpu, C, J, S, M2, with_rs)
 
 @pytest.mark.parametrize("M,N,Kd,gelu8,kernel", [(31360, 1024, 4096, False, "gemm_nt_8ph_kernel"), (7840, 512, 2048, False, "gemm_nt_8ph_kernel"),
                                                  (62880, 1536, 512, False, "gemm_nt_8phm_kernel"), (125600, 2048, 512, True, "gemm_nt_8phm_kernel"),
-                                                 (125600, 2048, 512, "d8", "gemm_nt_8phm_kernel"), (62880, 2048, 512, "d8", "gemm_nt_8phm_kernel")])
+                                                 (125600, 2048, 512, "d8", "gemm_nt_8phm_kernel"), (62880, 2048, 512, "d8", "gemm_nt_8phm_kernel"),
+                                                 # round 6, the NX forms at partial-panel shapes: 3 tiles with a 64-column last tile + a zero k-tile; 5 tiles with a
+                                                 # 128-column last tile; GELU + byte derivative over K = 192; the one-tile kernel with 192 valid columns / 9 k-tiles
+                                                 (98464, 576, 192, False, "gemm_nt_8phm_kernel"), (98464, 1152, 384, False, "gemm_nt_8phm_kernel"),
+                                                 (98464, 768, 192, True, "gemm_nt_8phm_kernel"), (31520, 192, 576, False, "gemm_nt_8ph_kernel"),
+                                                 (31520, 384, 1152, False, "gemm_nt_8ph_kernel")])
 def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd, gelu8, kernel):
     """Regression test of a race found in round 4: the 8-phase kernel pre-read the next k-tile's A0 fragments one phase BEFORE the counted
     wait that retires their LDS-DMA (it relied on "issued a k-tile ago"); when a DMA was slow, one k-tile of some rows was computed from the
@@ -621,6 +673,17 @@ def test_gemm_8phase_launches_are_reproducible(stg, gpu, M, N, Kd, gelu8, kernel
     from stgcma import kernels as K
     from stgcma._lib import ACT_GELU
     torch.manual_seed(0)
+    nx = N % 256 != 0 or Kd % 128 != 0
+    if nx:
+        stg.configure(lib_gemm_nx=2)    # route every legal NX shape to the 8-phase kernels (the default takes only N < 256, K >= 768)
+    try:
+        _gemm_8phase_repro(gpu, M, N, Kd, gelu8, kernel, K, ACT_GELU)
+    finally:
+        if nx:
+            stg.configure(lib_gemm_nx=1)
+
+
+def _gemm_8phase_repro(gpu, M, N, Kd, gelu8, kernel, K, ACT_GELU):
     A = (torch.randn(M, Kd, device=gpu) * 0.5).to(torch.bfloat16)
     W = (torch.randn(N, Kd, device=gpu) * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device=gpu) * 0.1
