@@ -16,6 +16,7 @@
 // group) serves rows 0..15 and a second rows 16..31: the eight rows touched by a 32-lane half are consecutive, and the
 // 32-byte column chunks of a row are XOR-swizzled by the row so that they fall into eight different bank groups.
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/stgcma.h"
 
@@ -72,9 +73,23 @@ constexpr int WMAX = 16;
 struct WgMulti { Wg2 p[WMAX]; };
 
 // accumulators per lane: NT1 * 8 product tiles + 8 bias tiles (bias_on == 1 uses the first NT1), each f32x4
-template <int NT1>
-__global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMulti pm) {   // 48 / 64 wide: 160+ accumulator registers, one wave per SIMD
-    const Wg2 p = pm.p[blockIdx.z];
+// Round 6: the chunk loop rewritten around its instruction count.  Rounds 2-5 computed, per 16-byte piece and chunk, a 64-bit row x leading-dimension
+// product, a clamp, an exec-masked "row beyond the split" test and -- with a DropPath row scale -- a 64-bit division (~4 400 instructions per
+// 32-row chunk around 27-51 MFMAs: the kernel ran at 2.3-2.4 TB/s at 48 x 768 however the launch was split).  Now a lane's pieces have constant
+// 32-bit byte offsets from a wave-uniform chunk base, the LDS slots are constants, only the LAST chunk of a row split takes the clamped / zero-filled
+// path (wave-uniform branch), and the row scale (template flag RS) is fetched once per row and chunk by lane row & 31 -- 32-bit index arithmetic,
+// prefetched with the chunk -- and handed to the pieces' lanes by ds_bpermute.
+template <int NT1, bool RS>
+__global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMulti pm) {   // 48+ wide: 128+ accumulator registers, one wave per SIMD -- with TWO chunks in flight per wave (PF)
+    // The column groups of one row split share the narrow operand's rows (re-read once per group: +37 % of the bytes at 48 x 768, +56 % at
+    // 96 x 768).  blockIdx -> (cg, sp, problem) goes through a chunked XCD map (XCD x takes virtual ids [x T / 8, (x + 1) T / 8), cg fastest), so the
+    // groups of a split are consecutive workgroups of ONE XCD and the re-reads hit its L2.
+    const int T = gridDim.x * gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int v = L;
+    if ((T & 7) == 0) v = (L & 7) * (T >> 3) + (L >> 3);
+    const int cg = v % gridDim.x, sp = (v / gridDim.x) % gridDim.y, pz = v / (gridDim.x * gridDim.y);
+    const Wg2 p = pm.p[pz];
     constexpr int TA = 16 * NT1;
     constexpr int NACC = NT1 * NTB + NTB;
     constexpr int CHA = NT1 > 4 ? 8 : (NT1 == 3 ? 4 : NT1);        // A-tile row pitch in 32-byte chunks (a power of two)
@@ -84,7 +99,6 @@ __global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMult
     __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kg = lane >> 4;
-    const int cg = blockIdx.x, sp = blockIdx.y;
     const int b0 = cg * WNB;
     const int64_t mbeg = (int64_t)sp * p.rows_per_block;
     int64_t mend = mbeg + p.rows_per_block;
@@ -107,54 +121,96 @@ __global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMult
 
     const int na8 = (p.NA + 7) & ~7, nb8 = (p.NB + 7) & ~7;
     constexpr int PA = 2 * NT1;                                    // 16-byte pieces per A row
-    uint4 va[NT1], vb[8];
-    auto gload = [&](int64_t mb) {                                 // unconditional clamped loads
+    // piece i of a lane: B: row (lane >> 4) + 4 i, 16-byte column piece lane & 15;  A: id = lane + 64 i -> row id / PA, piece id % PA
+    int colB, rowA[NT1], colA[NT1];
+    uint32_t offB[8], offA[NT1];
+    int slotB[8], slotA[NT1];
+    {
+        int gn = b0 + (lane & 15) * 8;
+        colB = gn < nb8 ? gn : 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int id = lane + 64 * i;
-            const int row = id >> 4, pc = id & 15;
-            int64_t gm = mb + row;
-            gm = gm < mend ? gm : mend - 1;
-            int gn = b0 + pc * 8;
-            gn = gn < nb8 ? gn : 0;
-            vb[i] = *reinterpret_cast<const uint4*>(p.B + gm * p.ldb + gn);
+            const int row = (lane >> 4) + 4 * i, pc = lane & 15;
+            offB[i] = (uint32_t)(((int64_t)row * p.ldb + colB) * 2);
+            slotB[i] = chunk_slot<8>(row, pc >> 1) * 16 + (pc & 1) * 8;
         }
 #pragma unroll
         for (int i = 0; i < NT1; ++i) {
             const int id = lane + 64 * i;
             const int row = id / PA, pc = id % PA;
-            int64_t gm = mb + row;
+            rowA[i] = row;
+            colA[i] = pc * 8 < na8 ? pc * 8 : 0;
+            offA[i] = (uint32_t)(((int64_t)row * p.lda + colA[i]) * 2);
+            slotA[i] = chunk_slot<CHA>(row, pc >> 1) * 16 + (pc & 1) * 8;
+        }
+    }
+    const uint32_t rso = (uint32_t)p.rs_outer, rsi = (uint32_t)p.rs_inner;      // row-scale index arithmetic in 32 bits (host: M < 2^31)
+    // PF register sets of a chunk's pieces: with one wave per SIMD (NT1 > 2: 512 registers) two chunks are in flight per wave -- the kernel is a
+    // latency-bound stream (a chunk is 11-14 KB per wave and ~600 clocks of LDS + MFMA work), and a second resident workgroup does not fit
+    // (NT1 = 3 at 256 registers: 34 spilled)
+    constexpr int PF = NT1 > 2 ? 2 : 1;
+    uint4 va[PF][NT1], vb[PF][8];
+    float rsl[PF];                                                 // RS: the scale of row (lane & 31) of the chunk in flight
+#pragma unroll
+    for (int s_ = 0; s_ < PF; ++s_) rsl[s_] = 1.0f;
+    auto gload = [&](auto SET, int64_t mb) {
+        constexpr int st = decltype(SET)::value;
+        const char* gB = reinterpret_cast<const char*>(p.B + mb * p.ldb);
+        const char* gA = reinterpret_cast<const char*>(p.A + mb * p.lda);
+        if (mb + WK <= mend) {                                     // wave-uniform: a whole chunk
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vb[st][i] = *reinterpret_cast<const uint4*>(gB + offB[i]);
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) va[st][i] = *reinterpret_cast<const uint4*>(gA + offA[i]);
+        } else {                                                   // the split's last chunk: rows clamped here, zero-filled at commit
+            const int last = (int)(mend - 1 - mb);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int row = (lane >> 4) + 4 * i;
+                row = row < last ? row : last;
+                vb[st][i] = *reinterpret_cast<const uint4*>(gB + ((int64_t)row * p.ldb + colB) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) {
+                const int row = rowA[i] < last ? rowA[i] : last;
+                va[st][i] = *reinterpret_cast<const uint4*>(gA + ((int64_t)row * p.lda + colA[i]) * 2);
+            }
+        }
+        if (RS && p.row_scale) {                                   // (a launch mixes problems with and without a scale: block-uniform)
+            int64_t gm = mb + (lane & 31);
             gm = gm < mend ? gm : mend - 1;
-            int gn = pc * 8;
-            gn = gn < na8 ? gn : 0;
-            va[i] = *reinterpret_cast<const uint4*>(p.A + gm * p.lda + gn);
+            const uint32_t g32 = (uint32_t)gm;
+            rsl[st] = p.row_scale[(g32 / rso) * rsi + (g32 % rsi)];
         }
     };
-
     const int64_t nchunks = (mend - mbeg + WK - 1) / WK;
-    int64_t c = wave;
-    if (c < nchunks) gload(mbeg + c * WK);
-    for (; c < nchunks; c += 4) {
+    // one chunk: commit register set SET to LDS (scaled / zero-filled), refill the set with chunk c + 4 PF, multiply
+    auto chunk = [&](auto SET, int64_t c) {
+        constexpr int st = decltype(SET)::value;
         const int64_t mb = mbeg + c * WK;
+        const bool tail = mb + WK > mend;                          // wave-uniform
+        if (RS && p.row_scale) {
+            if (p.scale_on == 2) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int id = lane + 64 * i;
-            const int row = id >> 4, pc = id & 15;
-            const int64_t gm = mb + row;
-            if (gm >= mend) vb[i] = make_uint4(0, 0, 0, 0);
-            else if (p.row_scale && p.scale_on == 2) scale8(vb[i], p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)]);
-            *reinterpret_cast<uint4*>(sB + chunk_slot<8>(row, pc >> 1) * 16 + (pc & 1) * 8) = vb[i];
+                for (int i = 0; i < 8; ++i) scale8(vb[st][i], __shfl(rsl[st], (lane >> 4) + 4 * i, 64));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT1; ++i) scale8(va[st][i], __shfl(rsl[st], rowA[i], 64));
+            }
+        }
+        if (tail) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (mb + (lane >> 4) + 4 * i >= mend) vb[st][i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NT1; ++i)
+                if (mb + rowA[i] >= mend) va[st][i] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NT1; ++i) {
-            const int id = lane + 64 * i;
-            const int row = id / PA, pc = id % PA;
-            const int64_t gm = mb + row;
-            if (gm >= mend) va[i] = make_uint4(0, 0, 0, 0);
-            else if (p.row_scale && p.scale_on == 1) scale8(va[i], p.row_scale[(gm / p.rs_outer) * p.rs_inner + (gm % p.rs_inner)]);
-            *reinterpret_cast<uint4*>(sA + chunk_slot<CHA>(row, pc >> 1) * 16 + (pc & 1) * 8) = va[i];
-        }
-        if (c + 4 < nchunks) gload(mb + 4 * WK);
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sB + slotB[i]) = vb[st][i];
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) *reinterpret_cast<uint4*>(sA + slotA[i]) = va[st][i];
+        if (c + 4 * PF < nchunks) gload(SET, mb + 4 * PF * WK);
         lds_fence();
         bf16x8_t af[NT1];
 #pragma unroll
@@ -170,6 +226,15 @@ __global__ void __launch_bounds__(256, (NT1 > 2 ? 1 : 2)) wgrad_ws_kernel(WgMult
             if (bias_b) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf, accb[j], 0, 0, 0);
         }
         lds_fence();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, PF - 1>;
+    int64_t c = wave;
+    if (c < nchunks) gload(I0{}, mbeg + c * WK);
+    if (PF == 2 && c + 4 < nchunks) gload(I1{}, mbeg + (c + 4) * WK);
+    for (; c < nchunks; c += 4 * PF) {
+        chunk(I0{}, c);
+        if (PF == 2 && c + 4 < nchunks) chunk(I1{}, c + 4);
     }
 
     // fold the four waves' accumulators (3 -> 2 -> 1 -> 0), then wave 0 stores the block's partial tile lane-major
@@ -279,7 +344,7 @@ Plan plan_for(int64_t M, int N1, int N2, int64_t lddy, int64_t ldx, const void* 
     const int NA = y_narrow ? N1 : N2, NB = y_narrow ? N2 : N1;
     const bool aligned = (lddy % 8 == 0) && (ldx % 8 == 0) && (((uintptr_t)dY & 15) == 0) && (((uintptr_t)X & 15) == 0) &&
                          lddy >= ((N1 + 7) & ~7) && ldx >= ((N2 + 7) & ~7);
-    if (!aligned || NA > 96 || M < 4096) return pl;
+    if (!aligned || NA > 96 || M < 4096 || M >= (1ll << 31)) return pl;      // (the kernel's row-scale index arithmetic is 32-bit)
     pl.ok = true; pl.y_narrow = y_narrow;
     pl.nt1 = (NA + 15) / 16;                       // 1 .. 6 column tiles of the narrow operand
     pl.ncg = (NB + WNB - 1) / WNB;
@@ -350,12 +415,12 @@ void fill_problem(const Plan& pl, const void* dY, int64_t lddy, const void* X, i
 
 int launch_multi(const Plan& pl, const WgMulti& pm, const WrMulti& rm, int n, hipStream_t st) {
     const dim3 grid(pl.ncg, pl.S, n);
-    if (pl.nt1 == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(256), 0, st, pm);
-    else if (pl.nt1 == 2) hipLaunchKernelGGL(wgrad_ws_kernel<2>, grid, dim3(256), 0, st, pm);
-    else if (pl.nt1 == 3) hipLaunchKernelGGL(wgrad_ws_kernel<3>, grid, dim3(256), 0, st, pm);
-    else if (pl.nt1 == 4) hipLaunchKernelGGL(wgrad_ws_kernel<4>, grid, dim3(256), 0, st, pm);
-    else if (pl.nt1 == 5) hipLaunchKernelGGL(wgrad_ws_kernel<5>, grid, dim3(256), 0, st, pm);
-    else hipLaunchKernelGGL(wgrad_ws_kernel<6>, grid, dim3(256), 0, st, pm);
+    bool rs = false;                                      // any problem with a row scale -> the RS instantiation (a problem without one reads its dummy 1.0)
+    for (int i = 0; i < n; ++i) rs = rs || pm.p[i].row_scale != nullptr;
+#define STG_WG(N) case N: if (rs) hipLaunchKernelGGL((wgrad_ws_kernel<N, true>), grid, dim3(256), 0, st, pm); \
+                          else hipLaunchKernelGGL((wgrad_ws_kernel<N, false>), grid, dim3(256), 0, st, pm); break;
+    switch (pl.nt1) { STG_WG(1) STG_WG(2) STG_WG(3) STG_WG(4) STG_WG(5) default: STG_WG(6) }
+#undef STG_WG
     STG_LAUNCH_CHECK();
     const int per_cg = (pl.nt1 * NTB + NTB) * 256;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(per_cg / 64, pl.ncg, n), dim3(256), 0, st, rm);
