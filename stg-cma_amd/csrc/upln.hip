@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) upln_fwd_kernel(UpLn
         }
         float rs = 1.0f;
         if (p.row_scale) {                                  // DropPath: scales the branch (h W^T + b), not the residual
-            rs = p.row_scale[(rc / p.rs_outer) * p.rs_inner + (rc % p.rs_inner)];
+            rs = p.row_scale[((uint32_t)rc / (uint32_t)p.rs_outer) * (uint32_t)p.rs_inner + ((uint32_t)rc % (uint32_t)p.rs_inner)];     // 32-bit: the host checks M < 2^31 (a 64-bit division is ~120 instructions per row group)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float v[8];
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) ln_bwd_down_kernel(L
         }
         if (valid && half == 0) {
             float sc = 1.0f;
-            if (p.row_scale) sc = p.row_scale[(row / p.rs_outer) * p.rs_inner + (row % p.rs_inner)];
+            if (p.row_scale) sc = p.row_scale[((uint32_t)row / (uint32_t)p.rs_outer) * (uint32_t)p.rs_inner + ((uint32_t)row % (uint32_t)p.rs_inner)];   // 32-bit: the host checks M < 2^31
             bf16_t* hp = p.dh + row * p.lddh;
 #pragma unroll
             for (int q = 0; q < NJ / 2; ++q) {
@@ -556,7 +556,7 @@ static int up_ln_impl(const char* who, const void* h, int64_t ldh, const void* w
                       void* stream) {
     STG_CHECK(h && w && bias && res32 && x && gamma && beta && y, -1, "%s: null pointer", who);
     STG_CHECK(stg_up_ln_supported(C, K), -2, "%s: unsupported C=%d K=%d (C in {128,256,512}: K <= 64; C in {192,384,768}: K <= 96; K %% 8 == 0)", who, C, K);
-    STG_CHECK(M >= 0, -2, "%s: bad M", who);
+    STG_CHECK(M >= 0 && M < (1ll << 31), -2, "%s: bad M (row-scale indices are 32-bit)", who);
     STG_CHECK(ldh % 8 == 0 && ldh >= K && ldw % 8 == 0 && ldw >= K, -2, "%s: ldh / ldw must be multiples of 8 and >= K", who);
     STG_CHECK(ld32 % 4 == 0 && ld32 >= C && ldx % 4 == 0 && ldx >= C && ldy % 8 == 0 && ldy >= C, -2, "%s: bad ld32 / ldx / ldy", who);
     STG_CHECK(res16 == nullptr || (ld16 % 8 == 0 && ld16 >= C), -2, "%s: bad ld16", who);
@@ -619,7 +619,7 @@ static int ln_bwd_down_impl(const char* who, bool xh, const void* dy, int64_t ld
                             const void* wt2, const float* row_scale2, void* dh2, int64_t split_m, void* stream) {
     STG_CHECK(dy && x && rstd && dx && wt && dh && (xh || (gamma && mean)), -1, "%s: null pointer", who);
     STG_CHECK(stg_ln_bwd_down_supported(C, J), -2, "%s: unsupported C=%d J=%d (C in {128,256,512}: J in {16,32,64}; C in {192,384,768}: J in {48,96})", who, C, J);
-    STG_CHECK(M >= 0, -2, "%s: bad M", who);
+    STG_CHECK(M >= 0 && M < (1ll << 31), -2, "%s: bad M (row-scale indices are 32-bit)", who);
     STG_CHECK(lddy % 8 == 0 && lddy >= C && ldx % (xh ? 8 : 4) == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C, -2, "%s: bad lddy / ldx / lddx", who);
     STG_CHECK(add_to == nullptr || (ldadd % 8 == 0 && ldadd >= C), -2, "%s: bad ldadd", who);
     STG_CHECK(ldwt % 8 == 0 && ldwt >= C && lddh % 4 == 0 && lddh >= J, -2, "%s: bad ldwt / lddh", who);
