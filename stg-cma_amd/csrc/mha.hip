@@ -315,15 +315,11 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq_kernel(MP a) 
 // and met only other WAVES' work to fill the gaps (SQ counters: waves waiting 52-57 % of their cycles, matrix pipe busy 28-30 %,
 // profiles/r05_mha_sq_counters.txt).  Here a trip covers 64 keys: the two tiles' MFMA chains are independent, so tile B's score MFMAs execute while
 // tile A's softmax issues, the statistics are updated once per 64 keys, and there is one barrier per 64 keys.  Staged tiles are [64][D + 8].
-// WF (round 6, "whole frame": frames of at most 256 tokens -- ViT-B's 197 / 49): ALL the frame's key trips are staged up front (every load of the
-// block in flight at once, one barrier) and the trip loop runs without staging or barriers.  With the per-trip form a block of such a frame is a
-// chain of 4 exposed global round trips around ~0.5 us of arithmetic each (mha_dq2 at 8 x 197 x 197 x 96: 19.7 us per block for ~2 us of MFMA work).
-constexpr int WF_TRIPS = 4;
-template <int D, bool KV1, int NW, bool WF = false>
+template <int D, bool KV1, int NW>
 __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW, 64>;
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];                  // two buffers x NTILE x [64][DP]  (WF: one per trip)
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];                  // two buffers x NTILE x [64][DP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
@@ -345,28 +341,14 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
+    stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
+    __syncthreads();
     const int np = (a.nt + 1) >> 1;
-    if (WF) {
-        u32x4_t svw[WF_TRIPS - 1][SC::PER];
-        stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-#pragma unroll
-        for (int t = 1; t < WF_TRIPS; ++t)
-            if (t < np) stage_fetch<D, NTILE, NW, 64>(svw[t - 1], sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * t);
-        stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
-#pragma unroll
-        for (int t = 1; t < WF_TRIPS; ++t)
-            if (t < np) stage_commit<D, NTILE, NW, 64>(smem + t * NTILE * SC::TILE, svw[t - 1], lo, rw);
-        __syncthreads();
-        if (!live) return;                             // (after the block's only barrier)
-    } else {
-        stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-        stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
-        __syncthreads();
-    }
     for (int kp = 0; kp < np; ++kp) {
-        const bf16_t* sK = smem + (WF ? kp : (kp & 1)) * NTILE * SC::TILE;
+        const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (!WF && kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
         if (live) {
         f32x16_t sA = zero16(), sB = zero16();         // St[key][q] of keys 64 kp .. + 31 / + 32 .. + 63
 #pragma unroll
@@ -415,10 +397,8 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a
             o[dt] = MFMA32(tr_frag<DP>(sV + 32 * DP, dt, 1, hh, r), pB1, o[dt]);
         }
         }
-        if (!WF) {
-            if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
-            __syncthreads();
-        }
+        if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
     }
     {
         const float inv = 1.0f / l;
@@ -429,7 +409,7 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a
     }
 }
 
-template <int D, bool KV1, int NW, bool WF = false>
+template <int D, bool KV1, int NW>
 __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq2_kernel(MP a) {
     constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
     using SC = StageC<D, NTILE, NW, 64>;
@@ -466,28 +446,14 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq2_kernel(MP a)
     int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
     u32x4_t sv[SC::PER];
     stage_plan<D, NTILE, NW, 64>(tid, h, lo, sc_, rw);
+    stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
+    stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
+    __syncthreads();
     const int np = (a.nt + 1) >> 1;
-    if (WF) {                                          // see mha_fwd2_kernel
-        u32x4_t svw[WF_TRIPS - 1][SC::PER];
-        stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-#pragma unroll
-        for (int t = 1; t < WF_TRIPS; ++t)
-            if (t < np) stage_fetch<D, NTILE, NW, 64>(svw[t - 1], sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * t);
-        stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
-#pragma unroll
-        for (int t = 1; t < WF_TRIPS; ++t)
-            if (t < np) stage_commit<D, NTILE, NW, 64>(smem + t * NTILE * SC::TILE, svw[t - 1], lo, rw);
-        __syncthreads();
-        if (!live) return;
-    } else {
-        stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-        stage_commit<D, NTILE, NW, 64>(smem, sv, lo, rw);
-        __syncthreads();
-    }
     for (int kp = 0; kp < np; ++kp) {
-        const bf16_t* sK = smem + (WF ? kp : (kp & 1)) * NTILE * SC::TILE;
+        const bf16_t* sK = smem + (kp & 1) * NTILE * SC::TILE;
         const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (!WF && kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
+        if (kp + 1 < np) stage_fetch<D, NTILE, NW, 64>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 64 * (kp + 1));
         if (live) {
         f32x16_t scA = zero16(), dpA = zero16(), scB = zero16(), dpB = zero16();         // St[key][q], dPt[key][q] of the two key tiles
 #pragma unroll
@@ -520,10 +486,8 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq2_kernel(MP a)
             dq[dt] = MFMA32(tr_frag<DP>(sK + 32 * DP, dt, 1, hh, r), b1, dq[dt]);
         }
         }
-        if (!WF) {
-            if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
-            __syncthreads();
-        }
+        if (kp + 1 < np) stage_commit<D, NTILE, NW, 64>(smem + ((kp + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
+        __syncthreads();
     }
     {
         bf16_t* op = a.dQ + mrow(a, p, q) * a.lddqkv + h * D;
@@ -785,17 +749,9 @@ int launch_dkv(const dim3& grid, const MP& p, hipStream_t stream) {
     return 0;
 }
 
-// whole-frame form: frames of <= 256 tokens (WF_TRIPS trips of 64 keys), LDS = one [64][D + 8] tile set per trip
-inline bool wf_ok(const MP& p) { return stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2 && (p.nt + 1) / 2 <= WF_TRIPS && p.ws == 0; }
 template <int D, bool KV1, int NW>
 int launch_fwd2(const dim3& grid, const MP& p, hipStream_t stream) {
-    static std::atomic<uint64_t> done{0}, done_wf{0};
-    if (wf_ok(p)) {
-        const int lds = ((p.nt + 1) / 2) * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
-        STG_CHECK(stg_reserve_lds(mha_fwd2_kernel<D, KV1, NW, true>, WF_TRIPS * (KV1 ? 1 : 2) * 64 * (D + 8) * 2, done_wf), -101, "stg_mha_fwd: cannot reserve the whole-frame LDS");
-        hipLaunchKernelGGL((mha_fwd2_kernel<D, KV1, NW, true>), grid, dim3(NW * 64), lds, stream, p);
-        return 0;
-    }
+    static std::atomic<uint64_t> done{0};
     constexpr int lds = 2 * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
     STG_CHECK(stg_reserve_lds(mha_fwd2_kernel<D, KV1, NW>, lds, done), -101, "stg_mha_fwd: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((mha_fwd2_kernel<D, KV1, NW>), grid, dim3(NW * 64), lds, stream, p);
@@ -803,13 +759,7 @@ int launch_fwd2(const dim3& grid, const MP& p, hipStream_t stream) {
 }
 template <int D, bool KV1, int NW>
 int launch_dq2(const dim3& grid, const MP& p, hipStream_t stream) {
-    static std::atomic<uint64_t> done{0}, done_wf{0};
-    if (wf_ok(p)) {
-        const int lds = ((p.nt + 1) / 2) * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
-        STG_CHECK(stg_reserve_lds(mha_dq2_kernel<D, KV1, NW, true>, WF_TRIPS * (KV1 ? 1 : 2) * 64 * (D + 8) * 2, done_wf), -101, "stg_mha_bwd: cannot reserve the whole-frame LDS");
-        hipLaunchKernelGGL((mha_dq2_kernel<D, KV1, NW, true>), grid, dim3(NW * 64), lds, stream, p);
-        return 0;
-    }
+    static std::atomic<uint64_t> done{0};
     constexpr int lds = 2 * (KV1 ? 1 : 2) * 64 * (D + 8) * 2;
     STG_CHECK(stg_reserve_lds(mha_dq2_kernel<D, KV1, NW>, lds, done), -101, "stg_mha_bwd: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL((mha_dq2_kernel<D, KV1, NW>), grid, dim3(NW * 64), lds, stream, p);
