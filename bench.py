@@ -55,15 +55,18 @@ WORKLOADS = {
                        "fwd+bwd+Adam on 5.6M adapter/head params"),
     "swin_l": (3989.0, "Swin-L + STG-CMA ftmode=fusion, AVE shape, adapter ratios [.5,.25,.125,.0625] (AVE/run_swin_adapt_ave29.sh:52), "
                        "fwd+bwd+Adam on the adapter/head params"),
-    # backbone-only workloads (the AVS decoder / AVQA head are SURVEY 8f, not built): fwd + bwd from seeded upstream gradients on
-    # every output the reference's head consumes + Adam on the adapters; GFLOP figures are analytic approximations
+    # backbone-only workloads (kept from round 1, when the AVS decoder / AVQA head -- SURVEY 8f -- were not built yet; "avs" / "avqa" below are the
+    # full models): fwd + bwd from seeded upstream gradients on every output the reference's head consumes + Adam on the adapters; GFLOP figures
+    # are analytic approximations
     "avs_backbone": (843.0, "Swin-B + STG-CMA AVS BACKBONE only (AVS/run_adapt_avs.py:146-160: T=5, adapter ratios [.25,.25,.125,.125]), "
                             "multi-scale taps + audio feature, synthetic upstream gradients, no decoder"),
     "avqa_backbone": (4920.0, "Swin-L + STG-CMA AVQA BACKBONE only (AVQA/run_adapt_avqa.py:288-301: T=10, third negative-video stream "
                               "forward-only), synthetic upstream gradients, no QA head"),
-    "avs": (843.0, "Swin-B + STG-CMA AVS shape, FULL model (AVS/run_adapt_avs.py:146-160): backbone (T=5) + dense decoder (ASPP, TPAVI, "
-                   "FeatureFusion path, output convolutions), loss = BCE on the first frame of each clip (AVS/loss.py:7-26), fwd+bwd+Adam on "
-                   "adapters + avstask_*; the GFLOP figure counts the backbone only"),
+    # 843.0 (backbone) + 590.8 (decoder: FlopCounterMode over oracle/avs_decoder.py, fwd + bwd with weight gradients of avstask_*, TPAVI's affinity in
+    # the collapsed form the product computes -- 4 N C_i^2 instead of the reference's explicit 4 N^2 C_i, which would add 399 more; tools/avs_decoder_flops.py)
+    "avs": (1433.8, "Swin-B + STG-CMA AVS shape, FULL model (AVS/run_adapt_avs.py:146-160): backbone (T=5) + dense decoder (ASPP, TPAVI, "
+                    "FeatureFusion path, output convolutions), loss = BCE on the first frame of each clip (AVS/loss.py:7-26), fwd+bwd+Adam on "
+                    "adapters + avstask_*; GFLOP = backbone 843.0 + decoder 590.8 (TPAVI affinity counted collapsed)"),
     "avqa": (4920.0, "Swin-L + STG-CMA AVQA shape, FULL model (AVQA/run_adapt_avqa.py:288-301): backbone with the negative-video stream + "
                      "QA head (question LSTM, grounding, single-query attentions), loss = CE(qa) + 0.5 CE(match) "
                      "(traintest_adapt_avqa.py:173-179), fwd+bwd+Adam on adapters + avqatask_* (no fp8 path)"),

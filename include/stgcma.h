@@ -32,17 +32,19 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 218
+#define STG_VERSION 219
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
 
 int stg_version(void);
 const char* stg_last_error(void);
-/* Dispatch options for A/B measurements (tools/, tests): "gemm_epi" (0: generic epilogue), "gemm_ktail" (0: register-staged
- * kernel for K % 64 != 0, 1: LDS-DMA k-tail kernel for K > 64 only, 2 = default: for every K), "gemm_big" (0 off / 1 auto / 2 whenever legal), "gemm_8ph" (0 off / 1 auto / 2 every legal shape /
- * 3 long-K only), "gemm_8phm" (multi-tile 8-phase kernel: 0 off / 1 auto / n >= 2: at most n column tiles per workgroup, any K), "xattn" (0: frame-global cross-modal attention on the generic kernels), "gemm_dbg" (diagnostics build only).
- * Returns -2 for an unknown name.  The product never calls it. */
+/* Dispatch options for A/B measurements (tools/, tests) -- eight names since ABI 219: "gemm_8ph" (8-phase GEMM kernels: 0 off / 1 auto / 2 every legal
+ * shape / 3 long-K only), "gemm_8phm" (their multi-tile form: 0 off / 1 auto / n >= 2: at most n column tiles per workgroup, any K), "gemm_nx" (their
+ * N % 64 == 0 / K % 64 == 0 forms: 0 off / 1 the classes measured faster / 2 every legal shape), "gemm_d8m" (fc2 dgrad's byte-derivative epilogue on
+ * them: 0 / 1 K <= 512 / 2 K <= 1024), "xattn" (0: frame-global cross-modal attention on the generic kernels), "wgrad_plan" (row splits of the
+ * workspace weight-gradient kernels: 0 round-1 rule / 1 / 2 per-launch chooser), "upln_cap" (workgroups of the wide join kernels), "gemm_dbg"
+ * (diagnostics build only).  Returns -2 for an unknown name.  The product never calls it. */
 int stg_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -108,7 +110,7 @@ typedef struct {
      * stage 2) fill the chip only together.  split_m % 128 == 0; bf16 operands, no convolution / batch; the 128 x 128 LDS-DMA kernels. */
     int64_t split_m; const void* W2; const float* bias2;
 } stg_gemm_args;
-enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
+enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2 /* retired in ABI 219: never reported */, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
        STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8 };
 int stg_gemm_nt(stg_gemm_args* args, void* stream);
 

@@ -53,9 +53,8 @@ SPEC = {
     "fp8":         ("STG_FP8", _b, False, [], "frozen backbone Linears on block-scaled e4m3 (opt-in; misses the 1e-2 logit bound, DESIGN section 8)"),
 }
 # options of the C library (stg_set_option): environment variable -> option name
-LIB_SPEC = {"STG_GEMM_EPI": "gemm_epi", "STG_GEMM_KTAIL": "gemm_ktail", "STG_GEMM_BIG": "gemm_big", "STG_GEMM_NX": "gemm_nx", "STG_GEMM_8PH": "gemm_8ph",
-            "STG_GEMM_8PHM": "gemm_8phm", "STG_GEMM_DBG": "gemm_dbg", "STG_XATTN": "xattn", "STG_WINATTN_BWD_OCC": "winattn_bwd_occ",
-            "STG_TATTN_KERNELS": "tattn", "STG_MHA_NW": "mha_nw", "STG_GEMM_D8M": "gemm_d8m", "STG_MHA_KT": "mha_kt", "STG_MHA_DKV1": "mha_dkv1", "STG_WGRAD_PLAN": "wgrad_plan", "STG_UPLN_CAP": "upln_cap", "STG_LN_FIT": "ln_fit"}
+LIB_SPEC = {"STG_GEMM_8PH": "gemm_8ph", "STG_GEMM_8PHM": "gemm_8phm", "STG_GEMM_NX": "gemm_nx", "STG_GEMM_D8M": "gemm_d8m", "STG_GEMM_DBG": "gemm_dbg",
+            "STG_XATTN": "xattn", "STG_WGRAD_PLAN": "wgrad_plan", "STG_UPLN_CAP": "upln_cap"}
 
 _values = {k: v[2] for k, v in SPEC.items()}
 _lib_values = {}

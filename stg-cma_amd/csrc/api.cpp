@@ -18,26 +18,17 @@ extern "C" int stg_version(void) { return STG_VERSION; }
 extern "C" const char* stg_last_error(void) { return g_err; }
 
 // ---- dispatch options (declared in common.h)
-std::atomic<int> stg_opt_gemm_epi{1}, stg_opt_gemm_ktail{2}, stg_opt_gemm_big{1}, stg_opt_gemm_8ph{1}, stg_opt_gemm_8phm{1}, stg_opt_gemm_dbg{0}, stg_opt_xattn{1}, stg_opt_winattn_bwd_occ{1}, stg_opt_tattn{1}, stg_opt_mha_nw{0}, stg_opt_gemm_d8m{2}, stg_opt_mha_kt{2}, stg_opt_mha_dkv1{0}, stg_opt_wgrad_plan{2}, stg_opt_upln_cap{256}, stg_opt_ln_fit{1}, stg_opt_gemm_nx{1};
+std::atomic<int> stg_opt_gemm_8ph{1}, stg_opt_gemm_8phm{1}, stg_opt_gemm_nx{1}, stg_opt_gemm_d8m{2}, stg_opt_gemm_dbg{0}, stg_opt_xattn{1}, stg_opt_wgrad_plan{2}, stg_opt_upln_cap{256};
 
 extern "C" int stg_set_option(const char* name, int value) {
     if (name == nullptr) { stg_set_error("stg_set_option: null name"); return -1; }
-    if (!strcmp(name, "gemm_epi")) stg_opt_gemm_epi = value;
-    else if (!strcmp(name, "gemm_ktail")) stg_opt_gemm_ktail = value;
-    else if (!strcmp(name, "gemm_big")) stg_opt_gemm_big = value;
-    else if (!strcmp(name, "gemm_nx")) stg_opt_gemm_nx = value;
-    else if (!strcmp(name, "gemm_8ph")) stg_opt_gemm_8ph = value;
+    if (!strcmp(name, "gemm_8ph")) stg_opt_gemm_8ph = value;
     else if (!strcmp(name, "gemm_8phm")) stg_opt_gemm_8phm = value;
+    else if (!strcmp(name, "gemm_nx")) stg_opt_gemm_nx = value;
+    else if (!strcmp(name, "gemm_d8m")) stg_opt_gemm_d8m = value;
     else if (!strcmp(name, "gemm_dbg")) stg_opt_gemm_dbg = value;     // read by the diagnostics build only
     else if (!strcmp(name, "xattn")) stg_opt_xattn = value;
-    else if (!strcmp(name, "winattn_bwd_occ")) stg_opt_winattn_bwd_occ = value;
-    else if (!strcmp(name, "tattn")) stg_opt_tattn = value;
-    else if (!strcmp(name, "mha_nw")) stg_opt_mha_nw = value;
-    else if (!strcmp(name, "gemm_d8m")) stg_opt_gemm_d8m = value;
-    else if (!strcmp(name, "mha_kt")) stg_opt_mha_kt = value;
-    else if (!strcmp(name, "mha_dkv1")) stg_opt_mha_dkv1 = value;
     else if (!strcmp(name, "wgrad_plan")) stg_opt_wgrad_plan = value;
-    else if (!strcmp(name, "ln_fit")) stg_opt_ln_fit = value;
     else if (!strcmp(name, "upln_cap")) stg_opt_upln_cap = value < 2 ? 2 : value;
     else { stg_set_error("stg_set_option: unknown option '%s'", name); return -2; }
     return 0;

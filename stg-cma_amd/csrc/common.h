@@ -175,24 +175,17 @@ void stg_set_error(const char* fmt, ...);
 
 // Dispatch options (A/B knobs of tools/ and of the tests): process-wide integers defined in api.cpp and written only by
 // stg_set_option -- nothing on a launch path reads the environment.
-extern std::atomic<int> stg_opt_gemm_epi;     // 0: every GEMM epilogue option a run-time test (EV_GENERIC)
-extern std::atomic<int> stg_opt_gemm_ktail;   // K % 64 != 0 shapes: 0 register-staged kernel, 1 LDS-DMA k-tail kernel for K > 64, 2 (default) for every K
-extern std::atomic<int> stg_opt_gemm_nx;      // 8-phase kernels for N % 64 == 0 / K % 64 == 0 shapes (NX forms, round 6): 0 off, 1 (default) the classes measured faster (N < 256, K >= 768), 2 every legal shape
-extern std::atomic<int> stg_opt_gemm_big;     // 256 x 256 simple-loop kernel: 0 off, 1 auto, 2 whenever legal
-extern std::atomic<int> stg_opt_gemm_8phm;    // multi-tile 8-phase kernel: 0 off, 1 auto (default), n >= 2: at most n column tiles per workgroup
+// EIGHT names since round 6 (sixteen knobs were sixteen configurations the suite ran a handful of times): the retired ones selected kernels
+// that no longer ship (round-1 window / temporal attention, one-tile mha forward / dQ, the simple-loop 256 x 256 GEMM) or A/B arms that were
+// settled (gemm_epi, gemm_ktail, ln_fit, mha_nw).
 extern std::atomic<int> stg_opt_gemm_8ph;     // 8-phase kernel: 0 off, 1 auto (default), 2 every legal shape, 3 long-K shapes only
+extern std::atomic<int> stg_opt_gemm_8phm;    // multi-tile 8-phase kernel: 0 off, 1 auto (default), n >= 2: at most n column tiles per workgroup
+extern std::atomic<int> stg_opt_gemm_nx;      // 8-phase kernels for N % 64 == 0 / K % 64 == 0 shapes (NX forms, round 6): 0 off, 1 (default) the classes measured faster (N < 256, K >= 768), 2 every legal shape
+extern std::atomic<int> stg_opt_gemm_d8m;     // the byte-derivative-source epilogue (fc2 dgrad) on the 8-phase kernels: 0 off, 1 K <= 512, 2 (default) K <= 1024
 extern std::atomic<int> stg_opt_gemm_dbg;     // diagnostics build only (-DSTG_GEMM_DIAG)
-extern std::atomic<int> stg_opt_winattn_bwd_occ;   // window attention: 1 (default) the coalesced round-2 kernels (winattn_fwd1 / winattn_bwd1); 2 / 3: the round-1
-                                                   // kernels, backward held to 2 / 3 waves per SIMD
-extern std::atomic<int> stg_opt_tattn;        // temporal attention (head dim 32): 1 the coalesced round-2 kernels, 0 the round-1 kernels
-extern std::atomic<int> stg_opt_gemm_d8m;     // 1 (default): the byte-derivative-source epilogue (fc2 dgrad, K <= 512, N >= 1024) on the multi-tile 8-phase kernel; 0: 128 x 128 kernel
-extern std::atomic<int> stg_opt_mha_dkv1;     // 1: keep the dK / dV kernel at one query tile per trip (A/B knob)
-extern std::atomic<int> stg_opt_ln_fit;       // 0: LayerNorm forward on the generic kernel for every width (A/B knob)
-extern std::atomic<int> stg_opt_upln_cap;     // workgroups per launch of the wide (NW >= 8) join kernels of upln.hip: 256 = one round (default), 2048 = rounds 1-5a
-extern std::atomic<int> stg_opt_wgrad_plan;   // wgrad_ws row splits: 0 = the round-1 rule (512 / column groups); 1 = per-launch chooser for nt1 > 2 only; 2 = for every width (default)
-extern std::atomic<int> stg_opt_mha_kt;       // mha.hip forward / dQ: key tiles per trip, 2 (default) or 1 (the round-4 structure)
-extern std::atomic<int> stg_opt_mha_nw;       // mha.hip: waves per block, 0 = by sequence length (default), 4 / 8 forced (tools)
 extern std::atomic<int> stg_opt_xattn;        // 0: frame-global cross-modal attention on the generic attention kernels
+extern std::atomic<int> stg_opt_wgrad_plan;   // wgrad_ws row splits: 0 = the round-1 rule (512 / column groups); 1 = per-launch chooser for nt1 > 2 only; 2 = for every width (default)
+extern std::atomic<int> stg_opt_upln_cap;     // workgroups per launch of the wide (NW >= 8) join kernels of upln.hip: 256 = one round (default), 2048 = rounds 1-5a
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE setting: `done` (one static per kernel instantiation) remembers the
 // devices that have it, so a model on cuda:1 (nn.DataParallel replicas, one process driving several GPUs) gets it too.

@@ -609,115 +609,17 @@ __global__ void __launch_bounds__(256, NST == 1 ? 4 : 2) gemm_nt_glds_kernel(Gem
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large-tile variant for the long-K shapes (K % 64 == 0, K >= 1024, N a multiple of 256): block tile 256 x 256 x 64, 512 threads =
-// 2 (M) x 4 (N) waves of 128 x 64, LDS double-buffered (2 x 64 KiB, one workgroup per CU), tile k+1's DMA in flight
-// during tile k's 64 MFMAs per wave, one barrier per k-tile.
-// Half the L2->LDS bytes and half the LDS-DMA instructions per FLOP of the 128 x 128 kernel.  Both main loops top out at
-// 1.1-1.2 PFLOP/s on random data (the chip holds ~1.9-2.0 GHz under MFMA load); with one workgroup per CU this kernel's
-// epilogue is not overlapped by a neighbour, so it only wins where the epilogue is a small share of the tile.
+// Block tile of the 8-phase kernels below.  (The simple-loop 256 x 256 kernel of round 1, gemm_nt_big_kernel -- one barrier per k-tile, a vmcnt(0) in
+// front of it -- was their bit-identical predecessor and A/B arm until round 6.)
 constexpr int GBM = 256, GBN = 256;
 
 // 16 bytes of zeros for the NX forms of the 8-phase kernels below (a zero-filled k-tile: every lane's LDS-DMA reads these)
 __device__ __attribute__((aligned(16))) const uint32_t gemm_zero16[4] = {0u, 0u, 0u, 0u};
 
-__global__ void __launch_bounds__(512, 1) gemm_nt_big_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem_big[];          // 2 x (GBM + GBN) x BK bf16 = 128 KiB
-    bf16_t* smem = smem_big;
-    const int nblk = p.nbm * p.nbn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / p.nbn, bn = bid % p.nbn;
-    const int64_t m0 = (int64_t)bm * GBM;
-    const int n0 = bn * GBN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int lrow = lane & 15, lk = lane >> 4;
-
-    // DMA pieces: LDS chunk q = (wave*4 + j)*64 + lane -> row q>>3 (0..255), position q&7 holds source chunk (q&7)^(row&7)
-    const bf16_t* pa[4];
-    const bf16_t* pw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = (wave * 4 + j) * 64 + lane;
-        const int row = q >> 3, c = (q & 7) ^ (row & 7);
-        int64_t gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;
-        int gn = n0 + row;
-        gn = gn < p.N ? gn : p.N - 1;
-        pa[j] = p.A + gm * p.lda + c * 8;
-        pw[j] = p.W + (int64_t)gn * p.ldw + c * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        bf16_t* sA = smem + buf * (GBM + GBN) * BK;
-        bf16_t* sW = sA + GBM * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sA + (wave * 4 + j) * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[j] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sW + (wave * 4 + j) * 512), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[4][8];   // [n tile][m tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const bf16_t* sA = smem + cur * (GBM + GBN) * BK;
-        const bf16_t* sW = sA + GBM * BK;
-        if (!DIAG_ON(p, 2))
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8_t af[8], wf[4];
-            const int c = 4 * s + lk;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ar = wm * 128 + i * 16 + lrow;
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + ar * BK + swz(ar, c) * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int wr = wn * 64 + i * 16 + lrow;
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(sW + wr * BK + swz(wr, c) * 8);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
-        __syncthreads();      // (drains vmcnt: tile kt+1 has landed) and every wave is done reading tile kt
-    }
-    // epilogue: the wave's 128 x 64 tile as two 64 x 64 halves through its private 8 KiB staging region
-    float* stg = reinterpret_cast<float*>(smem) + wave * 2048;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        AccTile t;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) t.v[ni][mi] = acc[ni][half * 4 + mi];
-        if (half) lds_wave_sync();
-        gemm_epilogue_dispatch(p, t, m0 + wm * 128 + half * 64, n0 + wn * 64, 0, 0, lane, stg);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // 8-phase variant of the 256 x 256 x 64 kernel (K % 64 == 0, N % 256 == 0, row-layout epilogue only).
-// Same block tile and the same MFMA / k order as gemm_nt_big_kernel (results are bit-identical), different pipeline: the
-// simple loop above stalls every k-tile on the vmcnt(0) in front of its barrier while the next tile's DMA is in flight and
+// Same block tile and the same MFMA / k order as the removed simple-loop kernel (results were bit-identical), different pipeline: the
+// simple loop stalled every k-tile on the vmcnt(0) in front of its barrier while the next tile's DMA is in flight and
 // leaves the MFMA pipe idle while fragments are read.  Here
 //   * a k-tile is staged as FOUR 16 KiB half-tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255) into 2 x 4 LDS slots, one
 //     half-tile per phase, two half-tiles always in flight across the barriers (counted vmcnt, raw s_barrier);
@@ -1502,7 +1404,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tn_fast_kernel(WgradFast p) {
     }
 }
 
-std::atomic<uint64_t> lds_8ph_done[2], lds_big_done{0}, lds_8phm_done[8];
+std::atomic<uint64_t> lds_8ph_done[2], lds_8phm_done[8];
 
 }  // namespace
 
@@ -1592,7 +1494,6 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
             else if (!p.c_f32 && !a->act && !a->dact_src && r1b && !a->res2) p.epi_variant = EV_R16;
             else if (p.c_f32 && !a->act && !a->dact_src && r1b && r2q) p.epi_variant = EV_BRQ;
         }
-        if (stg_opt_gemm_epi.load(std::memory_order_relaxed) == 0) p.epi_variant = EV_GENERIC;   // A/B knob: every option a run-time test
         if (d8 && (a->dact || a->dact_src)) {              // the 8-bit derivative exists in its dedicated variants only
             const int v0 = p.epi_variant;
             const bool out8 = a->dact && !a->dact_src && (a->alpha == 1.0f && !a->row_scale && !p.c_f32 && !a->res1 && !a->res2) && a->act != STG_ACT_NONE;
@@ -1614,11 +1515,8 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         STG_LAUNCH_CHECK();
         return 0;
     }
-    const int ktail_on = stg_opt_gemm_ktail.load(std::memory_order_relaxed);
-    const int big_mode = stg_opt_gemm_big.load(std::memory_order_relaxed);
-    const bool big_ok = !split && !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN;
-    // auto: only where the epilogue is a small share (K >= 1024): measured +8 % at 125440 x 512 x 2048, -10 % on K = 512 GELU shapes
-    const bool big = big_ok && (big_mode == 2 || (big_mode == 1 && a->N % GBN == 0 && a->K >= 1024));
+    // the long-K shapes (K >= 1024, whole 256-column tiles): the epilogue is a small share of a tile
+    const bool big = !split && !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN && a->N % GBN == 0 && a->K >= 1024;
     const int ph8_mode = stg_opt_gemm_8ph.load(std::memory_order_relaxed);   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
     // round 6, the NX forms (template flag of both 8-phase kernels): N % 64 == 0 with N >= 192 and K % 64 == 0 with K >= 192 -- Swin-L's widths
     // (C = 192 / 384: qkv N = 576 / 1152, K = 192 / 576, the N = 192 / 384 projections) kept 45-65 ms of its step on the 128 x 128 kernel
@@ -1704,13 +1602,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
         STG_LAUNCH_CHECK();
         return 0;
     }
-    if (big) {
-        STG_CHECK(stg_reserve_lds(gemm_nt_big_kernel, 2 * (GBM + GBN) * BK * 2, lds_big_done), -101, "stg_gemm_nt: cannot reserve 128 KiB of LDS");
-        const int64_t gbm = (a->M + GBM - 1) / GBM, gbn = (a->N + GBN - 1) / GBN;
-        p.nbm = (int)gbm; p.nbn = (int)gbn;
-        a->kernel_chosen = STG_GEMM_KERNEL_BIG;
-        hipLaunchKernelGGL(gemm_nt_big_kernel, dim3((unsigned)(gbm * gbn)), dim3(512), 2 * (GBM + GBN) * BK * 2, (hipStream_t)stream, p);
-    } else if (p.batch > 1) {
+    if (p.batch > 1) {
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS_BATCH;
         hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, true>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch), dim3(256), 0, (hipStream_t)stream, p);
     } else if (conv) {
@@ -1719,7 +1611,7 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     } else if (a->K % BK == 0) {
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS;
         hipLaunchKernelGGL(gemm_nt_glds_kernel<1>, dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
-    } else if ((split || (ktail_on && (a->K > BK || ktail_on >= 2))) && a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K = 96 ...: LDS-DMA kernel with a zero-filled k tail (option gemm_ktail = 2: K < 64 too)
+    } else if (a->conv_zero && ((uintptr_t)a->conv_zero & 15) == 0) {  // K % 64 != 0 (K = 96, 48, 16 ...): LDS-DMA kernel with a zero-filled k tail
         a->kernel_chosen = STG_GEMM_KERNEL_GLDS_KTAIL;
         hipLaunchKernelGGL((gemm_nt_glds_kernel<1, false, false, true>), dim3((unsigned)(nbm * nbn)), dim3(256), 0, (hipStream_t)stream, p);
     } else {

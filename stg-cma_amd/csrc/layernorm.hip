@@ -338,7 +338,7 @@ int launch_ln_fit(bool bwd, const LnParams& p, hipStream_t st) {
 
 int dispatch_ln(bool bwd, const LnParams& p, hipStream_t st) {
     const int nch = p.C / 8;
-    if (!(bwd && p.dgamma) && stg_opt_ln_fit.load(std::memory_order_relaxed) != 0) {   // (the fitted backward: frozen LayerNorms only)
+    if (!(bwd && p.dgamma)) {   // (the fitted backward: frozen LayerNorms only)
         // the widths of the four backbones: C = 8 * LPR * NC exactly
         switch (nch) {
             case 16: return launch_ln_fit<8, 2>(bwd, p, st);       // 128

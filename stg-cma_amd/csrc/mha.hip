@@ -145,173 +145,9 @@ __device__ __forceinline__ void stage_commit(bf16_t* s, const U4Arr<StageC<D, NT
         if (row[i] >= 0) *reinterpret_cast<u32x4_t*>(s + lds_off[i]) = v[i];
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-// KV1: K and V are the same tensor (one staged tile serves the score MFMA and, read transposed, the P.V MFMA)
-template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd_kernel(MP a) {
-    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
-    using SC = StageC<D, NTILE, NW>;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];      // two buffers
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
-    const int q0 = 32 * (qb * NW + wave);
-    const bool live = q0 < a.n;
-    const int q = q0 + r;
-    const int qc = q < a.n ? q : a.n - 1;
-    bf16x8_t qf[KS];
-    {
-        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) qf[s] = ld_frag(qp + 16 * s);
-    }
-    f32x16_t o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
-    float m = NEG_BIG, l = 0.f;
-
-    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
-    u32x4_t sv[SC::PER];
-    stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-    stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
-    __syncthreads();
-    for (int kt = 0; kt < a.nt; ++kt) {
-        const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
-        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 32 * (kt + 1));
-        if (live) {                                    // wave-uniform: a wave whose query tile lies past the frame only stages and synchronises
-        f32x16_t sc = zero16();                        // St[key][q]
-#pragma unroll
-        for (int s = 0; s < KS; ++s) sc = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sc);
-        float x[16];
-        float mx = m;
-        const int kbase = 32 * kt;
-        const bool tail = kbase + 32 > a.n;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            x[reg] = sc[reg] * a.scale2;
-            if (tail && kbase + ACC_ROW(reg, hh) >= a.n) x[reg] = NEG_BIG;
-            mx = fmaxf(mx, x[reg]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float alpha = __builtin_amdgcn_exp2f(m - mx);
-        m = mx;
-        float ls = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
-            ls += x[reg];
-        }
-        ls += __shfl_xor(ls, 32, 64);
-        l = l * alpha + ls;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // rescale only when some query's maximum moved
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) o[dt][reg] *= alpha;
-        }
-        const bf16x8_t p0 = pack8(x), p1 = pack8(x + 8);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 0, hh, r), p0, o[dt]);
-            o[dt] = MFMA32(tr_frag<DP>(sV, dt, 1, hh, r), p1, o[dt]);
-        }
-        }
-        // the other buffer was last read in trip kt - 1, and every wave has passed that trip's barrier
-        if (kt + 1 < a.nt) stage_commit<D, NTILE, NW>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
-        __syncthreads();
-    }
-    {
-        const float inv = 1.0f / l;
-        bf16_t* op = a.O + mrow(a, p, q) * a.ldo + h * D;                  // 16-byte stores (store_tile32: every lane takes part)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, o[dt], inv, hh, q < a.n);
-        if (q < a.n && a.lse && hh == 0) a.lse[((int64_t)p * a.H + h) * a.n + q] = m + __log2f(l);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <int D, bool KV1, int NW>
-__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dq_kernel(MP a) {
-    constexpr int KS = D / 16, DT = D / 32, DP = D + 8, NTILE = KV1 ? 1 : 2;
-    using SC = StageC<D, NTILE, NW>;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * NTILE * 32 * DP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, p = pair_select(a, blockIdx.z);
-    const int q = 32 * (qb * NW + wave) + r;
-    const bool live = 32 * (qb * NW + wave) < a.n;
-    const int qc = q < a.n ? q : a.n - 1;
-    bf16x8_t qf[KS], dof[KS];
-    float delta = 0.f;
-    {
-        const bf16_t* qp = a.Q + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
-        const bf16_t* dp = a.dO + mrow(a, p, qc) * a.lddo + h * D + 8 * hh;
-        const bf16_t* op = a.O + mrow(a, p, qc) * a.ldo + h * D + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            qf[s] = ld_frag(qp + 16 * s);
-            dof[s] = ld_frag(dp + 16 * s);
-            const bf16x8_t of = ld_frag(op + 16 * s);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)dof[s][j]) * bf2f((bf16_t)of[j]);
-        }
-    }
-    delta += __shfl_xor(delta, 32, 64);
-    const int64_t si = ((int64_t)p * a.H + h) * a.n + qc;
-    const float lse = a.lse[si];
-    if (q < a.n && hh == 0) a.delta[si] = delta;
-    f32x16_t dq[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
-
-    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
-    u32x4_t sv[SC::PER];
-    stage_plan<D, NTILE, NW>(tid, h, lo, sc_, rw);
-    stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 0);
-    stage_commit<D, NTILE, NW>(smem, sv, lo, rw);
-    __syncthreads();
-    for (int kt = 0; kt < a.nt; ++kt) {
-        const bf16_t* sK = smem + (kt & 1) * NTILE * SC::TILE;
-        const bf16_t* sV = KV1 ? sK : sK + SC::TILE;
-        if (kt + 1 < a.nt) stage_fetch<D, NTILE, NW>(sv, sc_, rw, a.K, a.ld, a.V, a.ld, a, p, a.n, 32 * (kt + 1));
-        if (live) {
-        f32x16_t sc = zero16(), dp = zero16();         // St[key][q], dPt[key][q]
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8_t kf = nat_frag<DP>(sK, r, hh, s);
-            sc = MFMA32(kf, qf[s], sc);
-            dp = MFMA32(KV1 ? kf : nat_frag<DP>(sV, r, hh, s), dof[s], dp);
-        }
-        float ds[16];
-        const int kbase = 32 * kt;
-        const bool tail = kbase + 32 > a.n;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            float pr = __builtin_amdgcn_exp2f(sc[reg] * a.scale2 - lse);
-            if (tail && kbase + ACC_ROW(reg, hh) >= a.n) pr = 0.f;
-            ds[reg] = pr * (dp[reg] - delta);
-        }
-        const bf16x8_t d0 = pack8(ds), d1 = pack8(ds + 8);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 0, hh, r), d0, dq[dt]);
-            dq[dt] = MFMA32(tr_frag<DP>(sK, dt, 1, hh, r), d1, dq[dt]);
-        }
-        }
-        if (kt + 1 < a.nt) stage_commit<D, NTILE, NW>(smem + ((kt + 1) & 1) * NTILE * SC::TILE, sv, lo, rw);
-        __syncthreads();
-    }
-    {
-        bf16_t* op = a.dQ + mrow(a, p, q) * a.lddqkv + h * D;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, dq[dt], a.scale, hh, q < a.n);
-    }
-}
-
+// KV1 (every kernel below): K and V are the same tensor (one staged tile serves the score MFMA and, read transposed, the P.V MFMA)
 // ------------------------------------------------------------------------------------------------ forward / dQ, TWO key tiles per trip (round 5)
-// The one-tile kernels above run a tile's phases one after the other inside a wave -- score MFMAs, wait, softmax VALU, transposed reads, P.V MFMAs --
+// The round-4 one-tile kernels (removed in round 6; the one-tile dK / dV kernel remains for the register-limited combinations) ran a tile's phases one after the other inside a wave -- score MFMAs, wait, softmax VALU, transposed reads, P.V MFMAs --
 // and met only other WAVES' work to fill the gaps (SQ counters: waves waiting 52-57 % of their cycles, matrix pipe busy 28-30 %,
 // profiles/r05_mha_sq_counters.txt).  Here a trip covers 64 keys: the two tiles' MFMA chains are independent, so tile B's score MFMAs execute while
 // tile A's softmax issues, the statistics are updated once per 64 keys, and there is one barrier per 64 keys.  Staged tiles are [64][D + 8].
@@ -777,12 +613,10 @@ int launch_dkv2(const dim3& grid, const MP& p, hipStream_t stream) {
 
 // waves per block.  Backward: 8 where a frame has more than 4 query tiles (one staging of a tile then serves 256 rows; ViT-B's 197 tokens take ONE
 // block per (frame, head)): measured -11 % at 3136 x 3136 x 96 (5589 -> 4971 us), -9 % at 8 x 197 x 197 x 96 (532 -> 485 us).  Forward: 4 -- with 8 it
-// measured +5 % on both shapes (its trip is shorter, the barrier among 8 waves weighs more).  Option mha_nw (tools) forces either.
+// measured +5 % on both shapes (its trip is shorter, the barrier among 8 waves weighs more).
 // Round 5b: 2 where a problem has at most two query tiles and K == V (the window-level cross-modal pairs: 49 tokens) -- with 4 waves per block half of
-// every block idled and a CU held 4 live waves; option mha_nw = 4 restores that.
+// every block idled and a CU held 4 live waves.
 int pick_nw(int nt, bool bwd, bool kv1 = false) {
-    const int o = stg_opt_mha_nw.load(std::memory_order_relaxed);
-    if (o == 4 || o == 8) return o;
     if (kv1 && nt <= 2) return 2;
     return bwd && nt > 4 ? 8 : 4;
 }
@@ -833,8 +667,7 @@ static int mha_fwd_impl(const stg_mha_args* f, const stg_mha_args* f1, void* str
     const int nw = pick_nw(p.nt, false, kv1);
     const dim3 grid((p.nt + nw - 1) / nw, p.H, f1 ? 2 * p.P : p.P);
     hipStream_t st = (hipStream_t)stream;
-    const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
-#define STG_MHA_FWD(DD, KV, NW) { if (kt2) { rc = launch_fwd2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_fwd_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); }
+#define STG_MHA_FWD(DD, KV, NW) { rc = launch_fwd2<DD, KV, NW>(grid, p, st); if (rc) return rc; }
 #define STG_MHA_FWD2(DD, KV) { if (nw == 8) STG_MHA_FWD(DD, KV, 8) else STG_MHA_FWD(DD, KV, 4) }
     if (nw == 2) { if (f->D == 64) STG_MHA_FWD(64, true, 2) else STG_MHA_FWD(96, true, 2) }
     else if (f->D == 64) { if (kv1) STG_MHA_FWD2(64, true) else STG_MHA_FWD2(64, false) }
@@ -886,9 +719,9 @@ static int mha_bwd_impl(const stg_mha_args* f, const void* dO, void* dQ, void* d
     const int nw = pick_nw(p.nt, true, kv1);
     const dim3 grid((p.nt + nw - 1) / nw, p.H, f1 ? 2 * p.P : p.P);
     hipStream_t st = (hipStream_t)stream;
-    const bool kt2 = stg_opt_mha_kt.load(std::memory_order_relaxed) == 2 && p.nt >= 2;
-#define STG_MHA_BWD(DD, KV, NW) { if (kt2) { rc = launch_dq2<DD, KV, NW>(grid, p, st); if (rc) return rc; } else hipLaunchKernelGGL((mha_dq_kernel<DD, KV, NW>), grid, dim3(NW * 64), 0, st, p); \
-                                  STG_LAUNCH_CHECK(); rc = (kt2 && dkv2_lds_bytes(DD, KV, NW) <= 160 * 1024 && !(DD == 96 && !KV && NW == 4) && !(DD == 96 && NW == 2) /* 256 VGPRs + spills */ && !stg_opt_mha_dkv1.load(std::memory_order_relaxed)) ? launch_dkv2<DD, KV, NW>(grid, p, st) : launch_dkv<DD, KV, NW>(grid, p, st); }
+    // dK / dV: two query tiles per trip where its 160 KiB of LDS and 256 registers allow (not at D = 96 with separate K / V and 4 waves, nor with 2 waves)
+#define STG_MHA_BWD(DD, KV, NW) { rc = launch_dq2<DD, KV, NW>(grid, p, st); if (rc) return rc; STG_LAUNCH_CHECK(); \
+                                  rc = (p.nt >= 2 && dkv2_lds_bytes(DD, KV, NW) <= 160 * 1024 && !(DD == 96 && !KV && NW == 4) && !(DD == 96 && NW == 2)) ? launch_dkv2<DD, KV, NW>(grid, p, st) : launch_dkv<DD, KV, NW>(grid, p, st); }
 #define STG_MHA_BWD2(DD, KV) { if (nw == 8) STG_MHA_BWD(DD, KV, 8) else STG_MHA_BWD(DD, KV, 4) }
     if (nw == 2) { if (f->D == 64) STG_MHA_BWD(64, true, 2) else STG_MHA_BWD(96, true, 2) }
     else if (f->D == 64) { if (kv1) STG_MHA_BWD2(64, true) else STG_MHA_BWD2(64, false) }

@@ -56,251 +56,12 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// [32 rows][32 dims] bf16 tile, 64-byte rows; the 16-byte chunk c4 of row `row` sits at position c4 ^ ((row >> 1) & 3), so the
-// fragment stores below (8 consecutive rows x one chunk per 8-lane pass) spread over all banks.
-__device__ __forceinline__ int tile_off(int row, int c4) { return row * TD + ((c4 ^ ((row >> 1) & 3)) << 3); }
-
-// lane (r, hh) holds row r, dims 8hh..8hh+7 (f0) and 16+8hh..16+8hh+7 (f1) of an operand: park it in the tile
-__device__ __forceinline__ void park(bf16_t* s, int r, int hh, bf16x8_t f0, bf16x8_t f1) {
-    *reinterpret_cast<bf16x8_t*>(s + tile_off(r, hh)) = f0;
-    *reinterpret_cast<bf16x8_t*>(s + tile_off(r, 2 + hh)) = f1;
-}
-
-// transposed fragment: A[i = d][k slot j] = tile[16*s2 + 4*hh + (j & 3) + 8*(j >> 2)][d], d = lane & 31 (the row order of
-// accumulator registers 8*s2 .. 8*s2+7), by two ds_read_b64_tr_b16: each 16-lane group reads a 4-row x 16-column block and
-// receives it column-major; lane 4q + p of the group supplies the address of row q, columns 4p..4p+3.  EXEC all ones.
 typedef short s4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* s, int s2, int hh, int d) {
-    const int gi = d & 15, c = d >> 4;
-    const int row = 16 * s2 + 4 * hh + (gi >> 2);
-    const int c4 = 2 * c + ((gi & 3) >> 1), sub = 4 * (gi & 1);
-    const bf16_t* p0 = s + tile_off(row, c4) + sub;
-    const bf16_t* p1 = s + tile_off(row + 8, c4) + sub;
-    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p0);
-    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)p1);
-    bf16x8_t f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
-}
 
 __device__ __forceinline__ float pick(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
-// ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(256, 2) tattn_fwd_kernel(TP a) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * 32 * TD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
-    if (h >= a.H) return;
-    const int nv = a.per * a.T;
-    int s = r / a.T, t = r - s * a.T;
-    if (r >= nv) { s = 0; t = 0; }
-    bf16_t* sV = smem + wave * 32 * TD;
-    const float* bmq = a.bm + ((int64_t)(m * a.H + h) * 32 + r) * 32;
-    float4 add[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) add[g4] = *reinterpret_cast<const float4*>(bmq + 8 * g4 + 4 * hh);
-
-    // operand fragments of the NEXT group are in flight while the current one is computed (the loop is latency-bound otherwise)
-    auto row_of = [&](int g, int& cnt) {
-        const int b = g / a.gpb, j = g - b * a.gpb;
-        const int n0 = j * a.per;
-        cnt = min(a.per, a.N - n0);
-        return ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
-    };
-    bf16x8_t nq0, nq1, nk0, nk1, nv0, nv1;
-    int ncnt = 0;
-    int64_t nrow = 0;
-    auto fetch = [&](int g) {
-        nrow = row_of(g, ncnt);
-        const int64_t off = nrow * a.ld + h * TD + 8 * hh;
-        nq0 = ld_frag(a.Q + off); nq1 = ld_frag(a.Q + off + 16);
-        nk0 = ld_frag(a.K + off); nk1 = ld_frag(a.K + off + 16);
-        nv0 = ld_frag(a.V + off); nv1 = ld_frag(a.V + off + 16);
-    };
-    if ((int)blockIdx.x < a.ngroups) fetch(blockIdx.x);
-    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
-        const int cnt = ncnt;
-        const int64_t row = nrow;
-        const bf16x8_t q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1;
-        if (g + (int)gridDim.x < a.ngroups) fetch(g + gridDim.x);
-        park(sV, r, hh, v0, v1);
-        f32x16_t st = zero16();                       // St[key][q]
-        st = MFMA32(k0, q0, st);
-        st = MFMA32(k1, q1, st);
-        lds_fence();
-        float x[16];
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
-            mx = fmaxf(mx, x[reg]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
-            l += x[reg];
-        }
-        l += __shfl_xor(l, 32, 64);
-        f32x16_t o = zero16();                        // O^T[d][q]
-        o = MFMA32(tr_frag(sV, 0, hh, r), pack8(x), o);
-        o = MFMA32(tr_frag(sV, 1, hh, r), pack8(x + 8), o);
-        lds_fence();                                  // the tile is rewritten by the next group
-        store_tile32(a.O + row * a.ldo + h * TD, o, 1.0f / l, hh, r < cnt * a.T);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ backward (dQ, dK, dV, dbias)
-__global__ void __launch_bounds__(256, 2) tattn_bwd_kernel(TP a) {
-    constexpr int PER_WAVE = 3 * 32 * TD + 128;      // K, Q, dO tiles (bf16) + lse[32] + delta[32] (fp32 = 128 bf16 slots)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y * 4 + wave, m = blockIdx.z;
-    if (h >= a.H) return;
-    const int nv = a.per * a.T;
-    int s = r / a.T, t = r - s * a.T;
-    if (r >= nv) { s = 0; t = 0; }
-    bf16_t* sK = smem + wave * PER_WAVE;
-    bf16_t* sQ = sK + 32 * TD;
-    bf16_t* sD = sQ + 32 * TD;
-    float* sLse = reinterpret_cast<float*>(sD + 32 * TD);
-    float* sDel = sLse + 32;
-    const int64_t tb = ((int64_t)(m * a.H + h) * 32 + r) * 32;
-    float4 add[4], addT[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        add[g4] = *reinterpret_cast<const float4*>(a.bm + tb + 8 * g4 + 4 * hh);      // lane = query, float4 along keys
-        addT[g4] = *reinterpret_cast<const float4*>(a.bmT + tb + 8 * g4 + 4 * hh);    // lane = key, float4 along queries
-    }
-    f32x16_t dbacc = zero16();                        // sum of dS^T[key][q] over this wave's groups
-
-    auto row_of = [&](int g, int& cnt) {
-        const int b = g / a.gpb, j = g - b * a.gpb;
-        const int n0 = j * a.per;
-        cnt = min(a.per, a.N - n0);
-        return ((int64_t)(m * a.B + b) * a.T + t) * a.N + n0 + (s < cnt ? s : cnt - 1);
-    };
-    bf16x8_t nq0, nq1, nk0, nk1, nv0, nv1, nd0, nd1;
-    int ncnt = 0;
-    int64_t nrow = 0;
-    auto fetch = [&](int g) {                          // the NEXT group's operands are in flight during the current one
-        nrow = row_of(g, ncnt);
-        const int64_t off = nrow * a.ld + h * TD + 8 * hh;
-        nq0 = ld_frag(a.Q + off); nq1 = ld_frag(a.Q + off + 16);
-        nk0 = ld_frag(a.K + off); nk1 = ld_frag(a.K + off + 16);
-        nv0 = ld_frag(a.V + off); nv1 = ld_frag(a.V + off + 16);
-        const bf16_t* dp_ = a.dO + nrow * a.lddo + h * TD + 8 * hh;
-        nd0 = ld_frag(dp_); nd1 = ld_frag(dp_ + 16);
-    };
-    if ((int)blockIdx.x < a.ngroups) fetch(blockIdx.x);
-    for (int g = blockIdx.x; g < a.ngroups; g += gridDim.x) {
-        const int cnt = ncnt;
-        const int nvalid = cnt * a.T;
-        const int64_t row = nrow;
-        const bf16x8_t q0 = nq0, q1 = nq1, k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1, d0 = nd0, d1 = nd1;
-        if (g + (int)gridDim.x < a.ngroups) fetch(g + gridDim.x);
-        park(sK, r, hh, k0, k1);
-        park(sQ, r, hh, q0, q1);
-        park(sD, r, hh, d0, d1);
-
-        // ---------------- phase A: query on the lane.  St[key][q], dPt[key][q]; dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
-        {
-            f32x16_t st = zero16(), dpt = zero16();
-            st = MFMA32(k0, q0, st);   st = MFMA32(k1, q1, st);
-            dpt = MFMA32(v0, d0, dpt); dpt = MFMA32(v1, d1, dpt);
-            float x[16];
-            float mx = NEG_BIG;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                x[reg] = st[reg] * a.scale2 + pick(add[reg >> 2], reg & 3);
-                mx = fmaxf(mx, x[reg]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                x[reg] = __builtin_amdgcn_exp2f(x[reg] - mx);
-                l += x[reg];
-            }
-            l += __shfl_xor(l, 32, 64);
-            const float inv = (r < nvalid) ? 1.0f / l : 0.f;      // padded / absent sequences contribute nothing
-            float delta = 0.f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                x[reg] *= inv;
-                delta += x[reg] * dpt[reg];
-            }
-            delta += __shfl_xor(delta, 32, 64);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                x[reg] *= dpt[reg] - delta;                         // dS^T[key][q]
-                dbacc[reg] += x[reg];
-            }
-            if (hh == 0) {
-                sLse[r] = mx + __log2f(l);
-                sDel[r] = delta;
-            }
-            lds_fence();
-            f32x16_t dq = zero16();
-            dq = MFMA32(tr_frag(sK, 0, hh, r), pack8(x), dq);
-            dq = MFMA32(tr_frag(sK, 1, hh, r), pack8(x + 8), dq);
-            store_tile32(a.dQ + row * a.lddqkv + h * TD, dq, a.scale, hh, r < nvalid);
-        }
-
-        // ---------------- phase B: key on the lane.  S[q][key], dP[q][key]; dV^T[d][key] = sum_q dO^T[d][q] P[q][key],
-        //                  dK^T[d][key] = sum_q Q^T[d][q] dS[q][key]
-        {
-            f32x16_t sc = zero16(), dp = zero16();
-            sc = MFMA32(q0, k0, sc); sc = MFMA32(q1, k1, sc);
-            dp = MFMA32(d0, v0, dp); dp = MFMA32(d1, v1, dp);
-            float pr[16], ds[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 ls = *reinterpret_cast<const float4*>(sLse + 8 * g4 + 4 * hh);
-                const float4 de = *reinterpret_cast<const float4*>(sDel + 8 * g4 + 4 * hh);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int reg = 4 * g4 + c;
-                    const bool okq = 8 * g4 + 4 * hh + c < nvalid;              // padded query rows contribute nothing
-                    const float pv = okq ? __builtin_amdgcn_exp2f(sc[reg] * a.scale2 + pick(addT[g4], c) - pick(ls, c)) : 0.f;
-                    pr[reg] = pv;
-                    ds[reg] = pv * (dp[reg] - pick(de, c));
-                }
-            }
-            f32x16_t dv = zero16(), dk = zero16();
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dv = MFMA32(tr_frag(sD, s2, hh, r), pack8(pr + 8 * s2), dv);
-                dk = MFMA32(tr_frag(sQ, s2, hh, r), pack8(ds + 8 * s2), dk);
-            }
-            store_tile32(a.dK + row * a.lddqkv + h * TD, dk, a.scale, hh, r < nvalid);
-            store_tile32(a.dV + row * a.lddqkv + h * TD, dv, 1.0f, hh, r < nvalid);
-        }
-        lds_fence();                                  // tiles / statistics are rewritten by the next group
-    }
-
-    if (a.dbias) {
-        // fold the `per` diagonal T x T blocks of the accumulated dS^T[key][q] and add them to dbias[m][h][tq][tk]
-        float* tile = reinterpret_cast<float*>(sK);   // 32 x 32 fp32 = the K + Q tiles
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) tile[ACC_ROW(reg, hh) * 32 + r] = dbacc[reg];
-        lds_fence();
-        const int TT = a.T * a.T;
-        for (int idx = lane; idx < TT; idx += 64) {
-            const int tq = idx / a.T, tk = idx - tq * a.T;
-            float acc = 0.f;
-            for (int sq = 0; sq < a.per; ++sq) acc += tile[(sq * a.T + tk) * 32 + sq * a.T + tq];
-            atomicAdd(a.dbias + (int64_t)(m * a.H + h) * TT + idx, acc);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ coalesced kernels (round 2)
-// The kernels above fetch their operand fragments and store their results ROW-PER-LANE (a lane moves 16 bytes of its own token row):
+// The round-1 kernels (removed in round 6) fetched their operand fragments and stored their results ROW-PER-LANE (a lane moves 16 bytes of its own token row):
 // 64 separate requests per wave-instruction, ~64 clocks each in the CU's address path, 8 / 14 such instructions per group.  Here every
 // global access is coalesced -- four lanes cover the 64 bytes of a head's row: the operand tiles of the NEXT group arrive by LDS-DMA
 // (two instructions per 32-row tile) in a second set of LDS tiles while the current group is computed, fragments are read from LDS, and
@@ -830,8 +591,7 @@ extern "C" int stg_tattn_fwd(const stg_tattn_args* f, void* stream) {
     hipLaunchKernelGGL(tattn_table_kernel, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, f->bias, f->bm, f->bmT, p.nm * p.H, p.T, p.per);
     STG_LAUNCH_CHECK();
-    if (stg_opt_tattn.load(std::memory_order_relaxed) >= 1) hipLaunchKernelGGL(tattn_fwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(tattn_fwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tattn_fwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }
@@ -860,8 +620,7 @@ extern "C" int stg_tattn_bwd(const stg_tattn_args* f, const void* dO, int64_t ld
         STG_LAUNCH_CHECK();
         return 0;
     }
-    if (stg_opt_tattn.load(std::memory_order_relaxed) >= 1) hipLaunchKernelGGL(tattn_bwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(tattn_bwd_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tattn_bwd1_kernel, grid_for(p), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
 }

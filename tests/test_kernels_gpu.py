@@ -820,3 +820,73 @@ def test_bilinear_up2_rows_spread_over_xcds(stg, gpu, F, H, W, C, align):
     ref.backward(dy.float().view(F, 2 * H, 2 * W, C).permute(0, 3, 1, 2))
     dx = k.bilinear_up2_bwd(dy.to(gpu), F, H, W, align)
     _close(dx, xi.grad.permute(0, 2, 3, 1).reshape(F * H * W, C), tol=1.5e-2, what="bilinear bwd")
+
+
+def test_counted_wait_and_path_switch_kernels_repeat_2000(stg, gpu):
+    """>= 2 000 launches, same bits every time, of the kernels with counted waits / a wave-uniform path switch that had only a
+    few hundred in-suite repetitions -- xattn_bwdm_kernel<16 / 32> on BOTH of its paths (a frame whose log-sum-exps span > 120 binary orders takes
+    the two-exponential path), the mha pair launches (mha_fwd2 / dq2 / dkv2, grid.z = 2 P, K == V, 3 136-token and 49-token window frames),
+    conv_wgrad_kernel<64, 2> (inline-asm transposing reads behind the LDS-DMA) -- and of round 6's: the window-attention backward with the
+    LDS-shared table (a workgroup barrier in front of wave-private work) and the rewritten wgrad_ws chunk loop (two chunks in flight)."""
+    from stgcma import kernels as K, ops
+    import oracle.swin as OS
+    torch.manual_seed(3)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, device=gpu) * sc).to(torch.bfloat16)
+
+    def stress(name, fn, reps=2000):
+        ref = [t.clone() for t in fn()]
+        bad = torch.zeros((), device=gpu, dtype=torch.int64)
+        for r in range(reps):
+            for t, q in zip(fn(), ref):
+                bad += (t.view(torch.int16) != q.view(torch.int16)).any() if t.dtype == torch.bfloat16 else (t != q).any()
+        assert int(bad) == 0, f"{name}: {int(bad)} of {reps} launches differ from the first"
+        for t in ref:
+            assert torch.isfinite(t.float()).all(), name
+
+    for D, nv, na in ((16, 197, 130), (32, 196, 196)):
+        P_ = 3
+        hv, ha = (torch.randn(P_ * nv, D, device=gpu) * 0.7), (torch.randn(P_ * na, D, device=gpu) * 0.7)
+        hv.view(P_, nv, D)[0, ::7] *= 40.0                          # frame 0: the slow (two-exponential) path; frames 1, 2: the fast path
+        hv, ha = hv.to(torch.bfloat16), ha.to(torch.bfloat16)
+        dv, da = bf(P_ * nv, D), bf(P_ * na, D)
+        gv = K.AttnGeom(P_, 1, nv, D, G=1, outer=nv, n_kv=na, outer_kv=na, scale=1.0)
+        ga = K.AttnGeom(P_, 1, na, D, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=1.0)
+        (Rv, Lv), (Ra, La) = K.attn_fwd2(gv, hv, ha, ha, ga, ha, hv, hv)
+        pv, pa = (gv, hv, ha, Rv, Lv, dv), (ga, ha, hv, Ra, La, da)
+        assert K.xattn_pair_bwd_supported(pv, pa)
+        stress(f"xattn_pair_bwd D={D}", lambda: K.xattn_pair_bwd(pv, pa))
+    for mg, rows in ((K.MhaGeom(2, 1, 3136, 96, 1.0), 2 * 3136), (K.MhaGeom(2 * 4, 1, 49, 96, 1.0, window=(14, 14, 7, 3)), 2 * 196)):
+        hq, hk, d0, d1 = bf(rows, 96, sc=0.3), bf(rows, 96, sc=0.3), bf(rows, 96), bf(rows, 96)
+        (r0, l0), (r1, l1) = K.mha_fwd_pair(mg, (hq, hk, hk), (hk, hq, hq))
+        reps = 2000 if rows < 1000 else 2000
+        stress(f"mha_fwd_pair n={mg.n}", lambda: [t for o in K.mha_fwd_pair(mg, (hq, hk, hk), (hk, hq, hq)) for t in o], reps=reps)
+        g0, g1, g2, g3 = (torch.empty_like(hq) for _ in range(4))
+
+        def bwd():
+            K.mha_bwd_pair(mg, (hq, hk, hk, r0, l0, d0, g0, g1, None), (hk, hq, hq, r1, l1, d1, g2, g3, None))
+            return g0, g1, g2, g3
+        stress(f"mha_bwd_pair n={mg.n}", bwd, reps=reps)
+    xc, dyc = bf(3 * 28 * 28, 64), bf(3 * 28 * 28, 256)
+    stress("conv3x3_wgrad 64 -> 256", lambda: (K.conv3x3_wgrad(dyc, xc, 3, 28, 28, 3),))
+    xc2, dyc2 = bf(2 * 14 * 14, 320), bf(2 * 14 * 14, 256)
+    stress("conv3x3_wgrad 320 -> 256", lambda: (K.conv3x3_wgrad(dyc2, xc2, 2, 14, 14, 6),))
+    # round 6
+    images, heads, Himg, ws = 37, 16, 14, 7                          # 37 frames: the last frame quad of the LT form has one live wave
+    n, N_, C = 49, Himg * Himg, heads * 32
+    qkv, dO = bf(images * N_, 3 * C), bf(images * N_, C)
+    bm, bmT = K.winattn_table((torch.randn(169, heads) * 0.5).to(gpu), OS.relative_position_index(ws).reshape(-1).to(gpu), ops.shift_mask(Himg, Himg, ws, 3).to(gpu), n)
+    wg = K.WinGeom(images, heads, Himg, Himg, ws, 3, 32 ** -0.5, bm, bmT)
+    Q, Kk, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    O, lse = K.winattn_fwd(wg, Q, Kk, V)
+    dq = torch.empty_like(qkv)
+    stress("winattn_bwd (LDS-shared table)", lambda: (K.winattn_bwd(wg, Q, Kk, V, O, lse, dO, dQ=dq[:, :C], dK=dq[:, C:2 * C], dV=dq[:, 2 * C:]) and dq,))
+    for J, Cw in ((48, 768), (96, 768), (32, 512)):
+        M = 4096 + 8 * 32 * 9 + 19                                   # whole chunks + a ragged last chunk in every row split
+        a, b = bf(M, J), bf(M, Cw)
+        rs = torch.rand(M // 64 + 1, device=gpu) + 0.5
+
+        def wg_():
+            dW, db = torch.zeros(J, Cw, device=gpu), torch.zeros(J, device=gpu)
+            K.wgrad_tn(a, b, dW, db, row_scale=rs, rs_outer=64, rs_inner=1)
+            return dW, db
+        stress(f"wgrad_ws {J} x {Cw}", wg_, reps=1000)
