@@ -205,7 +205,7 @@ def self_launch(n):
     raise SystemExit(r.returncode)
 
 
-PMC_BY_CLASS = ("r05_final_pmc_by_class.json", "r04_final_pmc_by_class.json", "r03_pmc_by_class.json")      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
+PMC_BY_CLASS = ("r06_final_pmc_by_class.json", "r05_final_pmc_by_class.json", "r04_final_pmc_by_class.json", "r03_pmc_by_class.json")      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
 
 
 def pmc_traffic(kernel, N, K, epi):
@@ -222,7 +222,9 @@ def pmc_traffic(kernel, N, K, epi):
         c = d.get("classes", {}).get(f"{kernel}|{N}|{K}|{epi}")
         if c is not None:
             PMC_MFMA[(kernel, N, K, epi)] = c.get("mfma_util_pmc")
-            return int(c["hbm_bytes_per_launch"]), f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {c['launches_per_step']} launches of this class per step)"
+            meta = d.get("meta") or {}
+            where = f"; counters taken on commit {meta['commit']} with `{meta.get('command', '?')}`" if meta.get("commit") else "; counters of an earlier tree (file without a commit record)"
+            return int(c["hbm_bytes_per_launch"]), f"profiles/{cand} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {c['launches_per_step']} launches of this class per step{where})"
     return None, None
 
 
@@ -324,7 +326,8 @@ def build_report(gp, fams, ctx):
         if c["traffic"] is not None:
             k["pmc_b"] += c["traffic"] * c["launches_per_step"]
             k["pmc_l"] += c["launches_per_step"]
-            k["src"] = (c["traffic_source"] or "").split(" ")[0]
+            src = c["traffic_source"] or ""
+            k["src"] = src.split(" ")[0] + (" (" + src.split("; ", 1)[1] if "; " in src else "")     # file + which commit / command its counters are from
     roofline, roofline_class = None, None
     if by_kernel:
         k = max(by_kernel.values(), key=lambda k: k["ms"])
@@ -575,9 +578,10 @@ def main():
         torch.cuda.synchronize()
 
     # micro-batches are exact where no operation looks across the clips of a batch: the AVE models and the AVQA model (LayerNorm, per-clip
-    # attention, mean-reduced losses) -- not the AVS decoder (BatchNorm over the batch).  Under DDP the AVQA task head's gradients travel in
-    # the end-of-backward bucket, which the micro-batch form does not carry: N > 1 then replays capture_train_step_ddp's two graphs.
-    MB_OK = ("swin_b", "swin_l", "vit_b") + (("avqa",) if world == 1 else ())
+    # attention, mean-reduced losses) -- not the AVS decoder (BatchNorm over the batch: two half batches are not the same function; it replays
+    # capture_train_step_ddp's graphs).  Round 6: under DDP the AVQA task head's gradients ride the micro-batch form too (its join graph packs them
+    # into one bucket), so configs 3 and 5 share one N > 1 step form.
+    MB_OK = ("swin_b", "swin_l", "vit_b", "avqa")
     nmb = args.microbatch if (args.workload in MB_OK and args.batch % max(args.microbatch, 1) == 0 and not args.fp8) else 1
     labels3 = labels.view(args.batch, -1, labels.shape[-1])
     mb_tensors = (a, v, labels3)

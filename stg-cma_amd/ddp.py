@@ -52,6 +52,7 @@ class GradSync:
         self.defer = False
         self._pending = []
         self._bucket = None
+        self.skip_bucket = False               # deferred mode inside recipe.capture_train_step_mb: the JOIN graph packs the bucket, once, from the summed gradients
 
     # ---------------------------------------------------------------- the collective
     def _average(self, flat):
@@ -91,6 +92,11 @@ class GradSync:
         self._armed = -1
         ps = [p for p in self.extra if p.requires_grad]
         if ps:
+            if self.defer and self.skip_bucket:            # capture_train_step_mb: the join graph packs the bucket from the SUMMED gradients
+                self._bucket = None
+                self._acc += sum(p.numel() for p in ps)
+                self.last_numel, self._acc = self._acc, 0
+                return
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in ps])
             if self.defer:                     # packed inside the capture; averaged by flush(), written back by scatter_back()
                 self._bucket = (flat, ps)

@@ -355,10 +355,16 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
       tensors           static batch tensors, every one with the batch on dimension 0 (copy new batches INTO them between replays)
       optimizer         build_optimizer's FusedAdam
       sync              ddp.attach(model) at N > 1: the micro-batch graphs run with the GradSync deferred, the summed arena is
-                        all-reduced eagerly between the join graph and the optimizer graph (models with task-head buckets: not here)
+                        all-reduced eagerly between the join graph and the optimizer graph.  Round 6: models with task-head gradients
+                        (sync.extra: the AVQA head) too -- the join graph packs their summed gradients into ONE flat bucket (zeros for
+                        a parameter without a gradient on this rank, like GradSync's own bucket), it is all-reduced beside the arena,
+                        and the optimizer graph first copies the averages back.  (The AVS model stays out for a different reason:
+                        BatchNorm over the batch -- half batches are not the same function.)
       require_overlap   (default) raise RuntimeError BEFORE capturing anything when no side stream measurably runs beside the launch stream:
                         the chains would then serialise and the step would cost MORE than the plain one (132 vs 123 ms measured) -- the caller
                         falls back to capture_train_step / eager steps.  False: capture anyway; `replay.streams_overlap` says what was found.
+    The caller must not keep an eager step's autograd graph alive across this call (drop the last `loss`, gc.collect()): its AccumulateGrad
+    nodes are bound to the stream they ran on, and a capture on another stream then fails hard (a segmentation fault was seen in torch 2.10).
     Returns (replay, static_loss, how).  replay() must be called on the stream the tensors are produced on (it forks from and joins
     back into the current stream).  If the capture raises, the parameters' .grad are reset to None (they would point into a discarded
     graph pool) and a deferred GradSync is restored."""
@@ -367,8 +373,6 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
     S = int(splits)
     if S < 2 or B % S != 0 or any(t.shape[0] != B for t in tensors):
         raise ValueError("capture_train_step_mb: the batch (dimension 0 of every tensor) must split evenly into >= 2 micro-batches")
-    if sync is not None and sync.extra:
-        raise RuntimeError("capture_train_step_mb: models with task-head gradient buckets (AVS / AVQA) are not micro-batched")
     h = B // S
     chunks = [tuple(t[i * h:(i + 1) * h] for t in tensors) for i in range(S)]
     params = [p for grp in optimizer.param_groups for p in grp["params"]]
@@ -396,8 +400,10 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
             optimizer.step()
     cur.wait_stream(side)
     torch.cuda.synchronize()
+    extra_ids = {id(p) for p in sync.extra} if sync is not None else set()
     if sync is not None:
         sync.defer, sync._pending, sync._bucket = True, [], None
+        sync.skip_bucket = True                             # the micro-batch graphs do not pack the task-head bucket: the join graph does, once
     try:
         graphs, losses, grads = [], [], []
         for c in chunks:
@@ -413,31 +419,48 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
         live = [k for k in range(len(params)) if all(gr[k] is not None for gr in grads)]
         if any(gr[k] is not None for gr in grads for k in range(len(params)) if k not in live):
             raise RuntimeError("capture_train_step_mb: a parameter received a gradient in one micro-batch only")
+        live_x = [k for k in live if id(params[k]) in extra_ids]          # task-head parameters (gradients outside the backbone's arena)
+        live_a = [k for k in live if id(params[k]) not in extra_ids]
         flats = []
         for gr in grads:                                    # one flat arena per micro-batch (ops.GradArena)?  then the sum is one launch
-            bases = {id(gr[k]._base): gr[k]._base for k in live if gr[k]._base is not None}
-            flats.append(next(iter(bases.values())) if len(bases) == 1 and all(gr[k]._base is not None for k in live) else None)
-        same_layout = all(f is not None and f.shape == flats[0].shape for f in flats) and all(
-            gr[k].storage_offset() == grads[0][k].storage_offset() for gr in grads for k in live)
+            bases = {id(gr[k]._base): gr[k]._base for k in live_a if gr[k]._base is not None}
+            flats.append(next(iter(bases.values())) if len(bases) == 1 and all(gr[k]._base is not None for k in live_a) else None)
+        same_layout = bool(live_a) and all(f is not None and f.shape == flats[0].shape for f in flats) and all(
+            gr[k].storage_offset() == grads[0][k].storage_offset() for gr in grads for k in live_a)
         gj = torch.cuda.CUDAGraph()
         ga = torch.cuda.CUDAGraph() if sync is not None else None
+        bucket, bucket_ps = None, []
         with torch.cuda.graph(gj, capture_error_mode="thread_local"):
             for i in range(1, S):
                 if same_layout:
                     flats[0].add_(flats[i])
-                else:
-                    torch._foreach_add_([grads[0][k] for k in live], [grads[i][k] for k in live])
+                elif live_a:
+                    torch._foreach_add_([grads[0][k] for k in live_a], [grads[i][k] for k in live_a])
+                if live_x:
+                    torch._foreach_add_([grads[0][k] for k in live_x], [grads[i][k] for k in live_x])
             static_loss = torch.stack(losses).sum()
             for k, p in enumerate(params):
                 p.grad = grads[0][k]
+            if sync is not None and extra_ids:                # ONE bucket of every trainable task-head tensor, in sync.extra's order on every rank
+                bucket_ps = [p for p in sync.extra if p.requires_grad]
+                bucket = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in bucket_ps])
             if sync is None:
                 optimizer.step()
         if sync is not None:
             with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                off = 0
+                for p in bucket_ps:                         # the averaged task-head gradients back into the .grad tensors the optimizer reads
+                    seg = bucket[off:off + p.numel()].view(p.shape)
+                    off += p.numel()
+                    if p.grad is None:
+                        p.grad = seg.to(p.dtype).clone()
+                    else:
+                        p.grad.copy_(seg)
                 optimizer.step()
     except BaseException:
         if sync is not None:
             sync.defer, sync._pending, sync._bucket = False, [], None
+            sync.skip_bucket = False
         for p in params:                                    # they point into the discarded graphs' pools
             p.grad = None
         raise
@@ -457,14 +480,17 @@ def capture_train_step_mb(fwd_loss, tensors, optimizer, splits=2, sync=None, war
             if red is not None:
                 sync._average(red)
             else:
-                for k in live:
+                for k in live_a:
                     sync._average(grads[0][k])
+            if bucket is not None:
+                sync._average(bucket)
             ga.replay()
         torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
 
     def release():
         if sync is not None:
             sync.defer, sync._pending, sync._bucket = False, [], None
+            sync.skip_bucket = False
     replay.release = release
     replay.graphs = tuple(graphs) + (gj,) + ((ga,) if ga is not None else ())
     replay.streams_overlap = overlap

@@ -103,6 +103,58 @@ fwd_bwd(opt)
 opt.step()
 torch.cuda.synchronize()
 out["start"] = {n: state0[n].detach().float().cpu().clone() for n in names}
+
+# ---- round 6: the micro-batch form with a TASK-HEAD bucket (the AVQA model: its head's gradients do not pass through the backbone's arena)
+del replay, opt, sync, m, d
+torch.cuda.empty_cache()
+from stgcma.model import Swin_AVQAModel_V1  # noqa: E402
+vt = v.permute(0, 2, 1, 3, 4).contiguous()
+vn = vt.flip(1)
+q = torch.randint(0, 93, (B, 14), generator=g).to(gpu)
+ans = torch.randint(0, 42, (B,), generator=g).to(gpu)
+torch.manual_seed(0)
+m = Swin_AVQAModel_V1.SwinTransformer2D_Adapter_AVQA(pretrained=None, num_frames=T, embed_dim=192, depths=[2, 2, 2, 2], num_heads=[6, 12, 24, 48],
+                                                     ftmode="fusion", adapter_mlp_ratio=[0.25, 0.125, 0.125, 0.0625])
+with torch.no_grad():
+    for n, p in m.named_parameters():
+        if "D_fc2" in n or "gate_" in n:
+            p.normal_(0.0, 0.05)
+m = m.to(gpu).eval()
+recipe.apply_freeze(m)
+ddp.broadcast_parameters(m)
+sync = ddp.attach(m)
+assert sync.extra, "the AVQA head's parameters must travel in the task-head bucket"
+state0 = {k: t.detach().clone() for k, t in m.state_dict().items()}
+names = [n for n, p in m.named_parameters() if p.requires_grad]
+d = dict(m.named_parameters())
+ce = torch.nn.CrossEntropyLoss()
+
+
+def q_loss(a_, vt_, vn_, q_, ans_):
+    out_qa, mp, mn = m(a_, vt_, vn_, q_, "fusion")
+    return ce(out_qa, ans_) + 0.5 * (mp.float().square().mean() + mn.float().square().mean())
+
+
+opt = fresh()
+for _ in range(1 + K):
+    loss = q_loss(a, vt, vn, q, ans)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+out["avqa_eager"] = snap()
+out["avqa_start"] = {n: state0[n].detach().float().cpu().clone() for n in names}
+del loss                                                     # the eager step's autograd graph (AccumulateGrad nodes bound to this stream) must not survive into the capture
+import gc  # noqa: E402
+gc.collect()
+print(f"rank {rank}: avqa eager steps done", flush=True)
+opt = fresh()
+replay, static_loss, how = recipe.capture_train_step_mb(q_loss, (a, vt, vn, q, ans), opt, splits=2, sync=sync, warmup=1, require_overlap=False)
+assert "2 micro-batch graphs" in how and "all-reduce" in how, how
+for _ in range(K):
+    replay()
+out["avqa_mb"] = snap()
+replay.release()
+print(f"rank {rank}: avqa micro-batch steps done", flush=True)
 torch.save(out, os.path.join(out_dir, f"steps_r{rank}.pt"))
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()

@@ -98,3 +98,17 @@ def test_two_ranks_replayed_step_forms_equal_the_eager_ddp_step(gpu, tmp_path):
         print(f"{form}: 99th percentile of |parameter - eager form's| / |eager form's movement| = {q99:.2e}; {same} of {len(names)} tensors bit-identical")
         assert q99 <= tol, (form, q99)
     assert abs(r0["ddp2g_loss"] - r1["ddp2g_loss"]) > 0            # different clips per rank: the exchange, not the data, made the parameters equal
+    # round 6: the micro-batch form with a task-head bucket (AVQA: backbone arena + ONE bucket of the head's summed gradients)
+    qn = list(r0["avqa_eager"])
+    assert any(n.startswith("avqatask_") for n in qn) and any(not n.startswith("avqatask_") for n in qn)
+    for form in ("avqa_eager", "avqa_mb"):
+        for n in qn:
+            assert torch.equal(r0[form][n], r1[form][n]), f"{form}: the ranks' parameters differ after the steps ({n})"
+    upd = torch.cat([(r0["avqa_eager"][n] - r0["avqa_start"][n]).reshape(-1).abs() for n in qn])
+    dev = torch.cat([(r0["avqa_mb"][n] - r0["avqa_eager"][n]).reshape(-1).abs() for n in qn])
+    rel = dev / upd.clamp_min(1e-12)
+    q99 = float(torch.quantile(rel[upd > 0][:: max(1, int((upd > 0).sum()) // 1_000_000)], 0.99))
+    print(f"avqa mb: 99th percentile of |parameter - eager form's| / |eager form's movement| = {q99:.2e}")
+    assert q99 <= 0.3, q99
+    head_moved = sum(float((r0["avqa_mb"][n] - r0["avqa_start"][n]).abs().max()) > 0 for n in qn if n.startswith("avqatask_"))
+    assert head_moved >= 0.8 * sum(n.startswith("avqatask_") for n in qn), "the task head's parameters did not move in the micro-batch form"

@@ -14,7 +14,7 @@ last two `adam_multi_kernel` launches (the optimizer step closes a step), so war
   achieved GB/s = bytes / duration.
 The three runs execute the same program, so dispatch i of the step is the same launch in each; names are checked.
 """
-import csv, gzip, json, re, sys, collections
+import csv, gzip, json, os, re, sys, collections
 
 
 def rows(path):
@@ -78,6 +78,8 @@ def by_class(tr, fe, wr, seq_path, dst, summary, mf=None, gu=None):
     json.dump({"note": "per GEMM class (kernel|N|K|epilogue): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of `bench.py --steps 2 "
                        "--warmup 1`, bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950: FETCH_SIZE tallies 128-B requests as 64 B), "
                        "dispatch i of the step joined with entry i of bench.py --gemm-seq; durations from the counter-free trace run",
+               # round 6: which tree / command the counters were taken on -- bench.py quotes it in roofline.traffic_source
+               "meta": {"commit": os.environ.get("LEDGER_COMMIT", "unknown"), "command": os.environ.get("LEDGER_COMMAND", "bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline")},
                "step": summary, "classes": out}, open(dst + "_pmc_by_class.json", "w"), indent=1)
     print("per-class file:", dst + "_pmc_by_class.json", len(out), "classes")
     for k, v in list(out.items())[:16]:
