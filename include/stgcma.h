@@ -324,7 +324,10 @@ int stg_xattn_fwd2_gate(const stg_attn_args* f0, const stg_attn_args* f1, const 
  *   bmT[g][h][k][q] = bm[g][h][q][k].
  *   table fp32 [L, H], index int64 [n*n], mask fp32 [Gt, n, n] or NULL (then Gt = 1).
  * Image pg = p / G occupies rows [pg*outer, pg*outer + Himg*Wimg); Q, K, V share one leading dimension (the fused qkv
- * buffer), Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*32.  lse: fp32 [P, H, 64] (entries >= n unused).
+ * buffer), Q/K/V/O/dO/dQ/dK/dV of head h at base + row*ld + h*D.  lse: fp32 [P, H, 64] (entries >= n unused).
+ * ABI 219: bm == bmT == NULL = no bias and no mask (the adapters' window-level cross-modal pair, Swin_AVE.py:750-760: the additive
+ * term is synthesised from the key index, nothing is fetched; 7 x 7 windows), and with it D == 16 (Swin-B stage 0's d_h: 32-byte
+ * rows in memory, staged beside a zero line into the 32-wide tiles the kernels work on).
  */
 typedef struct {
     const void* Q; const void* K; const void* V; int64_t ld;
@@ -342,7 +345,7 @@ int stg_winattn_table(const float* table, const int64_t* index, const float* mas
                       int L, int H, int n, int Gt, void* stream);
 int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
 /* dV == NULL: K and V are the same tensor (the adapters' window-level cross-modal attention softmax(h hother^T) hother,
- * AVE/model/Swin_AVE.py:750-760, run with H = 1 and an all-zero bias table) and dK receives dK + dV. */
+ * AVE/model/Swin_AVE.py:750-760, run with H = 1 and no table: bm == bmT == NULL) and dK receives dK + dV. */
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
 

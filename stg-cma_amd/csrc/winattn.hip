@@ -103,6 +103,20 @@ typedef short s4_t __attribute__((ext_vector_type(4)));
 // Score register `reg` of key tile kt holds keys 32 kt + (reg & 3) + 8 (reg >> 2) + 4 hh.  With NKEY > 0 (a compile-time key count: 49 for the 7 x 7
 // windows of every Swin stage) a register whose keys are padding for BOTH half-waves is skipped at compile time: its table entry is -1e30, so its
 // probability is exactly 0 either way (bit-identical results), and 7 of the 32 score registers of a query tile cost no VALU / exp.
+// Round 6: the window-level CROSS-MODAL pair of the adapters (softmax(h_v h_a^T) h_a per window, Swin_AVE.py:750-760) on these kernels without its
+// dummy table and at width 16 (Swin-B stage 0, the last backbone site on the generic attention kernels):
+//   NOTAB  no bias, no shift mask: the additive term is 0 (-1e30 on the padding keys), synthesised from the key index -- no 16 KiB table fetch;
+//   D16    head dim 16: rows of 32 bytes in global memory, staged into the SAME [64][32] LDS tiles with the upper 16 columns read from a zero
+//          line (the swizzled source chunk cs >= 2 of every row), so every fragment, MFMA and transposition below is unchanged -- the products' second
+//          k-step multiplies zeros -- and only the lower two 16-byte chunks of an output row are stored.  (Zero-padded COPIES of the operands were
+//          measured in round 5b: the attention family -1.25 ms per step, the copies +0.65.)
+__device__ __attribute__((aligned(16))) const uint32_t win_zero16[4] = {0u, 0u, 0u, 0u};
+template <int NKEY>
+__device__ __forceinline__ float4 notab_add(int kt, int g4, int hh) {       // keys 32 kt + 8 g4 + 4 hh + 0..3
+    const int k0 = 32 * kt + 8 * g4 + 4 * hh;
+    return make_float4(k0 >= NKEY ? NEG_BIG : 0.f, k0 + 1 >= NKEY ? NEG_BIG : 0.f, k0 + 2 >= NKEY ? NEG_BIG : 0.f, k0 + 3 >= NKEY ? NEG_BIG : 0.f);
+}
+
 template <int NKEY>
 __device__ __forceinline__ constexpr bool key_reg_live(int kt, int reg) { return NKEY <= 0 || 32 * kt + (reg & 3) + 8 * (reg >> 2) < NKEY; }
 
@@ -141,13 +155,14 @@ __device__ __forceinline__ void put_tile32(bf16_t* T, const f32x16_t& acc, float
             make_uint2(pack_bf2(acc[4 * g4] * sc, acc[4 * g4 + 1] * sc), pack_bf2(acc[4 * g4 + 2] * sc, acc[4 * g4 + 3] * sc));
 }
 // ... and out of it, 16 token rows x 64 bytes per store instruction; rowoff[j]: element offset of token 32 t + (lane >> 2) + 16 j
+template <bool D16 = false>
 __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const int64_t (&rowoff)[2], int t, int n, int lane) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int tl = (lane >> 2) + 16 * j, cq = lane & 3, sw = (tl >> 2) & 7;
         const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
         const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
-        if (32 * t + tl < n) *reinterpret_cast<uint4*>(dst + rowoff[j] + cq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (32 * t + tl < n && (!D16 || cq < 2)) *reinterpret_cast<uint4*>(dst + rowoff[j] + cq * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
 }
 
@@ -199,8 +214,9 @@ __device__ __forceinline__ float4 lt_read(const float* stab, int kt, int g4, int
     return hh ? make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG) : v;
 }
 
-template <int NKEY, bool LT>
+template <int NKEY, bool LT, bool NOTAB = false, bool D16 = false>
 __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
+    constexpr int HW = D16 ? 16 : WD;                      // head width in global memory
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
     constexpr int PER_WAVE = 4 * 64 * WD + 128;
@@ -244,16 +260,21 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     const int cs = (lane & 3) ^ ((lane >> 4) & 3);
     int64_t trow[4];
     uint4 vo[4];
+    const bool zc = D16 && cs >= 2;                        // D16: the upper two chunks of every LDS row come from the zero line
+    const bf16_t* zl = reinterpret_cast<const bf16_t*>(win_zero16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
-        const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kp + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qp + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vp + off), (__attribute__((address_space(3))) void*)(sP + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dOp + trow[i] * a.lddo + h * WD + cs * 8),
-                                         (__attribute__((address_space(3))) void*)(sD + i * 512), 16, 0, 0);
-        vo[i] = *reinterpret_cast<const uint4*>(Op + trow[i] * a.ldo + h * WD + cs * 8);
+        const int64_t off = trow[i] * a.ld + h * HW + cs * 8;
+        const bf16_t* sk = zc ? zl : Kp + off;
+        const bf16_t* sq = zc ? zl : Qp + off;
+        const bf16_t* sv = zc ? zl : Vp + off;
+        const bf16_t* sd = zc ? zl : dOp + trow[i] * a.lddo + h * HW + cs * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk, (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq, (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sv, (__attribute__((address_space(3))) void*)(sP + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sd, (__attribute__((address_space(3))) void*)(sD + i * 512), 16, 0, 0);
+        vo[i] = zc ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<const uint4*>(Op + trow[i] * a.ldo + h * HW + cs * 8);
     }
     float lse_q[2];
 #pragma unroll
@@ -270,7 +291,8 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             if (NKEY > 0 && 32 * kt + 8 * g4 >= NKEY) { dst[g4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-            if (LT) dst[g4] = lt_read<NKEY>(stab, kt, g4, hh, 32 * qt + r);
+            if (NOTAB) dst[g4] = notab_add<NKEY>(kt, g4, hh);
+            else if (LT) dst[g4] = lt_read<NKEY>(stab, kt, g4, hh, 32 * qt + r);
             else dst[g4] = *reinterpret_cast<const float4*>(bmq + 256 * ((kt * 4 + g4) * 2 + hh));
         }
     };
@@ -356,19 +378,19 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) addc[g4] = addn[g4];
         }
-        const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * WD, trow[2 * kt + 1] * a.lddqkv + h * WD};
+        const int64_t ro[2] = {trow[2 * kt] * a.lddqkv + h * HW, trow[2 * kt + 1] * a.lddqkv + h * HW};
         if (a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
 #pragma unroll
             for (int i = 0; i < 16; ++i) dk[i] = fmaf(dk[i], a.scale, dv[i]);
             put_tile32(sP, dk, 1.0f, r, hh);
             lds_fence();
-            flush_tile32(sP, dKp, ro, kt, a.n, lane);
+            flush_tile32<D16>(sP, dKp, ro, kt, a.n, lane);
         } else {
             put_tile32(sP, dk, a.scale, r, hh);
             put_tile32(sS, dv, 1.0f, r, hh);
             lds_fence();
-            flush_tile32(sP, dKp, ro, kt, a.n, lane);
-            flush_tile32(sS, a.dV, ro, kt, a.n, lane);
+            flush_tile32<D16>(sP, dKp, ro, kt, a.n, lane);
+            flush_tile32<D16>(sS, a.dV, ro, kt, a.n, lane);
         }
         lds_fence();
     }
@@ -376,18 +398,19 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     put_tile32(sS, dq[1], a.scale, r, hh);
     lds_fence();
     {
-        const int64_t r0[2] = {trow[0] * a.lddqkv + h * WD, trow[1] * a.lddqkv + h * WD};
-        const int64_t r1[2] = {trow[2] * a.lddqkv + h * WD, trow[3] * a.lddqkv + h * WD};
-        flush_tile32(sP, dQp, r0, 0, a.n, lane);
-        flush_tile32(sS, dQp, r1, 1, a.n, lane);
+        const int64_t r0[2] = {trow[0] * a.lddqkv + h * HW, trow[1] * a.lddqkv + h * HW};
+        const int64_t r1[2] = {trow[2] * a.lddqkv + h * HW, trow[3] * a.lddqkv + h * HW};
+        flush_tile32<D16>(sP, dQp, r0, 0, a.n, lane);
+        flush_tile32<D16>(sS, dQp, r1, 1, a.n, lane);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
 // winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
 // fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
-template <int NKEY>
+template <int NKEY, bool NOTAB = false, bool D16 = false>
 __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
+    constexpr int HW = D16 ? 16 : WD;                      // head width in global memory
     constexpr int PER_WAVE = 3 * 64 * WD;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -406,13 +429,18 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
 
     const int cs = (lane & 3) ^ ((lane >> 4) & 3);
     int64_t trow[4];
+    const bool zc = D16 && cs >= 2;                        // D16: the upper two chunks of every LDS row come from the zero line
+    const bf16_t* zl = reinterpret_cast<const bf16_t*>(win_zero16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         trow[i] = tok_row(a, pg, g, (lane >> 2) + 16 * i);
-        const int64_t off = trow[i] * a.ld + h * WD + cs * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qp + off), (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kp + off), (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vp + off), (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
+        const int64_t off = trow[i] * a.ld + h * HW + cs * 8;
+        const bf16_t* sq = zc ? zl : Qp + off;
+        const bf16_t* sk = zc ? zl : Kp + off;
+        const bf16_t* sv = zc ? zl : Vp + off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sq, (__attribute__((address_space(3))) void*)(sQ + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk, (__attribute__((address_space(3))) void*)(sK + i * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sv, (__attribute__((address_space(3))) void*)(sV + i * 512), 16, 0, 0);
     }
     // The additive table is 16 KiB per (window, head) -- more bytes through the CU's vector-memory path than the q / k / v / o tiles (12.5 KiB), all
     // L2 hits; with the loads removed (wrong results: a probe) the forward ran 10-22 % faster.  Round 5b: key groups entirely past NKEY are not
@@ -432,6 +460,7 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 if (NKEY > 0 && 32 * kt + 8 * g4 >= NKEY) { add[qt][kt][g4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // every key of the group is padding
+                if (NOTAB) { add[qt][kt][g4] = notab_add<NKEY>(kt, g4, hh); continue; }
                 add[qt][kt][g4] = *reinterpret_cast<const float4*>(bmq[qt] + 256 * ((kt * 4 + g4) * 2 + hh));      // (a half-padded group needs its -1e30s)
             }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -491,10 +520,10 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
         if (q < a.n && lsep && hh == 0) lsep[((int64_t)p * a.H + h) * 64 + q] = (m + __log2f(l)) * 0.6931471805599453f;
     }
     lds_fence();
-    const int64_t r0[2] = {trow[0] * a.ldo + h * WD, trow[1] * a.ldo + h * WD};
-    const int64_t r1[2] = {trow[2] * a.ldo + h * WD, trow[3] * a.ldo + h * WD};
-    flush_tile32(sQ, Op, r0, 0, a.n, lane);
-    flush_tile32(sK, Op, r1, 1, a.n, lane);
+    const int64_t r0[2] = {trow[0] * a.ldo + h * HW, trow[1] * a.ldo + h * HW};
+    const int64_t r1[2] = {trow[2] * a.ldo + h * HW, trow[3] * a.ldo + h * HW};
+    flush_tile32<D16>(sQ, Op, r0, 0, a.n, lane);
+    flush_tile32<D16>(sK, Op, r1, 1, a.n, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ bias + mask table
@@ -526,8 +555,10 @@ __global__ void win_table_kernel(const float* table, const int64_t* index, const
 }
 
 int fill(const stg_winattn_args* f, WinP& p, const char* who) {
-    STG_CHECK(f->Q && f->K && f->V && f->bm && f->bmT, -1, "%s: null pointer", who);
-    STG_CHECK(f->D == WD, -2, "%s: head dim must be 32", who);
+    STG_CHECK(f->Q && f->K && f->V, -1, "%s: null pointer", who);
+    STG_CHECK((f->bm == nullptr) == (f->bmT == nullptr), -1, "%s: bm and bmT go together (both NULL: no bias / mask, round 6)", who);
+    STG_CHECK(f->D == WD || (f->D == 16 && f->bm == nullptr), -2, "%s: head dim must be 32 (or 16 without a table)", who);
+    STG_CHECK(f->bm != nullptr || f->ws * f->ws == 49, -2, "%s: the table-free form is built for 7 x 7 windows", who);
     STG_CHECK(f->ws > 0 && f->n == f->ws * f->ws && f->n <= 64, -2, "%s: window must hold <= 64 tokens", who);
     STG_CHECK(f->Himg % f->ws == 0 && f->Wimg % f->ws == 0 && f->shift >= 0 && f->shift < f->ws, -2, "%s: bad window geometry", who);
     STG_CHECK(f->G == (f->Himg / f->ws) * (f->Wimg / f->ws) && (f->Gt == 1 || f->Gt == f->G), -2, "%s: bad G / Gt", who);
@@ -570,7 +601,9 @@ extern "C" int stg_winattn_fwd(const stg_winattn_args* f, void* stream) {
     if (rc) return rc;
     STG_CHECK(f->O && f->ldo % 8 == 0 && (((uintptr_t)f->O) & 15) == 0, -2, "stg_winattn_fwd: bad O (16-byte stores)");
     if (p.total == 0) return 0;
-    if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    if (!f->bm && f->D == 16) hipLaunchKernelGGL((winattn_fwd1_kernel<49, true, true>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (!f->bm) hipLaunchKernelGGL((winattn_fwd1_kernel<49, true, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (p.n == 49) hipLaunchKernelGGL(winattn_fwd1_kernel<49>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(winattn_fwd1_kernel<0>, dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();
     return 0;
@@ -584,14 +617,16 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     if (rc) return rc;
     // LT (the additive table staged once per workgroup of four same-(window, head) frames): measured on one box, bit-identical, stage 2 (16 heads)
     // 255.8 -> 242.5 us, stage 1 (8) 477 -> 461, stage 0 (4 heads) 905 -> 947: taken from 8 heads up
-    const bool lt = p.n == 49 && p.H >= 8;
+    const bool lt = p.n == 49 && p.H >= 8 && f->bm != nullptr;
     STG_CHECK(f->O && f->lse && dO && dQ && dK, -1, "stg_winattn_bwd: null pointer (dV == NULL -> dK receives dK + dV)");
     STG_CHECK(f->ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, -2, "stg_winattn_bwd: bad leading dims");
     STG_CHECK((((uintptr_t)f->O | (uintptr_t)dO) & 15) == 0 && (((uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15) == 0, -2,
               "stg_winattn_bwd: misaligned pointers");
     if (p.total == 0) return 0;
     p.dO = (const bf16_t*)dO; p.lddo = lddo; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV; p.lddqkv = lddqkv;
-    if (lt) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(lt_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
+    if (!f->bm && f->D == 16) hipLaunchKernelGGL((winattn_bwd1_kernel<49, false, true, true>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (!f->bm) hipLaunchKernelGGL((winattn_bwd1_kernel<49, false, true, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    else if (lt) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(lt_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     else if (p.n == 49) hipLaunchKernelGGL((winattn_bwd1_kernel<49, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((winattn_bwd1_kernel<0, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     STG_LAUNCH_CHECK();

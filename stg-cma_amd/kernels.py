@@ -1431,13 +1431,22 @@ class WinGeom:
     """One W-MSA / SW-MSA call over the fused qkv buffer: P = images * nW windows of n = ws*ws <= 64 tokens, head dim 32.
     bm / bmT come from winattn_table (bias + shift mask, padded to 64 x 64, times log2 e)."""
 
-    def __init__(self, images, H, Himg, Wimg, ws, shift, scale, bm, bmT):
+    def __init__(self, images, H, Himg, Wimg, ws, shift, scale, bm, bmT, D=32):
         self.Himg, self.Wimg, self.ws, self.shift = int(Himg), int(Wimg), int(ws), int(shift)
         self.G = (self.Himg // self.ws) * (self.Wimg // self.ws)
         self.n = self.ws * self.ws
-        self.P, self.H, self.scale = int(images) * self.G, int(H), float(scale)
+        self.P, self.H, self.scale, self.D = int(images) * self.G, int(H), float(scale), int(D)
         self.outer = self.Himg * self.Wimg
         self.bm, self.bmT = bm, bmT
+        if bm is None or bmT is None:                        # no bias, no mask (round 6): the window-level cross-modal pair; widths 32 and 16
+            if bm is not None or bmT is not None or self.n != 49 or self.D not in (16, 32):
+                raise RuntimeError("winattn: the table-free form takes bm = bmT = None, 7 x 7 windows and head dim 16 or 32")
+            self.Gt = 1
+            if self.Himg % self.ws or self.Wimg % self.ws or not 0 <= self.shift < self.ws:
+                raise RuntimeError("winattn: unsupported window geometry")
+            return
+        if self.D != 32:
+            raise RuntimeError("winattn: head dim 16 only without a table")
         for t in (bm, bmT):
             if t.dtype != F32 or not t.is_cuda or not t.is_contiguous() or t.dim() != 4 or tuple(t.shape[1:]) != (self.H, 64, 64) \
                     or t.shape[0] not in (1, self.G):
@@ -1449,7 +1458,10 @@ class WinGeom:
             raise RuntimeError("winattn: unsupported window geometry")
 
 
-def winattn_supported(n, hd):
+def winattn_supported(n, hd, table=True):
+    """table=False: the table-free form (no bias / mask): 7 x 7 windows, head dim 32 or 16."""
+    if not table:
+        return n == 49 and hd in (16, 32)
     return n <= 64 and hd == 32
 
 
@@ -1475,33 +1487,33 @@ def winattn_table(table, index, mask, n):
 def _win_fill(g, Q, K, V, O, lse):
     for t, name in ((Q, "Q"), (K, "K"), (V, "V"), (O, "O")):
         _chk2d(t, name, BF16)
-        if t.shape[1] < g.H * 32 or t.shape[0] < (g.P // g.G) * g.outer:
-            raise RuntimeError(f"winattn {name}: needs >= {(g.P // g.G) * g.outer} rows x {g.H * 32} columns, got {tuple(t.shape)}")
+        if t.shape[1] < g.H * g.D or t.shape[0] < (g.P // g.G) * g.outer:
+            raise RuntimeError(f"winattn {name}: needs >= {(g.P // g.G) * g.outer} rows x {g.H * g.D} columns, got {tuple(t.shape)}")
     if not (_ld(Q) == _ld(K) == _ld(V)):
         raise RuntimeError("winattn: Q, K, V must share one leading dimension (slices of the fused qkv buffer)")
     a = _lib.WinAttnArgs()
     a.Q, a.K, a.V, a.ld = _p(Q), _p(K), _p(V), _ld(Q)
     a.O, a.ldo = _p(O), _ld(O)
     a.lse = _p(lse)
-    a.bm, a.bmT, a.Gt = _p(g.bm), _p(g.bmT), g.Gt
+    a.bm, a.bmT, a.Gt = (_p(g.bm) if g.bm is not None else None), (_p(g.bmT) if g.bmT is not None else None), g.Gt
     a.outer = g.outer
     a.Himg, a.Wimg, a.ws, a.shift, a.G, a.n = g.Himg, g.Wimg, g.ws, g.shift, g.G, g.n
-    a.P, a.H, a.D, a.scale = g.P, g.H, 32, g.scale
+    a.P, a.H, a.D, a.scale = g.P, g.H, g.D, g.scale
     return a
 
 
-@_family("winattn_fwd", lambda g, Q, *a, **kw: (g.H * 32, 8.0 * (g.P // g.G) * g.outer * g.H * 32, 4.0 * g.P * g.H * g.n * g.n * 32))
+@_family("winattn_fwd", lambda g, Q, *a, **kw: (g.H * g.D, 8.0 * (g.P // g.G) * g.outer * g.H * g.D, 4.0 * g.P * g.H * g.n * g.n * g.D))
 def winattn_fwd(g, Q, K, V, out=None, want_lse=True):
     """Returns (O bf16 [rows, H*32], lse fp32 [P, H, 64] or None)."""
     if out is None:
-        out = torch.empty((Q.shape[0], g.H * 32), dtype=BF16, device=Q.device)
+        out = torch.empty((Q.shape[0], g.H * g.D), dtype=BF16, device=Q.device)
     lse = torch.empty((g.P, g.H, 64), dtype=F32, device=Q.device) if want_lse else None
     a = _win_fill(g, Q, K, V, out, lse)
     _lib.check(_lib.lib().stg_winattn_fwd(C.byref(a), _stream()), "stg_winattn_fwd")
     return out, lse
 
 
-@_family("winattn_bwd", lambda g, Q, *a, **kw: (g.H * 32, 16.0 * (g.P // g.G) * g.outer * g.H * 32, 10.0 * g.P * g.H * g.n * g.n * 32))
+@_family("winattn_bwd", lambda g, Q, *a, **kw: (g.H * g.D, 16.0 * (g.P // g.G) * g.outer * g.H * g.D, 10.0 * g.P * g.H * g.n * g.n * g.D))
 def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     """dQ / dK / dV: column slices of one bf16 buffer (same leading dimension), written in place."""
     if lse is None or lse.dtype != F32 or lse.numel() != g.P * g.H * 64:
@@ -1509,8 +1521,8 @@ def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     rows = (g.P // g.G) * g.outer
     for t, name in ((dO, "dO"), (dQ, "dQ"), (dK, "dK")) + (((dV, "dV"),) if dV is not None else ()):      # dV None: K is V, dK <- dK + dV
         _chk2d(t, name, BF16)
-        if t.shape[1] < g.H * 32 or t.shape[0] < rows:
-            raise RuntimeError(f"winattn_bwd {name}: needs >= {rows} rows x {g.H * 32} columns")
+        if t.shape[1] < g.H * g.D or t.shape[0] < rows:
+            raise RuntimeError(f"winattn_bwd {name}: needs >= {rows} rows x {g.H * g.D} columns")
     if not (_ld(dQ) == _ld(dK) == (_ld(dV) if dV is not None else _ld(dK))):
         raise RuntimeError("winattn_bwd: dQ, dK, dV must share one leading dimension")
     a = _win_fill(g, Q, K, V, O, lse)

@@ -509,19 +509,13 @@ def _xattn_geom(spec, BT, dh, window, g):
 
 USE_XWIN = _cfg.opt("xwin")     # 0 = window-level cross-modal attention on the generic kernels (A/B knob)
 USE_MHA_WIN = _cfg.opt("mha_win")   # 0 = WIDE (d_h = 64 / 96) window-level cross-modal attention on the generic kernels (A/B knob)
-_xwin_tabs = {}
 
 
-def _xwin_geom(spec, BT, dev):
-    """The window-level cross-modal pair on the whole-window kernels of winattn.hip: one head of width 32, K = V = the other
-    modality's hidden states, scale 1, no bias and no shift mask (an all-zero additive table, -1e30 on the padding keys)."""
-    n = spec.ws * spec.ws
-    key = (dev, spec.ws)
-    tabs = _xwin_tabs.get(key)
-    if tabs is None:
-        L = (2 * spec.ws - 1) ** 2
-        tabs = _xwin_tabs[key] = K.winattn_table(torch.zeros((L, 1), dtype=F32, device=dev), torch.zeros(n * n, dtype=torch.int64, device=dev), None, n)
-    return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, tabs[0], tabs[1])
+def _xwin_geom(spec, BT, dev, dh=32):
+    """The window-level cross-modal pair on the whole-window kernels of winattn.hip: one head of width 32 or 16, K = V = the other
+    modality's hidden states, scale 1, no bias and no shift mask (round 6: the table-free form -- the kernels synthesise the -1e30 of the
+    padding keys; rounds 2-5 fetched an all-zero 16 KiB table per window)."""
+    return K.WinGeom(BT, 1, spec.H, spec.W, spec.ws, spec.shift, 1.0, None, None, D=dh)
 
 
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
@@ -572,8 +566,8 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         mg = K.MhaGeom(BT * spec.nW, 1, spec.ws * spec.ws, hv.shape[1], 1.0, window=(spec.H, spec.W, spec.ws, spec.shift))
         (rv, lse_v), (ra, lse_a) = _mha_pair_fwd(mg, hv, ha)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
-    if geoms is None and window and USE_WINATTN and USE_XWIN and hv.shape[1] == 32 and K.winattn_supported(spec.ws * spec.ws, 32):
-        wg = _xwin_geom(spec, BT, hv.device)
+    if geoms is None and window and USE_WINATTN and USE_XWIN and K.winattn_supported(spec.ws * spec.ws, hv.shape[1], table=False):
+        wg = _xwin_geom(spec, BT, hv.device, hv.shape[1])      # d_h = 32, and since round 6 d_h = 16 (Swin-B stage 0: was on the generic kernels)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)

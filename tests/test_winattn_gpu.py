@@ -151,3 +151,66 @@ def test_window_shared_kv_single_head_sums_dk_dv(stg, gpu):
     dq_g, dkv_g, _ = k.attn_bwd(ag, q, kv, kv, O2, lse2, dO, shared_kv=True)
     _close(dQ2.float() / scale, dq_g.float() / scale, tol=1.5e-2, what="dQ vs generic")
     _close(dKV.float() / scale, dkv_g.float() / scale, tol=1.5e-2, what="dK + dV vs generic")
+
+
+def _window_index(F, Hi, Wi, ws, shift):
+    """rows of the [F * Hi * Wi] token tensor in window order: [F * nW, ws * ws] (torch.roll by -shift, then window_partition:
+    Swin_AVE.py:151-165 / :262-266 -- window (wi, wj) token (ti, tj) sits at ((wi ws + ti + shift) % Hi, (wj ws + tj + shift) % Wi))."""
+    f, wi, wj, ti, tj = torch.meshgrid(torch.arange(F), torch.arange(Hi // ws), torch.arange(Wi // ws), torch.arange(ws), torch.arange(ws),
+                                       indexing="ij")
+    y = (wi * ws + ti + shift) % Hi
+    x = (wj * ws + tj + shift) % Wi
+    return (f * Hi * Wi + y * Wi + x).reshape(F * (Hi // ws) * (Wi // ws), ws * ws)
+
+
+@pytest.mark.parametrize("images,Himg,shift", [(3, 14, 3), (5, 28, 0), (2, 56, 3), (1, 7, 0)])
+def test_window_cross_modal_table_free_and_16_wide(stg, gpu, images, Himg, shift):
+    """Round 6: the window-level cross-modal pair without its dummy table (bm = bmT = None: the kernels synthesise the padding keys' -1e30) and at
+    head dim 16 (Swin-B stage 0; 32-byte rows staged beside a zero line).  (i) D = 32 table-free == the all-zero-table run, bit for bit;
+    (ii) D = 16 == the same problem zero-padded to 32 columns on the D = 32 kernels, bit for bit (the padded columns multiply zeros), nothing
+    written beside the 16 columns; (iii) D = 16 against the fp32 softmax(q kv^T) kv of every window and its autograd gradients."""
+    from stgcma import kernels as k
+    ws = 7
+    n, N = ws * ws, Himg * Himg
+    g = torch.Generator().manual_seed(40 + Himg + shift)
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # (i)
+    q32 = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    kv32 = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    dO32 = torch.randn(images * N, 32, generator=g).to(BF16).to(gpu)
+    bm, bmT = k.winattn_table(torch.zeros(((2 * ws - 1) ** 2, 1), device=gpu), torch.zeros(n * n, dtype=torch.int64, device=gpu), None, n)
+    wz = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, bm, bmT)
+    wf = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, None, None)
+    O0, l0 = k.winattn_fwd(wz, q32, kv32, kv32)
+    O1, l1 = k.winattn_fwd(wf, q32, kv32, kv32)
+    assert eq(O0, O1) and torch.equal(l0[..., :n], l1[..., :n])
+    a0, b0, a1, b1 = (torch.full_like(q32, float("nan")) for _ in range(4))
+    k.winattn_bwd(wz, q32, kv32, kv32, O0, l0, dO32, dQ=a0, dK=b0, dV=None)
+    k.winattn_bwd(wf, q32, kv32, kv32, O1, l1, dO32, dQ=a1, dK=b1, dV=None)
+    assert eq(a0, a1) and eq(b0, b1)
+    # (ii) + (iii)
+    q16, kv16, dO16 = (torch.randn(images * N, 16, generator=g) * 0.7).to(BF16), (torch.randn(images * N, 16, generator=g) * 0.7).to(BF16), torch.randn(images * N, 16, generator=g).to(BF16)
+    pad = lambda t: torch.nn.functional.pad(t, (0, 16)).contiguous()
+    w16 = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, None, None, D=16)
+    wide = torch.full((images * N, 24), float("nan"), dtype=BF16, device=gpu)          # the 16-wide output is a column slice: columns 16.. must stay untouched
+    O16, l16 = k.winattn_fwd(w16, q16.to(gpu), kv16.to(gpu), kv16.to(gpu), out=wide[:, :16])
+    Op, lp = k.winattn_fwd(wf, pad(q16).to(gpu), pad(kv16).to(gpu), pad(kv16).to(gpu))
+    assert eq(O16.contiguous(), Op[:, :16].contiguous()) and torch.equal(l16[..., :n], lp[..., :n])
+    assert torch.isnan(wide[:, 16:].float()).all() and float(Op[:, 16:].float().abs().max()) == 0.0
+    gq = torch.full((images * N, 24), float("nan"), dtype=BF16, device=gpu)
+    gk = torch.full((images * N, 24), float("nan"), dtype=BF16, device=gpu)
+    k.winattn_bwd(w16, q16.to(gpu), kv16.to(gpu), kv16.to(gpu), O16, l16, dO16.to(gpu), dQ=gq[:, :16], dK=gk[:, :16], dV=None)
+    pq, pk = torch.full((images * N, 32), float("nan"), dtype=BF16, device=gpu), torch.full((images * N, 32), float("nan"), dtype=BF16, device=gpu)
+    k.winattn_bwd(wf, pad(q16).to(gpu), pad(kv16).to(gpu), pad(kv16).to(gpu), Op, lp, pad(dO16).to(gpu), dQ=pq, dK=pk, dV=None)
+    assert eq(gq[:, :16].contiguous(), pq[:, :16].contiguous()) and eq(gk[:, :16].contiguous(), pk[:, :16].contiguous())
+    assert torch.isnan(gq[:, 16:].float()).all() and torch.isnan(gk[:, 16:].float()).all()
+    idx = _window_index(images, Himg, Himg, ws, shift)                                 # [images * nW, n] rows in window order
+    xq, xk = q16.float().requires_grad_(True), kv16.float().requires_grad_(True)
+    S = torch.einsum("wid,wjd->wij", xq[idx], xk[idx])
+    R = torch.softmax(S, -1) @ xk[idx]
+    out = torch.zeros(images * N, 16).index_put((idx.reshape(-1),), R.reshape(-1, 16))
+    _close(O16, out, what="O (16 wide)")
+    (out * dO16.float()).sum().backward()
+    sc = float(max(xq.grad.abs().max(), xk.grad.abs().max()))
+    _close(gq[:, :16].float() / sc, xq.grad / sc, tol=1.5e-2, what="dQ (16 wide)")
+    _close(gk[:, :16].float() / sc, xk.grad / sc, tol=1.5e-2, what="dK + dV (16 wide)")
