@@ -405,6 +405,13 @@ int stg_mha_bwd(const stg_mha_args* a, const void* dO, int64_t lddo, void* dQ, v
 int stg_mha_fwd_pair(const stg_mha_args* a0, const stg_mha_args* a1, void* stream);
 int stg_mha_bwd_pair(const stg_mha_args* a0, const void* dO0, void* dQ0, void* dK0, void* dV0, float* delta0, const stg_mha_args* a1,
                      const void* dO1, void* dQ1, void* dK1, void* dV1, float* delta1, int64_t lddo, int64_t lddqkv, void* stream);
+/* ABI 219: the backward of a cross-modal PAIR as one pass per modality (Swin_AVE.py:796-811 / :750-760 with d_h 64 / 96): direction 0 = (Q = X, K = V = Y),
+ * direction 1 = (Q = Y, K = V = X) -- the same two tensors with their roles swapped (checked: -7 otherwise).  Both directions share S = X Y^T, so
+ * G0 = d loss / d X = dQ of direction 0 + dK + dV of direction 1 (and G1 for Y) costs three score-type and two output-type products per tile pair
+ * instead of the four + six of stg_mha_bwd_pair, which it replaces together with the caller's dQ + dKV addition.  delta0 / delta1: fp32 [P, H, n]
+ * workspaces (filled here).  G0 / G1 bf16 with leading dimension lddg. */
+int stg_mha_bwd_pair_merged(const stg_mha_args* a0, const void* dO0, void* G0, float* delta0, const stg_mha_args* a1, const void* dO1,
+                            void* G1, float* delta1, int64_t lddo, int64_t lddg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels

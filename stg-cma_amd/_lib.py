@@ -177,6 +177,7 @@ SIGNATURES = {
     "stg_mha_bwd": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_mha_fwd_pair": (C.c_int, [C.POINTER(MhaArgs), C.POINTER(MhaArgs), c_vp]),
     "stg_mha_bwd_pair": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "stg_mha_bwd_pair_merged": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_vp, c_vp, C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_im2col_patch": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),

@@ -574,6 +574,180 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_dkv2_kernel(MP a
     }
 }
 
+// ------------------------------------------------------------------------------------------------ merged pair backward (round 6)
+// The BACKWARD of a cross-modal pair (K == V in both directions, direction x: queries X, keys = values Y; direction y the mirror image) as ONE pass
+// per modality instead of dQ + (dK + dV) passes per direction.  Both directions share the score matrix S = X Y^T (x normalises its rows, y its
+// columns), and the gradient of a modality's rows is
+//     G_x[i] = dQ^x[i] + dK^y[i] + dV^y[i] = scale sum_j (dS^x[i, j] + dS^y[j, i]) Y[j] + sum_j P^y[j, i] dO_y[j],
+//     dS^x = P^x o (dO_x Y^T - delta_x[i]),     dS^y[j, i] = P^y[j, i] (dO_y[j] . X[i] - delta_y[j]),
+// so per 32-key tile a wave of 32 rows i needs THREE score-type products (S, dO_x Y^T, dO_y X^T: the first two share the Y fragments) and TWO
+// output-type products (the two dS folded into ONE operand before the product with Y^T; P^y with dO_y^T): 3 KS + 4 DT MFMAs = 30 at D = 96, where
+// dQ (2 KS + 2 DT = 18) + dK / dV (2 KS + 4 DT = 24) spend 42 and read 36 KB of LDS fragments instead of 24.  Staging is mha_dkv2_kernel's (the other
+// modality's rows Y and dO_y in 64-row tiles + its lse / delta), accumulators are mha_dq2_kernel's.  delta of both directions comes from
+// mha_delta_kernel (each pass needs the OTHER direction's, which no block of this launch could have produced in time).
+template <int D>
+__global__ void __launch_bounds__(256) mha_delta_kernel(MP a) {
+    // one 8-lane group per (problem, head, token): delta = sum_d dO[row][h D + d] O[row][h D + d]; blockIdx.y = direction
+    const bool second = blockIdx.y != 0;
+    const bf16_t* O = second ? a.O1 : a.O;
+    const bf16_t* dO = second ? a.dO1 : a.dO;
+    float* del = second ? a.delta1 : a.delta;
+    const int64_t total = (int64_t)a.P * a.H * a.n;
+    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int l = threadIdx.x & 7;
+    if (item >= total) return;                             // whole 8-lane groups leave together (the shuffles below stay inside a group)
+    const int tok = (int)(item % a.n);
+    const int64_t ph = item / a.n;
+    const int h = (int)(ph % a.H), p = (int)(ph / a.H);
+    const int64_t row = mrow(a, p, tok);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < (D / 8 + 7) / 8; ++c) {
+        const int ch = l + 8 * c;
+        if (ch < D / 8) {
+            const bf16x8_t x = ld_frag(dO + row * a.lddo + h * D + 8 * ch), y = ld_frag(O + row * a.ldo + h * D + 8 * ch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)x[j]) * bf2f((bf16_t)y[j]);
+        }
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (l == 0) del[item] = d;
+}
+
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_bwdm_kernel(MP a) {
+    constexpr int KS = D / 16, DT = D / 32, DP = D + 8;
+    using SC = StageC<D, 2, NW, 64>;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];      // two buffers of {Y and dO_y tiles of 64 rows + 128 floats of statistics}
+    constexpr int BUF = 2 * 64 * DP + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qb = blockIdx.x, h = blockIdx.y;
+    const bool second = (int)blockIdx.z >= a.P;                        // block-uniform: which modality's rows this block owns
+    const int p = second ? blockIdx.z - a.P : blockIdx.z;
+    const bf16_t* X = second ? a.Q1 : a.Q;
+    const bf16_t* Y = second ? a.K1 : a.K;
+    const bf16_t* dOx = second ? a.dO1 : a.dO;
+    const bf16_t* dOy = second ? a.dO : a.dO1;
+    const float* lse_x = second ? a.lse1 : a.lse;
+    const float* lse_y = second ? a.lse : a.lse1;
+    const float* del_x = second ? a.delta1 : a.delta;
+    const float* del_y = second ? a.delta : a.delta1;
+    bf16_t* G = second ? a.dQ1 : a.dQ;
+    const int q = 32 * (qb * NW + wave) + r;
+    const bool live = 32 * (qb * NW + wave) < a.n;
+    const int qc = q < a.n ? q : a.n - 1;
+    bf16x8_t xf[KS], dxf[KS];
+    {
+        const bf16_t* xp = X + mrow(a, p, qc) * a.ld + h * D + 8 * hh;
+        const bf16_t* dp = dOx + mrow(a, p, qc) * a.lddo + h * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { xf[s] = ld_frag(xp + 16 * s); dxf[s] = ld_frag(dp + 16 * s); }
+    }
+    const int64_t sbase = ((int64_t)p * a.H + h) * a.n;
+    const float nlse_q = -lse_x[sbase + qc], ndel_q = -del_x[sbase + qc];
+    const bool unit_scale = a.scale == 1.0f;               // (block-uniform) the cross-modal pairs run with scale 1
+    f32x16_t g[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) g[dt] = zero16();
+
+    int lo[SC::PER], sc_[SC::PER], rw[SC::PER];
+    u32x4_t sv[SC::PER];
+    stage_plan<D, 2, NW, 64>(tid, h, lo, sc_, rw);
+    float nl = 0.f, nd = 0.f;
+    auto fetch_stats = [&](int j0) {
+        if (tid < 64) {
+            int j = j0 + tid;
+            j = j < a.n ? j : a.n - 1;
+            nl = -lse_y[sbase + j];                          // stored NEGATED: the exponent is one fma, exp2(s scale2 - lse)
+            nd = del_y[sbase + j];
+        }
+    };
+    auto commit_all = [&](bf16_t* buf) {
+        stage_commit<D, 2, NW, 64>(buf, sv, lo, rw);
+        float* st = reinterpret_cast<float*>(buf + 2 * 64 * DP);
+        if (tid < 64) { st[tid] = nl; st[64 + tid] = nd; }
+    };
+    stage_fetch<D, 2, NW, 64>(sv, sc_, rw, Y, a.ld, dOy, a.lddo, a, p, a.n, 0);
+    fetch_stats(0);
+    commit_all(smem);
+    __syncthreads();
+    const int np = (a.nt + 1) >> 1;
+    for (int kp = 0; kp < np; ++kp) {
+        const bf16_t* sY = smem + (kp & 1) * BUF;
+        const bf16_t* sD = sY + 64 * DP;
+        const float* sLse = reinterpret_cast<const float*>(sY + 2 * 64 * DP);
+        const float* sDel = sLse + 64;
+        if (kp + 1 < np) {
+            stage_fetch<D, 2, NW, 64>(sv, sc_, rw, Y, a.ld, dOy, a.lddo, a, p, a.n, 64 * (kp + 1));
+            fetch_stats(64 * (kp + 1));
+        }
+        if (live) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {             // the two 32-row tiles of the trip, one after the other (register budget)
+            const int jbase = 64 * kp + 32 * half;
+            if (jbase >= a.n) continue;                     // (wave-uniform) an all-padding tile contributes nothing
+            const bf16_t* tY = sY + half * 32 * DP;
+            const bf16_t* tD = sD + half * 32 * DP;
+            const bool tail = jbase + 32 > a.n;             // (wave-uniform) only the frame's last tile masks its padded rows
+            f32x16_t st = zero16(), dpx, dpy = zero16();    // S^T[j][i], (dO_x Y^T)^T[j][i] - delta_x[i] (the MFMA's C operand starts there), (dO_y X^T)[j][i]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dpx[i] = ndel_q;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8_t yf = nat_frag<DP>(tY, r, hh, s);
+                st = MFMA32(yf, xf[s], st);
+                dpx = MFMA32(yf, dxf[s], dpx);
+                dpy = MFMA32(nat_frag<DP>(tD, r, hh, s), xf[s], dpy);
+            }
+            float ds[16], py[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 ls = *reinterpret_cast<const float4*>(sLse + 32 * half + 8 * g4 + 4 * hh);
+                const float4 de = *reinterpret_cast<const float4*>(sDel + 32 * half + 8 * g4 + 4 * hh);
+                const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int reg = 4 * g4 + c;
+                    float px = __builtin_amdgcn_exp2f(fmaf(st[reg], a.scale2, nlse_q));     // P^x[i, j]: direction x normalises over j
+                    float pv = __builtin_amdgcn_exp2f(fmaf(st[reg], a.scale2, lsv[c]));     // P^y[j, i]: direction y normalises over i (lsv = -lse_y[j])
+                    if (tail && jbase + 8 * g4 + 4 * hh + c >= a.n) { px = 0.f; pv = 0.f; }  // padded rows j contribute nothing
+                    py[reg] = pv;
+                    const float d = fmaf(px, dpx[reg], pv * (dpy[reg] - dev[c]));
+                    ds[reg] = unit_scale ? d : d * a.scale;
+                }
+            }
+            const bf16x8_t d0 = pack8(ds), d1 = pack8(ds + 8), p0 = pack8(py), p1 = pack8(py + 8);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                g[dt] = MFMA32(tr_frag<DP>(tY, dt, 0, hh, r), d0, g[dt]);
+                g[dt] = MFMA32(tr_frag<DP>(tY, dt, 1, hh, r), d1, g[dt]);
+                g[dt] = MFMA32(tr_frag<DP>(tD, dt, 0, hh, r), p0, g[dt]);
+                g[dt] = MFMA32(tr_frag<DP>(tD, dt, 1, hh, r), p1, g[dt]);
+            }
+        }
+        }
+        if (kp + 1 < np) commit_all(smem + ((kp + 1) & 1) * BUF);
+        __syncthreads();
+    }
+    {
+        bf16_t* op = G + mrow(a, p, q) * a.lddqkv + h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) store_tile32(op + 32 * dt, g[dt], 1.0f, hh, q < a.n);
+    }
+}
+
+constexpr int bwdm_lds_bytes(int D) { return 2 * (2 * 64 * (D + 8) + 256) * 2; }
+template <int D, int NW>
+int launch_bwdm(const dim3& grid, const MP& p, hipStream_t stream) {
+    static std::atomic<uint64_t> done{0};
+    STG_CHECK(stg_reserve_lds(mha_bwdm_kernel<D, NW>, bwdm_lds_bytes(D), done), -101, "stg_mha_bwd_pair_merged: cannot reserve %d bytes of LDS", bwdm_lds_bytes(D));
+    hipLaunchKernelGGL((mha_bwdm_kernel<D, NW>), grid, dim3(NW * 64), bwdm_lds_bytes(D), stream, p);
+    return 0;
+}
+
 constexpr int dkv_lds_bytes(int D, bool kv1, int nw) { return (2 * (2 * 32 * (D + 8) + 128) + nw * (kv1 ? 1 : 2) * 32 * (D + 8)) * 2; }
 
 template <int D, bool KV1, int NW>
@@ -749,4 +923,40 @@ extern "C" int stg_mha_bwd_pair(const stg_mha_args* f0, const void* dO0, void* d
         return r0 ? r0 : mha_bwd_impl(f1, dO1, dQ1, dK1, dV1, delta1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lddo, lddqkv, stream);
     }
     return mha_bwd_impl(f0, dO0, dQ0, dK0, dV0, delta0, f1, dO1, dQ1, dK1, dV1, delta1, lddo, lddqkv, stream);
+}
+
+// The merged backward of a cross-modal pair (see mha_bwdm_kernel): direction 0 = (Q = X, K = V = Y), direction 1 = (Q = Y, K = V = X) -- the SAME two
+// tensors with their roles swapped (checked).  G0 / G1: the whole gradient of X / of Y (dQ of its own direction + dK + dV of the other).
+extern "C" int stg_mha_bwd_pair_merged(const stg_mha_args* f0, const void* dO0, void* G0, float* delta0, const stg_mha_args* f1, const void* dO1,
+                                       void* G1, float* delta1, int64_t lddo, int64_t lddg, void* stream) {
+    STG_CHECK(f0 && f1 && dO0 && dO1 && G0 && G1 && delta0 && delta1, -1, "stg_mha_bwd_pair_merged: null pointer");
+    int rc = mha_pair_ok(f0, f1, "stg_mha_bwd_pair_merged");
+    if (rc) return rc;
+    STG_CHECK(f0->K == f0->V && f1->K == f1->V && f0->Q == f1->K && f1->Q == f0->K, -7,
+              "stg_mha_bwd_pair_merged: needs a cross pair (K == V, and each direction's keys are the other's queries)");
+    STG_CHECK(2 * f0->P < 65536, -7, "stg_mha_bwd_pair_merged: too many problems for one launch");
+    STG_CHECK(lddo % 8 == 0 && lddg % 8 == 0 && ((((uintptr_t)dO0 | (uintptr_t)dO1 | (uintptr_t)G0 | (uintptr_t)G1)) & 15) == 0, -2, "stg_mha_bwd_pair_merged: misaligned operands");
+    MP p = {}, q = {};
+    rc = fill(f0, p, "stg_mha_bwd_pair_merged");
+    if (rc) return rc;
+    rc = fill(f1, q, "stg_mha_bwd_pair_merged");
+    if (rc) return rc;
+    if (p.P == 0) return 0;
+    p.dO = (const bf16_t*)dO0; p.lddo = lddo; p.dQ = (bf16_t*)G0; p.lddqkv = lddg; p.delta = delta0;
+    p.Q1 = q.Q; p.K1 = q.K; p.V1 = q.V; p.O1 = q.O; p.lse1 = q.lse; p.delta1 = delta1;
+    p.dO1 = (const bf16_t*)dO1; p.dQ1 = (bf16_t*)G1;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t items = (int64_t)p.P * p.H * p.n;
+    const dim3 gd((unsigned)((items * 8 + 255) / 256), 2);
+    if (f0->D == 64) hipLaunchKernelGGL(mha_delta_kernel<64>, gd, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(mha_delta_kernel<96>, gd, dim3(256), 0, st, p);
+    STG_LAUNCH_CHECK();
+    const int nw = p.nt > 4 ? 8 : 4;
+    const dim3 grid((p.nt + nw - 1) / nw, p.H, 2 * p.P);
+#define STG_BWDM(DD) { if (nw == 8) rc = launch_bwdm<DD, 8>(grid, p, st); else rc = launch_bwdm<DD, 4>(grid, p, st); }
+    if (f0->D == 64) STG_BWDM(64) else STG_BWDM(96)
+#undef STG_BWDM
+    if (rc) return rc;
+    STG_LAUNCH_CHECK();
+    return 0;
 }

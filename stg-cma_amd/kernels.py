@@ -1032,6 +1032,28 @@ def mul_mask(a, mask):
     return out
 
 
+@_family("mha_bwd", lambda g, *a, **kw: tuple(x if i == 0 else 2 * x for i, x in enumerate(_attn_cost(g, 5, 3, 5))))
+def mha_bwd_pair_merged(g, p0, p1):
+    """The backward of a cross-modal pair as one pass per modality (stg_mha_bwd_pair_merged): p0 = (X, Y, O0, lse0, dO0) is direction 0 (queries X,
+    keys = values Y), p1 = (Y, X, O1, lse1, dO1) its mirror image -- the same two tensors.  Returns (G_X, G_Y) = the whole gradients of X and Y
+    (dQ of a tensor's own direction + dK + dV of the other).  Accounted like the two-direction mha_bwd_pair it replaces (same algorithmic work)."""
+    (X, Y, O0, l0, d0), (Y1, X1, O1, l1, d1) = p0, p1
+    if X.data_ptr() != X1.data_ptr() or Y.data_ptr() != Y1.data_ptr():
+        raise RuntimeError("mha_bwd_pair_merged: the two directions must be the same two tensors with their roles swapped")
+    for t, name in ((d0, "dO0"), (d1, "dO1")):
+        _chk2d(t, name, BF16)
+    if _ld(d0) != _ld(d1):
+        raise RuntimeError("mha_bwd_pair_merged: dO0 and dO1 must share one leading dimension")
+    G0 = torch.empty((X.shape[0], g.H * g.D), dtype=BF16, device=X.device)
+    G1 = torch.empty((Y.shape[0], g.H * g.D), dtype=BF16, device=X.device)
+    dl0 = torch.empty((g.P, g.H, g.n), dtype=F32, device=X.device)
+    dl1 = torch.empty((g.P, g.H, g.n), dtype=F32, device=X.device)
+    a0, a1 = _mha_fill(g, X, Y, Y, O0, l0), _mha_fill(g, Y, X, X, O1, l1)
+    _lib.check(_lib.lib().stg_mha_bwd_pair_merged(C.byref(a0), _p(d0), _p(G0), _p(dl0), C.byref(a1), _p(d1), _p(G1), _p(dl1), _ld(d0), _ld(G0), _stream()),
+               "stg_mha_bwd_pair_merged")
+    return G0, G1
+
+
 @_family_io("patch_embed")
 def im2col_patch(x, p, Kpad):
     """x: [B, Cin, T, H, W] fp32/bf16 contiguous -> [B*T*(H/p)*(W/p), Kpad] bf16."""

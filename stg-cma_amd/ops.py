@@ -545,6 +545,7 @@ def _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs):
 
 
 MHA_PAIR = _cfg.opt("mha_pair")     # 0 = one mha launch per direction of a cross-modal pair (A/B knob)
+MHA_MERGED = _cfg.opt("mha_merged")  # 0 = the wide frame-global pair's backward as dQ + dK/dV passes per direction (rounds 1-5)
 
 
 def _mha_pair_fwd(mg, hv, ha):
@@ -607,6 +608,18 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     if dgate_a is None:
         dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
     drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
+    if mg is not None and MHA_MERGED and mg.window[2] == 0 and hv.stride(0) == ha.stride(0) and rv.stride(0) == ra.stride(0) and drv.stride(0) == dra.stride(0) \
+            and 2 * mg.P < 65536:
+        # round 6: frame-global pairs of wide adapters -- one pass per modality over the pair's shared score tiles (mha.hip mha_bwdm_kernel): G = dQ of a
+        # tensor's own direction + dK + dV of the other (3 136-token frames at d_h = 96: 8.9 -> 7.1 ms per pair; the 49-token WINDOW pairs measured
+        # 13 % slower on it and keep the two-direction path)
+        G_v, G_a = K.mha_bwd_pair_merged(mg, (hv, ha, rv, lse_v, drv), (ha, hv, ra, lse_a, dra))
+        if zs is None:
+            return K.add(dhv2, G_v), K.add(dha2, G_a)
+        if PAIR_EW and dhv2.shape == dha2.shape:
+            return K.add3_mul2(dhv2, G_v, None, zs[0], dha2, G_a, None, zs[1], outs=outs)
+        return K.add3_mul(dhv2, G_v, torch.zeros_like(G_v), zs[0], out=None if outs is None else outs[0]), \
+            K.add3_mul(dha2, G_a, torch.zeros_like(G_a), zs[1], out=None if outs is None else outs[1])
     if mg is not None:
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         if MHA_PAIR and hv.stride(0) == ha.stride(0) and rv.stride(0) == ra.stride(0) and drv.stride(0) == dra.stride(0):

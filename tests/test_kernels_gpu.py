@@ -866,6 +866,8 @@ def test_counted_wait_and_path_switch_kernels_repeat_2000(stg, gpu):
             K.mha_bwd_pair(mg, (hq, hk, hk, r0, l0, d0, g0, g1, None), (hk, hq, hq, r1, l1, d1, g2, g3, None))
             return g0, g1, g2, g3
         stress(f"mha_bwd_pair n={mg.n}", bwd, reps=reps)
+        if mg.window[2] == 0:                                        # round 6: the merged pass (double-buffered staging + statistics behind one barrier per trip)
+            stress(f"mha_bwd_pair_merged n={mg.n}", lambda: K.mha_bwd_pair_merged(mg, (hq, hk, r0, l0, d0), (hk, hq, r1, l1, d1)), reps=reps)
     xc, dyc = bf(3 * 28 * 28, 64), bf(3 * 28 * 28, 256)
     stress("conv3x3_wgrad 64 -> 256", lambda: (K.conv3x3_wgrad(dyc, xc, 3, 28, 28, 3),))
     xc2, dyc2 = bf(2 * 14 * 14, 320), bf(2 * 14 * 14, 256)

@@ -188,3 +188,44 @@ def test_mha_pair_launch_equals_two_launches(stg, gpu, D, n, window):
     k.mha_bwd_pair(geo, (hv, ha, ha, rv, lv, d0, pair[0], pair[1], None), (ha, hv, hv, ra, la, d1, pair[2], pair[3], None))
     for a, b in zip(single, pair):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,n,window", [(96, 196, None), (64, 49, (14, 14, 7, 3)), (96, 49, (14, 14, 7, 0)), (96, 3136, None), (96, 97, None), (64, 130, None)])
+def test_mha_pair_merged_backward(stg, gpu, D, n, window):
+    """Round 6: stg_mha_bwd_pair_merged -- the backward of a cross-modal pair as ONE pass per modality (the two directions share S = X Y^T; G_X = dQ of
+    X's own direction + dK + dV of the other) -- against the fp32 autograd gradients of the pair and against the two-direction path it replaces
+    (mha_bwd_pair: dQ + dKV summed in fp32): frame-global and window-mapped problems, ragged token counts, both head dims."""
+    from stgcma import kernels as k
+    P = 2 if n > 1000 else 3
+    g = torch.Generator().manual_seed(7 * n + D)
+    if window is not None:
+        Hi, Wi, ws, shift = window
+        F = P
+        rows = F * Hi * Wi
+        idx = _window_index(F, Hi, Wi, ws, shift)                                   # [F * nW, n] rows
+        geo = k.MhaGeom(idx.shape[0], 1, n, D, 1.0, window=window)
+    else:
+        rows = P * n
+        idx = torch.arange(rows).view(P, n)
+        geo = k.MhaGeom(P, 1, n, D, 1.0)
+    xb = (torch.randn(rows, D, generator=g) * 0.35).to(BF16)
+    yb = (torch.randn(rows, D, generator=g) * 0.35).to(BF16)
+    dxo, dyo = torch.randn(rows, D, generator=g).to(BF16), torch.randn(rows, D, generator=g).to(BF16)
+    x, y = xb.float().requires_grad_(True), yb.float().requires_grad_(True)
+    S = torch.einsum("pid,pjd->pij", x[idx], y[idx])
+    rx = torch.softmax(S, 2) @ y[idx]                                               # direction 0: queries X, keys = values Y
+    ry = torch.softmax(S.transpose(1, 2), 2) @ x[idx]                               # direction 1: queries Y, keys = values X
+    ((rx * dxo.float()[idx]).sum() + (ry * dyo.float()[idx]).sum()).backward()
+    X, Y, dX, dY = xb.to(gpu), yb.to(gpu), dxo.to(gpu), dyo.to(gpu)
+    (r0, l0), (r1, l1) = k.mha_fwd_pair(geo, (X, Y, Y), (Y, X, X))
+    G0, G1 = k.mha_bwd_pair_merged(geo, (X, Y, r0, l0, dX), (Y, X, r1, l1, dY))
+    a0, a1, b0, b1 = (torch.full_like(X, float("nan")) for _ in range(4))
+    k.mha_bwd_pair(geo, (X, Y, Y, r0, l0, dX, a0, a1, None), (Y, X, X, r1, l1, dY, b0, b1, None))
+    two0, two1 = a0.float() + b1.float(), b0.float() + a1.float()                   # dQ0 + dKV1 -> X ; dQ1 + dKV0 -> Y
+    torch.cuda.synchronize()
+    for got, two, ref, name in ((G0, two0, x.grad, "G_X"), (G1, two1, y.grad, "G_Y")):
+        assert torch.isfinite(got.float()).all(), name
+        sc = float(ref.abs().max())
+        e_m = float((got.float().cpu() - ref).abs().max()) / sc
+        e_t = float((two.cpu() - ref).abs().max()) / sc
+        assert e_m <= max(1.5e-2, 2.0 * e_t), f"{name}: merged {e_m:.2e} of scale, two-direction path {e_t:.2e}"
