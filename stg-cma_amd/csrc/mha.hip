@@ -192,28 +192,31 @@ __global__ void __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) mha_fwd2_kernel(MP a
             sA = MFMA32(nat_frag<DP>(sK, r, hh, s), qf[s], sA);
             sB = MFMA32(nat_frag<DP>(sK + 32 * DP, r, hh, s), qf[s], sB);
         }
+        // round 6: the maximum is taken on the RAW scores (scale > 0) and the exponent is one fma, exp2(s scale2 - m): one VALU slot per score less
         float xA[16], xB[16];
-        float mx = m;
+        float mr = NEG_BIG;
         const int kbase = 64 * kp;
         const bool tail = kbase + 64 > a.n;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            xA[reg] = sA[reg] * a.scale2;
-            xB[reg] = sB[reg] * a.scale2;
+            xA[reg] = sA[reg];
+            xB[reg] = sB[reg];
             if (tail) {
                 if (kbase + ACC_ROW(reg, hh) >= a.n) xA[reg] = NEG_BIG;
                 if (kbase + 32 + ACC_ROW(reg, hh) >= a.n) xB[reg] = NEG_BIG;
             }
-            mx = fmaxf(mx, fmaxf(xA[reg], xB[reg]));
+            mr = fmaxf(mr, fmaxf(xA[reg], xB[reg]));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        const float mx = fmaxf(m, mr * a.scale2);
         const float alpha = __builtin_amdgcn_exp2f(m - mx);
         m = mx;
+        const float nmx = -mx;
         float ls = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            xA[reg] = __builtin_amdgcn_exp2f(xA[reg] - mx);
-            xB[reg] = __builtin_amdgcn_exp2f(xB[reg] - mx);
+            xA[reg] = __builtin_amdgcn_exp2f(fmaf(xA[reg], a.scale2, nmx));
+            xB[reg] = __builtin_amdgcn_exp2f(fmaf(xB[reg], a.scale2, nmx));
             ls += xA[reg] + xB[reg];
         }
         ls += __shfl_xor(ls, 32, 64);
@@ -798,6 +801,7 @@ int pick_nw(int nt, bool bwd, bool kv1 = false) {
 int fill(const stg_mha_args* f, MP& p, const char* who) {
     STG_CHECK(f->Q && f->K && f->V && f->O && f->lse, -1, "%s: null pointer", who);
     STG_CHECK(f->D == 64 || f->D == 96, -2, "%s: head dim must be 64 or 96", who);
+    STG_CHECK(f->scale > 0.f, -2, "%s: scale must be positive (the forward takes its running maximum on the raw scores)", who);
     STG_CHECK(f->P >= 0 && f->P < 65536 && f->H >= 1 && f->H < 65536 && f->n >= 1 && f->n <= (1 << 20), -2, "%s: bad shape", who);
     STG_CHECK(f->ld % 8 == 0 && f->ldo % 8 == 0, -2, "%s: leading dimensions must be multiples of 8", who);
     STG_CHECK((((uintptr_t)f->Q | (uintptr_t)f->K | (uintptr_t)f->V | (uintptr_t)f->O) & 15) == 0, -2, "%s: misaligned pointers", who);
