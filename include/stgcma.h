@@ -414,6 +414,26 @@ int stg_mha_bwd_pair_merged(const stg_mha_args* a0, const void* dO0, void* G0, f
                             void* G1, float* delta1, int64_t lddo, int64_t lddg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The cross-modal PAIR of the CLIP-ViT blocks on small frames (ABI 219; csrc/xsmall.hip): per frame p, video rows Xv[p*nv .. +nv) and audio rows
+ * Xa[p*na .. +na) of width D; Ov = softmax(scale Xv Xa^T) Xa, Oa = softmax(scale Xa Xv^T) Xv (CLIP_AVE.py:386-398; nv <= 256, na <= 64,
+ * D in {32, 48, 64}: ViT-B/16's 197 + 49 tokens at adapter width 48).  One workgroup per frame, both modalities' rows in LDS; forward = both
+ * directions in one launch (lse_v / lse_a: fp32 [P, nv] / [P, na], log2 domain), backward = both whole gradients in one launch:
+ * Gv = d loss / d Xv (dQ of the video direction + dK + dV of the audio direction), Ga likewise.  Replaces the generic stg_attn_fwd2 / _bwd2 pair
+ * launches (and the caller's dQ + dKV addition) for these shapes.
+ */
+typedef struct {
+    const void* Xv; const void* Xa; int64_t ldv, lda;
+    void* Ov; void* Oa; int64_t ldov, ldoa;
+    float* lse_v; float* lse_a;
+    int P, nv, na, D;
+    float scale;
+} stg_xsmall_args;
+int stg_xsmall_supported(int nv, int na, int D);
+int stg_xsmall_fwd(const stg_xsmall_args* a, void* stream);
+int stg_xsmall_bwd(const stg_xsmall_args* a, const void* dOv, const void* dOa, int64_t lddov, int64_t lddoa, void* Gv, void* Ga,
+                   int64_t ldgv, int64_t ldga, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Small element-wise / layout kernels
  */
 /* out = h + gate[0] * r  (Swin_AVE.py:759-760,807-808); all bf16 [rows, d] contiguous-ld tensors, gate fp32 scalar on device */

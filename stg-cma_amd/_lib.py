@@ -79,6 +79,11 @@ class AttnBwdArgs(C.Structure):
     ]
 
 
+class XsmallArgs(C.Structure):
+    _fields_ = [("Xv", c_vp), ("Xa", c_vp), ("ldv", c_i64), ("lda", c_i64), ("Ov", c_vp), ("Oa", c_vp), ("ldov", c_i64), ("ldoa", c_i64),
+                ("lse_v", c_vp), ("lse_a", c_vp), ("P", C.c_int), ("nv", C.c_int), ("na", C.c_int), ("D", C.c_int), ("scale", C.c_float)]
+
+
 class WinAttnArgs(C.Structure):
     _fields_ = [
         ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("ld", c_i64),
@@ -177,6 +182,9 @@ SIGNATURES = {
     "stg_mha_bwd": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_mha_fwd_pair": (C.c_int, [C.POINTER(MhaArgs), C.POINTER(MhaArgs), c_vp]),
     "stg_mha_bwd_pair": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "stg_xsmall_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "stg_xsmall_fwd": (C.c_int, [C.POINTER(XsmallArgs), c_vp]),
+    "stg_xsmall_bwd": (C.c_int, [C.POINTER(XsmallArgs), c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "stg_mha_bwd_pair_merged": (C.c_int, [C.POINTER(MhaArgs), c_vp, c_vp, c_vp, C.POINTER(MhaArgs), c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "stg_gate_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_gate_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

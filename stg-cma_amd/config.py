@@ -41,6 +41,7 @@ SPEC = {
     "mha_x":       ("STG_MHA_X", _b, True, [("ops", "USE_MHA_X")], "flash kernels for wide frame-global cross-modal attention"),
     "xwin":        ("STG_XWIN", _b, True, [("ops", "USE_XWIN")], "window-level cross-modal attention on the whole-window kernels"),
     "mha_pair":    ("STG_MHA_PAIR", _b, True, [("ops", "MHA_PAIR")], "both directions of a cross-modal pair per mha launch"),
+    "xsmall":      ("STG_XSMALL", _b, True, [("ops", "XSMALL")], "ViT cross-modal pair on small frames: one workgroup per frame, forward / merged backward in one launch each (xsmall.hip)"),
     "mha_merged":  ("STG_MHA_MERGED", _b, True, [("ops", "MHA_MERGED")], "wide frame-global cross-modal pair: backward as one merged pass per modality (mha.hip)"),
     "mha_win":     ("STG_MHA_WIN", _b, True, [("ops", "USE_MHA_WIN")], "flash kernels (window map) for wide window-level cross-modal attention"),
     "xattn_merged": ("STG_XATTN_MERGED", _b, True, [("ops", "XATTN_MERGED")], "frame-global cross-modal pair: backward as one merged pass per modality (one exponential per score)"),

@@ -1054,6 +1054,66 @@ def mha_bwd_pair_merged(g, p0, p1):
     return G0, G1
 
 
+# ------------------------------------------------------------------------------------------------ the ViT blocks' cross-modal pair on small frames (xsmall.hip)
+def xsmall_supported(nv, na, D):
+    return bool(_lib.lib().stg_xsmall_supported(int(nv), int(na), int(D)))
+
+
+class XsGeom:
+    """P frames of nv video + na audio rows of width D (CLIP_AVE.py:386-398: 197 + 49 tokens, adapter width 48 for ViT-B/16)."""
+
+    def __init__(self, P, nv, na, D, scale=1.0):
+        self.P, self.nv, self.na, self.D, self.scale = int(P), int(nv), int(na), int(D), float(scale)
+        if not xsmall_supported(self.nv, self.na, self.D):
+            raise RuntimeError(f"xsmall: unsupported geometry nv={nv} na={na} D={D}")
+        self.n, self.H = self.nv, 1                           # (for the family accounting)
+
+
+def _xs_fill(g, Xv, Xa, Ov, Oa, lv, la):
+    for t, name, rows in ((Xv, "Xv", g.P * g.nv), (Xa, "Xa", g.P * g.na), (Ov, "Ov", g.P * g.nv), (Oa, "Oa", g.P * g.na)):
+        _chk2d(t, name, BF16)
+        if t.shape[0] < rows or t.shape[1] < g.D:
+            raise RuntimeError(f"xsmall {name}: needs >= {rows} rows x {g.D} columns, got {tuple(t.shape)}")
+    for t, n in ((lv, g.P * g.nv), (la, g.P * g.na)):
+        if t.dtype != F32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("xsmall: lse must be contiguous fp32 [P, n] GPU tensors")
+    a = _lib.XsmallArgs()
+    a.Xv, a.Xa, a.ldv, a.lda = _p(Xv), _p(Xa), _ld(Xv), _ld(Xa)
+    a.Ov, a.Oa, a.ldov, a.ldoa = _p(Ov), _p(Oa), _ld(Ov), _ld(Oa)
+    a.lse_v, a.lse_a = _p(lv), _p(la)
+    a.P, a.nv, a.na, a.D, a.scale = g.P, g.nv, g.na, g.D, g.scale
+    return a
+
+
+def _xs_cost(g, nin, nout, nmm):
+    by = 2.0 * g.P * (g.nv + g.na) * g.D * (nin + nout)
+    return (g.D, g.nv, g.na), by, 2.0 * nmm * g.P * g.nv * g.na * g.D
+
+
+@_family("xattn_fwd", lambda g, *a, **kw: _xs_cost(g, 1, 1, 4))
+def xsmall_fwd(g, Xv, Xa):
+    """Both directions of the pair, one launch: ((Ov, lse_v), (Oa, lse_a)) with O = softmax(scale X Xother^T) Xother per frame (lse: log2 domain)."""
+    Ov = torch.empty((Xv.shape[0], g.D), dtype=BF16, device=Xv.device)
+    Oa = torch.empty((Xa.shape[0], g.D), dtype=BF16, device=Xa.device)
+    lv = torch.empty((g.P, g.nv), dtype=F32, device=Xv.device)
+    la = torch.empty((g.P, g.na), dtype=F32, device=Xv.device)
+    a = _xs_fill(g, Xv, Xa, Ov, Oa, lv, la)
+    _lib.check(_lib.lib().stg_xsmall_fwd(C.byref(a), _stream()), "stg_xsmall_fwd")
+    return (Ov, lv), (Oa, la)
+
+
+@_family("xattn_bwd", lambda g, *a, **kw: _xs_cost(g, 3, 1, 10))
+def xsmall_bwd(g, Xv, Xa, Ov, Oa, lv, la, dOv, dOa):
+    """The pair's backward, one launch: (Gv, Ga) = the whole gradients of Xv and Xa (dQ of a tensor's own direction + dK + dV of the other)."""
+    for t, name in ((dOv, "dOv"), (dOa, "dOa")):
+        _chk2d(t, name, BF16)
+    Gv = torch.empty((Xv.shape[0], g.D), dtype=BF16, device=Xv.device)
+    Ga = torch.empty((Xa.shape[0], g.D), dtype=BF16, device=Xa.device)
+    a = _xs_fill(g, Xv, Xa, Ov, Oa, lv, la)
+    _lib.check(_lib.lib().stg_xsmall_bwd(C.byref(a), _p(dOv), _p(dOa), _ld(dOv), _ld(dOa), _p(Gv), _p(Ga), _ld(Gv), _ld(Ga), _stream()), "stg_xsmall_bwd")
+    return Gv, Ga
+
+
 @_family_io("patch_embed")
 def im2col_patch(x, p, Kpad):
     """x: [B, Cin, T, H, W] fp32/bf16 contiguous -> [B*T*(H/p)*(W/p), Kpad] bf16."""

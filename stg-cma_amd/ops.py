@@ -545,6 +545,7 @@ def _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs):
 
 
 MHA_PAIR = _cfg.opt("mha_pair")     # 0 = one mha launch per direction of a cross-modal pair (A/B knob)
+XSMALL = _cfg.opt("xsmall")         # 0 = the ViT blocks' cross-modal pair on the generic attention kernels (rounds 1-5)
 MHA_MERGED = _cfg.opt("mha_merged")  # 0 = the wide frame-global pair's backward as dQ + dK/dV passes per direction (rounds 1-5)
 
 
@@ -573,6 +574,13 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
     ag_v, ag_a = geoms if geoms is not None else (_xattn_geom(spec, BT, hv.shape[1], window, g),) * 2
+    if geoms is not None and XSMALL and ag_v.H == 1 and ag_v.G == 1 and ag_v.scale == ag_a.scale and ag_v.outer == ag_v.n and ag_a.outer == ag_a.n \
+            and K.xsmall_supported(ag_v.n, ag_a.n, hv.shape[1]) and hv.shape[0] == ag_v.P * ag_v.n and ha.shape[0] == ag_a.P * ag_a.n:
+        # round 6: the ViT blocks' pair (197 video + 49 audio tokens, width 48): one workgroup per frame, both directions in one launch (xsmall.hip)
+        xg = K.XsGeom(ag_v.P, ag_v.n, ag_a.n, hv.shape[1], ag_v.scale)
+        (rv, lse_v), (ra, lse_a) = K.xsmall_fwd(xg, hv, ha)
+        hv2, ha2 = _gate2(hv, rv, gate_v, ha, ra, gate_a)
+        return hv2, ha2, (rv, ra, lse_v, lse_a, xg)
     if XATTN_MERGED and PAIR_EW and not window and hv.stride(0) == ha.stride(0) and K.xattn_pair_fwd_supported(ag_v, hv, ha, ag_a, ha, hv):
         # both directions and the gates in one launch (the frame-global kernels write x = q + gate o beside o)
         (rv, lse_v, hv2), (ra, lse_a, ha2) = K.xattn_fwd2_gate(ag_v, hv, ha, ag_a, ha, hv, gate_v, gate_a)
@@ -591,6 +599,16 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
     the adapters' D_fc1, the gradients wrt the D_fc1 pre-activations instead (the join and the activation backward in one pass)."""
     mg = saved[4] if len(saved) == 5 else None
     rv, ra, lse_v, lse_a = saved[:4]
+    if isinstance(mg, K.XsGeom):                                                      # the ViT pair on small frames: one merged backward launch
+        if dgate_v is None:
+            dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
+        if dgate_a is None:
+            dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
+        drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
+        G_v, G_a = K.xsmall_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, drv, dra)
+        if zs is None:
+            return K.add(dhv2, G_v), K.add(dha2, G_a)
+        return K.add3_mul2(dhv2, G_v, None, zs[0], dha2, G_a, None, zs[1], outs=outs)
     if isinstance(mg, K.WinGeom):                                                     # whole-window kernels, dK <- dK + dV
         if dgate_v is None:
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)

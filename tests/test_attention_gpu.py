@@ -350,3 +350,49 @@ def test_cross_modal_pair_fused_gate_and_join(stg, gpu, P, n, D):
     j1 = k.xattn_pair_bwd(pv, pa, join=(dxv, zv, dxa, za), outs=(buf[:P * n], buf[P * n:]))
     torch.cuda.synchronize()
     assert eq(j0[0], j1[0]) and eq(j0[1], j1[1]), "fused join differs from add3_mul2 on the merged kernel's output"
+
+
+@pytest.mark.parametrize("P,nv,na,D,scale", [(5, 197, 49, 48, 1.0), (3, 257, 64, 64, 1.0), (4, 50, 7, 48, 0.5), (2, 33, 33, 32, 1.0), (6, 256, 1, 48, 1.0)])
+def test_vit_pair_small_frames(stg, gpu, P, nv, na, D, scale):
+    """Round 6 (xsmall.hip): the ViT blocks' cross-modal pair with both modalities' rows of a frame in LDS -- forward (both directions) and the merged
+    backward (both whole gradients) in one launch each -- against fp32 autograd and against the generic pair launches it replaces; ViT-B's 197 + 49
+    tokens at width 48, ViT-L-like 257 + 64 at 64 (nv = 257 > 256: must be REFUSED), ragged tiles, one audio token."""
+    from stgcma import kernels as k
+    if nv > 256:
+        assert not k.xsmall_supported(nv, na, D)
+        with pytest.raises(RuntimeError):
+            k.XsGeom(P, nv, na, D, scale)
+        return
+    g = torch.Generator().manual_seed(11 * nv + na + D)
+    xv = (torch.randn(P * nv, D, generator=g) * 0.6).to(BF16)
+    xa = (torch.randn(P * na, D, generator=g) * 0.6).to(BF16)
+    dv, da = torch.randn(P * nv, D, generator=g).to(BF16), torch.randn(P * na, D, generator=g).to(BF16)
+    fv, fa = xv.float().requires_grad_(True), xa.float().requires_grad_(True)
+    S = scale * torch.einsum("pid,pjd->pij", fv.view(P, nv, D), fa.view(P, na, D))
+    rv = (torch.softmax(S, 2) @ fa.view(P, na, D)).reshape(P * nv, D)
+    ra = (torch.softmax(S.transpose(1, 2), 2) @ fv.view(P, nv, D)).reshape(P * na, D)
+    ((rv * dv.float()).sum() + (ra * da.float()).sum()).backward()
+    xg = k.XsGeom(P, nv, na, D, scale)
+    Xv, Xa, dV, dA = xv.to(gpu), xa.to(gpu), dv.to(gpu), da.to(gpu)
+    for n_ in (nv, na):                                       # poison the allocator's free blocks: an unwritten row must not look right by accident
+        t = torch.full((P * n_, D), float("nan"), dtype=BF16, device=gpu); del t
+    (Ov, lv), (Oa, la) = k.xsmall_fwd(xg, Xv, Xa)
+    _close(Ov, rv.detach(), what="O_v")
+    _close(Oa, ra.detach(), what="O_a")
+    _close(lv.view(-1), (torch.logsumexp(S, 2) * 1.4426950408889634).detach().reshape(-1), tol=2e-2, what="lse_v")
+    _close(la.view(-1), (torch.logsumexp(S.transpose(1, 2), 2) * 1.4426950408889634).detach().reshape(-1), tol=2e-2, what="lse_a")
+    Gv, Ga = k.xsmall_bwd(xg, Xv, Xa, Ov, Oa, lv, la, dV, dA)
+    torch.cuda.synchronize()
+    sc = float(max(fv.grad.abs().max(), fa.grad.abs().max()))
+    assert torch.isfinite(Gv.float()).all() and torch.isfinite(Ga.float()).all()
+    _close(Gv.float() / sc, fv.grad / sc, tol=1.5e-2, what="G_v")
+    _close(Ga.float() / sc, fa.grad / sc, tol=1.5e-2, what="G_a")
+    # the generic pair launches on the same problem
+    gv = k.AttnGeom(P, 1, nv, D, G=1, outer=nv, n_kv=na, outer_kv=na, scale=scale)
+    ga = k.AttnGeom(P, 1, na, D, G=1, outer=na, n_kv=nv, outer_kv=nv, scale=scale)
+    (r0, l0), (r1, l1) = k.attn_fwd2(gv, Xv, Xa, Xa, ga, Xa, Xv, Xv)
+    _close(Ov, r0.float(), what="O_v vs generic")
+    _close(Oa, r1.float(), what="O_a vs generic")
+    (dq_v, dkv_a), (dq_a, dkv_v) = k.attn_bwd2((gv, Xv, Xa, r0, l0, dV), (ga, Xa, Xv, r1, l1, dA))
+    _close(Gv.float() / sc, (dq_v.float() + dkv_v.float()) / sc, tol=1.5e-2, what="G_v vs generic")
+    _close(Ga.float() / sc, (dq_a.float() + dkv_a.float()) / sc, tol=1.5e-2, what="G_a vs generic")

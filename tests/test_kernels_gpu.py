@@ -868,6 +868,11 @@ def test_counted_wait_and_path_switch_kernels_repeat_2000(stg, gpu):
         stress(f"mha_bwd_pair n={mg.n}", bwd, reps=reps)
         if mg.window[2] == 0:                                        # round 6: the merged pass (double-buffered staging + statistics behind one barrier per trip)
             stress(f"mha_bwd_pair_merged n={mg.n}", lambda: K.mha_bwd_pair_merged(mg, (hq, hk, r0, l0, d0), (hk, hq, r1, l1, d1)), reps=reps)
+    xg = K.XsGeom(5, 197, 49, 48, 1.0)                                # round 6: the ViT pair on small frames (one barrier, wave-private task lists)
+    xv_, xa_, dv_, da_ = bf(5 * 197, 48, sc=0.6), bf(5 * 49, 48, sc=0.6), bf(5 * 197, 48), bf(5 * 49, 48)
+    (ov_, lv_), (oa_, la_) = K.xsmall_fwd(xg, xv_, xa_)
+    stress("xsmall_fwd", lambda: [t for o in K.xsmall_fwd(xg, xv_, xa_) for t in o])
+    stress("xsmall_bwd", lambda: K.xsmall_bwd(xg, xv_, xa_, ov_, oa_, lv_, la_, dv_, da_))
     xc, dyc = bf(3 * 28 * 28, 64), bf(3 * 28 * 28, 256)
     stress("conv3x3_wgrad 64 -> 256", lambda: (K.conv3x3_wgrad(dyc, xc, 3, 28, 28, 3),))
     xc2, dyc2 = bf(2 * 14 * 14, 320), bf(2 * 14 * 14, 256)
