@@ -111,7 +111,8 @@ typedef struct {
     int64_t split_m; const void* W2; const float* bias2;
 } stg_gemm_args;
 enum { STG_GEMM_KERNEL_REG = 0, STG_GEMM_KERNEL_GLDS = 1, STG_GEMM_KERNEL_BIG = 2 /* retired in ABI 219: never reported */, STG_GEMM_KERNEL_8PH = 3, STG_GEMM_KERNEL_GLDS_CONV = 4,
-       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8 };
+       STG_GEMM_KERNEL_GLDS_BATCH = 5, STG_GEMM_KERNEL_GLDS_KTAIL = 6, STG_GEMM_KERNEL_FP8 = 7, STG_GEMM_KERNEL_8PHM = 8,
+       STG_GEMM_KERNEL_SKINNY = 9 /* ABI 219: the adapters' down-projection as a row stream (csrc/skinny.hip) */ };
 int stg_gemm_nt(stg_gemm_args* args, void* stream);
 
 /* Block-scaled e4m3 quantisation of a bf16 matrix (the producer side of ab_dtype == STG_FP8_MX): for every row r and 32-wide

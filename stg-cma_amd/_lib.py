@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("STGCMA_LIB") or os.path.join(_HERE, "libstgcma_hip.so
 
 STG_F32, STG_BF16, STG_FP8_MX, STG_U8_LIN = 0, 1, 2, 3
 (GEMM_KERNEL_REG, GEMM_KERNEL_GLDS, GEMM_KERNEL_BIG, GEMM_KERNEL_8PH, GEMM_KERNEL_GLDS_CONV, GEMM_KERNEL_GLDS_BATCH, GEMM_KERNEL_GLDS_KTAIL,
- GEMM_KERNEL_FP8, GEMM_KERNEL_8PHM) = range(9)
+ GEMM_KERNEL_FP8, GEMM_KERNEL_8PHM, GEMM_KERNEL_SKINNY) = range(10)
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 
 c_i64 = C.c_int64

@@ -1408,6 +1408,9 @@ std::atomic<uint64_t> lds_8ph_done[2], lds_8phm_done[8];
 
 }  // namespace
 
+int stg_gemm_skinny_down(const void* A, int64_t lda, const void* W, const void* W2, int64_t ldw, const float* bias, const float* bias2, void* Cout, int64_t ldc,
+                         void* dact, int64_t ldp, int64_t M, int64_t split_m, int N, int K, void* stream);      // skinny.hip
+
 extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     STG_CHECK(a != nullptr, -1, "stg_gemm_nt: null args");
     STG_CHECK(a->A && a->W && a->C, -1, "stg_gemm_nt: null A/W/C");
@@ -1517,6 +1520,14 @@ extern "C" int stg_gemm_nt(stg_gemm_args* a, void* stream) {
     }
     // the long-K shapes (K >= 1024, whole 256-column tiles): the epilogue is a small share of a tile
     const bool big = !split && !conv && p.batch == 1 && a->K % BK == 0 && a->M >= GBM && a->N >= GBN && a->N % GBN == 0 && a->K >= 1024;
+    // round 6: the adapters' down-projection ([rows, C] -> [rows, d_h <= 64] + bias + GELU + bf16 derivative) as a row stream (skinny.hip): bit-identical,
+    // 1.6-1.8 x the byte floor on the 128 x 128 kernel -> ~1.2 x.  Option gemm_nx = 0 (the round-5 routing, A/B) keeps it off too.
+    if (p.epi_variant == EV_GELU && a->dact && !d8 && !conv && p.batch == 1 && a->M >= 8192 && a->N <= 64 && a->N % 16 == 0 && a->K >= 128 &&
+        (int64_t)a->N * a->K <= 32768 && a->ldp % 4 == 0 && a->ldc % 4 == 0 && stg_opt_gemm_nx.load(std::memory_order_relaxed) != 0) {
+        const int rc = stg_gemm_skinny_down(a->A, a->lda, a->W, split ? a->W2 : nullptr, a->ldw, a->bias, split ? a->bias2 : nullptr, a->C, a->ldc, a->dact, a->ldp,
+                                            a->M, split ? a->split_m : 0, a->N, a->K, stream);
+        if (rc <= 0) { if (rc == 0) a->kernel_chosen = STG_GEMM_KERNEL_SKINNY; return rc; }
+    }
     const int ph8_mode = stg_opt_gemm_8ph.load(std::memory_order_relaxed);   // 0 off, 1 = in place of the large-tile kernel (default), 2 = every legal shape
     // round 6, the NX forms (template flag of both 8-phase kernels): N % 64 == 0 with N >= 192 and K % 64 == 0 with K >= 192 -- Swin-L's widths
     // (C = 192 / 384: qkv N = 576 / 1152, K = 192 / 576, the N = 192 / 384 projections) kept 45-65 ms of its step on the 128 x 128 kernel

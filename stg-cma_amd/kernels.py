@@ -429,7 +429,8 @@ GEMM_KERNEL_NAMES = {_lib.GEMM_KERNEL_REG: "gemm_nt_kernel", _lib.GEMM_KERNEL_GL
                      _lib.GEMM_KERNEL_BIG: "gemm_nt_big_kernel", _lib.GEMM_KERNEL_8PH: "gemm_nt_8ph_kernel", _lib.GEMM_KERNEL_8PHM: "gemm_nt_8phm_kernel",
                      _lib.GEMM_KERNEL_GLDS_CONV: "gemm_nt_glds_kernel<1, true, false, false>",
                      _lib.GEMM_KERNEL_GLDS_BATCH: "gemm_nt_glds_kernel<1, false, true, false>",
-                     _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel"}
+                     _lib.GEMM_KERNEL_GLDS_KTAIL: "gemm_nt_glds_kernel<1, false, false, true>", _lib.GEMM_KERNEL_FP8: "gemm_nt_fp8_kernel",
+                     _lib.GEMM_KERNEL_SKINNY: "skinny_down_kernel"}
 
 
 def gemm_profile_start(stride=7, log_sequence=False):

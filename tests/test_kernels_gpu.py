@@ -399,6 +399,35 @@ def test_gemm_nx_shapes(stg, gpu, M, N, K, epi, kernel):
     assert float((o0.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(out.float().abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,split", [(125440, 32, 512, 62720), (8192, 16, 128, 0), (9999, 32, 256, 4096), (8200, 64, 512, 0), (20011, 16, 256, 128), (8192, 32, 128, 0)])
+def test_adapter_down_projection_row_stream(stg, gpu, M, N, K, split):
+    """Round 6 (skinny.hip): the adapters' down-projection + bias + GELU + saved bf16 derivative as a row stream with the weight's MFMA fragments in LDS,
+    routed from stg_gemm_nt -- BIT-IDENTICAL to the 128 x 128 tile kernel (same k order, same polynomial GELU forms) on whole and ragged row counts, with
+    and without the video | audio split (two weights, one launch), and against the fp32 product."""
+    from stgcma import kernels as k
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).to(BF16).to(gpu)
+    W1, W2 = (torch.randn(N, K, generator=g) * 0.06).to(BF16).to(gpu), (torch.randn(N, K, generator=g) * 0.06).to(BF16).to(gpu)
+    b1, b2 = (torch.randn(N, generator=g) * 0.2).to(gpu), (torch.randn(N, generator=g) * 0.2).to(gpu)
+    kw = dict(act=k.ACT_GELU, want_dact=True)
+    if split:
+        kw["split"] = (split, W2, b2)
+    t = torch.full((M, N), float("nan"), dtype=BF16, device=gpu); del t          # an unwritten row must not look right by accident
+    H, Z = k.gemm_nt(A, W1, b1, **kw)
+    assert k.LAST_GEMM_KERNEL == "skinny_down_kernel", k.LAST_GEMM_KERNEL
+    stg.configure(lib_gemm_nx=0)
+    try:
+        H0, Z0 = k.gemm_nt(A, W1, b1, **kw)
+        assert k.LAST_GEMM_KERNEL != "skinny_down_kernel"
+    finally:
+        stg.configure(lib_gemm_nx=1)
+    assert torch.equal(H.view(torch.int16), H0.view(torch.int16)) and torch.equal(Z.view(torch.int16), Z0.view(torch.int16)), "not bit-identical to the tile kernel"
+    s = split if split else M
+    z = torch.cat([A[:s].float() @ W1.float().t() + b1, A[s:].float() @ W2.float().t() + b2]) if split else A.float() @ W1.float().t() + b1
+    _close(H, torch.nn.functional.gelu(z).cpu(), what="gelu(down)")
+    _close(Z, _gelu_grad(z.cpu()), what="gelu'(down)")
+
+
 @pytest.mark.parametrize("F_,H,W,Cin,Cout,d", [(3, 14, 14, 64, 64, 1), (2, 28, 28, 256, 256, 3), (1, 7, 7, 128, 32, 1), (2, 14, 14, 256, 256, 18),
                                                (5, 56, 56, 64, 128, 6), (2, 28, 28, 32, 128, 1), (3, 14, 14, 16, 64, 2), (1, 14, 14, 8, 32, 1)])
 def test_implicit_conv3x3_equals_im2col_gemm(stg, gpu, F_, H, W, Cin, Cout, d):
