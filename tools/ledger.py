@@ -47,10 +47,15 @@ def mfma_util(mf_cycles, gui_cycles):
     return round(mf_cycles / max(gui_cycles / XCDS * SIMDS, 1.0), 4)
 
 
+def is_gemm(name):
+    """dispatches of stg_gemm_nt: the tile kernels and, since round 6, the adapters' down-projection row stream it routes to (csrc/skinny.hip)"""
+    return name.startswith("gemm_nt") or name.startswith("skinny_down")
+
+
 def by_class(tr, fe, wr, seq_path, dst, summary, mf=None, gu=None):
     seq = json.load(open(seq_path))["step"]
     extra = list(zip(mf, gu)) if mf is not None else [None] * len(tr)
-    gd = [(a, b, c, e) for a, b, c, e in zip(tr, fe, wr, extra) if short(a["Kernel_Name"]).startswith("gemm_nt")]
+    gd = [(a, b, c, e) for a, b, c, e in zip(tr, fe, wr, extra) if is_gemm(short(a["Kernel_Name"]))]
     if len(gd) != len(seq):
         raise SystemExit(f"{len(gd)} gemm dispatches in the step, {len(seq)} in the sequence file")
     cls = collections.OrderedDict()
@@ -129,14 +134,14 @@ def main(src, dst, seq_path=None):
     out.sort(key=lambda r: -r["ms_per_step"])
     tot_ms = sum(r["ms_per_step"] for r in out)
     tot_gb = sum(r["hbm_gb_per_step"] for r in out)
-    gemm_ms = sum(r["ms_per_step"] for r in out if r["kernel"].startswith("gemm_nt"))
+    gemm_ms = sum(r["ms_per_step"] for r in out if is_gemm(r["kernel"]))
     summary = {"step_kernel_ms": round(tot_ms, 2), "step_wall_ms": round((t1 - t0) / 1e6, 2), "launches": sum(r["launches_per_step"] for r in out),
                "hbm_gb_per_step": round(tot_gb, 1), "gemm_ms": round(gemm_ms, 2), "non_gemm_ms": round(tot_ms - gemm_ms, 2),
-               "gemm_gb": round(sum(r["hbm_gb_per_step"] for r in out if r["kernel"].startswith("gemm_nt")), 1),
+               "gemm_gb": round(sum(r["hbm_gb_per_step"] for r in out if is_gemm(r["kernel"])), 1),
                "bytes": "(2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, rocprofv3 --pmc in separate runs; durations from the counter-free run"}
     if mf is not None:
         tmf, tgu = sum(d["mf"] for d in cls.values()), sum(d["gui"] for d in cls.values())
-        gmf = sum(d["mf"] for k, d in cls.items() if k[0].startswith("gemm_nt")); ggu = sum(d["gui"] for k, d in cls.items() if k[0].startswith("gemm_nt"))
+        gmf = sum(d["mf"] for k, d in cls.items() if is_gemm(k[0])); ggu = sum(d["gui"] for k, d in cls.items() if is_gemm(k[0]))
         summary["mfma_util_pmc"] = mfma_util(tmf, tgu)
         summary["mfma_util_pmc_gemm_kernels"] = mfma_util(gmf, ggu)
         summary["mfma_util_pmc_what"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), both summed over the step's dispatches, separate "
