@@ -71,7 +71,7 @@ for (M, N, Kd, epi), n in sorted(cls.items(), key=lambda kv: -kv[1] * kv[0][0] *
     for m in med:
         tot[m] += med[m] * n
     best_tot += med[b] * n
-    print(f"{M:8d} {N:5d} {Kd:5d} {epi:6s} {n:6d} | " + " ".join(f"{med[v]:8.1f}" for v in VALS) + f"  {b}" + ("  <-- differs from the shipped rule" if abs(med[b] - med[1]) > 0.02 * med[1] else ""), flush=True)
+    print(f"{M:8d} {N:5d} {Kd:5d} {epi:6s} {n:6d} | " + " ".join(f"{med[v]:8.1f}" for v in VALS) + f"  {b}" + ("  <-- differs from the shipped rule" if 1 in med and abs(med[b] - med[1]) > 0.02 * med[1] else ""), flush=True)
     del A, W, bias, kw
-L.stg_set_option(OPT, 1)
+L.stg_set_option(OPT, 1 if 1 in VALS else VALS[0])
 print("step totals (ms): " + "   ".join(f"{OPT.decode()}={v} {tot[v]/1e3:.2f}" for v in VALS) + f"   per-class best {best_tot/1e3:.2f}")
