@@ -682,6 +682,7 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_8ph_kernel(GemmParams p) {
     const bool w1_live = NX ? p.N - n0 > 128 : true;     // does the tile's W1 half hold any column of C?
     const char* zsrc = reinterpret_cast<const char*>(gemm_zero16);
     auto issue = [&](int which, int kt) {                // which: HA0 / HA1 / HW0 / HW1 of k-tile kt (clamped: a dummy re-load past the end)
+        if (DIAG_ON(p, 1)) return;                       // diagnostics build: no LDS-DMA at all (tools/gemm_loop_bound.py)
         kt = kt < nk ? kt : nk - 1;
         bf16_t* dst = smem8 + ((kt & 1) * 4 + which) * SLOT + wave * 512;
         const bool isw = which >= HW0;
