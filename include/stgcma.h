@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STG_VERSION 219
+#define STG_VERSION 220
 
 enum stg_act { STG_ACT_NONE_ = 0, STG_ACT_GELU_ = 1, STG_ACT_QUICKGELU_ = 2 };
 enum stg_dtype { STG_F32 = 0, STG_BF16 = 1, STG_FP8_MX = 2, STG_U8_LIN = 3 };
@@ -349,6 +349,16 @@ int stg_winattn_fwd(const stg_winattn_args* a, void* stream);
  * AVE/model/Swin_AVE.py:750-760, run with H = 1 and no table: bm == bmT == NULL) and dK receives dK + dV. */
 int stg_winattn_bwd(const stg_winattn_args* a, const void* dO, int64_t lddo, void* dQ, void* dK, void* dV,
                     int64_t lddqkv, void* stream);
+/* ABI 220: the adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760: h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and its mirror image) as ONE
+ * launch per pass with the gates inside.  a0 / a1: the two directions, table-free (bm == bmT == NULL), H == 1, K == V == the other modality's rows, one
+ * window geometry.  Forward: O and lse per direction as stg_winattn_fwd writes them, and x_y = Q_y + gate_y[0] * O_y (stg_gate_fwd2's arithmetic on the
+ * bf16-rounded O) into x0 / x1 [rows, >= D].  Backward: dX_y = d(x_y); dQ_y / dK_y (dK receives dK + dV) are the gradients through the attention, scaled
+ * by gate_y[0] inside the kernel (the pass is linear in dO), and dgate_y[0] += <dX_y, O_y> (fp32 atomics, one per wavefront) -- stg_gate_bwd2 is not
+ * needed.  The gradient through the residual term (dX_y itself) is the caller's. */
+int stg_winattn_pair_fwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const float* gate0, const float* gate1, void* x0, void* x1,
+                         int64_t ldx, void* stream);
+int stg_winattn_pair_bwd(const stg_winattn_args* a0, const stg_winattn_args* a1, const void* dX0, const void* dX1, int64_t lddx, const float* gate0,
+                         const float* gate1, float* dgate0, float* dgate1, void* dQ0, void* dK0, void* dQ1, void* dK1, int64_t lddqkv, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Temporal attention: WindowAttention.forward's temporal branch (Swin_AVE.py:244-255; block call sites :705-716) with the

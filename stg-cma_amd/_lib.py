@@ -175,6 +175,8 @@ SIGNATURES = {
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),
     "stg_winattn_bwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_winattn_pair_fwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "stg_winattn_pair_bwd": (C.c_int, [C.POINTER(WinAttnArgs), C.POINTER(WinAttnArgs), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_tattn_fwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp]),
     "stg_tattn_bwd": (C.c_int, [C.POINTER(TAttnArgs), c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "stg_mha_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -239,7 +241,7 @@ SIGNATURES = {
     "stg_vit_embed": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.c_int, C.c_int, C.c_int, c_vp]),
 }
 
-ABI_VERSION = 219
+ABI_VERSION = 220
 _lib = None
 
 

@@ -37,7 +37,11 @@ struct WinP {
     const bf16_t* dO; int64_t lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; int64_t lddqkv;
     int total;
+    // the adapters' window-level cross-modal pair with its gate (round 6b, stg_winattn_pair_*): forward X = Q + gate[0] * O beside O;
+    // backward dO is d(X), every output is scaled by gate[0] (the pass is linear in dO) and dgate += sum_q delta[q] = <d(X), O>
+    const float* gate; bf16_t* X; int64_t ldx; float* dgate;
 };
+struct WinP2 { WinP a[2]; };
 
 __device__ __forceinline__ void unpack8f(const uint4& q, float* v) {
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -167,6 +171,28 @@ __device__ __forceinline__ void flush_tile32(const bf16_t* T, bf16_t* dst, const
 }
 
 
+// flush_tile32 of an O tile plus the gated residual X = Q + g O (stg_gate_fwd2's arithmetic on the bf16-rounded O): Q's 16 bytes come back from L2
+template <bool D16 = false>
+__device__ __forceinline__ void flush_tile32_gate(const bf16_t* T, bf16_t* dst, const int64_t (&rowoff)[2], const bf16_t* Q, const int64_t (&rowq)[2], bf16_t* X,
+                                                   const int64_t (&rowx)[2], float g, int t, int n, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tl = (lane >> 2) + 16 * j, cq = lane & 3, sw = (tl >> 2) & 7;
+        const uint2 lo = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq) ^ sw) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(T + tl * 32 + (((2 * cq + 1) ^ sw) << 2));
+        if (32 * t + tl < n && (!D16 || cq < 2)) {
+            const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            *reinterpret_cast<uint4*>(dst + rowoff[j] + cq * 8) = o;
+            const uint4 q = *reinterpret_cast<const uint4*>(Q + rowq[j] + cq * 8);
+            float qv[8], ov[8];
+            unpack8f(q, qv); unpack8f(o, ov);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] = qv[e] + g * ov[e];
+            *reinterpret_cast<uint4*>(X + rowx[j] + cq * 8) = pack8u(qv);
+        }
+    }
+}
+
 // ---- round 6: the additive table shared through LDS (template flag LT, used with NKEY = 49) --------------------------------------------------
 // The table is 16 KiB per (window type, head) -- more bytes through a CU's vector-memory path than the q / k / v / o tiles of a problem
 // (12.5 KiB), every wave fetching its own copy (L2 hits; a no-table probe ran the forward 10-22 % faster).  In the LT form a workgroup is
@@ -215,13 +241,18 @@ __device__ __forceinline__ float4 lt_read(const float* stab, int kt, int g4, int
 }
 
 template <int NKEY, bool LT, bool NOTAB = false, bool D16 = false>
-__global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
+__device__ __forceinline__ void winattn_bwd1_body(const WinP& a) {
     constexpr int HW = D16 ? 16 : WD;                      // head width in global memory
     // per wave: K, Q, dO tiles ([64][32] bf16), one more tile (V while the fragments are fetched, then the P and dS tiles of the current
     // pair, then the output transpositions), delta[64]
     constexpr int PER_WAVE = 4 * 64 * WD + 128;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
     __shared__ __attribute__((aligned(16))) float stab[LT ? LtTab<NKEY>::FLOATS : 4];
+    __shared__ float sgate[2];                             // the gated pair form: the workgroup's dgate sum and its ticket counter
+    if (a.dgate) {                                         // kernel-uniform; in front of every early exit
+        if (threadIdx.x == 0) { sgate[0] = 0.f; reinterpret_cast<int*>(sgate)[1] = 0; }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const bf16_t *Qp = a.Q, *Kp = a.K, *Vp = a.V, *Op = a.O, *dOp = a.dO;
@@ -322,6 +353,20 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         vf[t][0] = ld_frag(sP + sw_off(32 * t + r, hh)); vf[t][1] = ld_frag(sP + sw_off(32 * t + r, hh + 2));
         delta[t] = sDel[32 * t + r];
     }
+    const float gsc = a.gate ? a.gate[0] : 1.0f;           // kernel-uniform: the pair's gate (dO is d(X) = d(Q + gate O))
+    if (a.dgate) {                                         // dgate += <d(X), O> over the window's real queries
+        // ONE global atomic per workgroup: memory-side atomics on one address serialise at ~5 ns each (20 000 per-wave atomics of a stage-0 launch were
+        // 0.1 ms, more than the gate kernel this replaces).  The waves meet through LDS: each adds its sum, the last one to take a ticket sends the total
+        // (a wave's two DS operations execute in order, so every sum is in before its ticket is counted).
+        float dg = hh == 0 ? (r < a.n ? delta[0] : 0.f) + (32 + r < a.n ? delta[1] : 0.f) : 0.f;
+        dg = wave_sum<64>(dg);
+        if (lane == 0) {
+            const int nlive = a.total - (int)blockIdx.x * 4 < 4 ? a.total - (int)blockIdx.x * 4 : 4;
+            atomicAdd(&sgate[0], dg);
+            const int ticket = atomicAdd(reinterpret_cast<int*>(&sgate[1]), 1);
+            if (ticket == nlive - 1) atomicAdd(a.dgate, atomicAdd(&sgate[0], 0.f));
+        }
+    }
     lds_fence();                                           // the V tile becomes the P / dS tiles
     const int swz = (r >> 2) & 7;
 
@@ -382,20 +427,20 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
         if (a.dV == nullptr) {                             // K == V (the adapters' cross-modal attention): one gradient, dK + dV
 #pragma unroll
             for (int i = 0; i < 16; ++i) dk[i] = fmaf(dk[i], a.scale, dv[i]);
-            put_tile32(sP, dk, 1.0f, r, hh);
+            put_tile32(sP, dk, gsc, r, hh);
             lds_fence();
             flush_tile32<D16>(sP, dKp, ro, kt, a.n, lane);
         } else {
-            put_tile32(sP, dk, a.scale, r, hh);
-            put_tile32(sS, dv, 1.0f, r, hh);
+            put_tile32(sP, dk, a.scale * gsc, r, hh);
+            put_tile32(sS, dv, gsc, r, hh);
             lds_fence();
             flush_tile32<D16>(sP, dKp, ro, kt, a.n, lane);
             flush_tile32<D16>(sS, a.dV, ro, kt, a.n, lane);
         }
         lds_fence();
     }
-    put_tile32(sP, dq[0], a.scale, r, hh);
-    put_tile32(sS, dq[1], a.scale, r, hh);
+    put_tile32(sP, dq[0], a.scale * gsc, r, hh);
+    put_tile32(sS, dq[1], a.scale * gsc, r, hh);
     lds_fence();
     {
         const int64_t r0[2] = {trow[0] * a.lddqkv + h * HW, trow[1] * a.lddqkv + h * HW};
@@ -405,11 +450,17 @@ __global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) {
     }
 }
 
+template <int NKEY, bool LT, bool NOTAB = false, bool D16 = false>
+__global__ void __launch_bounds__(256, 2) winattn_bwd1_kernel(WinP a) { winattn_bwd1_body<NKEY, LT, NOTAB, D16>(a); }
+// both directions of a cross-modal pair in one launch (blockIdx.y = direction; table-free form)
+template <bool D16>
+__global__ void __launch_bounds__(256, 2) winattn_bwd1_pair_kernel(WinP2 pp) { winattn_bwd1_body<49, false, true, D16>(pp.a[blockIdx.y]); }
+
 // ------------------------------------------------------------------------------------------------ forward, coalesced (round 2)
 // winattn_fwd_kernel with every global access coalesced, like winattn_bwd1_kernel: Q, K, V by LDS-DMA into swizzled tiles, operand
 // fragments from LDS, O through a 32 x 32 LDS transposition (the Q / K tiles are dead once the scores exist).
 template <int NKEY, bool NOTAB = false, bool D16 = false>
-__global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
+__device__ __forceinline__ void winattn_fwd1_body(const WinP& a) {
     constexpr int HW = D16 ? 16 : WD;                      // head width in global memory
     constexpr int PER_WAVE = 3 * 64 * WD;
     __shared__ __attribute__((aligned(16))) bf16_t smem[4 * PER_WAVE];
@@ -522,9 +573,21 @@ __global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) {
     lds_fence();
     const int64_t r0[2] = {trow[0] * a.ldo + h * HW, trow[1] * a.ldo + h * HW};
     const int64_t r1[2] = {trow[2] * a.ldo + h * HW, trow[3] * a.ldo + h * HW};
+    if (a.X) {                                             // kernel-uniform: the pair's gated residual beside O
+        const float gsc = a.gate[0];
+        const int64_t q0[2] = {trow[0] * a.ld + h * HW, trow[1] * a.ld + h * HW}, q1[2] = {trow[2] * a.ld + h * HW, trow[3] * a.ld + h * HW};
+        const int64_t x0[2] = {trow[0] * a.ldx + h * HW, trow[1] * a.ldx + h * HW}, x1[2] = {trow[2] * a.ldx + h * HW, trow[3] * a.ldx + h * HW};
+        flush_tile32_gate<D16>(sQ, Op, r0, Qp, q0, a.X, x0, gsc, 0, a.n, lane);
+        flush_tile32_gate<D16>(sK, Op, r1, Qp, q1, a.X, x1, gsc, 1, a.n, lane);
+        return;
+    }
     flush_tile32<D16>(sQ, Op, r0, 0, a.n, lane);
     flush_tile32<D16>(sK, Op, r1, 1, a.n, lane);
 }
+template <int NKEY, bool NOTAB = false, bool D16 = false>
+__global__ void __launch_bounds__(256, 2) winattn_fwd1_kernel(WinP a) { winattn_fwd1_body<NKEY, NOTAB, D16>(a); }
+template <bool D16>
+__global__ void __launch_bounds__(256, 2) winattn_fwd1_pair_kernel(WinP2 pp) { winattn_fwd1_body<49, true, D16>(pp.a[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ bias + mask table
 // Additive score term v(q, k) = log2(e) * (table[index[q*n + k]][h] + mask[g][q][k])   (k >= n: -1e30; q >= n: 0), padded to
@@ -629,6 +692,65 @@ extern "C" int stg_winattn_bwd(const stg_winattn_args* f, const void* dO, int64_
     else if (lt) hipLaunchKernelGGL((winattn_bwd1_kernel<49, true>), dim3(lt_grid(p)), dim3(256), 0, (hipStream_t)stream, p);
     else if (p.n == 49) hipLaunchKernelGGL((winattn_bwd1_kernel<49, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((winattn_bwd1_kernel<0, false>), dim3((p.total + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- round 6b: the adapters' window-level cross-modal PAIR (Swin_AVE.py:750-760) as ONE launch per pass, its gates included -----------------------
+// h_v' = h_v + gate_v softmax(h_v h_a^T) h_a and the mirror image: a0 / a1 are the two directions (table-free: bm == bmT == NULL, H == 1, K == V == the
+// other modality's rows, same window geometry).  Before: two forward launches + stg_gate_fwd2; stg_gate_bwd2 + two backward launches -- at Swin-B's stage 2
+// the gate kernels (5.8 / 14.6 us) were as long as the attention launches beside them (6.3 / 11.2 us).
+static int pair_fill(const stg_winattn_args* f0, const stg_winattn_args* f1, WinP2& pp, const char* who) {
+    STG_CHECK(f0 && f1, -1, "%s: null args", who);
+    int rc = fill(f0, pp.a[0], who);
+    if (rc) return rc;
+    rc = fill(f1, pp.a[1], who);
+    if (rc) return rc;
+    STG_CHECK(!f0->bm && !f1->bm && f0->H == 1 && f1->H == 1 && f0->K == f0->V && f1->K == f1->V, -2, "%s: a table-free, one-head pair with K == V per direction", who);
+    STG_CHECK(f0->D == f1->D && f0->P == f1->P && f0->G == f1->G && f0->n == f1->n && f0->Himg == f1->Himg && f0->Wimg == f1->Wimg && f0->ws == f1->ws &&
+              f0->shift == f1->shift && f0->outer == f1->outer && f0->scale == f1->scale, -2, "%s: the two directions must share one geometry", who);
+    return 0;
+}
+
+extern "C" int stg_winattn_pair_fwd(const stg_winattn_args* f0, const stg_winattn_args* f1, const float* gate0, const float* gate1, void* x0, void* x1,
+                                    int64_t ldx, void* stream) {
+    WinP2 pp = {};
+    int rc = pair_fill(f0, f1, pp, "stg_winattn_pair_fwd");
+    if (rc) return rc;
+    STG_CHECK(gate0 && gate1 && x0 && x1 && f0->O && f1->O && f0->lse && f1->lse, -1, "stg_winattn_pair_fwd: null pointer");
+    STG_CHECK(f0->ldo % 8 == 0 && f1->ldo % 8 == 0 && ldx % 8 == 0 && ldx >= f0->D && (((uintptr_t)f0->O | (uintptr_t)f1->O | (uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, -2,
+              "stg_winattn_pair_fwd: bad O / x operands (16-byte stores)");
+    pp.a[0].gate = gate0; pp.a[0].X = (bf16_t*)x0; pp.a[0].ldx = ldx;
+    pp.a[1].gate = gate1; pp.a[1].X = (bf16_t*)x1; pp.a[1].ldx = ldx;
+    if (pp.a[0].total == 0) return 0;
+    const dim3 grid((pp.a[0].total + 3) / 4, 2);
+    if (f0->D == 16) hipLaunchKernelGGL(winattn_fwd1_pair_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(winattn_fwd1_pair_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pp);
+    STG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dX0 / dX1: the gradients of the gated outputs x0 / x1 [rows, >= D] (leading dimension lddx); dQ_y / dK_y: direction y's query / key-and-value gradients
+// (dK receives dK + dV), all with leading dimension lddqkv; dgate_y (fp32, accumulated atomically) += <dX_y, O_y>.
+extern "C" int stg_winattn_pair_bwd(const stg_winattn_args* f0, const stg_winattn_args* f1, const void* dX0, const void* dX1, int64_t lddx, const float* gate0,
+                                    const float* gate1, float* dgate0, float* dgate1, void* dQ0, void* dK0, void* dQ1, void* dK1, int64_t lddqkv, void* stream) {
+    WinP2 pp = {};
+    int rc = pair_fill(f0, f1, pp, "stg_winattn_pair_bwd");
+    if (rc) return rc;
+    STG_CHECK(dX0 && dX1 && gate0 && gate1 && dgate0 && dgate1 && dQ0 && dK0 && dQ1 && dK1 && f0->O && f1->O && f0->lse && f1->lse, -1, "stg_winattn_pair_bwd: null pointer");
+    STG_CHECK(f0->ldo % 8 == 0 && f1->ldo % 8 == 0 && lddx % 8 == 0 && lddqkv % 8 == 0, -2, "stg_winattn_pair_bwd: bad leading dims");
+    STG_CHECK((((uintptr_t)f0->O | (uintptr_t)f1->O | (uintptr_t)dX0 | (uintptr_t)dX1 | (uintptr_t)dQ0 | (uintptr_t)dK0 | (uintptr_t)dQ1 | (uintptr_t)dK1) & 15) == 0, -2,
+              "stg_winattn_pair_bwd: misaligned pointers");
+    const void* dX[2] = {dX0, dX1}; const float* gt[2] = {gate0, gate1}; float* dg[2] = {dgate0, dgate1}; void* dQ[2] = {dQ0, dQ1}; void* dK[2] = {dK0, dK1};
+    for (int y = 0; y < 2; ++y) {
+        WinP& p = pp.a[y];
+        p.dO = (const bf16_t*)dX[y]; p.lddo = lddx; p.dQ = (bf16_t*)dQ[y]; p.dK = (bf16_t*)dK[y]; p.dV = nullptr; p.lddqkv = lddqkv;
+        p.gate = gt[y]; p.dgate = dg[y];
+    }
+    if (pp.a[0].total == 0) return 0;
+    const dim3 grid((pp.a[0].total + 3) / 4, 2);
+    if (f0->D == 16) hipLaunchKernelGGL(winattn_bwd1_pair_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pp);
+    else hipLaunchKernelGGL(winattn_bwd1_pair_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pp);
     STG_LAUNCH_CHECK();
     return 0;
 }

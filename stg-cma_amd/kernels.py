@@ -1614,6 +1614,43 @@ def winattn_bwd(g, Q, K, V, O, lse, dO, *, dQ, dK, dV):
     return dQ, dK, dV
 
 
+@_family("winattn_fwd", lambda g, hv, *a, **kw: ("pair", 2 * 10.0 * (g.P // g.G) * g.outer * g.D, 2 * 4.0 * g.P * g.n * g.n * g.D))
+def winattn_pair_fwd(g, hv, ha, gate_v, gate_a):
+    """The window-level cross-modal pair with its gates in ONE launch (round 6b, stg_winattn_pair_fwd): g is the table-free one-head geometry
+    (ops._xwin_geom).  Returns ((r_v, lse_v, h_v'), (r_a, lse_a, h_a')) with h' = h + gate * r."""
+    for t in (hv, ha):
+        _chk2d(t, "winattn_pair_fwd operand", BF16)
+    if hv.shape != ha.shape or hv.shape[1] != g.D or g.H != 1 or g.bm is not None:
+        raise RuntimeError("winattn_pair_fwd: a table-free one-head pair over two [rows, D] tensors")
+    outs = []
+    args = []
+    for q, kv in ((hv, ha), (ha, hv)):
+        o = torch.empty((q.shape[0], g.D), dtype=BF16, device=q.device)
+        lse = torch.empty((g.P, 1, 64), dtype=F32, device=q.device)
+        x = torch.empty_like(o)
+        args.append(_win_fill(g, q, kv, kv, o, lse))
+        outs.append((o, lse, x))
+    _lib.check(_lib.lib().stg_winattn_pair_fwd(C.byref(args[0]), C.byref(args[1]), _p(gate_v), _p(gate_a), _p(outs[0][2]), _p(outs[1][2]), _ld(outs[0][2]), _stream()),
+               "stg_winattn_pair_fwd")
+    return outs[0], outs[1]
+
+
+@_family("winattn_bwd", lambda g, hv, *a, **kw: ("pair", 2 * 14.0 * (g.P // g.G) * g.outer * g.D, 2 * 10.0 * g.P * g.n * g.n * g.D))
+def winattn_pair_bwd(g, hv, ha, rv, ra, lse_v, lse_a, dxv, dxa, gate_v, gate_a, dgate_v, dgate_a):
+    """Backward of winattn_pair_fwd through the attention term: returns (dq_v, dkv_a, dq_a, dkv_v) -- direction v's query gradient (rows of h_v) and
+    key-and-value gradient (rows of h_a), then direction a's -- already scaled by the gates; dgate_* accumulate <dx, r>."""
+    for t in (hv, ha, rv, ra, dxv, dxa):
+        _chk2d(t, "winattn_pair_bwd operand", BF16)
+    if _ld(dxv) != _ld(dxa):
+        raise RuntimeError("winattn_pair_bwd: dx_v and dx_a must share one leading dimension")
+    dq_v, dkv_a, dq_a, dkv_v = (torch.empty((hv.shape[0], g.D), dtype=BF16, device=hv.device) for _ in range(4))
+    a0 = _win_fill(g, hv, ha, ha, rv, lse_v)
+    a1 = _win_fill(g, ha, hv, hv, ra, lse_a)
+    _lib.check(_lib.lib().stg_winattn_pair_bwd(C.byref(a0), C.byref(a1), _p(dxv), _p(dxa), _ld(dxv), _p(gate_v), _p(gate_a), _p(dgate_v), _p(dgate_a),
+                                               _p(dq_v), _p(dkv_a), _p(dq_a), _p(dkv_v), _ld(dq_v), _stream()), "stg_winattn_pair_bwd")
+    return dq_v, dkv_a, dq_a, dkv_v
+
+
 class TGeom:
     """One temporal-attention call over the fused qkv buffer: nm modality slabs x B clips x T frames x N tokens, H heads of
     dim 32; row(m, b, t, n) = ((m*B + b)*T + t)*N + n.  bias: fp32 [nm, H, T*T].  The additive tables the kernels read

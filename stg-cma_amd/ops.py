@@ -519,6 +519,7 @@ def _xwin_geom(spec, BT, dev, dh=32):
 
 
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
+XWIN_PAIR = _cfg.opt("xwin_pair")  # 0 = the window-level cross-modal pair as two launches per pass + the gate kernels (rounds 2-6a; A/B knob)
 XATTN_MERGED = _cfg.opt("xattn_merged")   # 0 = the frame-global cross-modal pair's backward as four passes (dQ, dK + dV per direction: rounds 1-4)
 
 
@@ -570,6 +571,10 @@ def _cross_modal_fwd(spec, BT, hv, ha, gate_v, gate_a, window, g, save, geoms=No
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, mg),)
     if geoms is None and window and USE_WINATTN and USE_XWIN and K.winattn_supported(spec.ws * spec.ws, hv.shape[1], table=False):
         wg = _xwin_geom(spec, BT, hv.device, hv.shape[1])      # d_h = 32, and since round 6 d_h = 16 (Swin-B stage 0: was on the generic kernels)
+        if XWIN_PAIR and PAIR_EW and hv.shape == ha.shape and hv.stride(0) == ha.stride(0):
+            # round 6b: both directions AND the gates in one launch (three launches before; the gate kernel was as long as an attention launch at stage 2)
+            (rv, lse_v, hv2), (ra, lse_a, ha2) = K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a)
+            return hv2, ha2, (rv, ra, lse_v, lse_a, wg)
         rv, lse_v = K.winattn_fwd(wg, hv, ha, ha, want_lse=True)
         ra, lse_a = K.winattn_fwd(wg, ha, hv, hv, want_lse=True)
         return _gate2(hv, rv, gate_v, ha, ra, gate_a) + ((rv, ra, lse_v, lse_a, wg),)
@@ -614,6 +619,10 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
             dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
         if dgate_a is None:
             dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
+        if XWIN_PAIR and PAIR_EW and hv.shape == ha.shape and hv.stride(0) == ha.stride(0) and dhv2.stride(0) == dha2.stride(0) and dhv2.stride(0) % 8 == 0:
+            # round 6b: one launch for both directions; the kernel scales by the gate and accumulates dgate = <dh', r> from the delta it computes anyway
+            dq_v, dkv_a, dq_a, dkv_v = K.winattn_pair_bwd(mg, hv, ha, rv, ra, lse_v, lse_a, dhv2, dha2, gate_v, gate_a, dgate_v, dgate_a)
+            return _join3(dhv2, dq_v, dkv_v, dha2, dq_a, dkv_a, zs, outs)
         drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
         dq_v, dkv_a, dq_a, dkv_v = (torch.empty_like(hv) for _ in range(4))
         K.winattn_bwd(mg, hv, ha, ha, rv, lse_v, drv, dQ=dq_v, dK=dkv_a, dV=None)      # direction a -> v

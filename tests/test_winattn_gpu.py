@@ -214,3 +214,62 @@ def test_window_cross_modal_table_free_and_16_wide(stg, gpu, images, Himg, shift
     sc = float(max(xq.grad.abs().max(), xk.grad.abs().max()))
     _close(gq[:, :16].float() / sc, xq.grad / sc, tol=1.5e-2, what="dQ (16 wide)")
     _close(gk[:, :16].float() / sc, xk.grad / sc, tol=1.5e-2, what="dK + dV (16 wide)")
+
+
+@pytest.mark.parametrize("images,Himg,shift,D", [(3, 14, 3, 32), (5, 28, 0, 32), (2, 56, 3, 16), (1, 7, 0, 16), (9, 14, 0, 16), (3, 21, 3, 32), (2, 21, 0, 16)])   # 21 x 21: 9 windows per image, a last workgroup of 3 / 2 waves
+def test_window_cross_modal_pair_one_launch_with_gates(stg, gpu, images, Himg, shift, D):
+    """Round 6b (stg_winattn_pair_fwd / _bwd, ABI 220): both directions of the window-level cross-modal pair and its gates in one launch per pass.
+    Forward: r, lse and h' = h + gate r are BIT-IDENTICAL to two stg_winattn_fwd launches + stg_gate_fwd2.  Backward: the kernel takes d(h'), scales its
+    outputs by the gate in fp32 (the two-launch path rounds gate * d(h') to bf16 first) and accumulates dgate from its own delta: compared with the
+    two-launch path at bf16 resolution, and with the fp32 autograd of h + gate softmax(h hother^T) hother per window."""
+    from stgcma import kernels as k
+    ws = 7
+    n, N = ws * ws, Himg * Himg
+    g = torch.Generator().manual_seed(7 * Himg + shift + D)
+    eq = lambda a, b: torch.equal(a.view(torch.int16), b.view(torch.int16))
+    hv, ha = ((torch.randn(images * N, D, generator=g) * 0.7).to(BF16).to(gpu) for _ in range(2))
+    dxv, dxa = (torch.randn(images * N, D, generator=g).to(BF16).to(gpu) for _ in range(2))
+    gate_v, gate_a = torch.tensor([0.37], device=gpu), torch.tensor([-1.21], device=gpu)
+    wg = k.WinGeom(images, 1, Himg, Himg, ws, shift, 1.0, None, None, D=D)
+    # forward
+    rv0, lv0 = k.winattn_fwd(wg, hv, ha, ha)
+    ra0, la0 = k.winattn_fwd(wg, ha, hv, hv)
+    xv0, xa0 = k.gate_fwd2(hv, rv0, gate_v, ha, ra0, gate_a)
+    (rv1, lv1, xv1), (ra1, la1, xa1) = k.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a)
+    assert eq(rv0, rv1) and eq(ra0, ra1) and torch.equal(lv0[..., :n], lv1[..., :n]) and torch.equal(la0[..., :n], la1[..., :n])
+    assert eq(xv0, xv1) and eq(xa0, xa1)
+    # backward against the two-launch path
+    dgv0, dga0 = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    drv, dra = k.gate_bwd2(dxv, rv0, gate_v, dgv0, dxa, ra0, gate_a, dga0)
+    q_v0, kv_a0, q_a0, kv_v0 = (torch.empty_like(hv) for _ in range(4))
+    k.winattn_bwd(wg, hv, ha, ha, rv0, lv0, drv, dQ=q_v0, dK=kv_a0, dV=None)
+    k.winattn_bwd(wg, ha, hv, hv, ra0, la0, dra, dQ=q_a0, dK=kv_v0, dV=None)
+    dgv1, dga1 = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    q_v1, kv_a1, q_a1, kv_v1 = k.winattn_pair_bwd(wg, hv, ha, rv1, ra1, lv1, la1, dxv, dxa, gate_v, gate_a, dgv1, dga1)
+    for a, b, what in ((q_v0, q_v1, "dq_v"), (kv_a0, kv_a1, "dkv_a"), (q_a0, q_a1, "dq_a"), (kv_v0, kv_v1, "dkv_v")):
+        sc = float(a.float().abs().max())
+        _close(b.float() / sc, a.float() / sc, tol=1.0e-2, what=what + " vs the two-launch path")
+    assert abs(float(dgv1) - float(dgv0)) <= 2e-3 * max(1.0, abs(float(dgv0))) and abs(float(dga1) - float(dga0)) <= 2e-3 * max(1.0, abs(float(dga0)))
+    # ... and against fp32 autograd
+    idx = _window_index(images, Himg, Himg, ws, shift).to("cpu")
+    xv, xa = hv.float().cpu().requires_grad_(True), ha.float().cpu().requires_grad_(True)
+    gv, ga = gate_v.cpu().clone().requires_grad_(True), gate_a.cpu().clone().requires_grad_(True)
+
+    def direction(xq, xk):
+        R = torch.softmax(torch.einsum("wid,wjd->wij", xq[idx], xk[idx]), -1) @ xk[idx]
+        return torch.zeros(images * N, D).index_put((idx.reshape(-1),), R.reshape(-1, D))
+    yv, ya = xv + gv * direction(xv, xa), xa + ga * direction(xa, xv)
+    _close(xv1, yv.detach(), what="h_v'")
+    _close(xa1, ya.detach(), what="h_a'")
+    ((yv * dxv.float().cpu()).sum() + (ya * dxa.float().cpu()).sum()).backward()
+    tot_v = dxv.float().cpu() + q_v1.float().cpu() + kv_v1.float().cpu()          # d h_v = d(h_v') + through direction v's queries + through direction a's keys / values
+    tot_a = dxa.float().cpu() + q_a1.float().cpu() + kv_a1.float().cpu()
+    sc = float(max(xv.grad.abs().max(), xa.grad.abs().max()))
+    _close(tot_v / sc, xv.grad / sc, tol=1.5e-2, what="d h_v")
+    _close(tot_a / sc, xa.grad / sc, tol=1.5e-2, what="d h_a")
+    # dgate = <d(h'), r>: exact (fp32 summation order aside) on the kernel's own bf16-rounded r; against autograd the bf16 rounding of r is a random walk
+    # over rows x D terms of relative size 2^-9
+    for dg, dx, r, ref in ((dgv1, dxv, rv1, gv.grad), (dga1, dxa, ra1, ga.grad)):
+        terms = dx.float() * r.float()
+        assert abs(float(dg) - float(terms.sum())) <= 2e-4 * float(terms.abs().sum()) ** 0.5 + 1e-4 * abs(float(terms.sum())), (float(dg), float(terms.sum()))
+        assert abs(float(dg) - float(ref)) <= 4 * 2.0 ** -9 * float((terms * terms).sum()) ** 0.5 + 1e-3 * abs(float(ref)), (float(dg), float(ref))
