@@ -308,6 +308,12 @@ int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1,
  * jz = saved activation derivative of D_fc1: stg_add3_mul2's arithmetic on the bf16-rounded G, no separate pass). */
 int stg_xattn_pair_bwd_join(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
                             const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream);
+/* ABI 220: the same with the pair's GATES inside: b0->dO / b1->dO are d(x) of x = q + gate o (stg_xattn_fwd2_gate's x), the kernels work on
+ * bf16(gate d(x)) -- stg_gate_bwd2's rounding: G is bit-identical to stg_gate_bwd2 followed by stg_xattn_pair_bwd(_join) -- and
+ * dgate_y[0] += <d(x_y), o_y> (fp32 atomics, one per workgroup of the preparation kernel).  jx / jz: the optional join (all four NULL: none). */
+int stg_xattn_pair_bwd_gate(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                            const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, const float* gate0, const float* gate1,
+                            float* dgate0, float* dgate1, void* ws, int64_t ws_bytes, void* stream);
 /* Forward of such a pair with its gates: O and lse per direction as stg_attn_fwd2 writes them, and x = q + gate[0] * o (stg_gate_fwd2's
  * arithmetic on the bf16-rounded o) into x0 / x1 [rows, D] -- h_v' = h_v + gate_v softmax(h_v h_a^T) h_a, Swin_AVE.py:799-808. */
 int stg_xattn_fwd2_gate(const stg_attn_args* f0, const stg_attn_args* f1, const float* gate0, const float* gate1, void* x0, void* x1,

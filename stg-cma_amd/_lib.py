@@ -171,6 +171,8 @@ SIGNATURES = {
     "stg_xattn_pair_bwd_supported": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs)]),
     "stg_xattn_pair_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "stg_xattn_pair_bwd_join": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "stg_xattn_pair_bwd_gate": (C.c_int, [C.POINTER(AttnBwdArgs), C.POINTER(AttnBwdArgs), c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_i64, c_vp]),
     "stg_xattn_fwd2_gate": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnArgs), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "stg_winattn_table": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_vp]),
     "stg_winattn_fwd": (C.c_int, [C.POINTER(WinAttnArgs), c_vp]),

@@ -46,6 +46,7 @@ SPEC = {
     "mha_win":     ("STG_MHA_WIN", _b, True, [("ops", "USE_MHA_WIN")], "flash kernels (window map) for wide window-level cross-modal attention"),
     "xattn_merged": ("STG_XATTN_MERGED", _b, True, [("ops", "XATTN_MERGED")], "frame-global cross-modal pair: backward as one merged pass per modality (one exponential per score)"),
     "pair_ew":     ("STG_PAIR_EW", _b, True, [("ops", "PAIR_EW")], "both directions of a cross-modal pair per element-wise launch"),
+    "xattn_gate":  ("STG_XATTN_GATE", _b, True, [("ops", "XATTN_GATE")], "the frame-global cross-modal pair's gates inside its merged backward (0 = gate kernel first)"),
     "xwin_pair":   ("STG_XWIN_PAIR", _b, True, [("ops", "XWIN_PAIR")], "the window-level cross-modal pair as one launch per pass with its gates (0 = two launches + gate kernels)"),
     "join_pair":   ("STG_JOIN_PAIR", _b, True, [("ops", "JOIN_PAIR")], "both modalities' residual joins (+ LayerNorm) and LayerNorm-backward + adapter dgrad in one launch each"),
     "gemm_split":  ("STG_GEMM_SPLIT", _b, True, [("ops", "GEMM_SPLIT")], "video | audio adapter GEMMs as one launch with two row groups"),

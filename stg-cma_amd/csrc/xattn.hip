@@ -533,6 +533,8 @@ struct XM {
     bf16_t* G; int64_t ldg;
     int n, n_kv, tiles, total;
     const bf16_t* jX; const bf16_t* jZ; int64_t ldjx, ldjz;     // optional join (round 5): G <- (jX + G) * jZ, the add3_mul that follows (jZ = saved act')
+    const float* gate; float* dgate;              // optional gate (round 6b): dO is d(x) of x = q + gate o -- the kernels work on bf16(gate dO), stg_gate_bwd2's
+                                                  // rounding, and the preparation kernel adds <d(x), o> to dgate (one atomic per workgroup)
 };
 struct XM2 { XM a[2]; float* c0; int* ok; float scale, c2; int P; };
 
@@ -559,9 +561,12 @@ __global__ void __launch_bounds__(256) xattn_prep_kernel(XM2 pp) {
     const bool ok = (mx - mn) <= 120.0f;                    // false for infinities / NaNs too
     const float c0 = ok ? 0.5f * (mx + mn) : 0.f;
     if (part == 0 && tid == 0) { pp.c0[p] = c0; pp.ok[p] = ok ? 1 : 0; }
+    float dgs[2] = {0.f, 0.f};
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const XM& a = pp.a[y];
+        const bool gated = a.gate != nullptr;               // kernel-uniform
+        const float gt = gated ? a.gate[0] : 1.0f;
         const int chunk = (a.n + nparts - 1) / nparts;
         const int r1 = min(a.n, (part + 1) * chunk);
         for (int r = part * chunk + tid; r < r1; r += 256) {
@@ -574,12 +579,29 @@ __global__ void __launch_bounds__(256) xattn_prep_kernel(XM2 pp) {
                 const bf16x8_t df = ld_frag(a.dO + row * a.lddo + 8 * s), of = ld_frag(a.O + row * a.ldo + 8 * s);
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float x = bf2f((bf16_t)df[j]); d += x * bf2f((bf16_t)of[j]); v[j] = x * c; }
+                for (int j = 0; j < 8; ++j) {
+                    float x = bf2f((bf16_t)df[j]);
+                    const float o = bf2f((bf16_t)of[j]);
+                    if (gated) { dgs[y] += x * o; x = bf2f(f2bf(gt * x)); }      // stg_gate_bwd2's sum and its bf16 rounding of gate d(x)
+                    d += x * o; v[j] = x * c;
+                }
                 *reinterpret_cast<bf16x8_t*>(oh + 8 * s) = pack_frag(v);
             }
             a.delta[row] = d;
             a.nd_own[row] = -c * d;
         }
+    }
+    if (pp.a[0].gate != nullptr) {                          // kernel-uniform: one atomic per workgroup and gate
+        __shared__ float gred[2][4];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            float v = dgs[y];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0) gred[y][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 2) atomicAdd(pp.a[tid].dgate, gred[tid][0] + gred[tid][1] + gred[tid][2] + gred[tid][3]);
     }
 }
 
@@ -610,6 +632,13 @@ __global__ void __launch_bounds__(256, 2) xattn_bwdm_kernel(XM2 pp) {
     for (int s = 0; s < KS; ++s) {
         qf[s] = ld_frag(a.Q + rowq * a.ldq + 8 * hh + 16 * s);
         dof[s] = ld_frag(a.dO + rowq * a.lddo + 8 * hh + 16 * s);
+        if (a.gate) {                                             // kernel-uniform: bf16(gate d(x)), the operand stg_gate_bwd2 used to write
+            const float gt = a.gate[0];
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gt * bf2f((bf16_t)dof[s][j]);
+            dof[s] = pack_frag(v);
+        }
         scale_split(qf[s], pp.c2, qh[s], ql[s]);
     }
     const float lse2 = a.lse[rowq] * LOG2E;
@@ -841,7 +870,8 @@ extern "C" int stg_xattn_pair_bwd_supported(const stg_attn_args* f0, const stg_a
 }
 
 static int xattn_pair_bwd_impl(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
-                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream);
+                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream,
+                               const float* gate0 = nullptr, const float* gate1 = nullptr, float* dgate0 = nullptr, float* dgate1 = nullptr);
 
 extern "C" int stg_xattn_pair_bwd(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, void* ws,
                                   int64_t ws_bytes, void* stream) {
@@ -858,8 +888,22 @@ extern "C" int stg_xattn_pair_bwd_join(const stg_attn_bwd_args* b0, const stg_at
     return xattn_pair_bwd_impl(b0, b1, g0, g1, ldg, jx0, jx1, ldjx, jz0, jz1, ldjz, ws, ws_bytes, stream);
 }
 
+/* ABI 220: ... with the pair's GATES inside: b0->dO / b1->dO are d(x) of x = q + gate o (what the forward's stg_xattn_fwd2_gate wrote), the kernels work on
+ * bf16(gate d(x)) -- stg_gate_bwd2's rounding, so G is bit-identical to stg_gate_bwd2 + stg_xattn_pair_bwd(_join) -- and dgate_y[0] += <d(x_y), o_y>.
+ * jx / jz: the optional join as in stg_xattn_pair_bwd_join (all four NULL: none). */
+extern "C" int stg_xattn_pair_bwd_gate(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
+                                       const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, const float* gate0, const float* gate1,
+                                       float* dgate0, float* dgate1, void* ws, int64_t ws_bytes, void* stream) {
+    STG_CHECK(gate0 && gate1 && dgate0 && dgate1, -1, "stg_xattn_pair_bwd_gate: null gate pointer");
+    const bool join = jx0 || jx1 || jz0 || jz1;
+    STG_CHECK(!join || (jx0 && jx1 && jz0 && jz1 && ldjx % 4 == 0 && ldjz % 4 == 0 && (((uintptr_t)jx0 | (uintptr_t)jx1 | (uintptr_t)jz0 | (uintptr_t)jz1) & 7) == 0), -2,
+              "stg_xattn_pair_bwd_gate: bad join operands");
+    return xattn_pair_bwd_impl(b0, b1, g0, g1, ldg, jx0, jx1, ldjx, jz0, jz1, ldjz, ws, ws_bytes, stream, gate0, gate1, dgate0, dgate1);
+}
+
 static int xattn_pair_bwd_impl(const stg_attn_bwd_args* b0, const stg_attn_bwd_args* b1, void* g0, void* g1, int64_t ldg, const void* jx0,
-                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream) {
+                               const void* jx1, int64_t ldjx, const void* jz0, const void* jz1, int64_t ldjz, void* ws, int64_t ws_bytes, void* stream,
+                               const float* gate0, const float* gate1, float* dgate0, float* dgate1) {
     STG_CHECK(b0 && b1 && g0 && g1 && ws, -1, "stg_xattn_pair_bwd: null pointer");
     STG_CHECK(stg_xattn_pair_bwd_supported(&b0->f, &b1->f), -2, "stg_xattn_pair_bwd: not a frame-global cross-modal pair these kernels take");
     const stg_attn_bwd_args* bs[2] = {b0, b1};
@@ -888,10 +932,14 @@ static int xattn_pair_bwd_impl(const stg_attn_bwd_args* b0, const stg_attn_bwd_a
         a.dOh_other = dOh[1 - y]; a.nd_other = nd[1 - y]; a.dOh_own = dOh[y]; a.nd_own = nd[y]; a.lse_other = bs[1 - y]->f.lse;
         a.G = (bf16_t*)gs[y]; a.ldg = ldg; a.n = b->f.n; a.n_kv = b->f.n_kv;
         a.jX = (const bf16_t*)(y ? jx1 : jx0); a.jZ = (const bf16_t*)(y ? jz1 : jz0); a.ldjx = ldjx; a.ldjz = ldjz;
+        a.gate = y ? gate1 : gate0; a.dgate = y ? dgate1 : dgate0;
         a.tiles = (a.n + 31) / 32; a.total = (int)(P * a.tiles);
     }
     hipStream_t st = (hipStream_t)stream;
-    const int parts = 8;
+    // preparation grid: one row per thread and part (8 parts of 25 rows at stage 2's 196-token frames were 2 560 workgroups of a tenth of a wave's work --
+    // and, with the gates inside, 2 560 same-address atomics)
+    const int nmax = pp.a[0].n > pp.a[1].n ? pp.a[0].n : pp.a[1].n;
+    const int parts = nmax >= 2048 ? 8 : (nmax + 255) / 256;
     const int tmax = pp.a[0].total > pp.a[1].total ? pp.a[0].total : pp.a[1].total;
     if (D == 16) {
         hipLaunchKernelGGL(xattn_prep_kernel<16>, dim3((unsigned)P, parts), dim3(256), 0, st, pp);

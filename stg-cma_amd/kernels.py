@@ -1408,13 +1408,14 @@ def xattn_pair_bwd_supported(p0, p1):
     return bool(_lib.lib().stg_xattn_pair_bwd_supported(C.byref(a0.f), C.byref(a1.f)))
 
 
-@_family("xattn_bwd", lambda p0, p1, join=None, outs=None: (("pair",) + tuple(_attn_cost(p0[0], 4, 2, 5)[0]), 2.0 * _attn_cost(p0[0], 5 if join is None else 7, 1, 5)[1],
-                                                             2.0 * _attn_cost(p0[0], 4, 2, 5)[2]))
-def xattn_pair_bwd(p0, p1, join=None, outs=None):
+@_family("xattn_bwd", lambda p0, p1, join=None, outs=None, gates=None: (("pair",) + tuple(_attn_cost(p0[0], 4, 2, 5)[0]), 2.0 * _attn_cost(p0[0], 5 if join is None else 7, 1, 5)[1],
+                                                                         2.0 * _attn_cost(p0[0], 4, 2, 5)[2]))
+def xattn_pair_bwd(p0, p1, join=None, outs=None, gates=None):
     """Backward of a frame-global cross-modal pair, one pass per modality: p0 = (g, h_v, h_a, r_v, lse_v, d r_v), p1 = the mirror image.
     Returns (G_v, G_a): the complete gradients of h_v / h_a through both directions (what attn_bwd2's dQ_0 + dKV_1 and dQ_1 + dKV_0 sum to).
     join = (dX_v, Z_v, dX_a, Z_a): returns ((dX_v + G_v) * Z_v, (dX_a + G_a) * Z_a) instead -- the join of the adapters' backward (add3_mul2)
-    inside the same launch; outs = destination tensors."""
+    inside the same launch; outs = destination tensors.  gates = (gate_v, gate_a, dgate_v, dgate_a) (round 6b): the last element of p0 / p1 is then
+    d(h') of h' = h + gate r, the kernels apply the gate themselves (bit-identical to gate_bwd2 first) and accumulate dgate += <d(h'), r>."""
     a0, a1 = _xpair_args(p0, p1)
     g0, g1 = p0[0], p1[0]
     dev = p0[1].device
@@ -1427,15 +1428,23 @@ def xattn_pair_bwd(p0, p1, join=None, outs=None):
         raise RuntimeError("xattn_pair_bwd: the two outputs must share one leading dimension")
     nb = int(_lib.lib().stg_xattn_pair_bwd_ws_bytes(g0.P, g0.n, g1.n, g0.D))
     ws = torch.empty((nb + 15) // 16 * 4, dtype=F32, device=dev)
-    if join is None:
+    if join is None and gates is None:
         _lib.check(_lib.lib().stg_xattn_pair_bwd(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(ws), ws.numel() * 4, _stream()),
                    "stg_xattn_pair_bwd")
+        return G0, G1
+    if join is None:
+        _lib.check(_lib.lib().stg_xattn_pair_bwd_gate(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), None, None, 0, None, None, 0, _p(gates[0]), _p(gates[1]),
+                                                      _p(gates[2]), _p(gates[3]), _p(ws), ws.numel() * 4, _stream()), "stg_xattn_pair_bwd_gate")
         return G0, G1
     dx0, z0, dx1, z1 = join
     for t, ref in ((dx0, p0[1]), (z0, p0[1]), (dx1, p1[1]), (z1, p1[1])):
         _chk2d(t, "join operand", BF16, cols=g0.D, rows=ref.shape[0])
     if _ld(dx0) != _ld(dx1) or _ld(z0) != _ld(z1):
         raise RuntimeError("xattn_pair_bwd: the join operands of the two modalities must share leading dimensions")
+    if gates is not None:
+        _lib.check(_lib.lib().stg_xattn_pair_bwd_gate(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(dx0), _p(dx1), _ld(dx0), _p(z0), _p(z1), _ld(z0),
+                                                      _p(gates[0]), _p(gates[1]), _p(gates[2]), _p(gates[3]), _p(ws), ws.numel() * 4, _stream()), "stg_xattn_pair_bwd_gate")
+        return G0, G1
     _lib.check(_lib.lib().stg_xattn_pair_bwd_join(C.byref(a0), C.byref(a1), _p(G0), _p(G1), _ld(G0), _p(dx0), _p(dx1), _ld(dx0), _p(z0), _p(z1),
                                                   _ld(z0), _p(ws), ws.numel() * 4, _stream()), "stg_xattn_pair_bwd_join")
     return G0, G1

@@ -519,6 +519,7 @@ def _xwin_geom(spec, BT, dev, dh=32):
 
 
 PAIR_EW = _cfg.opt("pair_ew")      # 0 = one element-wise launch per direction of a cross-modal pair (A/B knob)
+XATTN_GATE = _cfg.opt("xattn_gate")  # 0 = stg_gate_bwd2 in front of the frame-global pair's merged backward (rounds 4-6a; A/B knob)
 XWIN_PAIR = _cfg.opt("xwin_pair")  # 0 = the window-level cross-modal pair as two launches per pass + the gate kernels (rounds 2-6a; A/B knob)
 XATTN_MERGED = _cfg.opt("xattn_merged")   # 0 = the frame-global cross-modal pair's backward as four passes (dQ, dK + dV per direction: rounds 1-4)
 
@@ -634,6 +635,20 @@ def _cross_modal_bwd(spec, BT, hv, ha, gate_v, gate_a, window, g, saved, dhv2, d
         dgate_v = torch.zeros(1, dtype=F32, device=hv.device)
     if dgate_a is None:
         dgate_a = torch.zeros(1, dtype=F32, device=hv.device)
+    if mg is None and XATTN_MERGED and XATTN_GATE and PAIR_EW:
+        # round 6b: the frame-global pair's gates inside its merged backward (the preparation kernel rounds gate * d(h') as stg_gate_bwd2 did and sums dgate)
+        pv, pa = (ag_v, hv, ha, rv, lse_v, dhv2), (ag_a, ha, hv, ra, lse_a, dha2)
+        if K.xattn_pair_bwd_supported(pv, pa):
+            gates = (gate_v, gate_a, dgate_v, dgate_a)
+            if zs is not None and dhv2.stride(0) == dha2.stride(0) and zs[0].stride(0) == zs[1].stride(0) and (outs is None or outs[0].stride(0) == outs[1].stride(0)):
+                return K.xattn_pair_bwd(pv, pa, join=(dhv2, zs[0], dha2, zs[1]), outs=outs, gates=gates)
+            G_v, G_a = K.xattn_pair_bwd(pv, pa, gates=gates)
+            if zs is None:
+                return K.add(dhv2, G_v), K.add(dha2, G_a)
+            if dhv2.shape == dha2.shape:
+                return K.add3_mul2(dhv2, G_v, None, zs[0], dha2, G_a, None, zs[1], outs=outs)
+            return K.add3_mul(dhv2, G_v, torch.zeros_like(G_v), zs[0], out=None if outs is None else outs[0]), \
+                K.add3_mul(dha2, G_a, torch.zeros_like(G_a), zs[1], out=None if outs is None else outs[1])
     drv, dra = _gate_bwd2(dhv2, rv, gate_v, dgate_v, dha2, ra, gate_a, dgate_a)
     if mg is not None and MHA_MERGED and mg.window[2] == 0 and hv.stride(0) == ha.stride(0) and rv.stride(0) == ra.stride(0) and drv.stride(0) == dra.stride(0) \
             and 2 * mg.P < 65536:

@@ -350,6 +350,20 @@ def test_cross_modal_pair_fused_gate_and_join(stg, gpu, P, n, D):
     j1 = k.xattn_pair_bwd(pv, pa, join=(dxv, zv, dxa, za), outs=(buf[:P * n], buf[P * n:]))
     torch.cuda.synchronize()
     assert eq(j0[0], j1[0]) and eq(j0[1], j1[1]), "fused join differs from add3_mul2 on the merged kernel's output"
+    # round 6b (stg_xattn_pair_bwd_gate, ABI 220): the gates inside the merged backward -- the kernels take d(x), round gate * d(x) as gate_bwd2 did
+    # (G bit-identical) and sum dgate = <d(x), r> themselves (fp32 atomics: summation order differs)
+    pxv, pxa = (gv, hv, ha, rv, lv, dxv), (gv, ha, hv, ra, la, dxa)
+    dg2_v, dg2_a = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    G2v, G2a = k.xattn_pair_bwd(pxv, pxa, gates=(gate_v, gate_a, dg2_v, dg2_a))
+    assert eq(Gv, G2v) and eq(Ga, G2a), "gated merged backward differs from gate_bwd2 + merged backward"
+    dg3_v, dg3_a = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+    buf2 = torch.full((2 * P * n, D), float("nan"), dtype=BF16, device=gpu)
+    j2 = k.xattn_pair_bwd(pxv, pxa, join=(dxv, zv, dxa, za), outs=(buf2[:P * n], buf2[P * n:]), gates=(gate_v, gate_a, dg3_v, dg3_a))
+    torch.cuda.synchronize()
+    assert eq(j0[0], j2[0]) and eq(j0[1], j2[1]), "gated merged backward with the join differs"
+    for got, want, dx, r in ((dg2_v, dg_v, dxv, rv), (dg2_a, dg_a, dxa, ra), (dg3_v, dg_v, dxv, rv), (dg3_a, dg_a, dxa, ra)):
+        terms = dx.float() * r.float()
+        assert abs(float(got) - float(want)) <= 2e-4 * float(terms.abs().sum()) ** 0.5 + 1e-4 * abs(float(want)), (float(got), float(want))
 
 
 @pytest.mark.parametrize("P,nv,na,D,scale", [(5, 197, 49, 48, 1.0), (3, 257, 64, 64, 1.0), (4, 50, 7, 48, 0.5), (2, 33, 33, 32, 1.0), (6, 256, 1, 48, 1.0)])
