@@ -926,3 +926,48 @@ def test_counted_wait_and_path_switch_kernels_repeat_2000(stg, gpu):
             K.wgrad_tn(a, b, dW, db, row_scale=rs, rs_outer=64, rs_inner=1)
             return dW, db
         stress(f"wgrad_ws {J} x {Cw}", wg_, reps=1000)
+
+
+def test_gated_pair_launches_repeat_2000(stg, gpu):
+    """Round 6b: the cross-modal pairs with their gates inside (stg_winattn_pair_fwd / _bwd: an LDS ticket elects the wave that sends the workgroup's
+    dgate sum; stg_xattn_pair_bwd_gate: the preparation kernel's workgroup sum) -- 2 000 launches each: every tensor output the same bits every time
+    (dgate is a sum of fp32 atomics: its order may differ, its value must not drift beyond fp32 summation noise), a last workgroup of three waves."""
+    from stgcma import kernels as K
+    torch.manual_seed(5)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, device=gpu) * sc).to(torch.bfloat16)
+    gate_v, gate_a = torch.tensor([0.37], device=gpu), torch.tensor([-1.21], device=gpu)
+
+    def stress(name, fn, ndg, reps=2000):
+        out = fn()
+        ref, dg0 = [t.clone() for t in out[:-ndg]], [float(t) for t in out[-ndg:]]
+        bad = torch.zeros((), device=gpu, dtype=torch.int64)
+        dmax = torch.zeros(ndg, device=gpu)
+        for _ in range(reps):
+            out = fn()
+            for t, q in zip(out[:-ndg], ref):
+                bad += (t.view(torch.int16) != q.view(torch.int16)).any() if t.dtype == torch.bfloat16 else (t != q).any()
+            dmax = torch.maximum(dmax, torch.stack([(t.reshape(()) - d).abs() for t, d in zip(out[-ndg:], dg0)]))
+        assert int(bad) == 0, f"{name}: {int(bad)} of {reps} launches differ from the first"
+        for d, m in zip(dg0, dmax.tolist()):
+            assert m <= 1e-4 * max(1.0, abs(d)), f"{name}: dgate drifts by {m} around {d}"
+
+    for images, Himg, D in ((3, 21, 32), (6, 14, 16)):
+        hv, ha, dxv, dxa = bf(images * Himg * Himg, D, sc=0.7), bf(images * Himg * Himg, D, sc=0.7), bf(images * Himg * Himg, D), bf(images * Himg * Himg, D)
+        wg = K.WinGeom(images, 1, Himg, Himg, 7, 3, 1.0, None, None, D=D)
+        (rv, lv, xv), (ra, la, xa) = K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a)
+        stress(f"winattn_pair_fwd {Himg} D={D}", lambda: [t for o in K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a) for t in o] + [torch.zeros((), device=gpu)], 1)
+
+        def bwd():
+            dgv, dga = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+            return list(K.winattn_pair_bwd(wg, hv, ha, rv, ra, lv, la, dxv, dxa, gate_v, gate_a, dgv, dga)) + [dgv, dga]
+        stress(f"winattn_pair_bwd {Himg} D={D}", bwd, 2)
+    for D, n in ((16, 3136), (32, 196)):
+        P_ = 2 if n > 1000 else 5
+        hv, ha, dxv, dxa = bf(P_ * n, D, sc=0.7), bf(P_ * n, D, sc=0.7), bf(P_ * n, D), bf(P_ * n, D)
+        gv = K.AttnGeom(P_, 1, n, D, G=1, outer=n, n_kv=n, outer_kv=n, scale=1.0)
+        (rv, lv, _), (ra, la, _) = K.xattn_fwd2_gate(gv, hv, ha, gv, ha, hv, gate_v, gate_a)
+
+        def xb():
+            dgv, dga = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
+            return list(K.xattn_pair_bwd((gv, hv, ha, rv, lv, dxv), (gv, ha, hv, ra, la, dxa), gates=(gate_v, gate_a, dgv, dga))) + [dgv, dga]
+        stress(f"xattn_pair_bwd gated D={D} n={n}", xb, 2, reps=2000 if n < 1000 else 600)
