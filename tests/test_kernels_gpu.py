@@ -955,7 +955,9 @@ def test_gated_pair_launches_repeat_2000(stg, gpu):
         hv, ha, dxv, dxa = bf(images * Himg * Himg, D, sc=0.7), bf(images * Himg * Himg, D, sc=0.7), bf(images * Himg * Himg, D), bf(images * Himg * Himg, D)
         wg = K.WinGeom(images, 1, Himg, Himg, 7, 3, 1.0, None, None, D=D)
         (rv, lv, xv), (ra, la, xa) = K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a)
-        stress(f"winattn_pair_fwd {Himg} D={D}", lambda: [t for o in K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a) for t in o] + [torch.zeros((), device=gpu)], 1)
+        # (lse is [P, 1, 64] with the entries past the window's 49 tokens never written)
+        stress(f"winattn_pair_fwd {Himg} D={D}", lambda: [t if t.dim() == 2 else t[..., :49].contiguous() for o in K.winattn_pair_fwd(wg, hv, ha, gate_v, gate_a) for t in o]
+               + [torch.zeros((), device=gpu)], 1)
 
         def bwd():
             dgv, dga = torch.zeros(1, device=gpu), torch.zeros(1, device=gpu)
