@@ -205,7 +205,7 @@ def self_launch(n):
     raise SystemExit(r.returncode)
 
 
-PMC_BY_CLASS = ("r06_final_pmc_by_class.json", "r05_final_pmc_by_class.json", "r04_final_pmc_by_class.json", "r03_pmc_by_class.json")      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
+PMC_BY_CLASS = ("r06b_final_pmc_by_class.json", "r06_final_pmc_by_class.json", "r05_final_pmc_by_class.json", "r04_final_pmc_by_class.json", "r03_pmc_by_class.json")      # tools/ledger.py: PMC bytes per launch per GEMM class, joined by launch order
 
 
 def pmc_traffic(kernel, N, K, epi):
